@@ -1,0 +1,135 @@
+"""ctypes binding of libcommpy_amd.so (the HIP engine).  Declares exactly the symbols of
+include/commpy_amd.h.  There is NO CPU fallback: if the library is missing or no HIP device is
+usable, the decoders raise -- loudly -- instead of computing on the host.
+"""
+import ctypes
+import os
+from ctypes import (POINTER, c_char_p, c_double, c_float, c_int, c_int8, c_int32, c_int64, c_size_t,
+                    c_uint8, c_void_p)
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libcommpy_amd.so")
+
+CPX_OK, CPX_EINVAL, CPX_EHIP, CPX_ENOMEM, CPX_ENODEV, CPX_ELIMIT = 0, -1, -2, -3, -4, -5
+
+_dp = POINTER(c_double)
+_i32p = POINTER(c_int32)
+_u8p = POINTER(c_uint8)
+_i8p = POINTER(c_int8)
+
+# name -> (restype, argtypes); mirrors include/commpy_amd.h one to one
+SYMBOLS = {
+    "cpx_last_error": (c_char_p, []),
+    "cpx_version": (c_int, []),
+    "cpx_device_count": (c_int, [POINTER(c_int)]),
+    "cpx_set_device": (c_int, [c_int]),
+    "cpx_device_info": (c_int, [c_char_p, c_int, POINTER(c_int), POINTER(c_int64)]),
+    "cpx_malloc": (c_int, [POINTER(c_void_p), c_size_t]),
+    "cpx_free": (c_int, [c_void_p]),
+    "cpx_memset": (c_int, [c_void_p, c_int, c_size_t]),
+    "cpx_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "cpx_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "cpx_stream_sync": (c_int, [c_void_p]),
+    "cpx_default_stream": (c_void_p, []),
+    "cpx_timer_create": (c_int, [POINTER(c_void_p)]),
+    "cpx_timer_start": (c_int, [c_void_p, c_void_p]),
+    "cpx_timer_stop": (c_int, [c_void_p, c_void_p]),
+    "cpx_timer_elapsed_ms": (c_int, [c_void_p, POINTER(c_float)]),
+    "cpx_timer_destroy": (c_int, [c_void_p]),
+    "cpx_trellis_create": (c_int, [c_int, c_int, c_int, c_int, _i32p, _i32p, POINTER(c_void_p)]),
+    "cpx_trellis_destroy": (c_int, [c_void_p]),
+    "cpx_viterbi_decode_batch": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int,
+                                         c_void_p]),
+    "cpx_viterbi_decode_batch_dev": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int,
+                                             c_void_p, c_void_p]),
+    "cpx_map_decode_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_double, c_int,
+                                     c_void_p, c_void_p]),
+    "cpx_map_decode_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_double, c_int,
+                                         c_void_p, c_void_p, c_void_p]),
+    "cpx_turbo_decode_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                       c_double, c_int, c_void_p]),
+    "cpx_turbo_decode_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                           c_int64, c_double, c_int, c_void_p, c_void_p]),
+    "cpx_ldpc_create": (c_int, [c_int, c_int, c_int64, _i32p, _i32p, POINTER(c_void_p)]),
+    "cpx_ldpc_destroy": (c_int, [c_void_p]),
+    "cpx_ldpc_bp_decode_batch": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "cpx_ldpc_bp_decode_batch_dev": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                             c_void_p]),
+    "cpx_modem_create": (c_int, [c_void_p, c_int, POINTER(c_void_p)]),
+    "cpx_modem_destroy": (c_int, [c_void_p]),
+    "cpx_demod_soft": (c_int, [c_void_p, c_void_p, c_int64, c_double, c_void_p]),
+    "cpx_demod_soft_dev": (c_int, [c_void_p, c_void_p, c_int64, c_double, c_void_p, c_void_p]),
+    "cpx_demod_hard": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "cpx_demod_hard_dev": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+}
+
+
+class EngineError(RuntimeError):
+    """The HIP engine is missing or failed (no CPU fallback exists)."""
+
+
+_lib = None
+
+
+def load():
+    """Load libcommpy_amd.so once; raises EngineError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineError(
+            "libcommpy_amd.so not found at %s -- build it with `python -m commpy_amd.build` "
+            "(hipcc --offload-arch=gfx950). commpy_amd has no CPU fallback." % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as exc:  # pragma: no cover - depends on the host
+        raise EngineError("cannot load %s: %s" % (LIB_PATH, exc)) from exc
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error():
+    msg = load().cpx_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc, value_error=ValueError):
+    """Map an engine return code to the reference's exception types."""
+    if rc == CPX_OK:
+        return
+    msg = last_error()
+    if rc in (CPX_EINVAL, CPX_ELIMIT):
+        raise value_error(msg)
+    if rc == CPX_ENOMEM:
+        raise MemoryError(msg)
+    raise EngineError(msg or "libcommpy_amd error %d" % rc)
+
+
+def device_count():
+    n = c_int(0)
+    load().cpx_device_count(ctypes.byref(n))
+    return n.value
+
+
+def require_device():
+    if device_count() <= 0:
+        raise EngineError("no HIP device available; commpy_amd computes on MI355X only (no CPU fallback)")
+
+
+def ptr(arr):
+    """void* of a C-contiguous NumPy array."""
+    return arr.ctypes.data_as(c_void_p)
+
+
+def as_f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def as_i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)

@@ -1,0 +1,293 @@
+"""Convolutional codes: host-side code description + MI355X Viterbi decoder.
+
+Public names and argument meaning follow the reference module
+/root/reference/commpy/channelcoding/convcode.py:
+
+* ``Trellis``          (convcode.py:23-255)  host: builds next_state_table / output_table;
+* ``conv_encode``      (convcode.py:475-558) host: table-driven encoder (input generator);
+* ``puncturing`` / ``depuncturing`` (convcode.py:752-804) host;
+* ``viterbi_decode``   (convcode.py:661-749) DEVICE: the body is the HIP kernel
+  ``viterbi_wave_kernel`` (commpy_amd/csrc/viterbi.hip) reached through the C-ABI
+  ``cpx_viterbi_decode_batch`` (include/commpy_amd.h).  A 2-D input ``[B, len]`` decodes a
+  batch of independent codewords (extension; the reference is 1-D only).
+
+The kernels are table-driven: they never re-derive tables from polynomials (the legacy-int and the
+matrix feedback constructions give different RSC output tables).
+"""
+import ctypes
+import math
+from warnings import warn
+
+import numpy as np
+
+from commpy_amd import _lib
+from commpy_amd.utilities import dec2bitarray, bitarray2dec
+
+__all__ = ['Trellis', 'conv_encode', 'viterbi_decode', 'puncturing', 'depuncturing']
+
+_VIT_TYPES = {'hard': 0, 'soft': 1, 'unquantized': 2}
+
+
+def _poly_taps(value, width, msb_format):
+    """Taps of one polynomial as an int array ``taps[w]`` = coefficient of D^w (convcode.py:211-222).
+
+    'MSB' format: the least significant bit of the number is the D^0 tap (the reference reverses
+    ``dec2bitarray(value, width)``); 'LSB'/'Matlab': the most significant of the ``width`` bits is.
+    ``dec2bitarray`` keeps its wrap-around quirk for numbers wider than ``width`` bits.
+    """
+    bits = dec2bitarray(int(value), width)
+    return bits[::-1].copy() if msb_format else bits.copy()
+
+
+class Trellis:
+    """Trellis of a k/n convolutional code (same constructor as convcode.py:117).
+
+    Attributes: ``k, n, total_memory, number_states, number_inputs, next_state_table,
+    output_table, code_type`` -- identical meaning and values to the reference
+    (golden tables: commpy/channelcoding/tests/test_convcode.py:23-111).
+
+    State numbering: the state integer is the concatenation (MSB first) of the shift registers,
+    most recent bit first; ``output_table[s, i]`` packs the n output bits MSB = output 0.
+    """
+
+    def __init__(self, memory, g_matrix, feedback=None, code_type='default', polynomial_format='MSB'):
+        memory = np.asarray(memory)
+        [self.k, self.n] = g_matrix.shape
+        self.code_type = code_type
+        self.total_memory = int(memory.sum())
+        self.number_states = 2 ** self.total_memory
+        self.number_inputs = 2 ** self.k
+        self.next_state_table = np.zeros([self.number_states, self.number_inputs], 'int')
+        self.output_table = np.zeros([self.number_states, self.number_inputs], 'int')
+        self._cpx_handle = None
+
+        if isinstance(feedback, int):
+            warn('Trellis  will only accept feedback as a matrix in the future. '
+                 'Using the backwards compatibility version that may contain bugs for k > 1 or with LSB format.',
+                 DeprecationWarning)
+            self._build_legacy(memory, g_matrix, feedback)
+        else:
+            self._build_matrix(memory, g_matrix, feedback, polynomial_format)
+
+    # -- matrix construction, convcode.py:195-255 -------------------------------------------
+    def _build_matrix(self, memory, g_matrix, feedback, polynomial_format):
+        if polynomial_format == 'MSB':
+            msb = True
+        elif polynomial_format in ('LSB', 'Matlab'):
+            msb = False
+        else:
+            raise ValueError('polynomial_format must be "LSB", "MSB" or "Matlab"')
+        k, n = self.k, self.n
+        width = int(memory.max()) + 1
+        if feedback is None:
+            feedback = np.identity(k, int)
+            if not msb:
+                feedback = feedback * 2 ** int(memory.max())
+        feedback = np.asarray(feedback)
+        # fb[w, i, j]: tap on D^w of feedback polynomial (i, j);  gen[w, i, j]: same for g_matrix
+        fb = np.zeros((width, k, k), np.int64)
+        gen = np.zeros((width, k, n), np.int64)
+        for i in range(k):
+            for j in range(k):
+                fb[:, i, j] = _poly_taps(feedback[i, j], width, msb)
+            for j in range(n):
+                gen[:, i, j] = _poly_taps(g_matrix[i, j], width, msb)
+        offsets = np.concatenate(([0], np.cumsum(memory)))[:-1]
+        for state in range(self.number_states):
+            state_bits = dec2bitarray(state, self.total_memory).astype(np.int64)
+            for inp in range(self.number_inputs):
+                # regs[w, l]: row 0 = current input of register l, rows 1..mem_l = its delay line
+                regs = np.zeros((width, k), np.int64)
+                regs[0, :] = dec2bitarray(inp, k)
+                for l, mem in enumerate(memory):
+                    regs[1:mem + 1, l] = state_bits[offsets[l]:offsets[l] + mem]
+                # outputs use the RAW input (before feedback), convcode.py:243-244
+                out_bits = np.einsum('wl,wlj->j', regs, gen) % 2
+                self.output_table[state, inp] = bitarray2dec(out_bits)
+                # feedback-modified register inputs, convcode.py:247-248
+                new_in = np.einsum('wl,wjl->j', regs, fb) % 2
+                regs[0, :] = new_in
+                nxt = state_bits.copy()
+                for l, mem in enumerate(memory):
+                    nxt[offsets[l]:offsets[l] + mem] = regs[:mem, l]
+                self.next_state_table[state, inp] = bitarray2dec(nxt)
+
+    # -- legacy construction (integer feedback), convcode.py:130-193 ---------------------------
+    def _build_legacy(self, memory, g_matrix, feedback):
+        k, n = self.k, self.n
+        if self.code_type == 'rsc':
+            for i in range(k):
+                g_matrix[i][i] = feedback  # the reference mutates the caller's g_matrix (:135-137)
+        if k != 1:
+            # The reference's k > 1 legacy branch multiplies arrays of mismatching lengths
+            # (convcode.py:166-168) and fails with a broadcasting ValueError.
+            raise ValueError('legacy integer feedback is only usable for k = 1; pass feedback as a matrix')
+        m = int(memory[0])
+        fb_bits = dec2bitarray(feedback, m + 1).astype(np.int64)
+        for state in range(self.number_states):
+            for inp in range(self.number_inputs):
+                outbits = np.zeros(n, np.int64)
+                in_bit = int(dec2bitarray(inp, k)[0])
+                sr = None
+                for r in range(n):
+                    sr = dec2bitarray(state, self.total_memory).astype(np.int64)
+                    gen = dec2bitarray(g_matrix[0][r], m + 1).astype(np.int64)
+                    acc = int((sr[:m] * gen[1:m + 1]).sum()) % 2          # delay-line taps (:154-156)
+                    fa = int((fb_bits[1:] * sr[0:m]).sum())               # feedback sum (:160)
+                    sr[1:m] = sr[0:m - 1].copy()                           # shift (:161-162)
+                    sr[0] = (in_bit + fa) % 2                              # (:163-164)
+                    outbits[r] = (acc + ((in_bit * int(gen[0]) + fa) % 2)) % 2   # (:175-177)
+                self.output_table[state][inp] = bitarray2dec(outbits)
+                self.next_state_table[state][inp] = bitarray2dec(sr)
+
+    # -- device handle ---------------------------------------------------------------------------
+    def _device_handle(self):
+        """Opaque cpx_trellis* carrying the tables to the GPU (created on first use)."""
+        if self._cpx_handle is None:
+            lib = _lib.load()
+            _lib.require_device()
+            nxt = _lib.as_i32(self.next_state_table)
+            out = _lib.as_i32(self.output_table)
+            h = ctypes.c_void_p()
+            _lib.check(lib.cpx_trellis_create(int(self.k), int(self.n), int(self.number_states),
+                                              int(self.number_inputs),
+                                              nxt.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                                              out.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                                              ctypes.byref(h)))
+            self._cpx_handle = h
+        return self._cpx_handle
+
+    def __del__(self):
+        h = getattr(self, '_cpx_handle', None)
+        if h is not None:
+            try:
+                _lib.load().cpx_trellis_destroy(h)
+            except Exception:  # interpreter shutdown
+                pass
+
+
+def conv_encode(message_bits, trellis, termination='term', puncture_matrix=None):
+    """Table-driven convolutional encoder (host) -- convcode.py:475-558.
+
+    Same return as the reference, including its puncturing behaviour: only row 0 of
+    ``puncture_matrix`` is consulted, indexed by flat output position, and the result keeps the
+    unpunctured length with a zero tail (quirk B3, convcode.py:523-527, 552-556).
+    """
+    k, n, total_memory = trellis.k, trellis.n, trellis.total_memory
+    rate = float(k) / n
+    code_type = trellis.code_type
+    if puncture_matrix is None:
+        puncture_matrix = np.ones((k, n))
+    message_bits = np.asarray(message_bits)
+    number_message_bits = np.size(message_bits)
+
+    if termination == 'cont':
+        inbits = message_bits
+        number_inbits = number_message_bits
+        number_outbits = int(number_inbits / rate)
+    elif code_type == 'rsc':
+        inbits = message_bits
+        number_inbits = number_message_bits
+        number_outbits = int((number_inbits + k * total_memory) / rate)
+    else:
+        number_inbits = number_message_bits + total_memory + total_memory % k
+        inbits = np.zeros(number_inbits, 'int')
+        inbits[0:number_message_bits] = message_bits      # zero tail = trellis termination
+        number_outbits = int(number_inbits / rate)
+
+    outbits = np.zeros(number_outbits, 'int')
+    next_state_table, output_table = trellis.next_state_table, trellis.output_table
+    state = 0
+    j = 0
+    for i in range(int(number_inbits / k)):
+        cur_in = bitarray2dec(inbits[i * k:(i + 1) * k])
+        outbits[j * n:(j + 1) * n] = dec2bitarray(int(output_table[state][cur_in]), n)
+        state = next_state_table[state][cur_in]
+        j += 1
+
+    if code_type == 'rsc' and termination == 'term':
+        term_bits = dec2bitarray(int(state), total_memory)[::-1]         # :539-540
+        for i in range(total_memory):
+            cur_in = bitarray2dec(term_bits[i * k:(i + 1) * k])
+            outbits[j * n:(j + 1) * n] = dec2bitarray(int(output_table[state][cur_in]), n)
+            state = next_state_table[state][cur_in]
+            j += 1
+
+    p_outbits = np.zeros(number_outbits, 'int')
+    row0 = np.asarray(puncture_matrix)[0]
+    keep = row0[np.arange(number_outbits) % np.size(puncture_matrix, 1)] == 1
+    kept = outbits[keep]
+    p_outbits[:len(kept)] = kept
+    return p_outbits
+
+
+def puncturing(message, punct_vec):
+    """Drop the positions whose puncture-vector entry is 0 -- convcode.py:752-774 (same index walk)."""
+    shift = 0
+    N = len(punct_vec)
+    punctured = []
+    for idx, item in enumerate(message):
+        if punct_vec[idx - shift * N] == 1:
+            punctured.append(item)
+        if idx % N == 0:
+            shift = shift + 1
+    return np.array(punctured)
+
+
+def depuncturing(punctured, punct_vec, shouldbe):
+    """Re-insert zeros at punctured positions -- convcode.py:777-804 (same index walk)."""
+    shift = 0
+    shift2 = 0
+    N = len(punct_vec)
+    depunctured = np.zeros((shouldbe,))
+    for idx in range(shouldbe):
+        if punct_vec[idx - shift * N] == 1:
+            depunctured[idx] = float(punctured[idx - shift2])
+        else:
+            shift2 = shift2 + 1
+        if idx % N == 0:
+            shift = shift + 1
+    return depunctured
+
+
+def _viterbi_sizes(length, trellis, tb_depth):
+    """(L, n_steps, tb_depth) exactly as convcode.py:694-702, 721 computes them."""
+    k, n = trellis.k, trellis.n
+    rate = k / n
+    L = int(length * rate)
+    if tb_depth is None:
+        tb_depth = min(5 * trellis.total_memory, L)
+    n_steps = int((L + trellis.total_memory) / k) - 1
+    return L, n_steps, int(tb_depth)
+
+
+def viterbi_decode(coded_bits, trellis, tb_depth=None, decoding_type='hard'):
+    """Viterbi decoding on MI355X; same signature/return as convcode.py:661.
+
+    Parameters are those of the reference.  ``coded_bits`` may also be ``[B, len]`` (batch of
+    independent codewords -> ``[B, L]``).  Returns int64 bits of length ``L = int(len*k/n)``,
+    tail included (convcode.py:749).  'soft' inputs are LLRs log P1/P0, clipped to +-500.
+
+    Differences kept on purpose: the caller's array is never modified (the reference overwrites
+    the last received codeword with the padding value for 'hard'/'unquantized', convcode.py:724-732);
+    an invalid ``decoding_type`` raises ``ValueError`` immediately rather than only when the padding
+    steps are reached (convcode.py:733-734).
+    """
+    if decoding_type not in _VIT_TYPES:
+        raise ValueError('The available decoding types are "hard", "soft" and "unquantized')
+    lib = _lib.load()
+    arr = np.asarray(coded_bits)
+    single = arr.ndim == 1
+    x = _lib.as_f64(arr.reshape(1, -1) if single else arr)
+    if x.ndim != 2:
+        raise ValueError('coded_bits must be 1-D or 2-D [batch, len]')
+    B, length = x.shape
+    L, n_steps, tb = _viterbi_sizes(length, trellis, tb_depth)
+    out = np.zeros((B, L), dtype=np.uint8)
+    if B and L:
+        if tb < 2:
+            raise ValueError('tb_depth must be >= 2')
+        _lib.check(lib.cpx_viterbi_decode_batch(trellis._device_handle(), _lib.ptr(x), B, length, L, n_steps, tb,
+                                                _VIT_TYPES[decoding_type], _lib.ptr(out)))
+    res = out.astype(np.int64)
+    return res[0] if single else res

@@ -1,0 +1,86 @@
+// Internal helpers shared by the HIP translation units of libcommpy_amd.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "commpy_amd.h"
+
+namespace cpx {
+
+void set_error(const char *fmt, ...);
+hipStream_t lib_stream();   // lazily created per-process stream of the current device
+int ensure_device();        // CPX_OK if a HIP device is usable
+
+#define CPX_HIP(call)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (call);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            cpx::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return CPX_EHIP;                                                                   \
+        }                                                                                      \
+    } while (0)
+
+#define CPX_REQUIRE(cond, code, ...)            \
+    do {                                        \
+        if (!(cond)) {                          \
+            cpx::set_error(__VA_ARGS__);        \
+            return (code);                      \
+        }                                       \
+    } while (0)
+
+inline hipStream_t pick_stream(void *s) { return s ? reinterpret_cast<hipStream_t>(s) : lib_stream(); }
+
+// RAII device buffer for the host-buffer entry points.
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) {
+        if (bytes == 0) bytes = 8;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); p = nullptr; return CPX_ENOMEM; }
+        return CPX_OK;
+    }
+    template <class T> T *as() { return reinterpret_cast<T *>(p); }
+};
+
+}  // namespace cpx
+
+// ---- handles -----------------------------------------------------------------------------------
+#define CPX_MAX_STATES 128
+#define CPX_MAX_INPUTS 4
+#define CPX_MAX_N 6
+
+struct cpx_trellis {
+    int k, n, S, I;
+    int device;
+    // host copies
+    std::vector<int32_t> next_state, output;
+    std::vector<int32_t> pred_state, pred_input, pred_code;  // [S][I] in np.where order
+    // device tables (int32)
+    int32_t *d_next = nullptr, *d_out = nullptr;             // [S][I]
+    int32_t *d_pred_state = nullptr, *d_pred_input = nullptr, *d_pred_code = nullptr;  // [S][I]
+};
+
+struct cpx_ldpc {
+    int n_v, n_c;
+    int64_t n_edges;
+    int device;
+    int max_cdeg, max_vdeg;
+    // check-major edge list (sorted by check, then variable)
+    int32_t *d_edge_var = nullptr;    // [E] variable of edge e
+    int32_t *d_row_ptr = nullptr;     // [n_c+1]
+    // variable-major view: for each variable its edges in increasing check order
+    int32_t *d_col_ptr = nullptr;     // [n_v+1]
+    int32_t *d_col_edge = nullptr;    // [E] edge ids
+};
+
+struct cpx_modem {
+    int M, nbits;
+    int device;
+    double *d_const = nullptr;  // [M][2]
+};

@@ -1,0 +1,155 @@
+// Runtime plumbing of libcommpy_amd.so: error string, device selection, stream, memory and
+// HIP-event timers.  No compute here.
+#include "cpx_internal.h"
+
+namespace cpx {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static hipStream_t g_streams[64] = {};
+
+hipStream_t lib_stream() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!g_streams[dev]) {
+        if (hipStreamCreateWithFlags(&g_streams[dev], hipStreamNonBlocking) != hipSuccess) g_streams[dev] = nullptr;
+    }
+    return g_streams[dev];
+}
+
+int ensure_device() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("no HIP device available (%s); libcommpy_amd has no CPU fallback",
+                  e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+        return CPX_ENODEV;
+    }
+    return CPX_OK;
+}
+
+}  // namespace cpx
+
+using namespace cpx;
+
+extern "C" {
+
+const char *cpx_last_error(void) { return g_err; }
+
+int cpx_version(void) { return 100; }  // 0.1.0
+
+int cpx_device_count(int *n) {
+    CPX_REQUIRE(n, CPX_EINVAL, "cpx_device_count: null pointer");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { (void)hipGetLastError(); c = 0; }
+    *n = c;
+    return CPX_OK;
+}
+
+int cpx_set_device(int device) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    CPX_HIP(hipSetDevice(device));
+    return CPX_OK;
+}
+
+int cpx_device_info(char *name, int name_cap, int *compute_units, int64_t *hbm_bytes) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    int dev = 0;
+    CPX_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t p;
+    CPX_HIP(hipGetDeviceProperties(&p, dev));
+    if (name && name_cap > 0) snprintf(name, (size_t)name_cap, "%s (%s)", p.name, p.gcnArchName);
+    if (compute_units) *compute_units = p.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)p.totalGlobalMem;
+    return CPX_OK;
+}
+
+int cpx_malloc(void **dptr, size_t bytes) {
+    CPX_REQUIRE(dptr, CPX_EINVAL, "cpx_malloc: null pointer");
+    int rc = ensure_device();
+    if (rc) return rc;
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 8);
+    if (e != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return CPX_ENOMEM; }
+    return CPX_OK;
+}
+
+int cpx_free(void *dptr) {
+    if (dptr) CPX_HIP(hipFree(dptr));
+    return CPX_OK;
+}
+
+int cpx_memset(void *dptr, int value, size_t bytes) {
+    CPX_HIP(hipMemsetAsync(dptr, value, bytes, lib_stream()));
+    CPX_HIP(hipStreamSynchronize(lib_stream()));
+    return CPX_OK;
+}
+
+int cpx_memcpy_h2d(void *dst, const void *src, size_t bytes) {
+    CPX_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return CPX_OK;
+}
+
+int cpx_memcpy_d2h(void *dst, const void *src, size_t bytes) {
+    CPX_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return CPX_OK;
+}
+
+int cpx_stream_sync(void *stream) {
+    CPX_HIP(hipStreamSynchronize(pick_stream(stream)));
+    return CPX_OK;
+}
+
+void *cpx_default_stream(void) { return (void *)lib_stream(); }
+
+struct cpx_timer_t {
+    hipEvent_t a, b;
+};
+
+int cpx_timer_create(void **timer) {
+    CPX_REQUIRE(timer, CPX_EINVAL, "cpx_timer_create: null pointer");
+    int rc = ensure_device();
+    if (rc) return rc;
+    cpx_timer_t *t = new cpx_timer_t;
+    CPX_HIP(hipEventCreate(&t->a));
+    CPX_HIP(hipEventCreate(&t->b));
+    *timer = t;
+    return CPX_OK;
+}
+
+int cpx_timer_start(void *timer, void *stream) {
+    CPX_HIP(hipEventRecord(((cpx_timer_t *)timer)->a, pick_stream(stream)));
+    return CPX_OK;
+}
+
+int cpx_timer_stop(void *timer, void *stream) {
+    CPX_HIP(hipEventRecord(((cpx_timer_t *)timer)->b, pick_stream(stream)));
+    return CPX_OK;
+}
+
+int cpx_timer_elapsed_ms(void *timer, float *ms) {
+    cpx_timer_t *t = (cpx_timer_t *)timer;
+    CPX_HIP(hipEventSynchronize(t->b));
+    CPX_HIP(hipEventElapsedTime(ms, t->a, t->b));
+    return CPX_OK;
+}
+
+int cpx_timer_destroy(void *timer) {
+    cpx_timer_t *t = (cpx_timer_t *)timer;
+    if (!t) return CPX_OK;
+    (void)hipEventDestroy(t->a);
+    (void)hipEventDestroy(t->b);
+    delete t;
+    return CPX_OK;
+}
+
+}  // extern "C"

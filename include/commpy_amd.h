@@ -1,0 +1,168 @@
+/*
+ * commpy_amd.h -- C-ABI of libcommpy_amd.so, the MI355X (gfx950) decoding engine.
+ *
+ * The reference (veeresht/CommPy 0.8.0, pure Python) has no FFI/plugin layer: its boundary for the
+ * hot path is the set of Python callables exported by commpy/channelcoding/__init__.py:65-71 and
+ * commpy/modulation.py:35-36.  Each entry point below replaces the BODY of one of those callables;
+ * the Python mirror in commpy_amd/ keeps the reference signatures and reaches these symbols with
+ * ctypes (see INTEGRATION.md for the stub a CommPy maintainer would add).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.
+ *   - every function returns 0 on success, <0 on error (CPX_E*); cpx_last_error() gives a
+ *     thread-local message.  The Python layer maps errors to the reference's exception types.
+ *   - "host" entry points take caller-owned host buffers (C-contiguous NumPy memory), copy
+ *     H2D/D2H themselves on the library's stream and return after completion.
+ *   - "_dev" entry points take DEVICE pointers and a hipStream_t (as void*; NULL = the library's
+ *     own stream), enqueue the kernels and return immediately (asynchronous); used by bench.py and
+ *     the multi-GPU path where inputs are already resident in HBM.
+ *   - handles (cpx_trellis/cpx_ldpc/cpx_modem) own small device-side tables; they belong to the
+ *     device that was current at creation and are freed by the matching *_destroy.
+ *   - no CPU fallback exists: without a usable HIP device every compute entry point fails.
+ */
+#ifndef COMMPY_AMD_H
+#define COMMPY_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CPX_OK 0
+#define CPX_EINVAL (-1)   /* bad argument (Python: ValueError) */
+#define CPX_EHIP (-2)     /* HIP runtime error (Python: RuntimeError) */
+#define CPX_ENOMEM (-3)   /* allocation failure */
+#define CPX_ENODEV (-4)   /* no usable gfx950 device */
+#define CPX_ELIMIT (-5)   /* argument exceeds a documented engine limit */
+
+typedef struct cpx_trellis cpx_trellis;
+typedef struct cpx_ldpc cpx_ldpc;
+typedef struct cpx_modem cpx_modem;
+
+/* ---- runtime ---------------------------------------------------------------------------------*/
+const char *cpx_last_error(void);
+int cpx_version(void);
+int cpx_device_count(int *n);
+int cpx_set_device(int device);
+int cpx_device_info(char *name, int name_cap, int *compute_units, int64_t *hbm_bytes);
+int cpx_malloc(void **dptr, size_t bytes);
+int cpx_free(void *dptr);
+int cpx_memset(void *dptr, int value, size_t bytes);
+int cpx_memcpy_h2d(void *dst, const void *src, size_t bytes);
+int cpx_memcpy_d2h(void *dst, const void *src, size_t bytes);
+int cpx_stream_sync(void *stream);          /* NULL = the library's stream */
+void *cpx_default_stream(void);             /* the library's own hipStream_t */
+/* HIP-event timer on a stream (bench.py times the kernels on the stream they are launched on) */
+int cpx_timer_create(void **timer);
+int cpx_timer_start(void *timer, void *stream);
+int cpx_timer_stop(void *timer, void *stream);
+int cpx_timer_elapsed_ms(void *timer, float *ms);   /* synchronises on the stop event */
+int cpx_timer_destroy(void *timer);
+
+/* ---- convolutional codes: Viterbi ---------------------------------------------------------------
+ * cpx_trellis_create: device copy of the code description built by the host Trellis class.
+ *   Replaces nothing by itself; it carries Trellis.next_state_table / output_table
+ *   (reference commpy/channelcoding/convcode.py:117-255) to the device.  Tables are [S][I]
+ *   row-major int32.  Predecessor lists are derived in np.where order (convcode.py:561-572), which
+ *   defines the ACS tie-break.  Limits: S = 2^m <= 128, I = 2^k <= 4 for Viterbi, n <= 6.
+ */
+int cpx_trellis_create(int k, int n, int n_states, int n_inputs, const int32_t *next_state_table,
+                       const int32_t *output_table, cpx_trellis **out);
+int cpx_trellis_destroy(cpx_trellis *t);
+
+/* decoding_type */
+#define CPX_VIT_HARD 0
+#define CPX_VIT_SOFT 1
+#define CPX_VIT_UNQUANTIZED 2
+
+/* cpx_viterbi_decode_batch replaces the body of
+ *   viterbi_decode(coded_bits, trellis, tb_depth, decoding_type)   convcode.py:661-749
+ * (with _acs_traceback :590-657, _compute_branch_metrics :575-587) for B independent codewords.
+ *   coded      [B][len] float64 (hard: 0/1 values; soft: LLR log P1/P0, clipped to +-500 inside;
+ *              unquantized: real symbols)
+ *   L          number of decoded bits per codeword = int(len*k/n)  (convcode.py:698)
+ *   n_steps    trellis steps actually run = int((L+total_memory)/k) - 1  (convcode.py:721)
+ *   tb_depth   traceback depth (>= 2), the caller resolves the default min(5*m, L)
+ *   bits       [B][L] uint8 decoded bits, tail included (convcode.py:749)
+ * Decision rule: the bit(s) of step s come from the survivor of the
+ * first-minimum state at step min(s+tb_depth-2, n_steps), ties -> lowest index.
+ */
+int cpx_viterbi_decode_batch(const cpx_trellis *t, const double *coded, int64_t B, int64_t len,
+                             int64_t L, int64_t n_steps, int tb_depth, int decoding_type, uint8_t *bits);
+int cpx_viterbi_decode_batch_dev(const cpx_trellis *t, const double *d_coded, int64_t B, int64_t len,
+                                 int64_t L, int64_t n_steps, int tb_depth, int decoding_type,
+                                 uint8_t *d_bits, void *stream);
+
+/* ---- turbo codes: BCJR / MAP ---------------------------------------------------------------------
+ * cpx_map_decode_batch replaces map_decode(sys, non_sys, trellis, noise_variance, L_int, mode)
+ *   commpy/channelcoding/turbo.py:163-251 (+ _backward_recursion :78-111,
+ *   _forward_recursion_decoding :114-158, _compute_branch_prob :62-76) for B codewords.
+ *   sys, par, L_int [B][N] float64; L_ext [B][N] float64 (= L_int + log(app1/app0), turbo.py:145);
+ *   bits [B][N] uint8 (all zero unless want_bits, i.e. mode == 'decode').
+ * cpx_turbo_decode_batch replaces turbo_decode(...) turbo.py:254-333: n_iter x (MAP1, interleave,
+ *   MAP2, de-interleave); perm = interleaver.p_array (interleavers.py:13-47), shared by the batch;
+ *   L_int may be NULL (zeros).  bits [B][N] uint8, already de-interleaved.
+ * Limits: rate-1/2 component trellis (n == 2), I == 2, S <= 16.
+ */
+int cpx_map_decode_batch(const cpx_trellis *t, const double *sys, const double *par, const double *L_int,
+                         int64_t B, int64_t N, double noise_variance, int want_bits, double *L_ext,
+                         uint8_t *bits);
+int cpx_map_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const double *d_par,
+                             const double *d_L_int, int64_t B, int64_t N, double noise_variance,
+                             int want_bits, double *d_L_ext, uint8_t *d_bits, void *stream);
+int cpx_turbo_decode_batch(const cpx_trellis *t, const double *sys, const double *p1, const double *p2,
+                           const double *L_int_or_null, const int32_t *perm, int64_t B, int64_t N,
+                           double noise_variance, int n_iter, uint8_t *bits);
+int cpx_turbo_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const double *d_p1,
+                               const double *d_p2, const double *d_L_int_or_null, const int32_t *d_perm,
+                               int64_t B, int64_t N, double noise_variance, int n_iter, uint8_t *d_bits,
+                               void *stream);
+
+/* ---- LDPC belief propagation ---------------------------------------------------------------------
+ * cpx_ldpc_create: device copy of the Tanner graph produced by get_ldpc_code_params
+ *   (commpy/channelcoding/ldpc.py:51-141): the edge list sorted by (check, variable) -- the
+ *   row-major order SciPy keeps `message_matrix` in, which fixes the summation orders of
+ *   ldpc.py:217-219 and :243.
+ * cpx_ldpc_bp_decode_batch replaces ldpc_bp_decode(llr_vec, params, alg, n_iters) ldpc.py:144-254.
+ *   llr       [B][n_v] float64, positive = bit 0 (ldpc.py:193); CLIPPED IN PLACE to +-500 (:186)
+ *   alg       0 'SPA', 1 'MSA'
+ *   dec_word  [n_v][B] int8 and out_llrs [n_v][B] float64: one block per COLUMN, the reference's
+ *             output layout (ldpc.py:251-253)
+ *   iters_done[B] int32 executed iterations per block (early exit ldpc.py:205-206), may be NULL
+ */
+#define CPX_LDPC_SPA 0
+#define CPX_LDPC_MSA 1
+int cpx_ldpc_create(int n_vnodes, int n_cnodes, int64_t n_edges, const int32_t *edge_check,
+                    const int32_t *edge_var, cpx_ldpc **out);
+int cpx_ldpc_destroy(cpx_ldpc *c);
+int cpx_ldpc_bp_decode_batch(const cpx_ldpc *c, double *llr, int64_t B, int alg, int n_iters,
+                             int8_t *dec_word, double *out_llrs, int32_t *iters_done);
+int cpx_ldpc_bp_decode_batch_dev(const cpx_ldpc *c, double *d_llr, int64_t B, int alg, int n_iters,
+                                 int8_t *d_dec_word, double *d_out_llrs, int32_t *d_iters_done,
+                                 void *stream);
+
+/* ---- PSK/QAM demodulation ------------------------------------------------------------------------
+ * cpx_modem_create: device copy of Modem.constellation (commpy/modulation.py:68-77,159-172),
+ *   M = 2^nbits complex points as [M][2] float64 (re, im), index = Gray-reordered symbol label.
+ * cpx_demod_soft replaces Modem.demodulate(y, 'soft', noise_var) modulation.py:125-137:
+ *   llr[i*nb + nb-1-b] = log( sum_{m:(m>>b)&1} e^{-|y_i-c_m|^2/noise_var} / sum_{m:!..} ... ),
+ *   positive = bit 1, sums in increasing m.
+ * cpx_demod_hard replaces Modem.demodulate(y, 'hard') modulation.py:121-123: first-min nearest
+ *   point, MSB-first int8 bits.
+ *   y [Ns][2] float64 (complex128 memory), llr [Ns*nb] float64, bits [Ns*nb] int8.
+ */
+int cpx_modem_create(const double *constellation_re_im, int M, cpx_modem **out);
+int cpx_modem_destroy(cpx_modem *m);
+int cpx_demod_soft(const cpx_modem *m, const double *y_re_im, int64_t Ns, double noise_var, double *llr);
+int cpx_demod_soft_dev(const cpx_modem *m, const double *d_y_re_im, int64_t Ns, double noise_var,
+                       double *d_llr, void *stream);
+int cpx_demod_hard(const cpx_modem *m, const double *y_re_im, int64_t Ns, int8_t *bits);
+int cpx_demod_hard_dev(const cpx_modem *m, const double *d_y_re_im, int64_t Ns, int8_t *d_bits,
+                       void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COMMPY_AMD_H */

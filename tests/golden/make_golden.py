@@ -1,0 +1,460 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/*.npz from the LIVE reference.
+
+Run in the build container only (the GPU box has no /root/reference):
+
+    python tests/golden/make_golden.py [--only NAME]
+
+The script imports the unmodified reference (veeresht/CommPy 0.8.0) read-only
+from /root/reference, feeds it seeded synthetic inputs and stores
+inputs + reference outputs.  Nothing here is imported by the product;
+tests/ load the .npz files to pin the oracle (oracle/) and the HIP path.
+
+Reference entry points exercised (file:line in /root/reference):
+  Trellis                 commpy/channelcoding/convcode.py:117
+  conv_encode             commpy/channelcoding/convcode.py:475
+  viterbi_decode          commpy/channelcoding/convcode.py:661
+  puncturing/depuncturing commpy/channelcoding/convcode.py:752,777
+  map_decode/turbo_decode commpy/channelcoding/turbo.py:163,254
+  turbo_encode            commpy/channelcoding/turbo.py:14
+  RandInterlv             commpy/channelcoding/interleavers.py:50
+  get_ldpc_code_params    commpy/channelcoding/ldpc.py:51
+  ldpc_bp_decode          commpy/channelcoding/ldpc.py:144
+  Modem.demodulate        commpy/modulation.py:100
+"""
+import argparse
+import os
+import sys
+import time
+import warnings
+
+os.environ.setdefault("MPLBACKEND", "Agg")
+sys.dont_write_bytecode = True
+REF = "/root/reference"
+sys.path.insert(0, REF)
+
+import numpy as np  # noqa: E402
+
+warnings.simplefilter("ignore")
+
+from commpy.channelcoding.convcode import (Trellis, conv_encode, viterbi_decode,  # noqa: E402
+                                           puncturing, depuncturing)
+from commpy.channelcoding.turbo import turbo_encode, map_decode, turbo_decode  # noqa: E402
+from commpy.channelcoding.interleavers import RandInterlv  # noqa: E402
+from commpy.channelcoding.ldpc import (get_ldpc_code_params, ldpc_bp_decode,  # noqa: E402
+                                       write_ldpc_params, triang_ldpc_systematic_encode)
+from commpy.modulation import PSKModem, QAMModem, Modem  # noqa: E402
+from commpy.utilities import dec2bitarray, bitarray2dec  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print("wrote %s (%.1f kB, %d arrays)" % (path, os.path.getsize(path) / 1e3, len(arrs)))
+
+
+# ----------------------------------------------------------------------------------------------
+# Trellis constructions: (name, memory, g_matrix, feedback, code_type, polynomial_format)
+# The first five are the reference's own test trellises (test_convcode.py:23-111).
+# ----------------------------------------------------------------------------------------------
+def trellis_specs():
+    return [
+        ("t57", [2], [[5, 7]], None, "default", "MSB"),
+        ("rsc_legacy_4", [2], [[1, 7]], 5, "rsc", "MSB"),
+        ("k2_default", [2, 1], [[5, 7, 0], [0, 2, 3]], None, "default", "MSB"),
+        ("k2_lsb", [2, 1], [[5, 7, 0], [0, 2, 6]], None, "default", "LSB"),
+        ("k2_rsc_matrix", [1, 1], [[1, 0, 0], [0, 1, 3]], [[2, 2], [3, 1]], "rsc", "MSB"),
+        ("k7_133_171", [6], [[0o133, 0o171]], None, "default", "MSB"),
+        ("wifi_decimal_133_171", [6], [[133, 171]], None, "default", "MSB"),
+        ("rsc_legacy_8", [3], [[1, 0o15]], 0o13, "rsc", "MSB"),
+        ("rsc_matrix_4", [2], [[1, 7]], [[5]], "rsc", "MSB"),
+        ("r13_k4", [3], [[0o13, 0o15, 0o17]], None, "default", "MSB"),
+        ("k5_23_35", [4], [[0o23, 0o35]], None, "default", "MSB"),
+        ("k8_247_371", [7], [[0o247, 0o371]], None, "default", "MSB"),
+    ]
+
+
+def make_trellis(spec):
+    name, mem, g, fb, ctype, fmt = spec
+    mem = np.array(mem)
+    g = np.array(g)
+    if fb is None:
+        return Trellis(mem, g, code_type=ctype, polynomial_format=fmt)
+    if isinstance(fb, int):
+        return Trellis(mem, g, fb, ctype)
+    return Trellis(mem, g, np.array(fb), ctype, polynomial_format=fmt)
+
+
+def gen_trellis():
+    out = {}
+    for spec in trellis_specs():
+        tr = make_trellis(spec)
+        out[spec[0] + "__next"] = np.asarray(tr.next_state_table, dtype=np.int64)
+        out[spec[0] + "__out"] = np.asarray(tr.output_table, dtype=np.int64)
+        out[spec[0] + "__kn"] = np.array([tr.k, tr.n, tr.total_memory, tr.number_states, tr.number_inputs])
+    # bit helpers (test_utilities.py:12-13 + wrap quirk utilities.py:81-85)
+    out["dec2bit_17_8"] = dec2bitarray(17, 8)
+    out["dec2bit_17_12_5"] = dec2bitarray((17, 12), 5)
+    out["dec2bit_133_7"] = dec2bitarray(133, 7)
+    out["dec2bit_171_7"] = dec2bitarray(171, 7)
+    save("trellis", **out)
+
+
+def gen_conv_encode():
+    rs = np.random.RandomState(101)
+    out = {}
+    mes = np.array((0, 0, 1, 0))
+    for spec in trellis_specs():
+        tr = make_trellis(spec)
+        if 4 % tr.k == 0:
+            out[spec[0] + "__mes_cont"] = np.asarray(conv_encode(mes, tr, "cont"))
+        msg = rs.randint(0, 2, 60)
+        out[spec[0] + "__msg"] = msg
+        out[spec[0] + "__term"] = np.asarray(conv_encode(msg, tr))
+        out[spec[0] + "__cont"] = np.asarray(conv_encode(msg, tr, "cont"))
+    # puncturing / depuncturing (Wifi80211 vectors wifi80211.py:75-89)
+    for nm, pv in (("p23", [1, 1, 1, 0]), ("p34", [1, 1, 1, 0, 0, 1]), ("p56", [1, 1, 1, 0, 0, 1, 1, 0, 0, 1])):
+        pv = np.array(pv)
+        msg = rs.randint(0, 2, 120)
+        pu = puncturing(msg, pv)
+        out["punct_" + nm + "__vec"] = pv
+        out["punct_" + nm + "__msg"] = msg
+        out["punct_" + nm + "__punctured"] = pu
+        out["punct_" + nm + "__depunctured"] = depuncturing(pu.astype(float) * 2 - 1, pv, 120)
+    save("conv_encode", **out)
+
+
+def gen_viterbi_small():
+    """Grid: trellis x metric type x termination x tb_depth x noise. Mirrors test_convcode.py:133-178 variants."""
+    rs = np.random.RandomState(17121996)
+    out = {}
+    names = []
+    idx = 0
+    for spec in trellis_specs():
+        if spec[0] in ("k8_247_371",):
+            lens = (48,)
+        elif spec[0].startswith("k7") or spec[0].startswith("wifi"):
+            lens = (60, 96)
+        else:
+            lens = (40, 100)
+        tr = make_trellis(spec)
+        for nbits in lens:
+            nbits -= nbits % tr.k
+            for term in ("term", "cont"):
+                msg = rs.randint(0, 2, nbits)
+                coded = conv_encode(msg, tr, term)
+                for dtype in ("hard", "soft", "unquantized"):
+                    for tb in (None, 15):
+                        for noisy in (0, 1):
+                            if dtype == "hard":
+                                rx = coded.astype(float)
+                                if noisy:
+                                    flips = rs.rand(len(rx)) <= 0.06
+                                    rx = np.where(flips, 1 - rx, rx)
+                            elif dtype == "soft":
+                                if noisy == 0:
+                                    rx = 10.0 * coded - 5 + rs.randn(len(coded)) * 2
+                                else:
+                                    rx = 4.0 * coded - 2 + rs.randn(len(coded)) * 2.5
+                            else:
+                                rx = 2.0 * coded - 1 + rs.randn(len(coded)) * (0.3 if noisy == 0 else 0.9)
+                            rx_in = rx.copy()
+                            dec = viterbi_decode(rx.copy(), tr, tb, dtype)
+                            key = "c%04d" % idx
+                            names.append("%s|%s|%s|%s|%s|%d" % (key, spec[0], term, dtype, tb, noisy))
+                            out[key + "__in"] = rx_in
+                            out[key + "__out"] = np.asarray(dec, dtype=np.int64)
+                            out[key + "__msg"] = msg
+                            idx += 1
+        # +-inf soft inputs (test_convcode.py:166-178)
+        msg = rs.randint(0, 2, 40 - 40 % tr.k)
+        for term in ("term", "cont"):
+            coded = conv_encode(msg, tr, term)
+            rx = np.where(coded == 1, np.inf, -np.inf)
+            dec = viterbi_decode(rx.copy(), tr, 15, "soft")
+            key = "c%04d" % idx
+            names.append("%s|%s|%s|%s|%s|%d" % (key, spec[0], term, "soft", 15, 2))
+            out[key + "__in"] = rx
+            out[key + "__out"] = np.asarray(dec, dtype=np.int64)
+            out[key + "__msg"] = msg
+            idx += 1
+    out["names"] = np.array(names)
+    save("viterbi_small", **out)
+
+
+def gen_viterbi_c1():
+    """BASELINE config 1: K=3 [[5,7]], 64-bit blocks, hard decision over BSC(0.05)."""
+    tr = Trellis(np.array([2]), np.array([[5, 7]]))
+    B = 256
+    msg = np.random.RandomState(1).randint(0, 2, (1000, 64))[:B]
+    u = np.random.RandomState(2).rand(1000, 132)[:B]
+    rx = np.empty((B, 132))
+    dec = np.empty((B, 66), dtype=np.int64)
+    for b in range(B):
+        coded = conv_encode(msg[b], tr)
+        rx[b] = coded ^ (u[b] <= 0.05)
+        dec[b] = viterbi_decode(rx[b].copy(), tr, None, "hard")
+    save("viterbi_c1", msg=msg, rx=rx, dec=dec)
+
+
+def c2_inputs(B, ebn0_db, seed_msg=10, seed_noise=11):
+    """BASELINE config 2 inputs through the reference modem."""
+    tr = Trellis(np.array([6]), np.array([[0o133, 0o171]]))
+    md = QAMModem(4)
+    msg = np.random.RandomState(seed_msg).randint(0, 2, (B, 1024))
+    nrs = np.random.RandomState(seed_noise)
+    N0 = md.Es / (0.5 * 2 * 10 ** (ebn0_db / 10.0))
+    llr = np.empty((B, 2060))
+    for b in range(B):
+        c = conv_encode(msg[b], tr)
+        s = md.modulate(c)
+        y = s + np.sqrt(N0 / 2) * (nrs.randn(len(s)) + 1j * nrs.randn(len(s)))
+        llr[b] = md.demodulate(y, "soft", N0)
+    return tr, msg, llr, N0
+
+
+def gen_viterbi_c2():
+    out = {}
+    for ebn0, B in ((3.0, 16), (1.0, 6)):
+        tr, msg, llr, N0 = c2_inputs(B, ebn0)
+        dec = np.empty((B, 1030), dtype=np.int64)
+        t0 = time.time()
+        for b in range(B):
+            dec[b] = viterbi_decode(llr[b].copy(), tr, None, "soft")
+        print("c2 ebn0=%.1f: %d codewords in %.1fs, BER %.2e" % (ebn0, B, time.time() - t0,
+                                                                  np.mean(dec[:, :1024] != msg)))
+        tag = "e%d" % int(ebn0)
+        out[tag + "__msg"] = msg
+        out[tag + "__llr"] = llr
+        out[tag + "__dec"] = dec
+        out[tag + "__N0"] = np.array(N0)
+    save("viterbi_c2", **out)
+
+
+def gen_map_turbo():
+    out = {}
+    names = []
+    idx = 0
+    rs = np.random.RandomState(20)
+    specs = {s[0]: s for s in trellis_specs()}
+    for tname in ("rsc_legacy_4", "rsc_legacy_8", "rsc_matrix_4", "t57"):
+        tr = make_trellis(specs[tname])
+        for N, ebn0 in ((64, 0.0), (200, 1.5), (256, 4.0)):
+            msg = rs.randint(0, 2, N)
+            coded = conv_encode(msg, tr, "cont")
+            sys_b, par_b = coded[0::2], coded[1::2]
+            nv = 1 / (2 * 0.5 * 10 ** (ebn0 / 10.0))
+            sys_r = 2.0 * sys_b - 1 + np.sqrt(nv) * rs.randn(N)
+            par_r = 2.0 * par_b - 1 + np.sqrt(nv) * rs.randn(N)
+            for lint_kind in (0, 1):
+                L_int = np.zeros(N) if lint_kind == 0 else rs.randn(N) * 2.0
+                for mode in ("decode", "compute"):
+                    L, bits = map_decode(sys_r.copy(), par_r.copy(), tr, nv, L_int.copy(), mode)
+                    key = "m%03d" % idx
+                    names.append("%s|%s|%d|%g|%d|%s" % (key, tname, N, nv, lint_kind, mode))
+                    out[key + "__sys"] = sys_r
+                    out[key + "__par"] = par_r
+                    out[key + "__lint"] = L_int
+                    out[key + "__nv"] = np.array(nv)
+                    out[key + "__L"] = np.asarray(L)
+                    out[key + "__bits"] = np.asarray(bits, dtype=np.int64)
+                    idx += 1
+    out["map_names"] = np.array(names)
+    # turbo
+    tnames = []
+    idx = 0
+    for tname, N, ebn0, iters, nblk in (("rsc_legacy_4", 128, 1.0, 4, 3), ("rsc_legacy_8", 128, 1.5, 3, 2),
+                                        ("rsc_legacy_4", 1024, 1.5, 6, 2), ("rsc_legacy_4", 96, 3.0, 1, 1)):
+        tr = make_trellis(specs[tname])
+        il = RandInterlv(N, 1234)
+        for b in range(nblk):
+            msg = rs.randint(0, 2, N)
+            s, p1, p2 = turbo_encode(msg, tr, tr, il)
+            p2 = p2[:N]
+            nv = 1 / (2 * (1.0 / 3) * 10 ** (ebn0 / 10.0))
+            sr = 2.0 * s - 1 + np.sqrt(nv) * rs.randn(N)
+            p1r = 2.0 * p1 - 1 + np.sqrt(nv) * rs.randn(N)
+            p2r = 2.0 * p2 - 1 + np.sqrt(nv) * rs.randn(N)
+            t0 = time.time()
+            dec = turbo_decode(sr.copy(), p1r.copy(), p2r.copy(), tr, nv, iters, il)
+            key = "t%03d" % idx
+            tnames.append("%s|%s|%d|%g|%d" % (key, tname, N, nv, iters))
+            out[key + "__msg"] = msg
+            out[key + "__enc_s"] = np.asarray(s)
+            out[key + "__enc_p1"] = np.asarray(p1)
+            out[key + "__enc_p2"] = np.asarray(p2)
+            out[key + "__sys"] = sr
+            out[key + "__p1"] = p1r
+            out[key + "__p2"] = p2r
+            out[key + "__nv"] = np.array(nv)
+            out[key + "__perm"] = np.asarray(il.p_array, dtype=np.int64)
+            out[key + "__dec"] = np.asarray(dec, dtype=np.int64)
+            print("turbo %s N=%d iters=%d: %.1fs, errors %d" % (tname, N, iters, time.time() - t0,
+                                                                 int(np.sum(dec != msg))))
+            idx += 1
+    out["turbo_names"] = np.array(tnames)
+    out["randinterlv_16_7"] = np.asarray(RandInterlv(16, 7).p_array, dtype=np.int64)
+    save("map_turbo", **out)
+
+
+# 802.11n-style QC-LDPC (1944,1296), Z=81 prototype (not shipped by the reference).
+PROTO_1944_1296 = """
+61 75  4 63 56  -  -  -  -  -  -  8  -  2 17 25  1  0  -  -  -  -  -  -
+56 74 77 20  -  -  - 64 24  4 67  -  7  -  -  -  -  0  0  -  -  -  -  -
+28 21 68 10  7 14 65  -  -  - 23  -  -  - 75  -  -  -  0  0  -  -  -  -
+48 38 43 78 76  -  -  -  -  5 36  - 15 72  -  -  -  -  -  0  0  -  -  -
+40  2 53 25  - 52 62  - 20  -  - 44  -  -  -  -  0  -  -  -  0  0  -  -
+69 23 64 10 22  - 21  -  -  -  -  - 68 23 29  -  -  -  -  -  -  0  0  -
+12  0 68 20 55 61  - 40  -  -  - 52  -  -  - 44  -  -  -  -  -  -  0  0
+58  8 34 64 78  -  - 11 78 24  -  -  -  -  - 58  1  -  -  -  -  -  -  0
+"""
+
+
+def expand_qc(proto, Z):
+    rows = [r.split() for r in proto.strip().splitlines()]
+    mb, nb = len(rows), len(rows[0])
+    H = np.zeros((mb * Z, nb * Z), dtype=np.int8)
+    eye = np.eye(Z, dtype=np.int8)
+    for i in range(mb):
+        for j in range(nb):
+            if rows[i][j] != "-":
+                H[i * Z:(i + 1) * Z, j * Z:(j + 1) * Z] = np.roll(eye, int(rows[i][j]), axis=1)
+    return H
+
+
+def ldpc_param_arrays(p, prefix):
+    keys = ("cnode_adj_list", "cnode_vnode_map", "vnode_adj_list", "vnode_cnode_map", "cnode_deg_list",
+            "vnode_deg_list")
+    d = {prefix + "__" + k: np.asarray(p[k]) for k in keys}
+    d[prefix + "__dims"] = np.array([p["n_vnodes"], p["n_cnodes"], p["max_vnode_deg"], p["max_cnode_deg"]])
+    return d
+
+
+def gen_ldpc():
+    out = {}
+    names = []
+    rs = np.random.RandomState(31)
+    design_dir = os.path.join(REF, "commpy/channelcoding/designs/ldpc")
+    # authored 802.11n-style design file lives in OUR package (reference text format ldpc.py:51-107)
+    own = os.path.join(REPO, "commpy_amd/channelcoding/designs/ldpc/ieee80211n/1944.1296.txt")
+    if not os.path.exists(own):
+        os.makedirs(os.path.dirname(own), exist_ok=True)
+        write_ldpc_params(expand_qc(PROTO_1944_1296, 81), own)
+    codes = {
+        "gallager96": (os.path.join(design_dir, "gallager/96.33.964.txt"), 0.5),
+        "gallager96b": (os.path.join(design_dir, "gallager/96.3.963.txt"), 0.5),
+        "wimax960": (os.path.join(design_dir, "wimax/960.720.a.txt"), 0.75),
+        "wimax1440": (os.path.join(design_dir, "wimax/1440.720.txt"), 0.5),
+        "n1944": (own, 2.0 / 3),
+    }
+    idx = 0
+    for cname, (path, rate) in codes.items():
+        p = get_ldpc_code_params(path, True)
+        out.update(ldpc_param_arrays(p, cname))
+        n = p["n_vnodes"]
+        plan = {
+            "gallager96": [(1, 2.0, 100), (2, 2.5, 100), (3, 1.0, 7), (1, 6.0, 0), (2, 2.0, 1)],
+            "gallager96b": [(2, 2.5, 20)],
+            "wimax960": [(1, 3.5, 50), (2, 4.5, 5)],
+            "wimax1440": [(2, 2.0, 50), (1, 1.0, 8), (1, 3.0, 2)],
+            "n1944": [(1, 3.0, 50), (2, 3.6, 20)],
+        }[cname]
+        for (nblk, ebn0, iters) in plan:
+            sigma = 1 / np.sqrt(10 ** (ebn0 / 10.0) * rate * 2)
+            rx = 1.0 + sigma * rs.randn(n * nblk)          # all-zero codeword, BPSK 1-2c (test_ldpc.py:49-53)
+            llr = 2.0 * rx / sigma ** 2
+            for alg in ("SPA", "MSA"):
+                t0 = time.time()
+                dec, oll = ldpc_bp_decode(llr.copy(), p, alg, iters)
+                key = "l%03d" % idx
+                names.append("%s|%s|%d|%s|%d" % (key, cname, nblk, alg, iters))
+                out[key + "__llr"] = llr
+                out[key + "__dec"] = np.asarray(dec)
+                out[key + "__out"] = np.asarray(oll)
+                print("ldpc %s nblk=%d ebn0=%.1f %s iters=%d: %.2fs errs=%d" % (
+                    cname, nblk, ebn0, alg, iters, time.time() - t0, int(np.sum(dec))))
+                idx += 1
+    # noiseless encode -> decode (test_ldpc.py:77-106) on a WiMax code, non-zero codeword
+    p = get_ldpc_code_params(codes["wimax1440"][0], True)
+    msg = rs.randint(0, 2, 1450)
+    coded = triang_ldpc_systematic_encode(msg, p)
+    out["enc1440__msg"] = msg
+    out["enc1440__coded"] = np.asarray(coded)
+    sym = np.where(coded == 1, -1.0, 1.0).reshape(-1, order="F")
+    for alg in ("SPA", "MSA"):
+        dec, oll = ldpc_bp_decode(sym.copy(), p, alg, 10)
+        out["enc1440__dec_" + alg] = np.asarray(dec)
+        out["enc1440__out_" + alg] = np.asarray(oll)
+    # clipping case: huge LLRs
+    pg = get_ldpc_code_params(codes["gallager96"][0], True)
+    llr = rs.randn(96) * 400 + 300
+    for alg in ("SPA", "MSA"):
+        dec, oll = ldpc_bp_decode(llr.copy(), pg, alg, 10)
+        key = "l%03d" % idx
+        names.append("%s|%s|%d|%s|%d" % (key, "gallager96", 1, alg, 10))
+        out[key + "__llr"] = llr
+        out[key + "__dec"] = np.asarray(dec)
+        out[key + "__out"] = np.asarray(oll)
+        idx += 1
+    out["names"] = np.array(names)
+    save("ldpc", **out)
+
+
+def gen_demod():
+    out = {}
+    names = []
+    rs = np.random.RandomState(41)
+    modems = {
+        "qam4": QAMModem(4), "qam16": QAMModem(16), "qam64": QAMModem(64), "qam256": QAMModem(256),
+        "psk2": PSKModem(2), "psk4": PSKModem(4), "psk8": PSKModem(8), "psk16": PSKModem(16),
+        "custom4": Modem([1 + 1j, -1.2 + 0.8j, 0.3 - 1j, -1 - 1.5j]),
+        "custom8_nogray": Modem(np.exp(1j * np.arange(8) * 2 * np.pi / 8) * np.array([1, 2, 1, 2, 1, 2, 1, 2]),
+                                reorder_as_gray=False),
+    }
+    # custom8_nogray bypasses the constellation setter in the reference ctor path? (modulation.py:76-77 uses it)
+    idx = 0
+    for mname, md in modems.items():
+        out[mname + "__const"] = np.asarray(md.constellation, dtype=complex)
+        out[mname + "__Es"] = np.array(md.Es)
+        nb = md.num_bits_symbol
+        nsym = 24 if md.m >= 64 else 48
+        bits = rs.randint(0, 2, nsym * nb)
+        s = md.modulate(bits)
+        out[mname + "__bits"] = bits
+        out[mname + "__sym"] = np.asarray(s, dtype=complex)
+        for snr_db in (3.0, 12.0):
+            N0 = md.Es / 10 ** (snr_db / 10.0)
+            y = s + np.sqrt(N0 / 2) * (rs.randn(nsym) + 1j * rs.randn(nsym))
+            with np.errstate(all="ignore"):
+                soft = md.demodulate(y, "soft", N0)
+            hard = md.demodulate(y, "hard")
+            key = "d%03d" % idx
+            names.append("%s|%s|%g" % (key, mname, N0))
+            out[key + "__y"] = y
+            out[key + "__N0"] = np.array(N0)
+            out[key + "__soft"] = np.asarray(soft)
+            out[key + "__hard"] = np.asarray(hard)
+            idx += 1
+    out["names"] = np.array(names)
+    save("demod", **out)
+
+
+GENS = {
+    "trellis": gen_trellis, "conv_encode": gen_conv_encode, "viterbi_small": gen_viterbi_small,
+    "viterbi_c1": gen_viterbi_c1, "viterbi_c2": gen_viterbi_c2, "map_turbo": gen_map_turbo,
+    "ldpc": gen_ldpc, "demod": gen_demod,
+}
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    for nm, fn in GENS.items():
+        if a.only and nm not in a.only.split(","):
+            continue
+        t0 = time.time()
+        fn()
+        print("== %s done in %.1fs" % (nm, time.time() - t0))

@@ -1,0 +1,71 @@
+"""Shared helpers for the test-suite: golden loading and trellis construction by fixture name."""
+import os
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, "golden")
+
+# (name, memory, g_matrix, feedback, code_type, polynomial_format) -- same list as make_golden.py
+TRELLIS_SPECS = [
+    ("t57", [2], [[5, 7]], None, "default", "MSB"),
+    ("rsc_legacy_4", [2], [[1, 7]], 5, "rsc", "MSB"),
+    ("k2_default", [2, 1], [[5, 7, 0], [0, 2, 3]], None, "default", "MSB"),
+    ("k2_lsb", [2, 1], [[5, 7, 0], [0, 2, 6]], None, "default", "LSB"),
+    ("k2_rsc_matrix", [1, 1], [[1, 0, 0], [0, 1, 3]], [[2, 2], [3, 1]], "rsc", "MSB"),
+    ("k7_133_171", [6], [[0o133, 0o171]], None, "default", "MSB"),
+    ("wifi_decimal_133_171", [6], [[133, 171]], None, "default", "MSB"),
+    ("rsc_legacy_8", [3], [[1, 0o15]], 0o13, "rsc", "MSB"),
+    ("rsc_matrix_4", [2], [[1, 7]], [[5]], "rsc", "MSB"),
+    ("r13_k4", [3], [[0o13, 0o15, 0o17]], None, "default", "MSB"),
+    ("k5_23_35", [4], [[0o23, 0o35]], None, "default", "MSB"),
+    ("k8_247_371", [7], [[0o247, 0o371]], None, "default", "MSB"),
+]
+SPEC_BY_NAME = {s[0]: s for s in TRELLIS_SPECS}
+_cache = {}
+
+
+def golden(name):
+    if name not in _cache:
+        _cache[name] = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    return _cache[name]
+
+
+def make_trellis(name):
+    """Build a commpy_amd Trellis for a fixture name (host code only)."""
+    from commpy_amd.channelcoding.convcode import Trellis
+    _, mem, g, fb, ctype, fmt = SPEC_BY_NAME[name]
+    mem, g = np.array(mem), np.array(g)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", DeprecationWarning)
+        if fb is None:
+            return Trellis(mem, g, code_type=ctype, polynomial_format=fmt)
+        if isinstance(fb, int):
+            return Trellis(mem, g, fb, ctype)
+        return Trellis(mem, g, np.array(fb), ctype, polynomial_format=fmt)
+
+
+class TableTrellis:
+    """Minimal trellis-like object from golden tables (does not depend on the host Trellis code)."""
+
+    def __init__(self, name):
+        g = golden("trellis")
+        self.next_state_table = g[name + "__next"]
+        self.output_table = g[name + "__out"]
+        self.k, self.n, self.total_memory, self.number_states, self.number_inputs = [int(v) for v in g[name + "__kn"]]
+
+
+class Perm:
+    def __init__(self, p):
+        self.p_array = np.asarray(p)
+
+
+def ldpc_params(prefix):
+    g = golden("ldpc")
+    n_v, n_c, mvd, mcd = [int(v) for v in g[prefix + "__dims"]]
+    d = {"n_vnodes": n_v, "n_cnodes": n_c, "max_vnode_deg": mvd, "max_cnode_deg": mcd}
+    for k in ("cnode_adj_list", "cnode_vnode_map", "vnode_adj_list", "vnode_cnode_map", "cnode_deg_list",
+              "vnode_deg_list"):
+        d[k] = g[prefix + "__" + k]
+    return d
