@@ -1,0 +1,17 @@
+"""commpy_amd -- MI355X-native channel-decoding / demodulation engine with CommPy's Python API.
+
+Scope: the batched decoding hot path of veeresht/CommPy 0.8.0 -- Viterbi,
+BCJR/MAP + turbo, LDPC belief propagation and PSK/QAM hard/soft demodulation -- re-implemented as
+hand-written HIP kernels for gfx950 behind a ctypes C-ABI (include/commpy_amd.h), plus the host-side
+code descriptions either side of it (Trellis, interleavers, LDPC design files, constellations,
+encoders).  No PyTorch, no Triton, no CPU fallback: the decoders raise if the HIP library or the
+GPU is missing.
+
+    from commpy_amd.channelcoding import Trellis, viterbi_decode, map_decode, turbo_decode, ldpc_bp_decode
+    from commpy_amd.modulation import PSKModem, QAMModem
+"""
+__version__ = "0.1.0"
+
+from commpy_amd import utilities  # noqa: F401
+
+__all__ = ["channelcoding", "modulation", "utilities", "parallel"]

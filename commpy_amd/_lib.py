@@ -32,6 +32,7 @@ SYMBOLS = {
     "cpx_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_size_t]),
     "cpx_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_size_t]),
     "cpx_stream_sync": (c_int, [c_void_p]),
+    "cpx_release_workspace": (c_int, []),
     "cpx_default_stream": (c_void_p, []),
     "cpx_timer_create": (c_int, [POINTER(c_void_p)]),
     "cpx_timer_start": (c_int, [c_void_p, c_void_p]),

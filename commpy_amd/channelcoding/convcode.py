@@ -23,7 +23,7 @@ import numpy as np
 from commpy_amd import _lib
 from commpy_amd.utilities import dec2bitarray, bitarray2dec
 
-__all__ = ['Trellis', 'conv_encode', 'viterbi_decode', 'puncturing', 'depuncturing']
+__all__ = ['Trellis', 'conv_encode', 'conv_encode_batch', 'viterbi_decode', 'puncturing', 'depuncturing']
 
 _VIT_TYPES = {'hard': 0, 'soft': 1, 'unquantized': 2}
 
@@ -219,6 +219,48 @@ def conv_encode(message_bits, trellis, termination='term', puncture_matrix=None)
     kept = outbits[keep]
     p_outbits[:len(kept)] = kept
     return p_outbits
+
+
+def conv_encode_batch(message_bits, trellis, termination='term'):
+    """Vectorised host encoder for a batch ``[B, nbits]`` of messages (extension; no puncturing).
+
+    Row ``b`` equals ``conv_encode(message_bits[b], trellis, termination)`` (convcode.py:475-558): the
+    table walk is done for all codewords at once, one NumPy gather per trellis step.  Used to
+    synthesise the large benchmark batches (the per-codeword Python loop of ``conv_encode`` needs
+    minutes for 65536 codewords).
+    """
+    k, n, total_memory = trellis.k, trellis.n, trellis.total_memory
+    msgs = np.asarray(message_bits).astype(np.int64)
+    if msgs.ndim != 2:
+        raise ValueError('message_bits must be [B, nbits]')
+    B, nmsg = msgs.shape
+    rsc_term = trellis.code_type == 'rsc' and termination != 'cont'
+    if termination == 'cont' or rsc_term:
+        inbits = msgs
+    else:
+        pad = total_memory + total_memory % k
+        inbits = np.concatenate([msgs, np.zeros((B, pad), np.int64)], axis=1)
+    nsteps = int(inbits.shape[1] / k)
+    weights = 1 << np.arange(k - 1, -1, -1)
+    nxt = np.asarray(trellis.next_state_table)
+    outt = np.asarray(trellis.output_table)
+    state = np.zeros(B, np.int64)
+    symbols = []
+    for i in range(nsteps):
+        cur = inbits[:, i * k:(i + 1) * k].dot(weights)
+        symbols.append(outt[state, cur])
+        state = nxt[state, cur]
+    if rsc_term:
+        # term_bits = dec2bitarray(final_state, total_memory)[::-1], taken ONCE after the message (:539-540)
+        tb = (state[:, None] >> np.arange(total_memory)) & 1
+        for i in range(total_memory):
+            grp = tb[:, i * k:(i + 1) * k]
+            cur = grp.dot(1 << np.arange(grp.shape[1] - 1, -1, -1))
+            symbols.append(outt[state, cur])
+            state = nxt[state, cur]
+    sym = np.stack(symbols, axis=1)                                  # [B, steps]
+    bits = (sym[:, :, None] >> np.arange(n - 1, -1, -1)) & 1         # MSB-first n bits per step
+    return bits.reshape(B, -1).astype(np.int64)
 
 
 def puncturing(message, punct_vec):

@@ -256,10 +256,9 @@ int cpx_map_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const do
     p.sys = d_sys; p.par = d_par; p.Lin = d_L_int; p.Lout = d_L_ext; p.bits = d_bits;
     p.B = B; p.N = N; p.nv2 = 2 * noise_variance; p.want_bits = want_bits;
     p.slab = N + (N + 1) * S;
-    CPX_HIP(hipMallocAsync((void **)&p.scratch, sizeof(double) * (size_t)(p.slab * B), st));
+    if ((rc = workspace(st, 0, sizeof(double) * (size_t)(p.slab * B), (void **)&p.scratch))) return rc;
     hipLaunchKernelGGL(map_decode_kernel, dim3((unsigned)((B + G - 1) / G)), dim3(64), 0, st, p);
     CPX_HIP(hipGetLastError());
-    CPX_HIP(hipFreeAsync(p.scratch, st));
     return CPX_OK;
 }
 
@@ -276,10 +275,9 @@ int cpx_turbo_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const 
     p.sys = d_sys; p.p1 = d_p1; p.p2 = d_p2; p.Lint = d_L_int_or_null; p.perm = d_perm; p.bits = d_bits;
     p.B = B; p.N = N; p.nv2 = 2 * noise_variance; p.n_iter = n_iter;
     p.slab = 4 * N + (N + 1) * S;
-    CPX_HIP(hipMallocAsync((void **)&p.scratch, sizeof(double) * (size_t)(p.slab * B), st));
+    if ((rc = workspace(st, 0, sizeof(double) * (size_t)(p.slab * B), (void **)&p.scratch))) return rc;
     hipLaunchKernelGGL(turbo_decode_kernel, dim3((unsigned)((B + G - 1) / G)), dim3(64), 0, st, p);
     CPX_HIP(hipGetLastError());
-    CPX_HIP(hipFreeAsync(p.scratch, st));
     return CPX_OK;
 }
 

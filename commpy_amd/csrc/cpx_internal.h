@@ -15,6 +15,11 @@ namespace cpx {
 void set_error(const char *fmt, ...);
 hipStream_t lib_stream();   // lazily created per-process stream of the current device
 int ensure_device();        // CPX_OK if a HIP device is usable
+// Scratch arena keyed by (device, stream, slot): grown with hipMalloc on demand, reused by later calls and
+// released by cpx_release_workspace().  Kernels of one stream serialise, so one arena per stream is safe.
+// (Stream-ordered hipMallocAsync/hipFreeAsync was measured to hand out memory that is still in use on this
+//  stack -- 45/120 corrupted LDPC decodes -- so the engine never uses it.)
+int workspace(hipStream_t stream, int slot, size_t bytes, void **out);
 
 #define CPX_HIP(call)                                                                          \
     do {                                                                                       \

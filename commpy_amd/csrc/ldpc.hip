@@ -32,7 +32,8 @@ __device__ __forceinline__ double clip_nan(double v, double lo, double hi) {
 // llrT[v][b] = clip(llr[b][v]); llr clipped in place (ldpc.py:186); out = llr; dec = signbit (:193-194)
 __global__ __launch_bounds__(LB) void ldpc_init_kernel(double *__restrict__ llr, int64_t B, int n_v,
                                                        double *__restrict__ llrT, double *__restrict__ out,
-                                                       int8_t *__restrict__ dec, int32_t *__restrict__ iters) {
+                                                       int8_t *__restrict__ dec, int32_t *__restrict__ iters,
+                                                       int32_t *__restrict__ unsat) {
     __shared__ double tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
     const int64_t b0 = (int64_t)blockIdx.x * 32;
@@ -58,9 +59,12 @@ __global__ __launch_bounds__(LB) void ldpc_init_kernel(double *__restrict__ llr,
             dec[(int64_t)v * B + b] = (int8_t)(__builtin_signbit(x) ? 1 : 0);
         }
     }
-    if (blockIdx.y == 0 && iters) {
+    if (blockIdx.y == 0) {
         const int64_t b = b0 + threadIdx.x;
-        if (threadIdx.x < 32 && b < B) iters[b] = 0;
+        if (threadIdx.x < 32 && b < B) {
+            if (iters) iters[b] = 0;
+            unsat[b] = 0;
+        }
     }
 }
 
@@ -73,27 +77,27 @@ __global__ __launch_bounds__(LB) void ldpc_msg_init_kernel(const double *__restr
     for (int64_t e = blockIdx.y; e < E; e += gridDim.y) M[e * B + b] = 1.0 * llrT[(int64_t)edge_var[e] * B + b];
 }
 
-// Early-termination test (:205): unsat[b] = any check with odd parity of dec_word.
+// Early-termination test (:205): unsat[b] == stamp <=> some check of block b has odd parity of dec_word.
 __global__ __launch_bounds__(LB) void ldpc_syndrome_kernel(const int8_t *__restrict__ dec, int64_t B,
                                                            const int32_t *__restrict__ row_ptr,
                                                            const int32_t *__restrict__ edge_var,
-                                                           int32_t *__restrict__ unsat) {
+                                                           int32_t *__restrict__ unsat, int stamp) {
     const int64_t b = (int64_t)blockIdx.x * LB + threadIdx.x;
     const int c = blockIdx.y;
     if (b >= B) return;
     int par = 0;
     for (int e = row_ptr[c]; e < row_ptr[c + 1]; e++) par ^= dec[(int64_t)edge_var[e] * B + b];
-    if (par & 1) unsat[b] = 1;
+    if (par & 1) unsat[b] = stamp;      // stamp = iteration + 1: no per-iteration clearing pass needed
 }
 
 // Check-node update.  SPA (:209-227) / MSA (:229-238).
 template <int ALG, int DEG_CAP>
 __global__ __launch_bounds__(LB) void ldpc_cn_kernel(double *__restrict__ M, int64_t B,
                                                      const int32_t *__restrict__ row_ptr,
-                                                     const int32_t *__restrict__ unsat) {
+                                                     const int32_t *__restrict__ unsat, int stamp) {
     const int64_t b = (int64_t)blockIdx.x * LB + threadIdx.x;
     const int c = blockIdx.y;
-    if (b >= B || !unsat[b]) return;
+    if (b >= B || unsat[b] != stamp) return;
     const int e0 = row_ptr[c];
     const int deg = row_ptr[c + 1] - e0;
     double v[DEG_CAP];
@@ -150,10 +154,10 @@ __global__ __launch_bounds__(LB) void ldpc_vn_kernel(double *__restrict__ M, int
                                                      const int32_t *__restrict__ col_edge,
                                                      const double *__restrict__ llrT, double *__restrict__ out,
                                                      int8_t *__restrict__ dec, const int32_t *__restrict__ unsat,
-                                                     int32_t *__restrict__ iters) {
+                                                     int stamp, int32_t *__restrict__ iters) {
     const int64_t b = (int64_t)blockIdx.x * LB + threadIdx.x;
     const int v = blockIdx.y;
-    if (b >= B || !unsat[b]) return;
+    if (b >= B || unsat[b] != stamp) return;
     const int q0 = col_ptr[v], q1 = col_ptr[v + 1];
     double msum = 0.0;                                           // message_matrix.sum(0): increasing check
     for (int q = q0; q < q1; q++) msum += M[(int64_t)col_edge[q] * B + b];
@@ -234,34 +238,32 @@ int cpx_ldpc_bp_decode_batch_dev(const cpx_ldpc *c, double *d_llr, int64_t B, in
     const int64_t E = c->n_edges;
     double *M = nullptr, *llrT = nullptr;
     int32_t *unsat = nullptr;
-    CPX_HIP(hipMallocAsync((void **)&M, sizeof(double) * (size_t)(E * B), st));
-    CPX_HIP(hipMallocAsync((void **)&llrT, sizeof(double) * (size_t)((int64_t)c->n_v * B), st));
-    CPX_HIP(hipMallocAsync((void **)&unsat, sizeof(int32_t) * (size_t)B, st));
+    int rcw;
+    if ((rcw = workspace(st, 0, sizeof(double) * (size_t)(E * B), (void **)&M))) return rcw;
+    if ((rcw = workspace(st, 1, sizeof(double) * (size_t)((int64_t)c->n_v * B), (void **)&llrT))) return rcw;
+    if ((rcw = workspace(st, 2, sizeof(int32_t) * (size_t)B, (void **)&unsat))) return rcw;
     const unsigned bx = (unsigned)((B + LB - 1) / LB);
     {
         dim3 grid((unsigned)((B + 31) / 32), (unsigned)((c->n_v + 31) / 32));
-        hipLaunchKernelGGL(ldpc_init_kernel, grid, dim3(LB), 0, st, d_llr, B, c->n_v, llrT, d_out, d_dec, d_iters);
+        hipLaunchKernelGGL(ldpc_init_kernel, grid, dim3(LB), 0, st, d_llr, B, c->n_v, llrT, d_out, d_dec, d_iters, unsat);
         hipLaunchKernelGGL(ldpc_msg_init_kernel, dim3(bx, (unsigned)std::min<int64_t>(E, 65535)), dim3(LB), 0, st, llrT, B,
                            c->d_edge_var, E, M);
     }
     for (int it = 0; it < n_iters; it++) {
-        CPX_HIP(hipMemsetAsync(unsat, 0, sizeof(int32_t) * (size_t)B, st));
+        const int stamp = it + 1;
         hipLaunchKernelGGL(ldpc_syndrome_kernel, dim3(bx, (unsigned)c->n_c), dim3(LB), 0, st, d_dec, B, c->d_row_ptr,
-                           c->d_edge_var, unsat);
+                           c->d_edge_var, unsat, stamp);
         dim3 gc(bx, (unsigned)c->n_c);
 #define LAUNCH_CN(ALG)                                                                                              \
-    if (c->max_cdeg <= 8) hipLaunchKernelGGL((ldpc_cn_kernel<ALG, 8>), gc, dim3(LB), 0, st, M, B, c->d_row_ptr, unsat); \
-    else if (c->max_cdeg <= 16) hipLaunchKernelGGL((ldpc_cn_kernel<ALG, 16>), gc, dim3(LB), 0, st, M, B, c->d_row_ptr, unsat); \
-    else hipLaunchKernelGGL((ldpc_cn_kernel<ALG, MAXDEG>), gc, dim3(LB), 0, st, M, B, c->d_row_ptr, unsat);
+    if (c->max_cdeg <= 8) hipLaunchKernelGGL((ldpc_cn_kernel<ALG, 8>), gc, dim3(LB), 0, st, M, B, c->d_row_ptr, unsat, stamp); \
+    else if (c->max_cdeg <= 16) hipLaunchKernelGGL((ldpc_cn_kernel<ALG, 16>), gc, dim3(LB), 0, st, M, B, c->d_row_ptr, unsat, stamp); \
+    else hipLaunchKernelGGL((ldpc_cn_kernel<ALG, MAXDEG>), gc, dim3(LB), 0, st, M, B, c->d_row_ptr, unsat, stamp);
         if (alg == CPX_LDPC_SPA) { LAUNCH_CN(CPX_LDPC_SPA) } else { LAUNCH_CN(CPX_LDPC_MSA) }
 #undef LAUNCH_CN
         hipLaunchKernelGGL(ldpc_vn_kernel, dim3(bx, (unsigned)c->n_v), dim3(LB), 0, st, M, B, c->d_col_ptr,
-                           c->d_col_edge, llrT, d_out, d_dec, unsat, d_iters);
+                           c->d_col_edge, llrT, d_out, d_dec, unsat, stamp, d_iters);
     }
     CPX_HIP(hipGetLastError());
-    CPX_HIP(hipFreeAsync(M, st));
-    CPX_HIP(hipFreeAsync(llrT, st));
-    CPX_HIP(hipFreeAsync(unsat, st));
     return CPX_OK;
 }
 

@@ -2,6 +2,8 @@
 // HIP-event timers.  No compute here.
 #include "cpx_internal.h"
 
+#include <mutex>
+
 namespace cpx {
 
 static thread_local char g_err[1024] = "";
@@ -22,6 +24,37 @@ hipStream_t lib_stream() {
         if (hipStreamCreateWithFlags(&g_streams[dev], hipStreamNonBlocking) != hipSuccess) g_streams[dev] = nullptr;
     }
     return g_streams[dev];
+}
+
+struct WsEntry { int dev; hipStream_t st; int slot; void *p; size_t cap; };
+static std::vector<WsEntry> g_ws;
+static std::mutex g_ws_mu;
+
+int workspace(hipStream_t stream, int slot, size_t bytes, void **out) {
+    int dev = 0;
+    CPX_HIP(hipGetDevice(&dev));
+    if (bytes == 0) bytes = 8;
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    for (auto &e : g_ws)
+        if (e.dev == dev && e.st == stream && e.slot == slot) {
+            if (e.cap < bytes) {
+                CPX_HIP(hipStreamSynchronize(stream));          // nothing may still use the old block
+                CPX_HIP(hipFree(e.p));
+                e.p = nullptr; e.cap = 0;
+                hipError_t er = hipMalloc(&e.p, bytes);
+                if (er != hipSuccess) { set_error("workspace hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(er)); return CPX_ENOMEM; }
+                e.cap = bytes;
+            }
+            *out = e.p;
+            return CPX_OK;
+        }
+    WsEntry e{dev, stream, slot, nullptr, 0};
+    hipError_t er = hipMalloc(&e.p, bytes);
+    if (er != hipSuccess) { set_error("workspace hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(er)); return CPX_ENOMEM; }
+    e.cap = bytes;
+    g_ws.push_back(e);
+    *out = e.p;
+    return CPX_OK;
 }
 
 int ensure_device() {
@@ -101,6 +134,16 @@ int cpx_memcpy_h2d(void *dst, const void *src, size_t bytes) {
 
 int cpx_memcpy_d2h(void *dst, const void *src, size_t bytes) {
     CPX_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return CPX_OK;
+}
+
+int cpx_release_workspace(void) {
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    for (auto &e : g_ws) {
+        (void)hipStreamSynchronize(e.st);
+        (void)hipFree(e.p);
+    }
+    g_ws.clear();
     return CPX_OK;
 }
 

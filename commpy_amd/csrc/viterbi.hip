@@ -12,10 +12,14 @@
 //   * path metric of state s lives in one VGPR pair of lane s; predecessors are fetched with
 //     wavefront shuffles (ds_bpermute), no LDS round trip for the ACS recursion;
 //   * branch metrics: per chunk of CH = S steps, lane (g,i) loads the n received values of step
-//     t_base+i (coalesced), evaluates the reference's per-bit metrics once and writes the 2^n
-//     codeword metrics of that step to LDS; the ACS lanes read them back by codeword index;
-//   * survivor decisions: one 64-bit ballot word per step (two for I = 4) in an LDS ring of
-//     RS >= CH + tb - 2 steps, plus the per-step first-argmin state (1 byte per codeword slot);
+//     t_base+i (coalesced, prefetched one chunk ahead), evaluates the reference's per-bit metrics
+//     once and writes the 2^n codeword metrics of that step to LDS; the ACS lanes read them back
+//     by codeword index (wave-uniform broadcasts);
+//   * first-argmin state per step: all-lane minimum by DPP row permutes + v_permlane16/32_swap
+//     (no LDS); for S = 64 eight consecutive steps share ONE "transposed" reduction tree;
+//   * survivor decisions: one 64-bit ballot word per step (two for I = 4); lane i keeps the word
+//     and the argmin of step t_base+i in registers and the chunk is flushed to an LDS ring of
+//     RS >= CH + tb - 2 steps with one store per lane;
 //   * sliding traceback after every chunk, lane-parallel over output steps (lane (g,i) owns
 //     output step next_out + i of codeword g), walking tb-2 decision words of the ring.
 // HBM traffic is exactly the algorithmic one: each received value is read once, each decoded
@@ -35,8 +39,107 @@ struct VitParams {
     int k, n, lgS, I, NC, type, tb, RS;
 };
 
-__device__ __forceinline__ double shfl_f64(double v, int src_lane) { return __shfl(v, src_lane, 64); }
-__device__ __forceinline__ double shfl_xor_f64(double v, int mask) { return __shfl_xor(v, mask, 64); }
+// ---- cross-lane helpers -------------------------------------------------------------------------
+// ds_bpermute fetch of a float64 from the lane whose BYTE address (lane*4) is `addr4`.
+__device__ __forceinline__ double bperm_f64(double v, int addr4) {
+    const int lo = __builtin_amdgcn_ds_bpermute(addr4, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(addr4, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+// min of two non-NaN doubles as ONE v_min_f64 (the fmin builtin adds two canonicalising v_max_f64).
+// The trailing s_nop covers the VALU-write -> DPP / v_permlane read hazard of the consumer, which
+// hipcc does not pad for an asm statement.
+__device__ __forceinline__ double min_f64(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2\n\ts_nop 1" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+__device__ __forceinline__ double mk(unsigned hi, unsigned lo) { return __hiloint2double((int)hi, (int)lo); }
+
+// v_permlane16_swap(a, b): a' = [a.row0, b.row0, a.row2, b.row2], b' = [a.row1, b.row1, a.row3, b.row3]
+// v_permlane32_swap(a, b): a' = [a.low half, b.low half],          b' = [a.high half, b.high half]
+// With a == b == v the element-wise min of the two results is the all-reduce over the row pair / halves.
+__device__ __forceinline__ double rowpair_min(double v) {
+    const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+    const auto l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return min_f64(mk(h[0], l[0]), mk(h[1], l[1]));
+}
+
+__device__ __forceinline__ double halves_min(double v) {
+    const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+    const auto l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return min_f64(mk(h[0], l[0]), mk(h[1], l[1]));
+}
+
+// All-reduce minimum inside each aligned group of 2^LGS lanes: DPP quad/row permutes for the four
+// in-row stages, v_permlane16_swap / v_permlane32_swap (gfx950) across rows.  No LDS traffic.
+template <int LGS>
+__device__ __forceinline__ double group_min(double v) {
+    if (LGS >= 1) v = min_f64(v, dpp_f64<0xB1>(v));    // quad_perm [1,0,3,2]  (lane ^ 1)
+    if (LGS >= 2) v = min_f64(v, dpp_f64<0x4E>(v));    // quad_perm [2,3,0,1]  (lane ^ 2)
+    if (LGS >= 3) v = min_f64(v, dpp_f64<0x141>(v));   // row_half_mirror      (other quad of the 8)
+    if (LGS >= 4) v = min_f64(v, dpp_f64<0x140>(v));   // row_mirror           (other half of the row)
+    if (LGS >= 5) v = rowpair_min(v);
+    if (LGS >= 6) v = halves_min(v);
+    return v;
+}
+
+// ---- eight all-lane minima for the price of ~1.5 (S = 64) ------------------------------------------
+// Reduce EIGHT 64-lane vectors at once ("transposed" tree): every stage halves the number of live
+// vectors instead of repeating the full tree per vector.
+//   pair_halves(a, b):  v_permlane32_swap -> lanes 0-31: min(a[l], a[l+32]);  lanes 32-63: same for b
+//   pair_rows(a, b):    v_permlane16_swap -> rows 0,2 carry a reduced over row pairs, rows 1,3 carry b
+//   pair_octets(a, b):  two bank-masked DPP row shifts -> lanes 0-7 of each row carry a, 8-15 carry b
+// After the three pairing stages ONE vector holds all eight partial minima (8 lanes each); three
+// plain DPP stages finish them.  The minimum of input vector u ends up in lanes 8*bitrev3(u)..+7.
+__device__ __forceinline__ double pair_halves(double a, double b) {
+    const auto l = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto h = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return min_f64(mk(h[0], l[0]), mk(h[1], l[1]));
+}
+
+__device__ __forceinline__ double pair_rows(double a, double b) {
+    const auto l = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto h = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return min_f64(mk(h[0], l[0]), mk(h[1], l[1]));
+}
+
+__device__ __forceinline__ double pair_octets(double a, double b) {
+    // P = [a.lanes0-7 | b.lanes0-7 moved up by 8] (row_shr:8 into banks 2,3);  Q = [a.lanes8-15 moved down | b.lanes8-15]
+    const int plo = __builtin_amdgcn_update_dpp(__double2loint(a), __double2loint(b), 0x118, 0xf, 0xc, false);
+    const int phi = __builtin_amdgcn_update_dpp(__double2hiint(a), __double2hiint(b), 0x118, 0xf, 0xc, false);
+    const int qlo = __builtin_amdgcn_update_dpp(__double2loint(b), __double2loint(a), 0x108, 0xf, 0x3, false);
+    const int qhi = __builtin_amdgcn_update_dpp(__double2hiint(b), __double2hiint(a), 0x108, 0xf, 0x3, false);
+    return min_f64(__hiloint2double(phi, plo), __hiloint2double(qhi, qlo));
+}
+
+__device__ __forceinline__ double min8_transposed(const double (&h)[8]) {
+    const double c0 = pair_halves(h[0], h[1]), c1 = pair_halves(h[2], h[3]);
+    const double c2 = pair_halves(h[4], h[5]), c3 = pair_halves(h[6], h[7]);
+    const double d0 = pair_rows(c0, c1), d1 = pair_rows(c2, c3);
+    double e = pair_octets(d0, d1);
+    e = min_f64(e, dpp_f64<0x141>(e));     // row_half_mirror: lane i <-> 7-i inside each 8-lane segment
+    e = min_f64(e, dpp_f64<0xB1>(e));      // quad_perm xor 1
+    e = min_f64(e, dpp_f64<0x4E>(e));      // quad_perm xor 2
+    return e;
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
 
 // Per-bit metrics of one received value (convcode.py:575-587): m0 = cost of code bit 0, m1 = of bit 1.
 __device__ __forceinline__ void bit_metrics(int type, double r, double &m0, double &m1) {
@@ -55,14 +158,19 @@ __device__ __forceinline__ void bit_metrics(int type, double r, double &m0, doub
     }
 }
 
-template <int I_T>
+// LGS: log2(states) (S <= 64 lanes per codeword slot);  I_T: branches per state (2 or 4);
+// SR: shift-register trellis (feed-forward, k = 1): predecessor j of state s is ((s << 1) & (S-1)) | j
+//     and the input on every branch into s is s >> (LGS-1), so the traceback needs no table lookups;
+// N_T: outputs per trellis step when known at compile time (2, 3), 0 = run-time n <= CPX_MAX_N.
+template <int LGS, int I_T, bool SR, int N_T>
 __global__ __launch_bounds__(64) void viterbi_wave_kernel(VitParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int PL = (I_T == 2) ? 1 : 2;          // decision bit planes
+    constexpr int S = 1 << LGS, G = 64 >> LGS, CH = S;
+    constexpr int NMAX = N_T ? N_T : CPX_MAX_N;
     const int lane = threadIdx.x;
-    const int lgS = p.lgS, S = 1 << lgS, G = 64 >> lgS, CH = S;
-    const int NC = p.NC, n = p.n, k = p.k, RM = p.RS - 1;
-    const int g = lane >> lgS, s = lane & (S - 1);
+    const int n = N_T ? N_T : p.n, NC = N_T ? (1 << N_T) : p.NC, k = p.k, RM = p.RS - 1;
+    const int g = lane >> LGS, s = lane & (S - 1);
 
     double *bm = reinterpret_cast<double *>(smem);                              // [64][NC]
     unsigned long long *dring = reinterpret_cast<unsigned long long *>(bm + 64 * NC);  // [RS][PL]
@@ -73,74 +181,129 @@ __global__ __launch_bounds__(64) void viterbi_wave_kernel(VitParams p) {
     const bool valid_cw = cw < p.B;
     const double *x = p.coded + (valid_cw ? cw : 0) * p.len;
 
-    int predlane[I_T], pcode[I_T];
+    int paddr[I_T], pcode[I_T];                              // predecessor lane byte address / branch codeword
 #pragma unroll
     for (int j = 0; j < I_T; j++) {
-        predlane[j] = (g << lgS) + p.pred_state[s * I_T + j];
+        paddr[j] = ((g << LGS) + p.pred_state[s * I_T + j]) << 2;
         pcode[j] = p.pred_code[s * I_T + j];
     }
-    for (int idx = lane; idx < S * I_T; idx += 64)
-        ptab[idx] = (unsigned short)(p.pred_state[idx] | (p.pred_input[idx] << 8));
+    if (!SR)
+        for (int idx = lane; idx < S * I_T; idx += 64)
+            ptab[idx] = (unsigned short)(p.pred_state[idx] | (p.pred_input[idx] << 8));
 
     double pm = (s == 0) ? 0.0 : __builtin_huge_val();      // path_metrics[:,0] = inf, [0][0] = 0 (:705-706)
-    const int gshift = g << lgS;
-    const unsigned long long gmask = (S == 64) ? ~0ull : ((1ull << S) - 1ull);
+    const int gshift = g * S;
+    constexpr unsigned long long gmask = (S == 64) ? ~0ull : ((1ull << (S & 63)) - 1ull);
     int64_t next_out = 1;                                    // first output step not yet finalised
+
+    // received values of the chunk being prepared (software prefetch one chunk ahead)
+    double rcur[NMAX];
+    auto load_chunk = [&](int64_t t_base, double *r) {
+        const int64_t t = t_base + s;                        // lane (g, s) prepares step t of codeword g
+        const bool have = valid_cw && (t <= p.Lk) && (t <= p.T);   // t > L//k -> padding (:722-734)
+#pragma unroll
+        for (int j = 0; j < NMAX; j++) {
+            double v = (p.type == CPX_VIT_UNQUANTIZED) ? -1.0 : 0.0;
+            if (have && j < n) v = x[(t - 1) * n + j];
+            r[j] = v;
+        }
+    };
+    load_chunk(1, rcur);
 
     for (int64_t t_base = 1; t_base <= p.T; t_base += CH) {
         // ---------------- branch-metric table of this chunk ----------------
         {
-            const int64_t t = t_base + s;                    // lane (g, s) prepares step t of codeword g
-            double m0[CPX_MAX_N], m1[CPX_MAX_N];
-            const bool have = valid_cw && (t <= p.Lk) && (t <= p.T);   // t > L//k -> padding (:722-734)
-            for (int j = 0; j < n; j++) {
-                double r = (p.type == CPX_VIT_UNQUANTIZED) ? -1.0 : 0.0;
-                if (have) {
-                    r = x[(t - 1) * n + j];
-                    if (p.type == CPX_VIT_SOFT) r = fmin(fmax(r, -500.0), 500.0);   // coded_bits.clip(-500, 500) (:719)
-                }
-                bit_metrics(p.type, r, m0[j], m1[j]);
+            double m0[NMAX], m1[NMAX];
+#pragma unroll
+            for (int j = 0; j < NMAX; j++) {
+                double r = rcur[j];
+                if (p.type == CPX_VIT_SOFT) r = fmin(fmax(r, -500.0), 500.0);   // coded_bits.clip(-500, 500) (:719)
+                m0[j] = 0.0; m1[j] = 0.0;
+                if (j < n) bit_metrics(p.type, r, m0[j], m1[j]);
             }
             double *row = bm + lane * NC;
             for (int c = 0; c < NC; c++) {
                 double acc = 0.0;                            // NumPy add.reduce, n < 8: sequential from 0
-                for (int j = 0; j < n; j++) acc += ((c >> (n - 1 - j)) & 1) ? m1[j] : m0[j];   // MSB-first bits (:622)
+#pragma unroll
+                for (int j = 0; j < NMAX; j++)
+                    if (j < n) acc += ((c >> (n - 1 - j)) & 1) ? m1[j] : m0[j];   // MSB-first bits (:622)
                 row[c] = acc;
             }
         }
+        if (t_base + CH <= p.T) load_chunk(t_base + CH, rcur);   // prefetch: lands during the forward loop
         __syncthreads();
 
         // ---------------- forward add-compare-select ----------------
         const int nsteps = (int)((p.T - t_base + 1 < CH) ? (p.T - t_base + 1) : CH);
-        for (int i = 0; i < nsteps; i++) {
-            const int64_t t = t_base + i;
-            const double *row = bm + ((g << lgS) + i) * NC;
-            double best = shfl_f64(pm, predlane[0]) + row[pcode[0]];      // pmetrics[0] (:629)
-            int jb = 0;
+        unsigned long long mydec0 = 0, mydec1 = 0;           // decision word(s) of step t_base + s, kept by lane (g, s)
+        int mybest = 0;
+        const double *rowbase = bm + (g << LGS) * NC;
+        // one ACS step: updates pm, returns the decision ballot(s)
+        auto acs = [&](int i, unsigned long long &w0, unsigned long long &w1) {
+            const double *row = rowbase + i * NC;
+            double best = bperm_f64(pm, paddr[0]) + row[pcode[0]];        // pmetrics[0] (:629)
+            w1 = 0;
+            if (I_T == 2) {
+                const double c1 = bperm_f64(pm, paddr[1]) + row[pcode[1]];
+                const bool d = c1 < best;                                  // first minimum wins (:633-642)
+                best = d ? c1 : best;
+                w0 = __ballot(d);
+            } else {
+                int jb = 0;
 #pragma unroll
-            for (int j = 1; j < I_T; j++) {
-                double c = shfl_f64(pm, predlane[j]) + row[pcode[j]];
-                if (c < best) { best = c; jb = j; }                        // first minimum wins (:633-642)
+                for (int j = 1; j < I_T; j++) {
+                    const double c = bperm_f64(pm, paddr[j]) + row[pcode[j]];
+                    if (c < best) { best = c; jb = j; }
+                }
+                w0 = __ballot(jb & 1);
+                w1 = __ballot(jb & 2);
             }
             pm = best;
-            const unsigned long long w0 = __ballot(jb & 1);
-            unsigned long long w1 = 0;
-            if (PL == 2) w1 = __ballot(jb & 2);
-            // first-argmin state of this step (:645): wave min-reduce inside the S-lane group
-            double mn = pm;
-            for (int off = 1; off < S; off <<= 1) {
-                double o = shfl_xor_f64(mn, off);
-                mn = (o < mn) ? o : mn;
+        };
+        if constexpr (LGS == 6) {
+            // S = 64: eight steps per block; their eight first-argmin reductions (:645) share one transposed tree.
+            // A partial last block simply runs on (rows of steps > T hold padding metrics; their ring slots are never read).
+            for (int i0 = 0; i0 < nsteps; i0 += 8) {
+                double hist[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    unsigned long long w0, w1;
+                    acs(i0 + u, w0, w1);
+                    const bool mine = (s == i0 + u);
+                    mydec0 = mine ? w0 : mydec0;
+                    if (PL == 2) mydec1 = mine ? w1 : mydec1;
+                    hist[u] = pm;
+                }
+                const double e = min8_transposed(hist);
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    constexpr int SEG[8] = {0, 4, 2, 6, 1, 5, 3, 7};          // bitrev3(u): segment holding min(hist[u])
+                    const double mn = readlane_f64(e, 8 * SEG[u]);
+                    const unsigned long long eq = __ballot(hist[u] == mn);
+                    const int bst = eq ? (__ffsll((long long)eq) - 1) : 0;
+                    mybest = (s == i0 + u) ? bst : mybest;
+                }
             }
-            const unsigned long long eq = __ballot(pm == mn);
-            const unsigned long long grp = (eq >> gshift) & gmask;
-            const int bst = grp ? (__ffsll((long long)grp) - 1) : 0;
-            const int slot = (int)(t & RM);
-            if (lane == 0) {
-                dring[slot * PL] = w0;
-                if (PL == 2) dring[slot * PL + 1] = w1;
+        } else {
+            for (int i = 0; i < nsteps; i++) {
+                unsigned long long w0, w1;
+                acs(i, w0, w1);
+                // first-argmin state of this step (:645)
+                const double mn = group_min<LGS>(pm);
+                const unsigned long long eq = __ballot(pm == mn);
+                const unsigned long long grp = (eq >> gshift) & gmask;
+                const int bst = grp ? (__ffsll((long long)grp) - 1) : 0;
+                const bool mine = (s == i);
+                mydec0 = mine ? w0 : mydec0;
+                if (PL == 2) mydec1 = mine ? w1 : mydec1;
+                mybest = mine ? bst : mybest;
             }
-            if (s == 0) bring[slot * G + g] = (unsigned char)bst;
+        }
+        {
+            const int slot = (int)((t_base + s) & RM);       // slots of steps beyond T are never read
+            dring[slot * PL] = mydec0;                        // identical words from the G codeword slots
+            if (PL == 2) dring[slot * PL + 1] = mydec1;
+            bring[slot * G + g] = (unsigned char)mybest;
         }
         __syncthreads();
 
@@ -153,16 +316,25 @@ __global__ __launch_bounds__(64) void viterbi_wave_kernel(VitParams p) {
                 int64_t t0 = so + p.tb - 2;
                 if (t0 > p.T) t0 = p.T;
                 int st = bring[(int)(t0 & RM) * G + g];
-                for (int64_t tt = t0; tt > so; --tt) {
-                    const int slot = (int)(tt & RM);
+                int sym;
+                if (SR) {
+                    for (int64_t tt = t0; tt > so; --tt) {
+                        const int j = (int)((dring[(int)(tt & RM)] >> (gshift + st)) & 1ull);
+                        st = ((st << 1) & (S - 1)) | j;
+                    }
+                    sym = st >> (LGS - 1);
+                } else {
+                    for (int64_t tt = t0; tt > so; --tt) {
+                        const int slot = (int)(tt & RM);
+                        int j = (int)((dring[slot * PL] >> (gshift + st)) & 1ull);
+                        if (PL == 2) j |= (int)((dring[slot * PL + 1] >> (gshift + st)) & 1ull) << 1;
+                        st = ptab[st * I_T + j] & 0xff;      // paths[current_state, j] (:651)
+                    }
+                    const int slot = (int)(so & RM);
                     int j = (int)((dring[slot * PL] >> (gshift + st)) & 1ull);
                     if (PL == 2) j |= (int)((dring[slot * PL + 1] >> (gshift + st)) & 1ull) << 1;
-                    st = ptab[st * I_T + j] & 0xff;          // paths[current_state, j] (:651)
+                    sym = ptab[st * I_T + j] >> 8;           // decoded_symbols[current_state, j] (:650)
                 }
-                const int slot = (int)(so & RM);
-                int j = (int)((dring[slot * PL] >> (gshift + st)) & 1ull);
-                if (PL == 2) j |= (int)((dring[slot * PL + 1] >> (gshift + st)) & 1ull) << 1;
-                const int sym = ptab[st * I_T + j] >> 8;     // decoded_symbols[current_state, j] (:650)
                 for (int b = 0; b < k; b++) {
                     const int64_t pos = (so - 1) * k + b;
                     if (pos < p.L) p.bits[cw * p.L + pos] = (uint8_t)((sym >> (k - 1 - b)) & 1);   // dec2bitarray(sym, k) (:652)
@@ -223,7 +395,7 @@ int cpx_trellis_create(int k, int n, int n_states, int n_inputs, const int32_t *
                   "pmetrics[number_inputs], convcode.py:604-629)", I);
         return CPX_EINVAL;
     }
-    hipGetDevice(&t->device);
+    (void)hipGetDevice(&t->device);
     size_t bytes = sizeof(int32_t) * S * I;
     int32_t **dst[5] = {&t->d_next, &t->d_out, &t->d_pred_state, &t->d_pred_input, &t->d_pred_code};
     const int32_t *src[5] = {t->next_state.data(), t->output.data(), t->pred_state.data(), t->pred_input.data(),
@@ -254,7 +426,7 @@ int cpx_viterbi_decode_batch_dev(const cpx_trellis *t, const double *d_coded, in
     CPX_REQUIRE((L / t->k) * (int64_t)t->n <= len, CPX_EINVAL, "viterbi: L inconsistent with len");
     CPX_REQUIRE(t->I == 2 || t->I == 4, CPX_ELIMIT, "viterbi: trellis with %d inputs per step not supported (k <= 2)", t->I);
     CPX_REQUIRE(t->n <= CPX_MAX_N, CPX_ELIMIT, "viterbi: n = %d > %d not supported", t->n, CPX_MAX_N);
-    CPX_REQUIRE(t->S <= 64, CPX_ELIMIT, "viterbi: %d states not supported yet (<= 64)", t->S);
+    CPX_REQUIRE(t->S >= 2 && t->S <= 64, CPX_ELIMIT, "viterbi: %d states not supported yet (2..64)", t->S);
     if (B == 0 || L == 0) return CPX_OK;
     hipStream_t st = pick_stream(stream);
     if (n_steps <= 0 || n_steps * t->k < L) CPX_HIP(hipMemsetAsync(d_bits, 0, (size_t)(B * L), st));
@@ -276,8 +448,30 @@ int cpx_viterbi_decode_batch_dev(const cpx_trellis *t, const double *d_coded, in
     const int64_t nblocks = (B + G - 1) / G;
     CPX_REQUIRE(nblocks < (1ll << 31), CPX_ELIMIT, "viterbi: batch too large");
     dim3 grid((unsigned)nblocks), block(64);
-    if (t->I == 2) hipLaunchKernelGGL(viterbi_wave_kernel<2>, grid, block, lds, st, p);
-    else hipLaunchKernelGGL(viterbi_wave_kernel<4>, grid, block, lds, st, p);
+    // shift-register structure => arithmetic traceback (no predecessor table lookups)
+    bool sr = (t->I == 2 && t->k == 1 && lgS >= 1);
+    for (int s2 = 0; s2 < S && sr; s2++)
+        for (int j = 0; j < 2; j++)
+            if (t->pred_state[s2 * 2 + j] != (((s2 << 1) & (S - 1)) | j) || t->pred_input[s2 * 2 + j] != (s2 >> (lgS - 1)))
+                sr = false;
+#define VIT_LAUNCH(LG, IT, SRV)                                                                             \
+    do {                                                                                                    \
+        if (t->n == 2) hipLaunchKernelGGL((viterbi_wave_kernel<LG, IT, SRV, 2>), grid, block, lds, st, p);    \
+        else if (t->n == 3) hipLaunchKernelGGL((viterbi_wave_kernel<LG, IT, SRV, 3>), grid, block, lds, st, p); \
+        else hipLaunchKernelGGL((viterbi_wave_kernel<LG, IT, SRV, 0>), grid, block, lds, st, p);             \
+    } while (0)
+#define VIT_CASE(LG)                                       \
+    case LG:                                               \
+        if (t->I == 4) VIT_LAUNCH(LG, 4, false);           \
+        else if (sr) VIT_LAUNCH(LG, 2, true);              \
+        else VIT_LAUNCH(LG, 2, false);                     \
+        break;
+    switch (lgS) {
+        VIT_CASE(1) VIT_CASE(2) VIT_CASE(3) VIT_CASE(4) VIT_CASE(5) VIT_CASE(6)
+        default: set_error("viterbi: unsupported number of states %d", S); return CPX_ELIMIT;
+    }
+#undef VIT_CASE
+#undef VIT_LAUNCH
     CPX_HIP(hipGetLastError());
     return CPX_OK;
 }

@@ -53,6 +53,7 @@ int cpx_memset(void *dptr, int value, size_t bytes);
 int cpx_memcpy_h2d(void *dst, const void *src, size_t bytes);
 int cpx_memcpy_d2h(void *dst, const void *src, size_t bytes);
 int cpx_stream_sync(void *stream);          /* NULL = the library's stream */
+int cpx_release_workspace(void);            /* free the per-stream scratch arenas the decoders keep between calls */
 void *cpx_default_stream(void);             /* the library's own hipStream_t */
 /* HIP-event timer on a stream (bench.py times the kernels on the stream they are launched on) */
 int cpx_timer_create(void **timer);

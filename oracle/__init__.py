@@ -37,6 +37,8 @@ def load():
         lib.orc_dec2bitarray.argtypes = [c_int64, c_int, c_void_p]
         lib.orc_viterbi_decode.argtypes = [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                            c_int, c_int, c_void_p, POINTER(c_int64)]
+        lib.orc_viterbi_decode_batch.argtypes = [c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                                 c_void_p, c_int, c_int, c_void_p, c_int64]
         lib.orc_map_decode.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_double,
                                        c_void_p, c_int, c_void_p, c_void_p]
         lib.orc_turbo_decode.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p,
@@ -76,9 +78,18 @@ def viterbi_decode(coded_bits, trellis, tb_depth=None, decoding_type='hard'):
     """Oracle of convcode.py:661 for one codeword (1-D) or a batch (2-D, looped)."""
     lib = load()
     x = _f64(coded_bits)
-    if x.ndim == 2:
-        return np.stack([viterbi_decode(r, trellis, tb_depth, decoding_type) for r in x])
     nxt, out = _tables(trellis)
+    if x.ndim == 2:
+        B, length = x.shape
+        L = int(length * (trellis.k / trellis.n))
+        dec = np.zeros((B, max(L, 1)), dtype=np.int64)
+        rc = lib.orc_viterbi_decode_batch(_p(x), B, length, int(trellis.k), int(trellis.n), int(trellis.total_memory),
+                                          int(trellis.number_states), int(trellis.number_inputs), _p(nxt), _p(out),
+                                          0 if tb_depth is None else int(tb_depth), _VIT[decoding_type], _p(dec),
+                                          dec.shape[1])
+        if rc != 0:
+            raise ValueError("oracle viterbi_decode failed (%d)" % rc)
+        return dec[:, :L]
     L = int(len(x) * (trellis.k / trellis.n))
     dec = np.zeros(max(L, 1), dtype=np.int64)
     Lo = c_int64(0)

@@ -442,3 +442,17 @@ int orc_demod_hard(const double *y_re_im, int64_t nsym, const double *const_re_i
     }
     return ORC_OK;
 }
+
+/* Batch convenience for the CPU baseline timing: B codewords back to back through orc_viterbi_decode
+ * (one foreign call per thread keeps the Python GIL out of the timed region). */
+int orc_viterbi_decode_batch(const double *coded, int64_t B, int64_t len, int k, int n, int total_memory, int S, int I,
+                             const int32_t *next_state, const int32_t *output, int tb_depth, int type,
+                             int64_t *decoded /* [B][L] */, int64_t L)
+{
+    for (int64_t b = 0; b < B; b++) {
+        int rc = orc_viterbi_decode(coded + b * len, len, k, n, total_memory, S, I, next_state, output, tb_depth, type,
+                                    decoded + b * L, NULL);
+        if (rc) return rc;
+    }
+    return ORC_OK;
+}

@@ -1,0 +1,155 @@
+"""Host-side logic of commpy_amd (no GPU): trellis tables, encoders, bit helpers, interleaver,
+constellations, LDPC design files -- against the reference's own golden tables
+(commpy/channelcoding/tests/test_convcode.py:23-111, commpy/tests/test_utilities.py:12-13,
+commpy/tests/test_modulation.py:164-174) and the fixtures generated from the live reference."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+from helpers import TRELLIS_SPECS, golden, ldpc_params, make_trellis
+
+from commpy_amd.channelcoding.convcode import Trellis, conv_encode, depuncturing, puncturing
+from commpy_amd.channelcoding.interleavers import RandInterlv
+from commpy_amd.utilities import bitarray2dec, dec2bitarray, euclid_dist, hamming_dist
+
+# literal tables restated from the reference's test file (test_convcode.py:27-111)
+REF_TABLES = {
+    "t57": ([[0, 2], [0, 2], [1, 3], [1, 3]], [[0, 3], [3, 0], [1, 2], [2, 1]], [0, 0, 0, 0, 1, 1, 0, 1]),
+    "rsc_legacy_4": ([[0, 2], [2, 0], [1, 3], [3, 1]], [[0, 3], [0, 3], [1, 2], [1, 2]], [0, 0, 0, 0, 1, 1, 0, 1]),
+    "k2_default": ([[0, 1, 4, 5]] * 4 + [[2, 3, 6, 7]] * 4,
+                   [[0, 1, 6, 7], [3, 2, 5, 4], [6, 7, 0, 1], [5, 4, 3, 2], [2, 3, 4, 5], [1, 0, 7, 6], [4, 5, 2, 3],
+                    [7, 6, 1, 0]], [0, 0, 0, 1, 1, 0]),
+    "k2_lsb": ([[0, 1, 4, 5]] * 4 + [[2, 3, 6, 7]] * 4,
+               [[0, 1, 6, 7], [3, 2, 5, 4], [6, 7, 0, 1], [5, 4, 3, 2], [2, 3, 4, 5], [1, 0, 7, 6], [4, 5, 2, 3],
+                [7, 6, 1, 0]], [0, 0, 0, 1, 1, 0]),
+    "k2_rsc_matrix": ([[0, 1, 1, 0], [2, 3, 3, 2], [3, 2, 2, 3], [1, 0, 0, 1]],
+                      [[0, 3, 4, 7], [1, 2, 5, 6], [0, 3, 4, 7], [1, 2, 5, 6]], [0, 0, 0, 1, 0, 0]),
+}
+
+
+@pytest.mark.parametrize("name", list(REF_TABLES))
+def test_trellis_reference_golden_tables(name):
+    nxt, out, enc = REF_TABLES[name]
+    tr = make_trellis(name)
+    assert np.array_equal(tr.next_state_table, nxt)
+    assert np.array_equal(tr.output_table, out)
+    assert np.array_equal(conv_encode(np.array((0, 0, 1, 0)), tr, "cont"), enc)
+
+
+@pytest.mark.parametrize("spec", TRELLIS_SPECS, ids=[s[0] for s in TRELLIS_SPECS])
+def test_trellis_and_encoder_vs_live_reference(spec):
+    g, e = golden("trellis"), golden("conv_encode")
+    name = spec[0]
+    tr = make_trellis(name)
+    assert np.array_equal(tr.next_state_table, g[name + "__next"])
+    assert np.array_equal(tr.output_table, g[name + "__out"])
+    assert [tr.k, tr.n, tr.total_memory, tr.number_states, tr.number_inputs] == list(g[name + "__kn"])
+    assert np.array_equal(conv_encode(e[name + "__msg"], tr), e[name + "__term"])
+    assert np.array_equal(conv_encode(e[name + "__msg"], tr, "cont"), e[name + "__cont"])
+
+
+def test_trellis_quirks():
+    # B1: Wifi80211's decimal generators (133, 171) silently become (5, 43)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a = Trellis(np.array([6]), np.array([[133, 171]]))
+        b = Trellis(np.array([6]), np.array([[5, 43]]))
+    assert np.array_equal(a.output_table, b.output_table) and np.array_equal(a.next_state_table, b.next_state_table)
+    # legacy int feedback warns and mutates the caller's g_matrix for rsc codes
+    g = np.array([[1, 7]])
+    with pytest.warns(DeprecationWarning):
+        Trellis(np.array([2]), g, 5, "rsc")
+    assert g[0][0] == 5
+    with pytest.raises(ValueError):
+        Trellis(np.array([2]), np.array([[5, 7]]), polynomial_format="XSB")
+    # B2: legacy and matrix constructions give different RSC output tables
+    assert not np.array_equal(make_trellis("rsc_legacy_4").output_table, make_trellis("rsc_matrix_4").output_table)
+
+
+def test_bit_helpers():
+    g = golden("trellis")
+    assert np.array_equal(dec2bitarray(17, 8), [0, 0, 0, 1, 0, 0, 0, 1])           # test_utilities.py:12
+    assert np.array_equal(dec2bitarray((17, 12), 5), [1, 0, 0, 0, 1, 0, 1, 1, 0, 0])  # test_utilities.py:13
+    assert np.array_equal(dec2bitarray(133, 7), g["dec2bit_133_7"])                # wrap quirk
+    assert np.array_equal(dec2bitarray(171, 7), g["dec2bit_171_7"])
+    assert dec2bitarray(5, 4).dtype == np.int8
+    assert bitarray2dec(dec2bitarray(45, 9)) == 45
+    assert hamming_dist(np.array([1, 0, 1]), np.array([0, 0, 1])) == 1
+    assert euclid_dist(np.array([1., 2.]), np.array([0., 0.])) == 5.0
+
+
+def test_puncturing():
+    e = golden("conv_encode")
+    for nm in ("p23", "p34", "p56"):
+        pu = puncturing(e["punct_" + nm + "__msg"], e["punct_" + nm + "__vec"])
+        assert np.array_equal(pu, e["punct_" + nm + "__punctured"])
+        de = depuncturing(pu.astype(float) * 2 - 1, e["punct_" + nm + "__vec"], 120)
+        assert np.array_equal(de, e["punct_" + nm + "__depunctured"])
+
+
+def test_interleaver_and_turbo_encode():
+    from commpy_amd.channelcoding.turbo import turbo_encode
+    g = golden("map_turbo")
+    il = RandInterlv(16, 7)
+    assert np.array_equal(il.p_array, g["randinterlv_16_7"])
+    x = np.arange(16) * 1.5
+    assert np.array_equal(il.deinterlv(il.interlv(x)), x)
+    for nm in g["turbo_names"]:
+        key, tname, N, nv, iters = str(nm).split("|")
+        tr = make_trellis(tname)
+        il = RandInterlv(int(N), 1234)
+        assert np.array_equal(il.p_array, g[key + "__perm"])
+        s, p1, p2 = turbo_encode(g[key + "__msg"], tr, tr, il)
+        assert np.array_equal(s, g[key + "__enc_s"]) and np.array_equal(p1, g[key + "__enc_p1"])
+        assert np.array_equal(p2[:int(N)], g[key + "__enc_p2"])
+
+
+def test_modem_constellations():
+    from commpy_amd.modulation import Modem, PSKModem, QAMModem
+    g = golden("demod")
+    mods = {"qam4": QAMModem(4), "qam16": QAMModem(16), "qam64": QAMModem(64), "qam256": QAMModem(256),
+            "psk2": PSKModem(2), "psk4": PSKModem(4), "psk8": PSKModem(8), "psk16": PSKModem(16)}
+    for k, m in mods.items():
+        assert np.array_equal(m.constellation, g[k + "__const"]), k
+        assert m.Es == g[k + "__Es"], k
+        assert np.array_equal(m.modulate(g[k + "__bits"]), g[k + "__sym"]), k
+    # Es values pinned by the reference's own test (test_modulation.py:164-174): QAM Es = 2(m-1)/3, PSK Es = 1
+    assert np.isclose(QAMModem(64).Es, 42) and np.isclose(QAMModem(4).Es, 2) and np.isclose(PSKModem(8).Es, 1)
+    assert list(QAMModem(64).constellation[:4]) == [-7 - 7j, -7 - 5j, -7 - 1j, -7 - 3j]
+    with pytest.raises(ValueError):
+        QAMModem(32)
+    with pytest.raises(ValueError):
+        PSKModem(6)
+    with pytest.raises(ValueError):
+        Modem([1, 2, 3])
+
+
+def test_ldpc_design_files(tmp_path):
+    from commpy_amd.channelcoding.ldpc import (build_matrix, get_ldpc_code_params, triang_ldpc_systematic_encode,
+                                               write_ldpc_params)
+    here = os.path.dirname(os.path.abspath(__file__))
+    own = os.path.join(here, "..", "commpy_amd", "channelcoding", "designs", "ldpc", "ieee80211n", "1944.1296.txt")
+    p = get_ldpc_code_params(own)
+    q = ldpc_params("n1944")
+    for k in q:
+        assert np.array_equal(p[k], q[k]), k
+    assert p["cnode_adj_list"].dtype == np.int32
+    # write -> read round trip (test_ldpc.py:68-75)
+    rs = np.random.RandomState(4)
+    H = rs.choice((0, 1), (30, 60))
+    H[:, 0] = 1
+    H[0, :] = 1
+    path = str(tmp_path / "matrix.txt")
+    write_ldpc_params(H, path)
+    back = get_ldpc_code_params(path, True)
+    assert np.array_equal(back["parity_check_matrix"].toarray(), H)
+    # systematic encoder on a WiMax code: codeword of the reference, zero syndrome (test_ldpc.py:77-92)
+    g = golden("ldpc")
+    w = ldpc_params("wimax1440")
+    coded = triang_ldpc_systematic_encode(g["enc1440__msg"], w)
+    assert np.array_equal(coded, g["enc1440__coded"])
+    assert not (w["parity_check_matrix"].dot(coded) % 2).any()
+    with pytest.raises(ValueError):
+        triang_ldpc_systematic_encode(np.array([0, 1]), w, False)

@@ -58,7 +58,7 @@ def test_random_batches_vs_oracle(gpu, tname, dtype):
     from commpy_amd.channelcoding import conv_encode
     tr = make_trellis(tname)
     rs = np.random.RandomState(hash((tname, dtype)) % (2 ** 31))
-    for B, nbits, tb in ((37, 120, None), (5, 333, 15), (130, 64, 40)):
+    for B, nbits, tb in ((37, 120, None), (5, 333, 15), (130, 96, 40)):
         nbits -= nbits % tr.k
         msgs = rs.randint(0, 2, (B, nbits))
         coded = np.stack([conv_encode(m, tr) for m in msgs]).astype(float)
