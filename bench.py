@@ -202,6 +202,14 @@ def main():
         kavg = float(np.mean(kernel_ms))
         achieved = ALG_BYTES_PER_CW * B / (kavg * 1e-3) / 1e9
         value = world * B * MSG_BITS * args.steps / elapsed
+        traffic = None                       # HBM bytes per launch from the committed PMC passes (same workload only)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_viterbi_c2_traffic.json")) as f:
+                tj = json.load(f)
+            if B == 65536:
+                traffic = tj["traffic_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
         out = {
             "metric": "decoded info-bits/s at fixed Eb/N0 (Viterbi K=7 r=1/2, 1024b); BER match",
             "value": value, "unit": "info-bits/s", "n_gpus": world if distributed else 1, "steps": args.steps,
@@ -213,8 +221,9 @@ def main():
                        "parallelism": "batch-sharded x%d, all-gather of bits" % (world if distributed else 1)},
             "ber": ber, "oracle_mismatched_bits": mism, "oracle_sample_codewords": ns,
             "demod_max_abs_err_vs_oracle": demod_err,
-            "roofline": {"bound": "hbm", "kernel": "viterbi_wave_kernel<2>", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": "viterbi_wave_kernel<6,2,true,2>", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": "profiles/r01_viterbi_c2_traffic.json (rocprofv3 FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KiB)",
                          "kernel_ms_avg": kavg,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_CW * B,
                          "note": "serial ACS recursion: VALU/ds_bpermute bound, not HBM bound (SURVEY 8d)"},

@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Secondary benchmarks: the other kernels of the hot path on their BASELINE.json configurations
+(device-resident inputs, HIP-event timing on the launch stream).  One JSON line per kernel.
+
+    python benchmarks/bench_kernels.py [--which demod,ldpc,turbo,map,viterbi_small] [--scale 1.0]
+
+  demod   64-QAM soft LLR, 324 symbols x 32768 codewords (config 4's per-GPU share)   -> HBM roofline
+  ldpc    (1944,1296) BP, 50 iterations max, B = 32768 (config 4 per-GPU share), SPA and MSA
+  turbo   rate-1/3, N = 1024, 6 iterations, random interleaver, B = 16384 (config 3)
+  map     one MAP pass of the same
+  viterbi_small  config 1 (K=3, 64-bit, hard) scaled to B = 1M codewords
+bench.py (repo root) stays the headline Viterbi benchmark.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from commpy_amd import _lib  # noqa: E402
+
+HBM_PEAK = 8000.0
+
+
+class Dev:
+    """Tiny device-buffer helper on top of the C-ABI."""
+
+    def __init__(self, lib):
+        self.lib = lib
+        self.bufs = []
+
+    def put(self, arr):
+        arr = np.ascontiguousarray(arr)
+        p = ctypes.c_void_p()
+        _lib.check(self.lib.cpx_malloc(ctypes.byref(p), arr.nbytes))
+        _lib.check(self.lib.cpx_memcpy_h2d(p, _lib.ptr(arr), arr.nbytes))
+        self.bufs.append(p)
+        return p
+
+    def empty(self, nbytes):
+        p = ctypes.c_void_p()
+        _lib.check(self.lib.cpx_malloc(ctypes.byref(p), nbytes))
+        self.bufs.append(p)
+        return p
+
+    def get(self, p, shape, dtype):
+        out = np.empty(shape, dtype=dtype)
+        _lib.check(self.lib.cpx_memcpy_d2h(_lib.ptr(out), p, out.nbytes))
+        return out
+
+    def free(self):
+        for p in self.bufs:
+            self.lib.cpx_free(p)
+        self.bufs = []
+
+
+def timeit(lib, fn, steps=5, warmup=1):
+    tm = ctypes.c_void_p()
+    _lib.check(lib.cpx_timer_create(ctypes.byref(tm)))
+    for _ in range(warmup):
+        fn()
+    ms = []
+    for _ in range(steps):
+        _lib.check(lib.cpx_timer_start(tm, None))
+        fn()
+        _lib.check(lib.cpx_timer_stop(tm, None))
+        v = ctypes.c_float()
+        _lib.check(lib.cpx_timer_elapsed_ms(tm, ctypes.byref(v)))
+        ms.append(v.value)
+    lib.cpx_timer_destroy(tm)
+    return float(np.mean(ms)), float(np.min(ms))
+
+
+def emit(name, workload, units, unit_name, ms, alg_bytes, bound, extra=None):
+    ach = alg_bytes / (ms * 1e-3) / 1e9
+    d = {"kernel": name, "workload": workload, "value": units / (ms * 1e-3), "unit": unit_name + "/s", "ms": ms,
+         "dtype": "f64", "roofline": {"bound": bound, "achieved": ach, "peak": HBM_PEAK, "unit": "GB/s",
+                                      "frac": ach / HBM_PEAK, "algorithmic_bytes_per_launch": alg_bytes}}
+    if extra:
+        d.update(extra)
+    print(json.dumps(d), flush=True)
+
+
+def bench_demod(lib, scale):
+    from commpy_amd.modulation import QAMModem
+    for m, ncw, per_cw in ((64, int(32768 * scale), 324), (4, int(65536 * scale), 1030)):
+        md = QAMModem(m)
+        ns = ncw * per_cw
+        rs = np.random.RandomState(31)
+        N0 = md.Es / ((2.0 / 3) * md.num_bits_symbol * 10 ** 0.8) if m == 64 else md.Es / (0.5 * 2 * 10 ** 0.3)
+        y = md.constellation[rs.randint(0, m, ns)] + np.sqrt(N0 / 2) * (rs.randn(ns) + 1j * rs.randn(ns))
+        dev = Dev(lib)
+        d_y = dev.put(y)
+        d_l = dev.empty(ns * md.num_bits_symbol * 8)
+        d_b = dev.empty(ns * md.num_bits_symbol)
+        h = md._device_handle()
+        ms, _ = timeit(lib, lambda: _lib.check(lib.cpx_demod_soft_dev(h, d_y, ns, float(N0), d_l, None)))
+        emit("demod_soft_kernel<%d>" % md.num_bits_symbol, "%d-QAM soft LLR, %d symbols" % (m, ns), ns, "symbols", ms,
+             ns * (16 + 8 * md.num_bits_symbol), "hbm")
+        ms, _ = timeit(lib, lambda: _lib.check(lib.cpx_demod_hard_dev(h, d_y, ns, d_b, None)))
+        emit("demod_hard_kernel", "%d-QAM hard decision, %d symbols" % (m, ns), ns, "symbols", ms,
+             ns * (16 + md.num_bits_symbol), "hbm")
+        dev.free()
+
+
+def bench_ldpc(lib, scale):
+    from commpy_amd.channelcoding.ldpc import _device_code, get_ldpc_code_params
+    p = get_ldpc_code_params(os.path.join(ROOT, "commpy_amd/channelcoding/designs/ldpc/ieee80211n/1944.1296.txt"), True)
+    n, E = 1944, 7128
+    B = int(32768 * scale)
+    rs = np.random.RandomState(31)
+    for ebn0 in (2.2, 3.0):
+        sigma = 1 / np.sqrt(10 ** (ebn0 / 10.0) * (2.0 / 3) * 2)
+        llr = (2.0 * (1.0 + sigma * rs.randn(B, n)) / sigma ** 2)
+        dev = Dev(lib)
+        d_llr0 = dev.put(llr)
+        d_llr = dev.empty(llr.nbytes)
+        d_dec, d_out, d_it = dev.empty(B * n), dev.empty(B * n * 8), dev.empty(B * 4)
+        code = _device_code(p)
+        for alg, name in ((1, "MSA"), (0, "SPA")):
+            def run():
+                _lib.check(lib.cpx_memcpy_h2d(d_llr, _lib.ptr(llr), llr.nbytes))   # decode clips in place: restore input
+                _lib.check(lib.cpx_ldpc_bp_decode_batch_dev(code, d_llr, B, alg, 50, d_dec, d_out, d_it, None))
+
+            tm = ctypes.c_void_p()
+            lib.cpx_timer_create(ctypes.byref(tm))
+            run()
+            _lib.check(lib.cpx_stream_sync(None))
+            _lib.check(lib.cpx_memcpy_h2d(d_llr, _lib.ptr(llr), llr.nbytes))
+            lib.cpx_timer_start(tm, None)
+            _lib.check(lib.cpx_ldpc_bp_decode_batch_dev(code, d_llr, B, alg, 50, d_dec, d_out, d_it, None))
+            lib.cpx_timer_stop(tm, None)
+            v = ctypes.c_float()
+            lib.cpx_timer_elapsed_ms(tm, ctypes.byref(v))
+            its = dev.get(d_it, (B,), np.int32)
+            dec = dev.get(d_dec, (n, B), np.int8)
+            alg_bytes = int(its.sum()) * (4 * E + 2 * n) * 8 + B * n * 17
+            emit("ldpc_bp_%s" % name, "(1944,1296) Eb/N0=%.1f dB, <=50 its, B=%d, mean executed its %.2f" % (
+                ebn0, B, its.mean()), B * 1296, "info-bits", v.value, alg_bytes, "hbm" if alg else "f64-transcendental",
+                 {"frame_error_rate": float(np.mean(dec.any(axis=0))), "mean_iterations": float(its.mean()),
+                  "max_iterations": int(its.max())})
+        dev.free()
+
+
+def bench_turbo(lib, scale, which):
+    import warnings
+    from commpy_amd.channelcoding import RandInterlv, Trellis, turbo_encode
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tr = Trellis(np.array([2]), np.array([[1, 7]]), 5, "rsc")
+    N, B = 1024, int(16384 * scale)
+    il = RandInterlv(N, 1234)
+    rs = np.random.RandomState(20)
+    msgs = rs.randint(0, 2, (16, N))
+    enc = [turbo_encode(m, tr, tr, il) for m in msgs]
+    rep = B // 16
+    s, p1, p2 = (np.tile(np.stack([e[i][:N] for e in enc]), (rep, 1)) * 2.0 - 1 for i in range(3))
+    nv = 1 / (2 * (1.0 / 3) * 10 ** (1.5 / 10.0))
+    nrs = np.random.RandomState(21)
+    s, p1, p2 = (a + np.sqrt(nv) * nrs.randn(B, N) for a in (s, p1, p2))
+    dev = Dev(lib)
+    d_s, d_p1, d_p2 = dev.put(s), dev.put(p1), dev.put(p2)
+    d_perm = dev.put(np.asarray(il.p_array, dtype=np.int32))
+    d_bits = dev.empty(B * N)
+    d_L = dev.empty(B * N * 8)
+    d_zero = dev.put(np.zeros((B, N)))
+    h = tr._device_handle()
+    if "turbo" in which:
+        ms, _ = timeit(lib, lambda: _lib.check(lib.cpx_turbo_decode_batch_dev(h, d_s, d_p1, d_p2, None, d_perm, B, N, nv, 6,
+                                                                             d_bits, None)), steps=3)
+        bits = dev.get(d_bits, (B, N), np.uint8)
+        emit("turbo_decode_kernel", "rate-1/3 4-state RSC, N=1024, 6 iterations, Eb/N0=1.5 dB, B=%d" % B, B * N,
+             "info-bits", ms, B * 25600, "latency/valu", {"ber": float(np.mean(bits != np.tile(msgs, (rep, 1))))})
+    if "map" in which:
+        ms, _ = timeit(lib, lambda: _lib.check(lib.cpx_map_decode_batch_dev(h, d_s, d_p1, d_zero, B, N, nv, 1, d_L, d_bits,
+                                                                           None)), steps=3)
+        emit("map_decode_kernel", "one MAP pass, 4-state RSC, N=1024, B=%d" % B, B * N, "info-bits", ms, B * 33792,
+             "latency/valu")
+    dev.free()
+
+
+def bench_viterbi_small(lib, scale):
+    from commpy_amd.channelcoding import Trellis, conv_encode_batch
+    tr = Trellis(np.array([2]), np.array([[5, 7]]))
+    B = int((1 << 20) * scale)
+    rs = np.random.RandomState(1)
+    coded = conv_encode_batch(rs.randint(0, 2, (B, 64)), tr).astype(np.float64)
+    rx = np.where(rs.rand(*coded.shape) <= 0.05, 1 - coded, coded)
+    dev = Dev(lib)
+    d_in, d_out = dev.put(rx), dev.empty(B * 66)
+    h = tr._device_handle()
+    ms, _ = timeit(lib, lambda: _lib.check(lib.cpx_viterbi_decode_batch_dev(h, d_in, B, 132, 66, 67, 10, 0, d_out, None)))
+    emit("viterbi_wave_kernel<2,2,true,2>", "config 1: K=3 [[5,7]] 64-bit blocks, hard/BSC(0.05), B=%d" % B, B * 64,
+         "info-bits", ms, B * (132 * 8 + 66), "valu")
+    dev.free()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--which", default="demod,ldpc,turbo,map,viterbi_small")
+    ap.add_argument("--scale", type=float, default=1.0)
+    a = ap.parse_args()
+    lib = _lib.load()
+    _lib.require_device()
+    which = a.which.split(",")
+    if "demod" in which:
+        bench_demod(lib, a.scale)
+    if "viterbi_small" in which:
+        bench_viterbi_small(lib, a.scale)
+    if "turbo" in which or "map" in which:
+        bench_turbo(lib, a.scale, which)
+    if "ldpc" in which:
+        bench_ldpc(lib, a.scale)
+
+
+if __name__ == "__main__":
+    main()

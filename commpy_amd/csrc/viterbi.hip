@@ -346,6 +346,134 @@ __global__ __launch_bounds__(64) void viterbi_wave_kernel(VitParams p) {
     }
 }
 
+// ---- S > 64 (total_memory 7: 128 states): SPL = S/64 states per lane, one codeword per wavefront ----
+// State q*64 + lane lives in register q of that lane.  Predecessor metrics go through a small LDS
+// buffer (write all S metrics, read the I predecessors by address) instead of shuffles; everything
+// else (branch-metric table, decision ring, sliding traceback, first-argmin rule) is as above.
+// Table-driven traceback only.  The reference cannot build larger trellises (Trellis overflows int8
+// for total_memory >= 8 on NumPy 2), so 128 states is the practical maximum.
+template <int SPL, int I_T>
+__global__ __launch_bounds__(64) void viterbi_wide_kernel(VitParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int PL = (I_T == 2) ? 1 : 2;
+    constexpr int S = 64 * SPL, CH = 64;
+    const int lane = threadIdx.x;
+    const int n = p.n, NC = p.NC, k = p.k, RM = p.RS - 1;
+
+    double *bm = reinterpret_cast<double *>(smem);                                   // [64][NC]
+    double *pmbuf = bm + 64 * NC;                                                    // [S]
+    unsigned long long *dring = reinterpret_cast<unsigned long long *>(pmbuf + S);   // [RS][PL][SPL]
+    unsigned short *ptab = reinterpret_cast<unsigned short *>(dring + (size_t)p.RS * PL * SPL);   // [S*I]
+    unsigned char *bring = reinterpret_cast<unsigned char *>(ptab + S * I_T);        // [RS]
+
+    const int64_t cw = blockIdx.x;
+    const double *x = p.coded + cw * p.len;
+    int pst[SPL][I_T], pcode[SPL][I_T];
+#pragma unroll
+    for (int q = 0; q < SPL; q++)
+#pragma unroll
+        for (int j = 0; j < I_T; j++) {
+            pst[q][j] = p.pred_state[(q * 64 + lane) * I_T + j];
+            pcode[q][j] = p.pred_code[(q * 64 + lane) * I_T + j];
+        }
+    for (int idx = lane; idx < S * I_T; idx += 64)
+        ptab[idx] = (unsigned short)(p.pred_state[idx] | (p.pred_input[idx] << 8));
+    double pm[SPL];
+#pragma unroll
+    for (int q = 0; q < SPL; q++) pm[q] = (q == 0 && lane == 0) ? 0.0 : __builtin_huge_val();
+    int64_t next_out = 1;
+
+    for (int64_t t_base = 1; t_base <= p.T; t_base += CH) {
+        {   // branch-metric table: lane i prepares step t_base + i
+            const int64_t t = t_base + lane;
+            const bool have = (t <= p.Lk) && (t <= p.T);
+            double m0[CPX_MAX_N], m1[CPX_MAX_N];
+#pragma unroll
+            for (int j = 0; j < CPX_MAX_N; j++) {
+                double r = (p.type == CPX_VIT_UNQUANTIZED) ? -1.0 : 0.0;
+                if (have && j < n) r = x[(t - 1) * n + j];
+                if (p.type == CPX_VIT_SOFT) r = fmin(fmax(r, -500.0), 500.0);
+                m0[j] = 0.0; m1[j] = 0.0;
+                if (j < n) bit_metrics(p.type, r, m0[j], m1[j]);
+            }
+            for (int c = 0; c < NC; c++) {
+                double acc = 0.0;
+#pragma unroll
+                for (int j = 0; j < CPX_MAX_N; j++)
+                    if (j < n) acc += ((c >> (n - 1 - j)) & 1) ? m1[j] : m0[j];
+                bm[lane * NC + c] = acc;
+            }
+        }
+        __syncthreads();
+        const int nsteps = (int)((p.T - t_base + 1 < CH) ? (p.T - t_base + 1) : CH);
+        for (int i = 0; i < nsteps; i++) {
+            const int64_t t = t_base + i;
+            const double *row = bm + i * NC;
+#pragma unroll
+            for (int q = 0; q < SPL; q++) pmbuf[q * 64 + lane] = pm[q];
+            __syncthreads();
+            unsigned long long w[SPL][2];
+#pragma unroll
+            for (int q = 0; q < SPL; q++) {
+                double best = pmbuf[pst[q][0]] + row[pcode[q][0]];
+                int jb = 0;
+#pragma unroll
+                for (int j = 1; j < I_T; j++) {
+                    const double c = pmbuf[pst[q][j]] + row[pcode[q][j]];
+                    if (c < best) { best = c; jb = j; }                        // first minimum wins
+                }
+                pm[q] = best;
+                w[q][0] = __ballot(jb & 1);
+                w[q][1] = (PL == 2) ? __ballot(jb & 2) : 0ull;
+            }
+            double mn = pm[0];
+#pragma unroll
+            for (int q = 1; q < SPL; q++) mn = (pm[q] < mn) ? pm[q] : mn;
+            mn = group_min<6>(mn);
+            int bst = -1;
+#pragma unroll
+            for (int q = 0; q < SPL; q++) {
+                const unsigned long long eq = __ballot(pm[q] == mn);
+                if (bst < 0 && eq) bst = q * 64 + __ffsll((long long)eq) - 1;   // lowest state index among ties
+            }
+            const int slot = (int)(t & RM);
+            if (lane == 0) {
+#pragma unroll
+                for (int q = 0; q < SPL; q++) {
+                    dring[(slot * PL) * SPL + q] = w[q][0];
+                    if (PL == 2) dring[(slot * PL + 1) * SPL + q] = w[q][1];
+                }
+                bring[slot] = (unsigned char)(bst < 0 ? 0 : bst);
+            }
+            __syncthreads();
+        }
+        const int64_t t_done = t_base + nsteps - 1;
+        const int64_t s_hi = (t_done >= p.T) ? p.T : (t_done - p.tb + 2);
+        auto decision = [&](int64_t tt, int st) {
+            const int slot = (int)(tt & RM);
+            int j = (int)((dring[(slot * PL) * SPL + (st >> 6)] >> (st & 63)) & 1ull);
+            if (PL == 2) j |= (int)((dring[(slot * PL + 1) * SPL + (st >> 6)] >> (st & 63)) & 1ull) << 1;
+            return j;
+        };
+        while (next_out <= s_hi) {
+            const int64_t so = next_out + lane;
+            if (so <= s_hi) {
+                int64_t t0 = so + p.tb - 2;
+                if (t0 > p.T) t0 = p.T;
+                int st = bring[(int)(t0 & RM)];
+                for (int64_t tt = t0; tt > so; --tt) st = ptab[st * I_T + decision(tt, st)] & 0xff;
+                const int sym = ptab[st * I_T + decision(so, st)] >> 8;
+                for (int b = 0; b < k; b++) {
+                    const int64_t pos = (so - 1) * k + b;
+                    if (pos < p.L) p.bits[cw * p.L + pos] = (uint8_t)((sym >> (k - 1 - b)) & 1);
+                }
+            }
+            next_out = (next_out + CH <= s_hi + 1) ? next_out + CH : s_hi + 1;
+        }
+        __syncthreads();
+    }
+}
+
 int next_pow2(int v) {
     int r = 1;
     while (r < v) r <<= 1;
@@ -426,7 +554,7 @@ int cpx_viterbi_decode_batch_dev(const cpx_trellis *t, const double *d_coded, in
     CPX_REQUIRE((L / t->k) * (int64_t)t->n <= len, CPX_EINVAL, "viterbi: L inconsistent with len");
     CPX_REQUIRE(t->I == 2 || t->I == 4, CPX_ELIMIT, "viterbi: trellis with %d inputs per step not supported (k <= 2)", t->I);
     CPX_REQUIRE(t->n <= CPX_MAX_N, CPX_ELIMIT, "viterbi: n = %d > %d not supported", t->n, CPX_MAX_N);
-    CPX_REQUIRE(t->S >= 2 && t->S <= 64, CPX_ELIMIT, "viterbi: %d states not supported yet (2..64)", t->S);
+    CPX_REQUIRE(t->S >= 2 && t->S <= 128, CPX_ELIMIT, "viterbi: %d states not supported (2..128)", t->S);
     if (B == 0 || L == 0) return CPX_OK;
     hipStream_t st = pick_stream(stream);
     if (n_steps <= 0 || n_steps * t->k < L) CPX_HIP(hipMemsetAsync(d_bits, 0, (size_t)(B * L), st));
@@ -440,7 +568,20 @@ int cpx_viterbi_decode_batch_dev(const cpx_trellis *t, const double *d_coded, in
     int lgS = 0;
     while ((1 << lgS) < t->S) lgS++;
     p.lgS = lgS;
-    const int S = t->S, G = 64 / S, CH = S, PL = (t->I == 2) ? 1 : 2;
+    const int PL = (t->I == 2) ? 1 : 2;
+    if (t->S > 64) {                                             // 128 states: two states per lane
+        const int SPL = t->S / 64;
+        p.RS = next_pow2(64 + tb_depth);
+        size_t ldsw = sizeof(double) * 64 * p.NC + sizeof(double) * t->S + sizeof(unsigned long long) * p.RS * PL * SPL +
+                      sizeof(unsigned short) * t->S * t->I + (size_t)p.RS;
+        CPX_REQUIRE(ldsw <= 64 * 1024, CPX_ELIMIT, "viterbi: tb_depth %d needs %zu B of LDS (> 64 KiB)", tb_depth, ldsw);
+        CPX_REQUIRE(B < (1ll << 31), CPX_ELIMIT, "viterbi: batch too large");
+        if (t->I == 2) hipLaunchKernelGGL((viterbi_wide_kernel<2, 2>), dim3((unsigned)B), dim3(64), ldsw, st, p);
+        else hipLaunchKernelGGL((viterbi_wide_kernel<2, 4>), dim3((unsigned)B), dim3(64), ldsw, st, p);
+        CPX_HIP(hipGetLastError());
+        return CPX_OK;
+    }
+    const int S = t->S, G = 64 / S, CH = S;
     p.RS = next_pow2(CH + tb_depth);
     size_t lds = sizeof(double) * 64 * p.NC + sizeof(unsigned long long) * p.RS * PL + sizeof(unsigned short) * S * t->I +
                  (size_t)p.RS * G;
