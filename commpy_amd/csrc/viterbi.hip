@@ -9,8 +9,10 @@
 //
 // Mapping (wave64):
 //   lane = g*S + s : codeword slot g (G = 64/S slots per wave), trellis state s.
-//   * path metric of state s lives in one VGPR pair of lane s; predecessors are fetched with
-//     wavefront shuffles (ds_bpermute), no LDS round trip for the ACS recursion;
+//   * path metric of state s lives in one VGPR pair of lane s; the predecessors' metrics are
+//     exchanged across lanes through a 512-byte LDS buffer (ds_write_b64 + one ds_read_b128 per
+//     step; measured 2.4x cheaper on the LDS pipe than the four ds_bpermute_b32 of a float64
+//     shuffle pair, which bounded the first versions of this kernel);
 //   * branch metrics: per chunk of CH = S steps, lane (g,i) loads the n received values of step
 //     t_base+i (coalesced, prefetched one chunk ahead), evaluates the reference's per-bit metrics
 //     once and writes the 2^n codeword metrics of that step to LDS; the ACS lanes read them back
@@ -173,7 +175,8 @@ __global__ __launch_bounds__(64) void viterbi_wave_kernel(VitParams p) {
     const int g = lane >> LGS, s = lane & (S - 1);
 
     double *bm = reinterpret_cast<double *>(smem);                              // [64][NC]
-    unsigned long long *dring = reinterpret_cast<unsigned long long *>(bm + 64 * NC);  // [RS][PL]
+    double *pmbuf = bm + 64 * NC;                                               // [64] path metrics of the previous step
+    unsigned long long *dring = reinterpret_cast<unsigned long long *>(pmbuf + 64);    // [RS][PL]
     unsigned short *ptab = reinterpret_cast<unsigned short *>(dring + (size_t)p.RS * PL);  // [S*I]
     unsigned char *bring = reinterpret_cast<unsigned char *>(ptab + S * I_T);   // [RS][G]
 
@@ -181,12 +184,17 @@ __global__ __launch_bounds__(64) void viterbi_wave_kernel(VitParams p) {
     const bool valid_cw = cw < p.B;
     const double *x = p.coded + (valid_cw ? cw : 0) * p.len;
 
-    int paddr[I_T], pcode[I_T];                              // predecessor lane byte address / branch codeword
+    // Predecessor metrics are exchanged through a 512-byte LDS buffer (one ds_write_b64 + ONE ds_read_b128
+    // per step for shift-register trellises, whose two predecessors 2*(s mod S/2), +1 are adjacent):
+    // 10 LDS cycles per step against 24 for the four ds_bpermute_b32 of a float64 shuffle pair
+    // (measured 6.1 cycles per ds_bpermute_b32 per CU on MI355X, scripts/micro/bperm_bench.hip).
+    int pidx[I_T], pcode[I_T];                               // predecessor slot in pmbuf / branch codeword
 #pragma unroll
     for (int j = 0; j < I_T; j++) {
-        paddr[j] = ((g << LGS) + p.pred_state[s * I_T + j]) << 2;
+        pidx[j] = (g << LGS) + p.pred_state[s * I_T + j];
         pcode[j] = p.pred_code[s * I_T + j];
     }
+    const double2 *ppair = reinterpret_cast<const double2 *>(pmbuf + (g << LGS) + 2 * (s & (S / 2 - 1)));
     if (!SR)
         for (int idx = lane; idx < S * I_T; idx += 64)
             ptab[idx] = (unsigned short)(p.pred_state[idx] | (p.pred_input[idx] << 8));
@@ -241,23 +249,35 @@ __global__ __launch_bounds__(64) void viterbi_wave_kernel(VitParams p) {
         // one ACS step: updates pm, returns the decision ballot(s)
         auto acs = [&](int i, unsigned long long &w0, unsigned long long &w1) {
             const double *row = rowbase + i * NC;
-            double best = bperm_f64(pm, paddr[0]) + row[pcode[0]];        // pmetrics[0] (:629)
+            pmbuf[lane] = pm;                                              // LDS ops of one wave execute in order:
+            asm volatile("" ::: "memory");                                 // the reads below see this step's metrics
+            double best;
             w1 = 0;
             if (I_T == 2) {
-                const double c1 = bperm_f64(pm, paddr[1]) + row[pcode[1]];
+                double a0, a1;
+                if (SR) {
+                    const double2 pp = *ppair;                             // both predecessors in one ds_read_b128
+                    a0 = pp.x; a1 = pp.y;
+                } else {
+                    a0 = pmbuf[pidx[0]]; a1 = pmbuf[pidx[1]];
+                }
+                best = a0 + row[pcode[0]];                                 // pmetrics[0] (:629)
+                const double c1 = a1 + row[pcode[1]];
                 const bool d = c1 < best;                                  // first minimum wins (:633-642)
                 best = d ? c1 : best;
                 w0 = __ballot(d);
             } else {
+                best = pmbuf[pidx[0]] + row[pcode[0]];
                 int jb = 0;
 #pragma unroll
                 for (int j = 1; j < I_T; j++) {
-                    const double c = bperm_f64(pm, paddr[j]) + row[pcode[j]];
+                    const double c = pmbuf[pidx[j]] + row[pcode[j]];
                     if (c < best) { best = c; jb = j; }
                 }
                 w0 = __ballot(jb & 1);
                 w1 = __ballot(jb & 2);
             }
+            asm volatile("" ::: "memory");
             pm = best;
         };
         if constexpr (LGS == 6) {
@@ -269,7 +289,7 @@ __global__ __launch_bounds__(64) void viterbi_wave_kernel(VitParams p) {
                 for (int u = 0; u < 8; u++) {
                     unsigned long long w0, w1;
                     acs(i0 + u, w0, w1);
-                    const bool mine = (s == i0 + u);
+                    const bool mine = (s == i0 + u);         // (a v_writelane staging was measured: same speed)
                     mydec0 = mine ? w0 : mydec0;
                     if (PL == 2) mydec1 = mine ? w1 : mydec1;
                     hist[u] = pm;
@@ -583,8 +603,8 @@ int cpx_viterbi_decode_batch_dev(const cpx_trellis *t, const double *d_coded, in
     }
     const int S = t->S, G = 64 / S, CH = S;
     p.RS = next_pow2(CH + tb_depth);
-    size_t lds = sizeof(double) * 64 * p.NC + sizeof(unsigned long long) * p.RS * PL + sizeof(unsigned short) * S * t->I +
-                 (size_t)p.RS * G;
+    size_t lds = sizeof(double) * 64 * p.NC + sizeof(double) * 64 + sizeof(unsigned long long) * p.RS * PL +
+                 sizeof(unsigned short) * S * t->I + (size_t)p.RS * G;
     CPX_REQUIRE(lds <= 64 * 1024, CPX_ELIMIT, "viterbi: tb_depth %d needs %zu B of LDS (> 64 KiB)", tb_depth, lds);
     const int64_t nblocks = (B + G - 1) / G;
     CPX_REQUIRE(nblocks < (1ll << 31), CPX_ELIMIT, "viterbi: batch too large");
