@@ -1,0 +1,112 @@
+"""Flat SISO channel models used to drive the decoders (host side, NumPy RNG).
+
+Mirrors the part of /root/reference/commpy/channels.py the decoding path uses:
+``SISOFlatChannel`` (channels.py:99-240, with ``_FlatChannel.set_SNR_dB`` :57-74 and
+``generate_noises`` :37-55) and the ``bec`` / ``bsc`` / ``awgn`` helpers (:630-708).
+MIMO channels are out of scope.  ``propagate`` also accepts a 2-D
+``[batch, nsym]`` message so that a whole Monte-Carlo batch is generated at once.
+
+Kept quirk B7: for a complex channel the generated noise is
+``(randn + 1j*randn) * noise_std * 0.5`` (channels.py:53) while receivers are told
+``noise_std**2`` (links.py:242-243).
+"""
+from numpy import abs, absolute, asarray, isrealobj, sqrt, where, zeros
+from numpy.random import randn, random, standard_normal
+
+__all__ = ['SISOFlatChannel', 'bec', 'bsc', 'awgn']
+
+
+class SISOFlatChannel:
+    """AWGN / Rice / Rayleigh flat SISO channel -- same constructor and attributes as channels.py:99."""
+
+    def __init__(self, noise_std=None, fading_param=(1, 0)):
+        self.noises = None
+        self.channel_gains = None
+        self.unnoisy_output = None
+        self.noise_std = noise_std
+        self.fading_param = fading_param
+
+    @property
+    def nb_tx(self):
+        return 1
+
+    @property
+    def nb_rx(self):
+        return 1
+
+    @property
+    def isComplex(self):
+        return self._isComplex
+
+    @property
+    def fading_param(self):
+        return self._fading_param
+
+    @fading_param.setter
+    def fading_param(self, fading_param):
+        if fading_param[1] + absolute(fading_param[0]) ** 2 != 1:
+            raise ValueError("With this parameters, the channel would add or remove energy.")
+        self._fading_param = fading_param
+        self._isComplex = isinstance(fading_param[0], complex)
+
+    @property
+    def k_factor(self):
+        return absolute(self.fading_param[0]) ** 2 / absolute(self.fading_param[1])
+
+    def set_SNR_dB(self, SNR_dB, code_rate=1., Es=1):
+        """noise_std = sqrt((isComplex + 1) * nb_tx * Es / (code_rate * 10^(SNR/10)))  (channels.py:74)."""
+        self.noise_std = sqrt((self.isComplex + 1) * self.nb_tx * Es / (code_rate * 10 ** (SNR_dB / 10)))
+
+    def set_SNR_lin(self, SNR_lin, code_rate=1, Es=1):
+        self.noise_std = sqrt((self.isComplex + 1) * self.nb_tx * Es / (code_rate * SNR_lin))
+
+    def generate_noises(self, dims):
+        assert self.noise_std is not None, "Noise standard deviation must be set before propagation."
+        if self.isComplex:
+            self.noises = (standard_normal(dims) + 1j * standard_normal(dims)) * self.noise_std * 0.5
+        else:
+            self.noises = standard_normal(dims) * self.noise_std
+
+    def propagate(self, msg):
+        """Fading + noise (channels.py:181-221); ``msg`` may be 1-D or ``[batch, nsym]``."""
+        msg = asarray(msg)
+        if not isrealobj(msg) and not self.isComplex:
+            raise TypeError('Trying to propagate a complex message in a real channel.')
+        dims = msg.shape
+        self.generate_noises(dims)
+        self.channel_gains = self.fading_param[0]
+        if self.isComplex:
+            self.channel_gains = self.channel_gains + (standard_normal(dims) + 1j * standard_normal(dims)) * \
+                sqrt(0.5 * self.fading_param[1])
+        else:
+            self.channel_gains = self.channel_gains + standard_normal(dims) * sqrt(self.fading_param[1])
+        self.unnoisy_output = self.channel_gains * msg
+        return self.unnoisy_output + self.noises
+
+
+def bec(input_bits, p_e):
+    """Binary erasure channel: erased bits become -1 (channels.py:630-649)."""
+    output_bits = asarray(input_bits).copy()
+    output_bits[random(len(output_bits)) <= p_e] = -1
+    return output_bits
+
+
+def bsc(input_bits, p_t):
+    """Binary symmetric channel (channels.py:652-673)."""
+    output_bits = asarray(input_bits).copy()
+    flip_locs = (random(len(output_bits)) <= p_t)
+    output_bits[flip_locs] = 1 ^ output_bits[flip_locs]
+    return output_bits
+
+
+def awgn(input_signal, snr_dB, rate=1.0):
+    """Add white Gaussian noise at the given SNR (dB) (channels.py:676-708)."""
+    input_signal = asarray(input_signal)
+    avg_energy = sum(abs(input_signal) * abs(input_signal)) / len(input_signal)
+    snr_linear = 10 ** (snr_dB / 10.0)
+    noise_variance = avg_energy / (2 * rate * snr_linear)
+    if not isrealobj(input_signal):
+        noise = (sqrt(noise_variance) * randn(len(input_signal))) + (sqrt(noise_variance) * randn(len(input_signal)) * 1j)
+    else:
+        noise = sqrt(2 * noise_variance) * randn(len(input_signal))      # real signal: full variance on one axis (:703)
+    return input_signal + noise

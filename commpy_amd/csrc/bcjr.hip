@@ -2,28 +2,42 @@
 //   map_decode    (/root/reference/commpy/channelcoding/turbo.py:163-251)
 //     _backward_recursion (:78-111), _forward_recursion_decoding (:114-158), _compute_branch_prob (:62-76)
 //   turbo_decode  (turbo.py:254-333) with interlv/deinterlv (interleavers.py:13-47)
-// Probability-domain recursions with per-step sum-normalisation, float64, exactly the reference's
-// formulas (no log-MAP): gamma = exp(-((r0-c0)^2+(r1-c1)^2)/(2*nv)), priors p0 = 1/(1+e^L), p1 = 1-p0,
-// beta_N = 1 (unterminated), alpha_0 = delta(state 0), L = L_int + log(app1/app0) (app without prior).
+// Probability-domain recursions, float64, the reference's formulas (no log-MAP):
+//   gamma = exp(-((r0-c0)^2+(r1-c1)^2)/(2*nv)), priors p0 = 1/(1+e^L), p1 = 1-p0, beta_N = 1 (unterminated),
+//   alpha_0 = delta(state 0), L = L_int + log(app1/app0) (app without prior).
 //
 // Mapping (wave64): lane = g*S + s -- G = 64/S codewords per wavefront, one trellis state per lane.
-//   * alpha / beta live in one VGPR pair per lane; neighbours (next states for beta, predecessors for
-//     alpha) are fetched with wavefront shuffles; the sums over states (normalisation, app) are
-//     xor-butterfly shuffle reductions inside the S-lane group;
-//   * the 4 distinct branch probabilities of a step are computed once per group (lane s evaluates
-//     code s&3) and shared by shuffle, so a step costs ONE exp per lane;
-//   * priors are evaluated time-parallel (64 lanes over t) before the recursions;
-//   * beta[t][s] (needed again by the forward pass) and the per-iteration L arrays of the turbo
-//     loop stay in a per-codeword HBM scratch slab (L2/MALL resident at these sizes); the whole
-//     iteration loop of turbo_decode runs inside ONE kernel launch, the interleaver being a
-//     gather/scatter through that slab.
-// Summation inside a group uses a butterfly instead of the reference's sequential order: the
-// difference is O(1e-16) relative, far inside the 1e-5 parity tolerance for soft outputs.
+// Time is processed in chunks of CH steps; every chunk has
+//   (1) a TIME-PARALLEL stage: the 64 lanes load the chunk's received values (coalesced segments), evaluate
+//       the four distinct branch probabilities and the prior of every (codeword, step) pair -- all the exp()
+//       work, off the serial chain -- and park them in LDS;
+//   (2) the SERIAL recursion over the chunk: alpha/beta of a state live in one VGPR pair of its lane, the
+//       neighbours' values are exchanged through a 512-byte LDS buffer (cheaper than ds_bpermute for
+//       float64, see viterbi.hip), sums over the states of a codeword are DPP butterflies (no LDS).
+// With one wavefront per SIMD (B = 16384 codewords fill the chip exactly once) the recursion is bound by the
+// LATENCY of its dependent chain, so everything that is not alpha/beta itself is moved off it:
+//   * the sum-normalisation of the reference (turbo.py:110-111, :155-158) is applied every KNORM = 4 steps
+//     instead of every step (a common positive factor per time step cancels in app1/app0 and in every later
+//     normalisation: LLRs differ from the reference's only by rounding, measured <= 1e-13; tolerance 1e-5);
+//   * for 4-state trellises the neighbour exchange is 4 quad-broadcast DPP moves + per-lane selects (depth ~25
+//     cycles) instead of an LDS round trip (~130 cycles);
+//   * the a-posteriori sums are not reduced in the loop: every lane parks its two branch products in LDS and the
+//     time-parallel epilogue of the chunk adds them, divides and takes the log;
+//   * received values of the NEXT chunk are prefetched into registers before the serial loop of the current one.
+// beta is CHECKPOINTED, not stored: the backward pass keeps beta only at chunk boundaries ([chunk][lane] rows in
+// an HBM slab, 1/16 of the per-step traffic that made the first version HBM-bound); the forward pass recomputes
+// the chunk's beta rows into LDS from the checkpoint with the same operations in the same order (bit-identical),
+// then runs alpha over the chunk.
+// Butterfly / epilogue sums differ from the reference's sequential order by O(1e-16) relative.
+// LLRs of a chunk are staged in LDS, log() evaluated time-parallel, and written back as coalesced segments.  turbo_decode runs its whole iteration loop inside ONE launch; the
+// interleaver is a gather/scatter through per-codeword L arrays in the slab.
 #include "cpx_internal.h"
 
 using namespace cpx;
 
 namespace {
+
+constexpr int MAXCH = 16;      // steps per chunk (upper bound; keeps LDS <= 37 KiB per wave)
 
 struct MapTables {
     const int32_t *next_state, *output;                       // [S][2]
@@ -31,129 +45,235 @@ struct MapTables {
     int lgS, n;
 };
 
-struct LaneCtx {
-    int lane, lgS, S, G, g, s, gbase;
-    int nxt[2], code[2];         // outgoing branches of state s: next-state lane, 2-bit code (sys,parity)
-    int plane[2], pin[2], pcode[2];  // incoming branches in np.where order: predecessor lane, input, code
-};
+template <int CTRL>
+__device__ __forceinline__ double dppd(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
 
-__device__ __forceinline__ double shf(double v, int src) { return __shfl(v, src, 64); }
-
-__device__ __forceinline__ double group_sum(double v, int S) {
-    for (int off = 1; off < S; off <<= 1) v += __shfl_xor(v, off, 64);
+// all-reduce sum inside aligned groups of 2^LGS lanes (LGS <= 4: DPP only)
+template <int LGS>
+__device__ __forceinline__ double group_sum(double v) {
+    if (LGS >= 1) v += dppd<0xB1>(v);     // quad_perm [1,0,3,2]
+    if (LGS >= 2) v += dppd<0x4E>(v);     // quad_perm [2,3,0,1]
+    if (LGS >= 3) v += dppd<0x141>(v);    // row_half_mirror
+    if (LGS >= 4) v += dppd<0x140>(v);    // row_mirror
     return v;
 }
 
-__device__ __forceinline__ void init_ctx(LaneCtx &c, const MapTables &tb) {
+template <int LGS>
+struct Ctx {
+    static constexpr int S = 1 << LGS, G = 64 >> LGS;
+    static constexpr int CH = (256 / G) < MAXCH ? (256 / G) : MAXCH;   // CH * G <= 256 items per chunk
+    static constexpr int NI = CH * G / 64;                             // (codeword, step) items per lane: 4, 4, 2, 1
+    int lane, g, s;
+    int nxt[2], code[2];              // outgoing branches of state s: next-state lane, 2-bit code (sys, parity)
+    int plane[2], pin[2], pcode[2];   // incoming branches in np.where order: predecessor lane, input, code
+    // LDS carve-up
+    double *gam;    // [CH][G][4]
+    double *pr0;    // [CH][G]
+    double *lin;    // [CH][G]   L_int of the chunk
+    double *xs;     // [CH][64][2] per-lane branch products a*gamma*beta of the chunk (forward pass)
+    double *bt;     // [CH][64]  beta rows of the chunk (forward pass)
+    double *xch;    // [64]      exchange buffer
+};
+
+template <int LGS>
+__device__ __forceinline__ void init_ctx(Ctx<LGS> &c, const MapTables &tb, unsigned char *smem) {
+    constexpr int S = Ctx<LGS>::S, G = Ctx<LGS>::G, CH = Ctx<LGS>::CH;
     c.lane = threadIdx.x;
-    c.lgS = tb.lgS;
-    c.S = 1 << tb.lgS;
-    c.G = 64 >> tb.lgS;
-    c.g = c.lane >> tb.lgS;
-    c.s = c.lane & (c.S - 1);
-    c.gbase = c.g << tb.lgS;
-    const int sh = tb.n - 2;
+    c.g = c.lane >> LGS;
+    c.s = c.lane & (S - 1);
+    const int gbase = c.g << LGS, sh = tb.n - 2;
     for (int i = 0; i < 2; i++) {
-        c.nxt[i] = c.gbase + tb.next_state[c.s * 2 + i];
+        c.nxt[i] = gbase + tb.next_state[c.s * 2 + i];
         c.code[i] = (tb.output[c.s * 2 + i] >> sh) & 3;       // [msg_bit, parity_bit] = codeword_array[0:2] (:96-98)
-        c.plane[i] = c.gbase + tb.pred_state[c.s * 2 + i];
+        c.plane[i] = gbase + tb.pred_state[c.s * 2 + i];
         c.pin[i] = tb.pred_input[c.s * 2 + i];
         c.pcode[i] = (tb.pred_code[c.s * 2 + i] >> sh) & 3;
     }
+    double *p = reinterpret_cast<double *>(smem);
+    c.gam = p; p += CH * G * 4;
+    c.pr0 = p; p += CH * G;
+    c.lin = p; p += CH * G;
+    c.xs = p;  p += CH * 64 * 2;
+    c.bt = p;  p += CH * 64;
+    c.xch = p;
 }
 
-// branch probability of 2-bit code `code` (:62-76)
-__device__ __forceinline__ double branch_prob(int code, double r0, double r1, double nv2) {
-    const double c0 = (double)(2 * ((code >> 1) & 1) - 1);
-    const double c1 = (double)(2 * (code & 1) - 1);
-    const double x = r0 - c0, y = r1 - c1;
-    return exp(-(x * x + y * y) / nv2);
+template <int LGS>
+constexpr size_t lds_bytes() {
+    return sizeof(double) * (Ctx<LGS>::CH * Ctx<LGS>::G * 6 + Ctx<LGS>::CH * 64 * 3 + 64);
 }
 
-// gamma of the two branches `codeA`, `codeB` needed by this lane; shared through the group when S >= 4.
-__device__ __forceinline__ void gammas(const LaneCtx &c, double r0, double r1, double nv2, int codeA, int codeB,
-                                       double &gA, double &gB) {
-    if (c.S >= 4) {
-        const double mine = branch_prob(c.s & 3, r0, r1, nv2);
-        gA = shf(mine, c.gbase + codeA);
-        gB = shf(mine, c.gbase + codeB);
+constexpr int KNORM = 4;       // renormalise alpha / beta every KNORM steps
+
+// value of `v` in lane (quad base + idx), idx in 0..3 per lane: 4 quad broadcasts + selects (no LDS)
+__device__ __forceinline__ double quad_fetch(double v, int idx) {
+    const double q0 = dppd<0x00>(v), q1 = dppd<0x55>(v), q2 = dppd<0xAA>(v), q3 = dppd<0xFF>(v);
+    const double lo = (idx & 1) ? q1 : q0, hi = (idx & 1) ? q3 : q2;
+    return (idx & 2) ? hi : lo;
+}
+
+// neighbour exchange: values of `v` held by lanes la and lb of the same codeword
+template <int LGS>
+__device__ __forceinline__ void exchange2(const Ctx<LGS> &c, double v, int la, int lb, double &va, double &vb) {
+    if (LGS == 2) {
+        va = quad_fetch(v, la & 3);
+        vb = quad_fetch(v, lb & 3);
     } else {
-        gA = branch_prob(codeA, r0, r1, nv2);
-        gB = branch_prob(codeB, r0, r1, nv2);
+        c.xch[c.lane] = v;
+        asm volatile("" ::: "memory");                            // in-order LDS: the reads below see this step's values
+        va = c.xch[la];
+        vb = c.xch[lb];
+        asm volatile("" ::: "memory");
     }
 }
 
-// One MAP pass over the G codewords of this wavefront.
-//   sys/par/Lin: per-lane base pointers of the lane's codeword (length N); sys is read through
-//   `perm` when sys_perm != nullptr (sys_symbols_i = interlv(sys), turbo.py:310).
-//   pr0/beta: scratch of the lane's codeword: pr0[N], beta[(N+1)*S].
-//   Lout[N] receives L_int + log(app1/app0).
-__device__ void map_pass(const LaneCtx &c, bool valid, int64_t N, double nv2, const double *sys, const int32_t *sys_perm,
-                         const double *par, const double *Lin, double *pr0, double *beta, double *Lout) {
-    const int S = c.S, G = c.G;
-    // ---- priors, time-parallel: lane (g, s) handles t = s, s+S, ... of codeword g (:238-240) ----
-    if (valid)
-        for (int64_t t = c.s; t < N; t += S) pr0[t] = 1.0 / (1.0 + exp(Lin[t]));
-    __syncthreads();
-    // ---- backward recursion (:78-111) ----
-    double b = 1.0;                                              // b_state_metrics[:, N] = 1 (:225)
-    if (valid) beta[N * S + c.s] = b;
-    for (int64_t t = N; t >= 1; --t) {
-        double r0 = 0, r1 = 0, p0 = 0.5;
-        if (valid) {
-            r0 = sys[sys_perm ? sys_perm[t - 1] : (t - 1)];
-            r1 = par[t - 1];
-            p0 = pr0[t - 1];
+// ---- time-parallel stage of a chunk --------------------------------------------------------------------------
+// A chunk has CH*G (codeword, step) items, NI = CH*G/64 per lane: item p = lane + 64*q -> codeword p / CH,
+// step p % CH (consecutive lanes -> consecutive steps of one codeword: coalesced segments).
+struct RawChunk {
+    double r0[4], r1[4], li[4];
+};
+
+template <int LGS>
+__device__ __forceinline__ void load_raw(const Ctx<LGS> &c, RawChunk &rc, int64_t cw0, int64_t B, int64_t N, int64_t t0,
+                                         int len, const double *sys, const int32_t *sys_perm, const double *par,
+                                         const double *Lin, int64_t lstride) {
+    constexpr int CH = Ctx<LGS>::CH;
+#pragma unroll
+    for (int q = 0; q < Ctx<LGS>::NI; q++) {
+        const int p = c.lane + 64 * q, gg = p / CH, tl = p % CH;
+        const int64_t cw = cw0 + gg, t = t0 + tl;                 // 0-based step index
+        rc.r0[q] = 0.0; rc.r1[q] = 0.0; rc.li[q] = 0.0;
+        if (cw < B && tl < len) {
+            rc.r0[q] = sys[cw * N + (sys_perm ? sys_perm[t] : t)];   // sys_symbols_i = interlv(sys) (turbo.py:310)
+            rc.r1[q] = par[cw * N + t];
+            rc.li[q] = Lin[cw * lstride + t];
         }
-        const double p1 = 1.0 - p0;                              // priors[1] = 1 - priors[0] (:240)
-        double g0, g1;
-        gammas(c, r0, r1, nv2, c.code[0], c.code[1], g0, g1);
-        const double bn0 = shf(b, c.nxt[0]), bn1 = shf(b, c.nxt[1]);
+    }
+}
+
+// gam[tl][g][code] (_compute_branch_prob :62-76), pr0[tl][g] (priors[0] :239), lin[tl][g] into LDS
+template <int LGS>
+__device__ __forceinline__ void stage_chunk(const Ctx<LGS> &c, const RawChunk &rc, double nv2) {
+    constexpr int G = Ctx<LGS>::G, CH = Ctx<LGS>::CH;
+#pragma unroll
+    for (int q = 0; q < Ctx<LGS>::NI; q++) {
+        const int p = c.lane + 64 * q, gg = p / CH, tl = p % CH;
+        double *gm = c.gam + (tl * G + gg) * 4;
+#pragma unroll
+        for (int code = 0; code < 4; code++) {
+            const double x = rc.r0[q] - (double)(2 * ((code >> 1) & 1) - 1);
+            const double y = rc.r1[q] - (double)(2 * (code & 1) - 1);
+            gm[code] = exp(-(x * x + y * y) / nv2);
+        }
+        c.pr0[tl * G + gg] = 1.0 / (1.0 + exp(rc.li[q]));
+        c.lin[tl * G + gg] = rc.li[q];
+    }
+}
+
+// Backward recursion over one staged chunk (:78-111): beta of reference time t_lo+tl for tl = len-1 .. 0, starting
+// from `b` = beta at the chunk's upper boundary.  When ROWS, every row is also written to c.bt[tl] (LDS).
+template <int LGS, bool ROWS>
+__device__ __forceinline__ double beta_chunk(const Ctx<LGS> &c, double b, int len) {
+    constexpr int G = Ctx<LGS>::G;
+    if (ROWS && len > 0) c.bt[(len - 1) * 64 + c.lane] = b;       // beta[t_lo + len]: row used by the last step of the chunk
+    for (int tl = len - 1; tl >= 0; --tl) {
+        const double *gm = c.gam + (tl * G + c.g) * 4;
+        const double p0 = c.pr0[tl * G + c.g], p1 = 1.0 - p0;     // priors[1] = 1 - priors[0] (:240)
+        double bn0, bn1;
+        exchange2<LGS>(c, b, c.nxt[0], c.nxt[1], bn0, bn1);
         double nb = 0.0;
-        nb += (bn0 * g0 * p0);                                   // (:106-108), input 0 then input 1
-        nb += (bn1 * g1 * p1);
-        const double sum = group_sum(nb, S);
-        b = nb / sum;                                            // (:110-111)
-        if (valid) beta[(t - 1) * S + c.s] = b;
+        nb += (bn0 * gm[c.code[0]] * p0);                         // (:106-108), input 0 then input 1
+        nb += (bn1 * gm[c.code[1]] * p1);
+        b = nb;
+        if ((tl & (KNORM - 1)) == 0) b = b / group_sum<LGS>(b);   // (:110-111), every KNORM steps
+        if (ROWS && tl > 0) c.bt[(tl - 1) * 64 + c.lane] = b;     // beta[t_lo + tl]: row used by step tl-1
+    }
+    return b;
+}
+
+// One MAP pass over the G codewords of this wavefront.  ckpt: [nchunks + 1][64] beta checkpoints of this wave.
+// Lout (stride lstride per codeword) receives L_int + log(app1/app0).
+template <int LGS>
+__device__ void map_pass(const Ctx<LGS> &c, int64_t cw0, int64_t B, int64_t N, double nv2, const double *sys,
+                         const int32_t *sys_perm, const double *par, const double *Lin, int64_t lstride,
+                         double *ckpt, double *Lout) {
+    constexpr int S = Ctx<LGS>::S, G = Ctx<LGS>::G, CH = Ctx<LGS>::CH;
+    const int64_t nchunks = (N + CH - 1) / CH;
+    RawChunk cur, nxt;
+    // ---------------- backward pass: chunks from the end, checkpoints only ----------------
+    double b = 1.0;                                               // b_state_metrics[:, N] = 1 (:225)
+    ckpt[nchunks * 64 + c.lane] = b;
+    {
+        const int64_t t_lo = (nchunks - 1) * CH;
+        load_raw<LGS>(c, cur, cw0, B, N, t_lo, (int)(N - t_lo), sys, sys_perm, par, Lin, lstride);
+    }
+    for (int64_t k = nchunks - 1; k >= 0; --k) {                  // chunk k = 0-based steps [k*CH, min(N, (k+1)*CH))
+        const int64_t t_lo = k * CH;
+        const int len = (int)((N - t_lo < CH) ? (N - t_lo) : CH);
+        __syncthreads();
+        stage_chunk<LGS>(c, cur, nv2);
+        if (k > 0) load_raw<LGS>(c, nxt, cw0, B, N, t_lo - CH, CH, sys, sys_perm, par, Lin, lstride);   // prefetch
+        __syncthreads();
+        b = beta_chunk<LGS, false>(c, b, len);
+        ckpt[k * 64 + c.lane] = b;                                // beta at the chunk's lower boundary (time t_lo)
+        cur = nxt;
     }
     __syncthreads();
-    // ---- forward recursion + LLR (:114-158) ----
-    double a = (c.s == 0) ? 1.0 : 0.0;                           // f_state_metrics[0][0] = 1 (:221)
-    for (int64_t t = 1; t <= N; ++t) {
-        double r0 = 0, r1 = 0, p0 = 0.5, bt = 1.0, lin = 0.0;
-        if (valid) {
-            r0 = sys[sys_perm ? sys_perm[t - 1] : (t - 1)];
-            r1 = par[t - 1];
-            p0 = pr0[t - 1];
-            bt = beta[t * S + c.s];
-            lin = Lin[t - 1];
+    // ---------------- forward pass: recompute the chunk's beta rows, then alpha + LLR (:114-158) ----------------
+    double a = (c.s == 0) ? 1.0 : 0.0;                            // f_state_metrics[0][0] = 1 (:221)
+    load_raw<LGS>(c, cur, cw0, B, N, 0, (int)((N < CH) ? N : CH), sys, sys_perm, par, Lin, lstride);
+    for (int64_t k = 0; k < nchunks; ++k) {
+        const int64_t t_lo = k * CH;
+        const int len = (int)((N - t_lo < CH) ? (N - t_lo) : CH);
+        __syncthreads();
+        stage_chunk<LGS>(c, cur, nv2);
+        const double bhi = ckpt[(k + 1) * 64 + c.lane];
+        if (k + 1 < nchunks) {
+            const int64_t t2 = t_lo + CH;
+            load_raw<LGS>(c, nxt, cw0, B, N, t2, (int)((N - t2 < CH) ? (N - t2) : CH), sys, sys_perm, par, Lin, lstride);
         }
-        const double p1 = 1.0 - p0;
-        double mine = 0.0, go0, go1, gi0, gi1;
-        if (S >= 4) {
-            mine = branch_prob(c.s & 3, r0, r1, nv2);
-            go0 = shf(mine, c.gbase + c.code[0]);  go1 = shf(mine, c.gbase + c.code[1]);
-            gi0 = shf(mine, c.gbase + c.pcode[0]); gi1 = shf(mine, c.gbase + c.pcode[1]);
-        } else {
-            go0 = branch_prob(c.code[0], r0, r1, nv2);  go1 = branch_prob(c.code[1], r0, r1, nv2);
-            gi0 = branch_prob(c.pcode[0], r0, r1, nv2); gi1 = branch_prob(c.pcode[1], r0, r1, nv2);
+        __syncthreads();
+        (void)beta_chunk<LGS, true>(c, bhi, len);                 // bt[tl] = beta[t_lo + tl + 1], bit-identical to the backward pass
+        __syncthreads();
+        for (int tl = 0; tl < len; tl++) {
+            const double *gm = c.gam + (tl * G + c.g) * 4;
+            const double p0 = c.pr0[tl * G + c.g], p1 = 1.0 - p0;
+            // app[i] += f[cs,0] * branch_prob * b[next_state, t]   (:141-143): products parked, summed in the epilogue
+            double2 xv;
+            xv.x = a * gm[c.code[0]] * c.bt[tl * 64 + c.nxt[0]];
+            xv.y = a * gm[c.code[1]] * c.bt[tl * 64 + c.nxt[1]];
+            *reinterpret_cast<double2 *>(c.xs + (tl * 64 + c.lane) * 2) = xv;
+            // f[next,1] += f[cs,0] * branch_prob * priors[input]     (:136-138), accumulation in (cs, input) order
+            double ap0, ap1;
+            exchange2<LGS>(c, a, c.plane[0], c.plane[1], ap0, ap1);
+            double na = 0.0;
+            na += (ap0 * gm[c.pcode[0]] * (c.pin[0] ? p1 : p0));
+            na += (ap1 * gm[c.pcode[1]] * (c.pin[1] ? p1 : p0));
+            a = na;
+            if ((tl & (KNORM - 1)) == KNORM - 1) a = a / group_sum<LGS>(a);   // (:155-158), every KNORM steps
         }
-        // app[i] += f[cs,0] * branch_prob * b[next_state, t]   (:141-143)
-        const double x0 = a * go0 * shf(bt, c.nxt[0]);
-        const double x1 = a * go1 * shf(bt, c.nxt[1]);
-        const double app0 = group_sum(x0, S), app1 = group_sum(x1, S);
-        const double lappr = lin + log(app1 / app0);             // (:145)
-        if (valid && c.s == 0) Lout[t - 1] = lappr;
-        // f[next,1] += f[cs,0] * branch_prob * priors[input]     (:136-138), accumulation in (cs, input) order
-        const double ap0 = shf(a, c.plane[0]), ap1 = shf(a, c.plane[1]);
-        double na = 0.0;
-        na += (ap0 * gi0 * (c.pin[0] ? p1 : p0));
-        na += (ap1 * gi1 * (c.pin[1] ? p1 : p0));
-        const double sum = group_sum(na, S);
-        a = na / sum;                                            // (:155-158)
+        __syncthreads();
+        // time-parallel epilogue of the chunk: app sums in state order, L = L_int + log(app1/app0) (:145)
+#pragma unroll
+        for (int q = 0; q < Ctx<LGS>::NI; q++) {
+            const int p = c.lane + 64 * q, gg = p / CH, tl = p % CH;
+            const int64_t cw = cw0 + gg;
+            if (cw < B && tl < len) {
+                const double *x = c.xs + (tl * 64 + gg * S) * 2;
+                double app0 = 0.0, app1 = 0.0;
+#pragma unroll
+                for (int st = 0; st < S; st++) { app0 += x[2 * st]; app1 += x[2 * st + 1]; }
+                Lout[cw * lstride + t_lo + tl] = c.lin[tl * G + gg] + log(app1 / app0);
+            }
+        }
+        cur = nxt;
     }
     __syncthreads();
-    (void)G;
 }
 
 struct MapParams {
@@ -161,23 +281,26 @@ struct MapParams {
     const double *sys, *par, *Lin;     // [B][N]
     double *Lout;                      // [B][N]
     uint8_t *bits;                     // [B][N]
-    double *scratch;                   // per codeword: pr0[N] + beta[(N+1)*S]
-    int64_t B, N, slab;
+    double *scratch;                   // per wave: beta checkpoints [nchunks + 1][64]
+    int64_t B, N;
     double nv2;
     int want_bits;
 };
 
+template <int LGS>
 __global__ __launch_bounds__(64) void map_decode_kernel(MapParams p) {
-    LaneCtx c;
-    init_ctx(c, p.tb);
-    const int64_t cw = (int64_t)blockIdx.x * c.G + c.g;
-    const bool valid = cw < p.B;
-    const int64_t o = (valid ? cw : 0) * p.N;
-    double *slab = p.scratch + (valid ? cw : 0) * p.slab;
-    map_pass(c, valid, p.N, p.nv2, p.sys + o, nullptr, p.par + o, p.Lin + o, slab, slab + p.N, p.Lout + o);
-    if (valid)
-        for (int64_t t = c.s; t < p.N; t += c.S)                  // decoded_bits: L > 0 in 'decode' mode only (:148-152)
-            p.bits[o + t] = (uint8_t)((p.want_bits && p.Lout[o + t] > 0) ? 1 : 0);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    Ctx<LGS> c;
+    init_ctx<LGS>(c, p.tb, smem);
+    constexpr int G = Ctx<LGS>::G;
+    const int64_t cw0 = (int64_t)blockIdx.x * G;
+    const int64_t wslab = ((p.N + Ctx<LGS>::CH - 1) / Ctx<LGS>::CH + 1) * 64;
+    double *ckpt = p.scratch + (int64_t)blockIdx.x * wslab;
+    map_pass<LGS>(c, cw0, p.B, p.N, p.nv2, p.sys, nullptr, p.par, p.Lin, p.N, ckpt, p.Lout);
+    const int64_t cw = cw0 + c.g;
+    if (cw < p.B)
+        for (int64_t t = c.s; t < p.N; t += Ctx<LGS>::S)           // decoded_bits: L > 0 in 'decode' mode only (:148-152)
+            p.bits[cw * p.N + t] = (uint8_t)((p.want_bits && p.Lout[cw * p.N + t] > 0) ? 1 : 0);
 }
 
 struct TurboParams {
@@ -185,27 +308,34 @@ struct TurboParams {
     const double *sys, *p1, *p2, *Lint;   // [B][N], Lint may be null
     const int32_t *perm;                  // [N]
     uint8_t *bits;                        // [B][N]
-    double *scratch;                      // per codeword: A[N] B[N] C[N] pr0[N] beta[(N+1)*S]
-    int64_t B, N, slab;
+    double *beta;                         // per wave: beta checkpoints [nchunks + 1][64]
+    double *larr;                         // per codeword: A[N] B[N] C[N]
+    int64_t B, N;
     double nv2;
     int n_iter;
 };
 
+template <int LGS>
 __global__ __launch_bounds__(64) void turbo_decode_kernel(TurboParams p) {
-    LaneCtx c;
-    init_ctx(c, p.tb);
-    const int64_t cw = (int64_t)blockIdx.x * c.G + c.g;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    Ctx<LGS> c;
+    init_ctx<LGS>(c, p.tb, smem);
+    constexpr int G = Ctx<LGS>::G, S = Ctx<LGS>::S;
+    const int64_t cw0 = (int64_t)blockIdx.x * G, N = p.N;
+    const int64_t cw = cw0 + c.g;
     const bool valid = cw < p.B;
-    const int64_t N = p.N, o = (valid ? cw : 0) * N;
-    double *slab = p.scratch + (valid ? cw : 0) * p.slab;
-    double *A = slab, *Bb = slab + N, *C = slab + 2 * N, *pr0 = slab + 3 * N, *beta = slab + 4 * N;
-    const int S = c.S;
+    const int64_t wslab = ((N + Ctx<LGS>::CH - 1) / Ctx<LGS>::CH + 1) * 64;
+    double *beta = p.beta + (int64_t)blockIdx.x * wslab;
+    // L arrays of all codewords: [B][3][N] -> per-codeword stride 3N; A at +0, B at +N, C at +2N
+    double *A0 = p.larr, *B0 = p.larr + N, *C0 = p.larr + 2 * N;
+    const int64_t ls = 3 * N;
+    double *A = A0 + (valid ? cw : 0) * ls, *Bb = B0 + (valid ? cw : 0) * ls, *C = C0 + (valid ? cw : 0) * ls;
     if (valid)
-        for (int64_t t = c.s; t < N; t += S) A[t] = p.Lint ? p.Lint[o + t] : 0.0;     // L_int_1 (:305-308)
+        for (int64_t t = c.s; t < N; t += S) A[t] = p.Lint ? p.Lint[cw * N + t] : 0.0;     // L_int_1 (:305-308)
     __syncthreads();
     for (int it = 0; it < p.n_iter; it++) {
         // [L_ext_1, _] = map_decode(sys, non_sys_1, trellis, nv, L_int_1, 'compute')   (:315)
-        map_pass(c, valid, N, p.nv2, p.sys + o, nullptr, p.p1 + o, A, pr0, beta, Bb);
+        map_pass<LGS>(c, cw0, p.B, N, p.nv2, p.sys, nullptr, p.p1, A0, ls, beta, B0);
         // L_ext_1 -= L_int_1 ; L_int_2 = interlv(L_ext_1)                               (:318-319)
         if (valid)
             for (int64_t t = c.s; t < N; t += S) Bb[t] = Bb[t] - A[t];
@@ -214,7 +344,7 @@ __global__ __launch_bounds__(64) void turbo_decode_kernel(TurboParams p) {
             for (int64_t t = c.s; t < N; t += S) C[t] = Bb[p.perm[t]];
         __syncthreads();
         // [L_2, bits] = map_decode(sys_i, non_sys_2, trellis, nv, L_int_2, mode)          (:326)
-        map_pass(c, valid, N, p.nv2, p.sys + o, p.perm, p.p2 + o, C, pr0, beta, Bb);
+        map_pass<LGS>(c, cw0, p.B, N, p.nv2, p.sys, p.perm, p.p2, C0, ls, beta, B0);
         // L_ext_2 = L_2 - L_int_2 ; L_int_1 = deinterlv(L_ext_2)                          (:328-329)
         if (valid)
             for (int64_t t = c.s; t < N; t += S) A[p.perm[t]] = Bb[t] - C[t];
@@ -223,14 +353,14 @@ __global__ __launch_bounds__(64) void turbo_decode_kernel(TurboParams p) {
     // decoded_bits = deinterlv(decoded_bits of the last MAP2)                              (:331)
     if (valid)
         for (int64_t t = c.s; t < N; t += S)
-            p.bits[o + p.perm[t]] = (uint8_t)((p.n_iter > 0 && Bb[t] > 0) ? 1 : 0);
+            p.bits[cw * N + p.perm[t]] = (uint8_t)((p.n_iter > 0 && Bb[t] > 0) ? 1 : 0);
 }
 
 int fill_tables(const cpx_trellis *t, MapTables &tb) {
     CPX_REQUIRE(t, CPX_EINVAL, "map_decode: null trellis");
     CPX_REQUIRE(t->I == 2 && t->k == 1, CPX_ELIMIT, "map_decode: only k = 1 (two inputs per step) trellises are supported, like the reference's priors[2]");
     CPX_REQUIRE(t->n >= 2, CPX_EINVAL, "map_decode: needs a rate-1/2 trellis (n >= 2)");
-    CPX_REQUIRE(t->S <= 64, CPX_ELIMIT, "map_decode: at most 64 states");
+    CPX_REQUIRE(t->S >= 2 && t->S <= 16, CPX_ELIMIT, "map_decode: 2..16 states supported (got %d)", t->S);
     tb.next_state = t->d_next; tb.output = t->d_out;
     tb.pred_state = t->d_pred_state; tb.pred_input = t->d_pred_input; tb.pred_code = t->d_pred_code;
     tb.n = t->n;
@@ -253,11 +383,17 @@ int cpx_map_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const do
     if (B == 0 || N == 0) return CPX_OK;
     hipStream_t st = pick_stream(stream);
     const int S = t->S, G = 64 / S;
+    const int64_t nblocks = (B + G - 1) / G;
     p.sys = d_sys; p.par = d_par; p.Lin = d_L_int; p.Lout = d_L_ext; p.bits = d_bits;
     p.B = B; p.N = N; p.nv2 = 2 * noise_variance; p.want_bits = want_bits;
-    p.slab = N + (N + 1) * S;
-    if ((rc = workspace(st, 0, sizeof(double) * (size_t)(p.slab * B), (void **)&p.scratch))) return rc;
-    hipLaunchKernelGGL(map_decode_kernel, dim3((unsigned)((B + G - 1) / G)), dim3(64), 0, st, p);
+    if ((rc = workspace(st, 0, sizeof(double) * (size_t)(nblocks * (N / 8 + 2) * 64), (void **)&p.scratch))) return rc;
+    dim3 grid((unsigned)nblocks), block(64);
+    switch (p.tb.lgS) {
+#define CASE(LG) case LG: hipLaunchKernelGGL(map_decode_kernel<LG>, grid, block, lds_bytes<LG>(), st, p); break;
+        CASE(1) CASE(2) CASE(3) CASE(4)
+#undef CASE
+        default: set_error("map_decode: unsupported state count"); return CPX_ELIMIT;
+    }
     CPX_HIP(hipGetLastError());
     return CPX_OK;
 }
@@ -272,11 +408,18 @@ int cpx_turbo_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const 
     if (B == 0 || N == 0) return CPX_OK;
     hipStream_t st = pick_stream(stream);
     const int S = t->S, G = 64 / S;
+    const int64_t nblocks = (B + G - 1) / G;
     p.sys = d_sys; p.p1 = d_p1; p.p2 = d_p2; p.Lint = d_L_int_or_null; p.perm = d_perm; p.bits = d_bits;
     p.B = B; p.N = N; p.nv2 = 2 * noise_variance; p.n_iter = n_iter;
-    p.slab = 4 * N + (N + 1) * S;
-    if ((rc = workspace(st, 0, sizeof(double) * (size_t)(p.slab * B), (void **)&p.scratch))) return rc;
-    hipLaunchKernelGGL(turbo_decode_kernel, dim3((unsigned)((B + G - 1) / G)), dim3(64), 0, st, p);
+    if ((rc = workspace(st, 0, sizeof(double) * (size_t)(nblocks * (N / 8 + 2) * 64), (void **)&p.beta))) return rc;
+    if ((rc = workspace(st, 1, sizeof(double) * (size_t)(B * 3 * N), (void **)&p.larr))) return rc;
+    dim3 grid((unsigned)nblocks), block(64);
+    switch (p.tb.lgS) {
+#define CASE(LG) case LG: hipLaunchKernelGGL(turbo_decode_kernel<LG>, grid, block, lds_bytes<LG>(), st, p); break;
+        CASE(1) CASE(2) CASE(3) CASE(4)
+#undef CASE
+        default: set_error("turbo_decode: unsupported state count"); return CPX_ELIMIT;
+    }
     CPX_HIP(hipGetLastError());
     return CPX_OK;
 }

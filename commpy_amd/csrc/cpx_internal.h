@@ -88,4 +88,7 @@ struct cpx_modem {
     int M, nbits;
     int device;
     double *d_const = nullptr;  // [M][2]
+    // axis-separable square constellations (QAMModem): label = (a << nbits/2) | b, point = xs[a] + 1j*ys[b]
+    bool separable = false;
+    double *d_axes = nullptr;   // [2][sqrt(M)]: xs then ys
 };

@@ -3,11 +3,25 @@
 //   soft (:125-137): LLR(b) = log( sum_{m:(m>>b)&1} e^{-|y-c_m|^2/noise_var} / sum_{m:!(..)} ... ),
 //                    written at index i*nb + nb-1-b, sums in increasing constellation index m;
 //   hard (:121-123): first-minimum nearest point |y-c_m| -> MSB-first nb bits (int8).
-// Element-wise map: one received symbol per lane, constellation (<= 256 points, 4 KiB) staged in LDS
-// and read as wave-uniform broadcasts.  float64 like the reference; |.| is hypot like np.abs of a
-// complex scalar.  Each symbol is read once (16 B) and nb outputs written once: HBM traffic equals
-// the algorithmic bytes (16 + 8*nb per symbol); the naive float64 formula costs M exps per symbol.
+// Element-wise map: one received symbol per lane, tables (<= 256 points, 4 KiB) staged in LDS and read
+// as wave-uniform broadcasts.  float64 like the reference.  Each symbol is read once (16 B) and nb
+// outputs written once: HBM traffic equals the algorithmic bytes (16 + 8*nb per symbol).
+//
+// Two code paths, chosen when the modem handle is created:
+//   * generic constellation (PSK, custom): the reference's naive formula, M exps per symbol, |.| is
+//     hypot like np.abs of a complex scalar;
+//   * axis-separable square QAM (every constellation QAMModem builds): label m = (a << NH) | b with
+//     c_m = xs[a] + 1j*ys[b], so e_m = ex[a]*ey[b] and a bit of `a` only needs the real axis:
+//       sum_{m:bit} e_m / sum_{m:!bit} e_m = (sum_{a:bit} ex[a] * sum_b ey[b]) / (sum_{a:!bit} ex[a] * sum_b ey[b])
+//     i.e. 2*sqrt(M) exps per symbol instead of M (64-QAM: 16 vs 64).  Numerator and denominator are
+//     still formed as those products so that the reference's underflow pattern at very high SNR
+//     (log(0/x) = -inf, 0/0 = NaN, modulation.py:134-137) is kept; finite values differ from the
+//     sequential sums by O(1e-16) relative (tolerance 1e-5).  Hard decisions decompose per axis
+//     exactly (nearest grid point, first minimum = lowest label); symbols whose two best axis
+//     distances are closer than 1e-12 relative are re-decided with the reference's full hypot scan.
 #include "cpx_internal.h"
+
+#include <cmath>
 
 using namespace cpx;
 
@@ -15,7 +29,6 @@ namespace {
 
 constexpr int DEMOD_BLOCK = 256;
 constexpr int MAX_M = 256;
-constexpr int MAX_NB = 8;
 
 template <int NB>
 __global__ __launch_bounds__(DEMOD_BLOCK) void demod_soft_kernel(const double2 *__restrict__ y, int64_t Ns,
@@ -43,6 +56,51 @@ __global__ __launch_bounds__(DEMOD_BLOCK) void demod_soft_kernel(const double2 *
     }
 }
 
+template <int NH>
+__global__ __launch_bounds__(DEMOD_BLOCK) void demod_soft_sep_kernel(const double2 *__restrict__ y, int64_t Ns,
+                                                                     const double *__restrict__ axes, double noise_var,
+                                                                     double *__restrict__ llr) {
+    constexpr int R = 1 << NH, NB = 2 * NH;
+    __shared__ double ax_s[2 * R];
+    for (int m = threadIdx.x; m < 2 * R; m += DEMOD_BLOCK) ax_s[m] = axes[m];
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * DEMOD_BLOCK + threadIdx.x; i < Ns; i += (int64_t)gridDim.x * DEMOD_BLOCK) {
+        const double2 cur = y[i];
+        double ex[R], ey[R], sx = 0.0, sy = 0.0;
+#pragma unroll
+        for (int a = 0; a < R; a++) {
+            const double dx = cur.x - ax_s[a], dy = cur.y - ax_s[R + a];
+            ex[a] = exp((-(dx * dx)) / noise_var);
+            ey[a] = exp((-(dy * dy)) / noise_var);
+            sx += ex[a];
+            sy += ey[a];
+        }
+        double out[NB];
+#pragma unroll
+        for (int b = 0; b < NH; b++) {
+            double nx = 0.0, qx = 0.0, ny = 0.0, qy = 0.0;
+#pragma unroll
+            for (int a = 0; a < R; a++) {
+                if ((a >> b) & 1) { nx += ex[a]; ny += ey[a]; } else { qx += ex[a]; qy += ey[a]; }
+            }
+            out[NH + b] = log((nx * sy) / (qx * sy));    // label bit NH+b = bit b of the real-axis index a
+            out[b] = log((ny * sx) / (qy * sx));         // label bit b    = bit b of the imag-axis index b
+        }
+#pragma unroll
+        for (int b = 0; b < NB; b++) llr[i * NB + NB - 1 - b] = out[b];   // (:137)
+    }
+}
+
+__device__ __forceinline__ int hard_scan(const double2 *c_s, int M, double2 cur) {
+    int best = 0;
+    double bd = hypot(cur.x - c_s[0].x, cur.y - c_s[0].y);
+    for (int m = 1; m < M; m++) {                                 // abs(y - c[:, None]).argmin(0): first minimum (:122)
+        const double a = hypot(cur.x - c_s[m].x, cur.y - c_s[m].y);
+        if (a < bd) { bd = a; best = m; }
+    }
+    return best;
+}
+
 __global__ __launch_bounds__(DEMOD_BLOCK) void demod_hard_kernel(const double2 *__restrict__ y, int64_t Ns,
                                                                  const double2 *__restrict__ cst, int M, int nb,
                                                                  int8_t *__restrict__ bits) {
@@ -50,14 +108,37 @@ __global__ __launch_bounds__(DEMOD_BLOCK) void demod_hard_kernel(const double2 *
     for (int m = threadIdx.x; m < M; m += DEMOD_BLOCK) c_s[m] = cst[m];
     __syncthreads();
     for (int64_t i = (int64_t)blockIdx.x * DEMOD_BLOCK + threadIdx.x; i < Ns; i += (int64_t)gridDim.x * DEMOD_BLOCK) {
-        const double2 cur = y[i];
-        int best = 0;
-        double bd = hypot(cur.x - c_s[0].x, cur.y - c_s[0].y);
-        for (int m = 1; m < M; m++) {                                 // abs(y - c[:, None]).argmin(0): first minimum (:122)
-            const double a = hypot(cur.x - c_s[m].x, cur.y - c_s[m].y);
-            if (a < bd) { bd = a; best = m; }
-        }
+        const int best = hard_scan(c_s, M, y[i]);
         for (int b = 0; b < nb; b++) bits[i * nb + b] = (int8_t)((best >> (nb - 1 - b)) & 1);   // dec2bitarray (:123)
+    }
+}
+
+template <int NH>
+__global__ __launch_bounds__(DEMOD_BLOCK) void demod_hard_sep_kernel(const double2 *__restrict__ y, int64_t Ns,
+                                                                     const double2 *__restrict__ cst,
+                                                                     const double *__restrict__ axes,
+                                                                     int8_t *__restrict__ bits) {
+    constexpr int R = 1 << NH, NB = 2 * NH, M = R * R;
+    __shared__ double2 c_s[M];
+    __shared__ double ax_s[2 * R];
+    for (int m = threadIdx.x; m < M; m += DEMOD_BLOCK) c_s[m] = cst[m];
+    for (int m = threadIdx.x; m < 2 * R; m += DEMOD_BLOCK) ax_s[m] = axes[m];
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * DEMOD_BLOCK + threadIdx.x; i < Ns; i += (int64_t)gridDim.x * DEMOD_BLOCK) {
+        const double2 cur = y[i];
+        int ia = 0, ib = 0;
+        double da = fabs(cur.x - ax_s[0]), db = fabs(cur.y - ax_s[R]), da2 = __builtin_huge_val(), db2 = da2;
+#pragma unroll
+        for (int a = 1; a < R; a++) {
+            const double dx = fabs(cur.x - ax_s[a]), dy = fabs(cur.y - ax_s[R + a]);
+            if (dx < da) { da2 = da; da = dx; ia = a; } else if (dx < da2) da2 = dx;
+            if (dy < db) { db2 = db; db = dy; ib = a; } else if (dy < db2) db2 = dy;
+        }
+        int best = (ia << NH) | ib;
+        // near-tie between the two closest grid lines on either axis: decide like the reference (full hypot scan)
+        if (da2 - da <= 1e-12 * da2 || db2 - db <= 1e-12 * db2) best = hard_scan(c_s, M, cur);
+#pragma unroll
+        for (int b = 0; b < NB; b++) bits[i * NB + b] = (int8_t)((best >> (NB - 1 - b)) & 1);   // dec2bitarray (:123)
     }
 }
 
@@ -86,6 +167,25 @@ int cpx_modem_create(const double *constellation_re_im, int M, cpx_modem **out) 
     (void)hipGetDevice(&m->device);
     CPX_HIP(hipMalloc((void **)&m->d_const, sizeof(double) * 2 * M));
     CPX_HIP(hipMemcpy(m->d_const, constellation_re_im, sizeof(double) * 2 * M, hipMemcpyHostToDevice));
+    // axis-separable?  label = (a << nh) | b, real part a function of a only, imaginary part of b only (exactly)
+    if (m->nbits % 2 == 0 && m->nbits >= 2 && m->nbits <= 8) {
+        const int nh = m->nbits / 2, R = 1 << nh;
+        std::vector<double> axes(2 * R);
+        bool sep = true;
+        for (int a = 0; a < R; a++) axes[a] = constellation_re_im[2 * (a << nh)];
+        for (int b = 0; b < R; b++) axes[R + b] = constellation_re_im[2 * b + 1];
+        for (int mm = 0; mm < M && sep; mm++)
+            sep = constellation_re_im[2 * mm] == axes[mm >> nh] && constellation_re_im[2 * mm + 1] == axes[R + (mm & (R - 1))] &&
+                  std::isfinite(constellation_re_im[2 * mm]) && std::isfinite(constellation_re_im[2 * mm + 1]);
+        for (int a = 0; a < R && sep; a++)                      // distinct grid lines (a degenerate grid keeps the generic path)
+            for (int b = a + 1; b < R; b++)
+                if (axes[a] == axes[b] || axes[R + a] == axes[R + b]) sep = false;
+        if (sep) {
+            CPX_HIP(hipMalloc((void **)&m->d_axes, sizeof(double) * 2 * R));
+            CPX_HIP(hipMemcpy(m->d_axes, axes.data(), sizeof(double) * 2 * R, hipMemcpyHostToDevice));
+            m->separable = true;
+        }
+    }
     *out = m;
     return CPX_OK;
 }
@@ -93,6 +193,7 @@ int cpx_modem_create(const double *constellation_re_im, int M, cpx_modem **out) 
 int cpx_modem_destroy(cpx_modem *m) {
     if (!m) return CPX_OK;
     (void)hipFree(m->d_const);
+    if (m->d_axes) (void)hipFree(m->d_axes);
     delete m;
     return CPX_OK;
 }
@@ -105,11 +206,20 @@ int cpx_demod_soft_dev(const cpx_modem *m, const double *d_y, int64_t Ns, double
     const double2 *y = reinterpret_cast<const double2 *>(d_y);
     const double2 *c = reinterpret_cast<const double2 *>(m->d_const);
     dim3 grid(grid_for(Ns)), block(DEMOD_BLOCK);
-    switch (m->nbits) {
-#define CASE(NB) case NB: hipLaunchKernelGGL(demod_soft_kernel<NB>, grid, block, 0, st, y, Ns, c, m->M, noise_var, d_llr); break;
-        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+    if (m->separable) {
+        switch (m->nbits / 2) {
+#define CASE(NH) case NH: hipLaunchKernelGGL(demod_soft_sep_kernel<NH>, grid, block, 0, st, y, Ns, m->d_axes, noise_var, d_llr); break;
+            CASE(1) CASE(2) CASE(3) CASE(4)
 #undef CASE
-        default: set_error("demod: unsupported bits per symbol %d", m->nbits); return CPX_ELIMIT;
+            default: set_error("demod: unsupported bits per symbol %d", m->nbits); return CPX_ELIMIT;
+        }
+    } else {
+        switch (m->nbits) {
+#define CASE(NB) case NB: hipLaunchKernelGGL(demod_soft_kernel<NB>, grid, block, 0, st, y, Ns, c, m->M, noise_var, d_llr); break;
+            CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+#undef CASE
+            default: set_error("demod: unsupported bits per symbol %d", m->nbits); return CPX_ELIMIT;
+        }
     }
     CPX_HIP(hipGetLastError());
     return CPX_OK;
@@ -121,8 +231,18 @@ int cpx_demod_hard_dev(const cpx_modem *m, const double *d_y, int64_t Ns, int8_t
     if (Ns == 0) return CPX_OK;
     hipStream_t st = pick_stream(stream);
     dim3 grid(grid_for(Ns)), block(DEMOD_BLOCK);
-    hipLaunchKernelGGL(demod_hard_kernel, grid, block, 0, st, reinterpret_cast<const double2 *>(d_y), Ns,
-                       reinterpret_cast<const double2 *>(m->d_const), m->M, m->nbits, d_bits);
+    const double2 *y = reinterpret_cast<const double2 *>(d_y);
+    const double2 *c = reinterpret_cast<const double2 *>(m->d_const);
+    if (m->separable) {
+        switch (m->nbits / 2) {
+#define CASE(NH) case NH: hipLaunchKernelGGL(demod_hard_sep_kernel<NH>, grid, block, 0, st, y, Ns, c, m->d_axes, d_bits); break;
+            CASE(1) CASE(2) CASE(3) CASE(4)
+#undef CASE
+            default: set_error("demod: unsupported bits per symbol %d", m->nbits); return CPX_ELIMIT;
+        }
+    } else {
+        hipLaunchKernelGGL(demod_hard_kernel, grid, block, 0, st, y, Ns, c, m->M, m->nbits, d_bits);
+    }
     CPX_HIP(hipGetLastError());
     return CPX_OK;
 }

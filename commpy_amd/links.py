@@ -1,0 +1,146 @@
+"""Monte-Carlo link simulation around the GPU decoders (host orchestration).
+
+Mirrors /root/reference/commpy/links.py: ``LinkModel`` (links.py:67-343) with
+``link_performance_full_metrics`` (:155-267) and ``link_performance`` (:269-343), and the module-level
+``link_performance`` (:29-64).  The callback protocol is the reference's
+(``modulate(bits)``, ``channel.propagate``, ``receive(y, H, constellation, noise_var)``,
+``decoder(msg)``); the estimators (BER denominators incl. quirk B11, stop rules) are reproduced.
+
+MI355X-first difference: the transmissions of one SNR point are *batched*.  When the callbacks are
+marked batch-capable (attribute ``batched = True``; the ones built by ``commpy_amd.wifi80211`` are) a block
+of ``tx_batch`` transmissions is generated, modulated, propagated, demodulated and decoded as 2-D
+arrays -- one GPU launch per stage instead of one Python call per transmission -- and the reference's
+sequential stop rule is applied to the per-transmission error counts afterwards.  Unmarked callbacks
+are called per transmission exactly like the reference.  MIMO channels are out of scope.
+"""
+from fractions import Fraction
+
+import numpy as np
+
+__all__ = ['link_performance', 'LinkModel']
+
+
+def link_performance(link_model, SNRs, send_max, err_min, send_chunk=None, code_rate=1):
+    """Module-level convenience wrapper (links.py:29-64)."""
+    if not send_chunk:
+        send_chunk = err_min
+    return link_model.link_performance(SNRs, send_max, err_min, send_chunk, code_rate)
+
+
+def _is_batched(fn):
+    return bool(getattr(fn, 'batched', False))
+
+
+class LinkModel:
+    """Same constructor and attributes as links.py:67-153."""
+
+    def __init__(self, modulate, channel, receive, num_bits_symbol, constellation, Es=1, decoder=None,
+                 rate=Fraction(1, 1)):
+        self.modulate = modulate
+        self.channel = channel
+        self.receive = receive
+        self.num_bits_symbol = num_bits_symbol
+        self.constellation = constellation
+        self.Es = Es
+        if type(rate) is float:
+            rate = Fraction(rate).limit_denominator(100)
+        self.rate = rate
+        self.decoder = (lambda msg: msg) if decoder is None else decoder
+        self.full_simulation_results = None
+        self.tx_batch = 64            # transmissions generated / decoded per GPU batch
+
+    # -- one block of transmissions ------------------------------------------------------------
+    def _run_block(self, n_tx, n_bits):
+        """Returns (msgs [n_tx, n_bits], decoded [n_tx, >= n_bits]) for n_tx independent transmissions."""
+        batched = _is_batched(self.modulate) and _is_batched(self.receive) and _is_batched(self.decoder)
+        noise_var = None
+        if batched:
+            msgs = np.random.choice((0, 1), (n_tx, n_bits))
+            symbs = self.modulate(msgs)
+            out = self.channel.propagate(symbs)
+            noise_var = self.channel.noise_std ** 2
+            received = self.receive(out, self.channel.channel_gains, self.constellation, noise_var)
+            return msgs, np.asarray(self.decoder(received))
+        msgs, decs = [], []
+        for _ in range(n_tx):
+            msg = np.random.choice((0, 1), n_bits)
+            out = self.channel.propagate(self.modulate(msg))
+            received = self.receive(out, self.channel.channel_gains, self.constellation, self.channel.noise_std ** 2)
+            msgs.append(msg)
+            decs.append(np.asarray(self.decoder(received)))
+        return np.stack(msgs), np.stack(decs)
+
+    def _prepare(self, send_chunk, err_min, code_rate):
+        if send_chunk is None:
+            send_chunk = err_min
+        if type(code_rate) is float:
+            code_rate = Fraction(code_rate).limit_denominator(100)
+        self.rate = code_rate
+        divider = (Fraction(1, self.num_bits_symbol * self.channel.nb_tx) * 1 / code_rate).denominator
+        return max(divider, send_chunk // divider * divider), code_rate
+
+    def link_performance_full_metrics(self, SNRs, tx_max, err_min, send_chunk=None, code_rate=Fraction(1, 1),
+                                      number_chunks_per_send=1, stop_on_surpass_error=True):
+        """BER / bit errors / chunk errors / chunk counts per SNR and transmission (links.py:155-267).
+
+        Stop rules as in the reference: a transmission is only counted while the accumulated bit
+        errors of the SNR point do not exceed ``err_min`` (``stop_on_surpass_error``), and the sweep
+        stops after the first SNR whose total errors stay below ``err_min``.  The BER denominator is
+        ``total_tx_send * send_chunk`` -- it ignores ``number_chunks_per_send`` (quirk B11).
+        """
+        BERs = np.zeros_like(SNRs, dtype=float)
+        BEs = np.zeros((len(SNRs), tx_max), dtype=int)
+        CEs = np.zeros((len(SNRs), tx_max), dtype=int)
+        NCs = np.zeros((len(SNRs), tx_max), dtype=int)
+        send_chunk, code_rate = self._prepare(send_chunk, err_min, code_rate)
+        n_bits = send_chunk * number_chunks_per_send
+        for id_SNR in range(len(SNRs)):
+            self.channel.set_SNR_dB(SNRs[id_SNR], float(code_rate), self.Es)
+            bit_err = np.zeros(tx_max, dtype=int)
+            chunk_count = np.zeros(tx_max, dtype=int)
+            total_tx_send = 0
+            id_tx = 0
+            stopped = False
+            while id_tx < tx_max and not stopped:
+                n_blk = min(self.tx_batch, tx_max - id_tx)
+                msgs, dec = self._run_block(n_blk, n_bits)
+                errs = (msgs != dec[:, :n_bits].astype(int)).reshape(n_blk, number_chunks_per_send, send_chunk).sum(2)
+                for j in range(n_blk):                      # the reference's per-transmission bookkeeping
+                    if stop_on_surpass_error and bit_err.sum() > err_min:
+                        stopped = True
+                        break
+                    bit_err[id_tx] = errs[j].sum()
+                    chunk_count[id_tx] = number_chunks_per_send
+                    total_tx_send += 1
+                    id_tx += 1
+            BERs[id_SNR] = bit_err.sum() / (total_tx_send * send_chunk)
+            BEs[id_SNR] = bit_err
+            CEs[id_SNR] = np.where(bit_err > 0, 1, 0)
+            NCs[id_SNR] = chunk_count
+            if BEs[id_SNR].sum() < err_min:
+                break
+        self.full_simulation_results = BERs, BEs, CEs, NCs
+        return BERs, BEs, CEs, NCs
+
+    def link_performance(self, SNRs, send_max, err_min, send_chunk=None, code_rate=1):
+        """BER per SNR: send chunks until ``send_max`` bits or ``err_min`` errors (links.py:269-343)."""
+        BERs = np.zeros_like(SNRs, dtype=float)
+        send_chunk, code_rate = self._prepare(send_chunk, err_min, code_rate)
+        for id_SNR in range(len(SNRs)):
+            self.channel.set_SNR_dB(SNRs[id_SNR], float(code_rate), self.Es)
+            bit_send = 0
+            bit_err = 0
+            while bit_send < send_max and bit_err < err_min:
+                remaining = int(np.ceil((send_max - bit_send) / send_chunk))
+                n_blk = max(1, min(self.tx_batch, remaining))
+                msgs, dec = self._run_block(n_blk, send_chunk)
+                errs = (msgs != dec[:, :send_chunk].astype(int)).sum(1)
+                for j in range(n_blk):                      # sequential stop rule of the reference
+                    if not (bit_send < send_max and bit_err < err_min):
+                        break
+                    bit_err += int(errs[j])
+                    bit_send += send_chunk
+            BERs[id_SNR] = bit_err / bit_send
+            if bit_err < err_min:
+                break
+        return BERs

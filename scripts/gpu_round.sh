@@ -16,6 +16,7 @@ if [[ $SEC == *s* ]]; then
 fi
 if [[ $SEC == *b* ]]; then
   timeout 900 python bench.py --gpus 1 --steps 20 --warmup 3 2>&1 | tail -3 | tee $OUT/bench_n1.json
+  timeout 1200 python benchmarks/bench_kernels.py 2>&1 | tee $OUT/bench_kernels.jsonl | cut -c1-220
 fi
 if [[ $SEC == *d* ]]; then
   timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 \

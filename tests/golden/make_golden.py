@@ -448,6 +448,39 @@ GENS = {
     "ldpc": gen_ldpc, "demod": gen_demod,
 }
 
+
+
+
+def gen_wifi():
+    """Wifi80211 link BER points (config 5 semantics, wifi80211.py:132-216 + links.py:155-267) from the live
+    reference: decimal generators as shipped (quirk B1, catastrophic code) and the intended octal ones
+    (class attribute overridden).  Statistical fixtures: the GPU path uses another RNG stream."""
+    from commpy.wifi80211 import Wifi80211
+    from commpy.channels import SISOFlatChannel
+    out = {}
+    names = []
+    for gname, gm in (("decimal", np.array((133, 171), ndmin=2)), ("octal", np.array((0o133, 0o171), ndmin=2))):
+        Wifi80211.generator_matrix = gm
+        for mcs, snrs, tx in ((1, [3.0, 5.0, 7.0], 30), (5, [15.0, 18.0, 21.0], 12), (3, [9.0, 12.0], 16)):
+            np.random.seed(2024 + mcs)
+            w = Wifi80211(mcs)
+            ch = SISOFlatChannel(fading_param=(1 + 0j, 0j))
+            t0 = time.time()
+            bers, bes, ces, ncs = w.link_performance(ch, np.array(snrs), tx, 1, 600, stop_on_surpass_error=False)
+            key = "w_%s_mcs%d" % (gname, mcs)
+            names.append(key)
+            out[key + "__snrs"] = np.array(snrs)
+            out[key + "__ber"] = np.asarray(bers)
+            out[key + "__bes"] = np.asarray(bes)
+            out[key + "__tx"] = np.array(tx)
+            print("wifi %s mcs=%d snrs=%s -> BER %s (%.0fs)" % (gname, mcs, snrs, bers, time.time() - t0))
+    Wifi80211.generator_matrix = np.array((133, 171), ndmin=2)
+    out["names"] = np.array(names)
+    save("wifi", **out)
+
+
+GENS["wifi"] = gen_wifi
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
