@@ -62,30 +62,36 @@ __device__ __forceinline__ double group_sum(double v) {
     return v;
 }
 
+// GW = codewords actually decoded by a wavefront (power of two, <= 64/S and <= 16).  When the batch cannot fill
+// the chip with full wavefronts (B*S/64 < ~4 waves per SIMD) the host picks GW < 64/S: lanes of the unused
+// codeword slots idle, but four times as many wavefronts hide the latency of the serial recursion.
 template <int LGS>
 struct Ctx {
     static constexpr int S = 1 << LGS, G = 64 >> LGS;
-    static constexpr int CH = (256 / G) < MAXCH ? (256 / G) : MAXCH;   // CH * G <= 256 items per chunk
-    static constexpr int NI = CH * G / 64;                             // (codeword, step) items per lane: 4, 4, 2, 1
-    int lane, g, s;
+    static constexpr int CH = MAXCH;                                   // steps per chunk
+    static constexpr int NI = 4;                                       // max (codeword, step) items per lane (CH*GW <= 256)
+    int lane, g, s, GW;
+    bool active;                                                       // lane belongs to one of the GW decoded slots
     int nxt[2], code[2];              // outgoing branches of state s: next-state lane, 2-bit code (sys, parity)
     int plane[2], pin[2], pcode[2];   // incoming branches in np.where order: predecessor lane, input, code
     // LDS carve-up
-    double *gam;    // [CH][G][4]
-    double *pr0;    // [CH][G]
-    double *lin;    // [CH][G]   L_int of the chunk
-    double *xs;     // [CH][64][2] per-lane branch products a*gamma*beta of the chunk (forward pass)
-    double *bt;     // [CH][64]  beta rows of the chunk (forward pass)
-    double *xch;    // [64]      exchange buffer
+    double *gam;    // [CH][GW][4]
+    double *pr0;    // [CH][GW]
+    double *lin;    // [CH][GW]   L_int of the chunk
+    double *xs;     // [CH][GW*S][2] per-lane branch products a*gamma*beta of the chunk (forward pass)
+    double *bt;     // [CH][GW*S]  beta rows of the chunk (forward pass)
+    double *xch;    // [64]       exchange buffer
 };
 
 template <int LGS>
-__device__ __forceinline__ void init_ctx(Ctx<LGS> &c, const MapTables &tb, unsigned char *smem) {
-    constexpr int S = Ctx<LGS>::S, G = Ctx<LGS>::G, CH = Ctx<LGS>::CH;
+__device__ __forceinline__ void init_ctx(Ctx<LGS> &c, const MapTables &tb, unsigned char *smem, int GW) {
+    constexpr int S = Ctx<LGS>::S, CH = Ctx<LGS>::CH;
     c.lane = threadIdx.x;
-    c.g = c.lane >> LGS;
+    c.GW = GW;
+    c.active = (c.lane >> LGS) < GW;
+    c.g = c.active ? (c.lane >> LGS) : 0;                         // idle lanes shadow slot 0 (reads only)
     c.s = c.lane & (S - 1);
-    const int gbase = c.g << LGS, sh = tb.n - 2;
+    const int gbase = (c.lane >> LGS) << LGS, sh = tb.n - 2;      // exchanges stay inside the lane's own group
     for (int i = 0; i < 2; i++) {
         c.nxt[i] = gbase + tb.next_state[c.s * 2 + i];
         c.code[i] = (tb.output[c.s * 2 + i] >> sh) & 3;       // [msg_bit, parity_bit] = codeword_array[0:2] (:96-98)
@@ -94,17 +100,17 @@ __device__ __forceinline__ void init_ctx(Ctx<LGS> &c, const MapTables &tb, unsig
         c.pcode[i] = (tb.pred_code[c.s * 2 + i] >> sh) & 3;
     }
     double *p = reinterpret_cast<double *>(smem);
-    c.gam = p; p += CH * G * 4;
-    c.pr0 = p; p += CH * G;
-    c.lin = p; p += CH * G;
-    c.xs = p;  p += CH * 64 * 2;
-    c.bt = p;  p += CH * 64;
+    c.gam = p; p += CH * GW * 4;
+    c.pr0 = p; p += CH * GW;
+    c.lin = p; p += CH * GW;
+    c.xs = p;  p += CH * GW * S * 2;
+    c.bt = p;  p += CH * GW * S;
     c.xch = p;
 }
 
 template <int LGS>
-constexpr size_t lds_bytes() {
-    return sizeof(double) * (Ctx<LGS>::CH * Ctx<LGS>::G * 6 + Ctx<LGS>::CH * 64 * 3 + 64);
+size_t lds_bytes(int GW) {
+    return sizeof(double) * (size_t)(Ctx<LGS>::CH * GW * 6 + Ctx<LGS>::CH * GW * Ctx<LGS>::S * 3 + 64);
 }
 
 constexpr int KNORM = 4;       // renormalise alpha / beta every KNORM steps
@@ -132,8 +138,8 @@ __device__ __forceinline__ void exchange2(const Ctx<LGS> &c, double v, int la, i
 }
 
 // ---- time-parallel stage of a chunk --------------------------------------------------------------------------
-// A chunk has CH*G (codeword, step) items, NI = CH*G/64 per lane: item p = lane + 64*q -> codeword p / CH,
-// step p % CH (consecutive lanes -> consecutive steps of one codeword: coalesced segments).
+// A chunk has CH*GW (codeword, step) items, at most 4 per lane: item p = lane + 64*q -> codeword slot p / CH,
+// step p % CH (consecutive lanes -> consecutive steps of one codeword: coalesced 128-byte segments).
 struct RawChunk {
     double r0[4], r1[4], li[4];
 };
@@ -144,11 +150,11 @@ __device__ __forceinline__ void load_raw(const Ctx<LGS> &c, RawChunk &rc, int64_
                                          const double *Lin, int64_t lstride) {
     constexpr int CH = Ctx<LGS>::CH;
 #pragma unroll
-    for (int q = 0; q < Ctx<LGS>::NI; q++) {
+    for (int q = 0; q < 4; q++) {
         const int p = c.lane + 64 * q, gg = p / CH, tl = p % CH;
         const int64_t cw = cw0 + gg, t = t0 + tl;                 // 0-based step index
         rc.r0[q] = 0.0; rc.r1[q] = 0.0; rc.li[q] = 0.0;
-        if (cw < B && tl < len) {
+        if (gg < c.GW && cw < B && tl < len) {
             rc.r0[q] = sys[cw * N + (sys_perm ? sys_perm[t] : t)];   // sys_symbols_i = interlv(sys) (turbo.py:310)
             rc.r1[q] = par[cw * N + t];
             rc.li[q] = Lin[cw * lstride + t];
@@ -159,19 +165,22 @@ __device__ __forceinline__ void load_raw(const Ctx<LGS> &c, RawChunk &rc, int64_
 // gam[tl][g][code] (_compute_branch_prob :62-76), pr0[tl][g] (priors[0] :239), lin[tl][g] into LDS
 template <int LGS>
 __device__ __forceinline__ void stage_chunk(const Ctx<LGS> &c, const RawChunk &rc, double nv2) {
-    constexpr int G = Ctx<LGS>::G, CH = Ctx<LGS>::CH;
+    constexpr int CH = Ctx<LGS>::CH;
+    const int GW = c.GW;
 #pragma unroll
-    for (int q = 0; q < Ctx<LGS>::NI; q++) {
+    for (int q = 0; q < 4; q++) {
         const int p = c.lane + 64 * q, gg = p / CH, tl = p % CH;
-        double *gm = c.gam + (tl * G + gg) * 4;
+        if (gg < GW) {
+            double *gm = c.gam + (tl * GW + gg) * 4;
 #pragma unroll
-        for (int code = 0; code < 4; code++) {
-            const double x = rc.r0[q] - (double)(2 * ((code >> 1) & 1) - 1);
-            const double y = rc.r1[q] - (double)(2 * (code & 1) - 1);
-            gm[code] = exp(-(x * x + y * y) / nv2);
+            for (int code = 0; code < 4; code++) {
+                const double x = rc.r0[q] - (double)(2 * ((code >> 1) & 1) - 1);
+                const double y = rc.r1[q] - (double)(2 * (code & 1) - 1);
+                gm[code] = exp(-(x * x + y * y) / nv2);
+            }
+            c.pr0[tl * GW + gg] = 1.0 / (1.0 + exp(rc.li[q]));
+            c.lin[tl * GW + gg] = rc.li[q];
         }
-        c.pr0[tl * G + gg] = 1.0 / (1.0 + exp(rc.li[q]));
-        c.lin[tl * G + gg] = rc.li[q];
     }
 }
 
@@ -179,30 +188,44 @@ __device__ __forceinline__ void stage_chunk(const Ctx<LGS> &c, const RawChunk &r
 // from `b` = beta at the chunk's upper boundary.  When ROWS, every row is also written to c.bt[tl] (LDS).
 template <int LGS, bool ROWS>
 __device__ __forceinline__ double beta_chunk(const Ctx<LGS> &c, double b, int len) {
-    constexpr int G = Ctx<LGS>::G;
-    if (ROWS && len > 0) c.bt[(len - 1) * 64 + c.lane] = b;       // beta[t_lo + len]: row used by the last step of the chunk
+    constexpr int S = Ctx<LGS>::S;
+    const int GW = c.GW, W = GW * S, col = c.g * S + c.s;
+    if (len <= 0) return b;
+    if (ROWS && c.active) c.bt[(len - 1) * W + col] = b;          // beta[t_lo + len]: row used by the last step of the chunk
+    // operands of step tl are fetched from LDS one step ahead (software pipelining)
+    const double *gm = c.gam + ((len - 1) * GW + c.g) * 4;
+    double g0 = gm[c.code[0]], g1 = gm[c.code[1]], p0 = c.pr0[(len - 1) * GW + c.g];
     for (int tl = len - 1; tl >= 0; --tl) {
-        const double *gm = c.gam + (tl * G + c.g) * 4;
-        const double p0 = c.pr0[tl * G + c.g], p1 = 1.0 - p0;     // priors[1] = 1 - priors[0] (:240)
+        double g0n = 0.0, g1n = 0.0, p0n = 0.0;
+        if (tl > 0) {
+            const double *gn = c.gam + ((tl - 1) * GW + c.g) * 4;
+            g0n = gn[c.code[0]]; g1n = gn[c.code[1]]; p0n = c.pr0[(tl - 1) * GW + c.g];
+        }
+        const double p1 = 1.0 - p0;                               // priors[1] = 1 - priors[0] (:240)
         double bn0, bn1;
         exchange2<LGS>(c, b, c.nxt[0], c.nxt[1], bn0, bn1);
         double nb = 0.0;
-        nb += (bn0 * gm[c.code[0]] * p0);                         // (:106-108), input 0 then input 1
-        nb += (bn1 * gm[c.code[1]] * p1);
+        nb += (bn0 * g0 * p0);                                    // (:106-108), input 0 then input 1
+        nb += (bn1 * g1 * p1);
         b = nb;
-        if ((tl & (KNORM - 1)) == 0) b = b / group_sum<LGS>(b);   // (:110-111), every KNORM steps
-        if (ROWS && tl > 0) c.bt[(tl - 1) * 64 + c.lane] = b;     // beta[t_lo + tl]: row used by step tl-1
+        // (:110-111) every KNORM steps; any positive common factor is a valid normalisation, so the hardware
+        // reciprocal (v_rcp_f64) is used instead of a correctly rounded division
+        if ((tl & (KNORM - 1)) == 0) b = b * __builtin_amdgcn_rcp(group_sum<LGS>(b));
+        if (ROWS && tl > 0 && c.active) c.bt[(tl - 1) * W + col] = b;   // beta[t_lo + tl]: row used by step tl-1
+        g0 = g0n; g1 = g1n; p0 = p0n;
     }
     return b;
 }
 
-// One MAP pass over the G codewords of this wavefront.  ckpt: [nchunks + 1][64] beta checkpoints of this wave.
+// One MAP pass over the GW codewords of this wavefront.  ckpt: [nchunks + 1][64] beta checkpoints of this wave.
 // Lout (stride lstride per codeword) receives L_int + log(app1/app0).
 template <int LGS>
 __device__ void map_pass(const Ctx<LGS> &c, int64_t cw0, int64_t B, int64_t N, double nv2, const double *sys,
                          const int32_t *sys_perm, const double *par, const double *Lin, int64_t lstride,
                          double *ckpt, double *Lout) {
-    constexpr int S = Ctx<LGS>::S, G = Ctx<LGS>::G, CH = Ctx<LGS>::CH;
+    constexpr int S = Ctx<LGS>::S, CH = Ctx<LGS>::CH;
+    const int GW = c.GW, W = GW * S, col = c.g * S + c.s;
+    const int nx0 = c.nxt[0] & (W - 1), nx1 = c.nxt[1] & (W - 1);   // next-state columns inside the bt rows
     const int64_t nchunks = (N + CH - 1) / CH;
     RawChunk cur, nxt;
     // ---------------- backward pass: chunks from the end, checkpoints only ----------------
@@ -240,35 +263,48 @@ __device__ void map_pass(const Ctx<LGS> &c, int64_t cw0, int64_t B, int64_t N, d
         __syncthreads();
         (void)beta_chunk<LGS, true>(c, bhi, len);                 // bt[tl] = beta[t_lo + tl + 1], bit-identical to the backward pass
         __syncthreads();
-        for (int tl = 0; tl < len; tl++) {
-            const double *gm = c.gam + (tl * G + c.g) * 4;
-            const double p0 = c.pr0[tl * G + c.g], p1 = 1.0 - p0;
-            // app[i] += f[cs,0] * branch_prob * b[next_state, t]   (:141-143): products parked, summed in the epilogue
-            double2 xv;
-            xv.x = a * gm[c.code[0]] * c.bt[tl * 64 + c.nxt[0]];
-            xv.y = a * gm[c.code[1]] * c.bt[tl * 64 + c.nxt[1]];
-            *reinterpret_cast<double2 *>(c.xs + (tl * 64 + c.lane) * 2) = xv;
-            // f[next,1] += f[cs,0] * branch_prob * priors[input]     (:136-138), accumulation in (cs, input) order
-            double ap0, ap1;
-            exchange2<LGS>(c, a, c.plane[0], c.plane[1], ap0, ap1);
-            double na = 0.0;
-            na += (ap0 * gm[c.pcode[0]] * (c.pin[0] ? p1 : p0));
-            na += (ap1 * gm[c.pcode[1]] * (c.pin[1] ? p1 : p0));
-            a = na;
-            if ((tl & (KNORM - 1)) == KNORM - 1) a = a / group_sum<LGS>(a);   // (:155-158), every KNORM steps
+        {
+            const double *gm = c.gam + c.g * 4;
+            double go0 = gm[c.code[0]], go1 = gm[c.code[1]], gi0 = gm[c.pcode[0]], gi1 = gm[c.pcode[1]];
+            double p0 = c.pr0[c.g], bt0 = c.bt[(c.g * S) + (nx0 & (S - 1))], bt1 = c.bt[(c.g * S) + (nx1 & (S - 1))];
+            for (int tl = 0; tl < len; tl++) {
+                double go0n = 0, go1n = 0, gi0n = 0, gi1n = 0, p0n = 0, bt0n = 0, bt1n = 0;   // operands of step tl+1
+                if (tl + 1 < len) {
+                    const double *gn = c.gam + ((tl + 1) * GW + c.g) * 4;
+                    go0n = gn[c.code[0]]; go1n = gn[c.code[1]]; gi0n = gn[c.pcode[0]]; gi1n = gn[c.pcode[1]];
+                    p0n = c.pr0[(tl + 1) * GW + c.g];
+                    bt0n = c.bt[(tl + 1) * W + c.g * S + (nx0 & (S - 1))];
+                    bt1n = c.bt[(tl + 1) * W + c.g * S + (nx1 & (S - 1))];
+                }
+                const double p1 = 1.0 - p0;
+                // app[i] += f[cs,0] * branch_prob * b[next_state, t]   (:141-143): products parked, summed in the epilogue
+                double2 xv;
+                xv.x = a * go0 * bt0;
+                xv.y = a * go1 * bt1;
+                if (c.active) *reinterpret_cast<double2 *>(c.xs + (tl * W + col) * 2) = xv;
+                // f[next,1] += f[cs,0] * branch_prob * priors[input]     (:136-138), accumulation in (cs, input) order
+                double ap0, ap1;
+                exchange2<LGS>(c, a, c.plane[0], c.plane[1], ap0, ap1);
+                double na = 0.0;
+                na += (ap0 * gi0 * (c.pin[0] ? p1 : p0));
+                na += (ap1 * gi1 * (c.pin[1] ? p1 : p0));
+                a = na;
+                if ((tl & (KNORM - 1)) == KNORM - 1) a = a * __builtin_amdgcn_rcp(group_sum<LGS>(a));   // (:155-158), every KNORM steps
+                go0 = go0n; go1 = go1n; gi0 = gi0n; gi1 = gi1n; p0 = p0n; bt0 = bt0n; bt1 = bt1n;
+            }
         }
         __syncthreads();
         // time-parallel epilogue of the chunk: app sums in state order, L = L_int + log(app1/app0) (:145)
 #pragma unroll
-        for (int q = 0; q < Ctx<LGS>::NI; q++) {
+        for (int q = 0; q < 4; q++) {
             const int p = c.lane + 64 * q, gg = p / CH, tl = p % CH;
             const int64_t cw = cw0 + gg;
-            if (cw < B && tl < len) {
-                const double *x = c.xs + (tl * 64 + gg * S) * 2;
+            if (gg < GW && cw < B && tl < len) {
+                const double *x = c.xs + (tl * W + gg * S) * 2;
                 double app0 = 0.0, app1 = 0.0;
 #pragma unroll
                 for (int st = 0; st < S; st++) { app0 += x[2 * st]; app1 += x[2 * st + 1]; }
-                Lout[cw * lstride + t_lo + tl] = c.lin[tl * G + gg] + log(app1 / app0);
+                Lout[cw * lstride + t_lo + tl] = c.lin[tl * GW + gg] + log(app1 / app0);
             }
         }
         cur = nxt;
@@ -284,21 +320,20 @@ struct MapParams {
     double *scratch;                   // per wave: beta checkpoints [nchunks + 1][64]
     int64_t B, N;
     double nv2;
-    int want_bits;
+    int want_bits, GW;
 };
 
 template <int LGS>
 __global__ __launch_bounds__(64) void map_decode_kernel(MapParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Ctx<LGS> c;
-    init_ctx<LGS>(c, p.tb, smem);
-    constexpr int G = Ctx<LGS>::G;
-    const int64_t cw0 = (int64_t)blockIdx.x * G;
+    init_ctx<LGS>(c, p.tb, smem, p.GW);
+    const int64_t cw0 = (int64_t)blockIdx.x * p.GW;
     const int64_t wslab = ((p.N + Ctx<LGS>::CH - 1) / Ctx<LGS>::CH + 1) * 64;
     double *ckpt = p.scratch + (int64_t)blockIdx.x * wslab;
     map_pass<LGS>(c, cw0, p.B, p.N, p.nv2, p.sys, nullptr, p.par, p.Lin, p.N, ckpt, p.Lout);
     const int64_t cw = cw0 + c.g;
-    if (cw < p.B)
+    if (c.active && cw < p.B)
         for (int64_t t = c.s; t < p.N; t += Ctx<LGS>::S)           // decoded_bits: L > 0 in 'decode' mode only (:148-152)
             p.bits[cw * p.N + t] = (uint8_t)((p.want_bits && p.Lout[cw * p.N + t] > 0) ? 1 : 0);
 }
@@ -312,18 +347,18 @@ struct TurboParams {
     double *larr;                         // per codeword: A[N] B[N] C[N]
     int64_t B, N;
     double nv2;
-    int n_iter;
+    int n_iter, GW;
 };
 
 template <int LGS>
 __global__ __launch_bounds__(64) void turbo_decode_kernel(TurboParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Ctx<LGS> c;
-    init_ctx<LGS>(c, p.tb, smem);
-    constexpr int G = Ctx<LGS>::G, S = Ctx<LGS>::S;
-    const int64_t cw0 = (int64_t)blockIdx.x * G, N = p.N;
+    init_ctx<LGS>(c, p.tb, smem, p.GW);
+    constexpr int S = Ctx<LGS>::S;
+    const int64_t cw0 = (int64_t)blockIdx.x * p.GW, N = p.N;
     const int64_t cw = cw0 + c.g;
-    const bool valid = cw < p.B;
+    const bool valid = c.active && cw < p.B;
     const int64_t wslab = ((N + Ctx<LGS>::CH - 1) / Ctx<LGS>::CH + 1) * 64;
     double *beta = p.beta + (int64_t)blockIdx.x * wslab;
     // L arrays of all codewords: [B][3][N] -> per-codeword stride 3N; A at +0, B at +N, C at +2N
@@ -356,6 +391,18 @@ __global__ __launch_bounds__(64) void turbo_decode_kernel(TurboParams p) {
             p.bits[cw * N + p.perm[t]] = (uint8_t)((p.n_iter > 0 && Bb[t] > 0) ? 1 : 0);
 }
 
+// codewords per wavefront: full wavefronts as soon as the batch gives every SIMD of the chip one of them; for
+// smaller batches fewer codewords per wavefront (idle lanes) spread the work over more SIMDs.  (Measured on
+// MI355X, B = 16384 x N = 1024: GW = 16 -> 1.07 ms per MAP pass, GW = 4 -> 1.78 ms: the pass is bound by
+// instruction issue, not by latency, so idle lanes do not pay once the chip is full.)
+int pick_gw(int S, int64_t B) {
+    int G = 64 / S;
+    if (G > 16) G = 16;                                            // CH*GW <= 256 items per chunk
+    int gw = G;
+    while (gw > 1 && (B + gw - 1) / gw < 1024) gw >>= 1;
+    return gw;
+}
+
 int fill_tables(const cpx_trellis *t, MapTables &tb) {
     CPX_REQUIRE(t, CPX_EINVAL, "map_decode: null trellis");
     CPX_REQUIRE(t->I == 2 && t->k == 1, CPX_ELIMIT, "map_decode: only k = 1 (two inputs per step) trellises are supported, like the reference's priors[2]");
@@ -382,14 +429,15 @@ int cpx_map_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const do
     CPX_REQUIRE(B >= 0 && N >= 0, CPX_EINVAL, "map_decode: negative size");
     if (B == 0 || N == 0) return CPX_OK;
     hipStream_t st = pick_stream(stream);
-    const int S = t->S, G = 64 / S;
-    const int64_t nblocks = (B + G - 1) / G;
+    const int GW = pick_gw(t->S, B);
+    const int64_t nblocks = (B + GW - 1) / GW;
+    p.GW = GW;
     p.sys = d_sys; p.par = d_par; p.Lin = d_L_int; p.Lout = d_L_ext; p.bits = d_bits;
     p.B = B; p.N = N; p.nv2 = 2 * noise_variance; p.want_bits = want_bits;
     if ((rc = workspace(st, 0, sizeof(double) * (size_t)(nblocks * (N / 8 + 2) * 64), (void **)&p.scratch))) return rc;
     dim3 grid((unsigned)nblocks), block(64);
     switch (p.tb.lgS) {
-#define CASE(LG) case LG: hipLaunchKernelGGL(map_decode_kernel<LG>, grid, block, lds_bytes<LG>(), st, p); break;
+#define CASE(LG) case LG: hipLaunchKernelGGL(map_decode_kernel<LG>, grid, block, lds_bytes<LG>(GW), st, p); break;
         CASE(1) CASE(2) CASE(3) CASE(4)
 #undef CASE
         default: set_error("map_decode: unsupported state count"); return CPX_ELIMIT;
@@ -407,15 +455,16 @@ int cpx_turbo_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const 
     CPX_REQUIRE(B >= 0 && N >= 0 && n_iter >= 0, CPX_EINVAL, "turbo_decode: negative size");
     if (B == 0 || N == 0) return CPX_OK;
     hipStream_t st = pick_stream(stream);
-    const int S = t->S, G = 64 / S;
-    const int64_t nblocks = (B + G - 1) / G;
+    const int GW = pick_gw(t->S, B);
+    const int64_t nblocks = (B + GW - 1) / GW;
+    p.GW = GW;
     p.sys = d_sys; p.p1 = d_p1; p.p2 = d_p2; p.Lint = d_L_int_or_null; p.perm = d_perm; p.bits = d_bits;
     p.B = B; p.N = N; p.nv2 = 2 * noise_variance; p.n_iter = n_iter;
     if ((rc = workspace(st, 0, sizeof(double) * (size_t)(nblocks * (N / 8 + 2) * 64), (void **)&p.beta))) return rc;
     if ((rc = workspace(st, 1, sizeof(double) * (size_t)(B * 3 * N), (void **)&p.larr))) return rc;
     dim3 grid((unsigned)nblocks), block(64);
     switch (p.tb.lgS) {
-#define CASE(LG) case LG: hipLaunchKernelGGL(turbo_decode_kernel<LG>, grid, block, lds_bytes<LG>(), st, p); break;
+#define CASE(LG) case LG: hipLaunchKernelGGL(turbo_decode_kernel<LG>, grid, block, lds_bytes<LG>(GW), st, p); break;
         CASE(1) CASE(2) CASE(3) CASE(4)
 #undef CASE
         default: set_error("turbo_decode: unsupported state count"); return CPX_ELIMIT;
