@@ -5,7 +5,7 @@ usable, the decoders raise -- loudly -- instead of computing on the host.
 import ctypes
 import os
 from ctypes import (POINTER, c_char_p, c_double, c_float, c_int, c_int8, c_int32, c_int64, c_size_t,
-                    c_uint8, c_void_p)
+                    c_uint8, c_uint64, c_void_p)
 
 import numpy as np
 
@@ -64,6 +64,13 @@ SYMBOLS = {
     "cpx_demod_soft_dev": (c_int, [c_void_p, c_void_p, c_int64, c_double, c_void_p, c_void_p]),
     "cpx_demod_hard": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "cpx_demod_hard_dev": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "cpx_random_bits_dev": (c_int, [c_void_p, c_int64, c_uint64, c_uint64, c_void_p]),
+    "cpx_conv_encode_batch_dev": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_int64, c_void_p]),
+    "cpx_gather_u8_dev": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
+    "cpx_gather_f64_dev": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
+    "cpx_modulate_dev": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "cpx_awgn_dev": (c_int, [c_void_p, c_int64, c_double, c_double, c_uint64, c_uint64, c_void_p, c_void_p]),
+    "cpx_count_errors_dev": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
 }
 
 

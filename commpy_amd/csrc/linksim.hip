@@ -1,0 +1,266 @@
+// Device-side link-simulation stages around the decoders ("next" rows of SURVEY 8f): the transmit
+// chain and channel of the reference's Monte-Carlo loops, batched, so that a BER sweep never leaves HBM.
+//   conv_encode        /root/reference/commpy/channelcoding/convcode.py:475-558 (table walk, both terminations)
+//   puncturing         convcode.py:752-774  / depuncturing :777-804 (as index gathers built by the host)
+//   Modem.modulate     /root/reference/commpy/modulation.py:79-98 (MSB-first label -> constellation point)
+//   random messages    commpy/links.py:229 (np.random.choice((0,1), n)) -- Philox4x32-10 stream instead of MT19937
+//   AWGN               commpy/channels.py:37-55 (noise = (randn + 1j*randn) * scale per component, or real)
+//   error counting     links.py:252-256 (per-chunk XOR popcount)
+// Bit-exact stages (encode, (de)puncture, modulate, error count) are tested against the host mirror and
+// the reference goldens; the random stages are statistical (different generator than the reference).
+// All kernels are byte/element-wise streams: HBM bound, one codeword row or one element per lane.
+#include "cpx_internal.h"
+
+using namespace cpx;
+
+namespace {
+
+constexpr int LS_BLOCK = 256;
+
+unsigned ls_grid(int64_t n) {
+    int64_t blocks = (n + LS_BLOCK - 1) / LS_BLOCK;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (blocks < 1) blocks = 1;
+    return (unsigned)blocks;
+}
+
+// ---- Philox4x32-10 counter-based generator (Salmon et al., SC'11) -------------------------------------------
+struct Philox {
+    uint32_t c[4];
+};
+
+__device__ __forceinline__ Philox philox4x32_10(uint64_t ctr_lo, uint64_t ctr_hi, uint64_t key) {
+    uint32_t c0 = (uint32_t)ctr_lo, c1 = (uint32_t)(ctr_lo >> 32), c2 = (uint32_t)ctr_hi, c3 = (uint32_t)(ctr_hi >> 32);
+    uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return Philox{{c0, c1, c2, c3}};
+}
+
+// uniform in (0, 1] with 53 bits
+__device__ __forceinline__ double u01(uint32_t hi, uint32_t lo) {
+    const uint64_t m = ((uint64_t)(hi >> 5) << 26) | (uint64_t)(lo >> 6);
+    return ((double)m + 1.0) * (1.0 / 9007199254740992.0);
+}
+
+// ---- random message bits ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(LS_BLOCK) void random_bits_kernel(uint8_t *__restrict__ bits, int64_t n, uint64_t seed,
+                                                               uint64_t stream) {
+    // one Philox call = 128 random bits -> 128 output bytes? keep it simple: 16 bytes (one bit each) per call uses
+    // 16 of the 128 bits; throughput is irrelevant next to the decoders
+    const int64_t n16 = (n + 15) / 16;
+    for (int64_t i = (int64_t)blockIdx.x * LS_BLOCK + threadIdx.x; i < n16; i += (int64_t)gridDim.x * LS_BLOCK) {
+        const Philox r = philox4x32_10((uint64_t)i, stream, seed);
+        const uint32_t w = r.c[0];
+        for (int j = 0; j < 16; j++) {
+            const int64_t pos = i * 16 + j;
+            if (pos < n) bits[pos] = (uint8_t)((w >> j) & 1u);
+        }
+    }
+}
+
+// ---- convolutional encoder: one codeword per lane, table walk (convcode.py:531-550) -----------------------------
+// msg [B][nmsg] uint8 -> coded [B][nout] uint8.  term: 0 'cont', 1 'term'.  rsc: code_type == 'rsc'.
+__global__ __launch_bounds__(LS_BLOCK) void conv_encode_kernel(const uint8_t *__restrict__ msg, int64_t B, int64_t nmsg,
+                                                               const int32_t *__restrict__ next_state,
+                                                               const int32_t *__restrict__ output, int k, int n, int S,
+                                                               int I, int total_memory, int term, int rsc,
+                                                               uint8_t *__restrict__ coded, int64_t nout) {
+    extern __shared__ int32_t tabs[];
+    int32_t *nx = tabs, *ot = tabs + S * I;
+    for (int i = threadIdx.x; i < S * I; i += LS_BLOCK) { nx[i] = next_state[i]; ot[i] = output[i]; }
+    __syncthreads();
+    const int64_t b = (int64_t)blockIdx.x * LS_BLOCK + threadIdx.x;
+    if (b >= B) return;
+    const uint8_t *m = msg + b * nmsg;
+    uint8_t *c = coded + b * nout;
+    // number of input bits actually clocked in (:505-520): message, plus the zero tail for non-recursive 'term'
+    int64_t ninb = nmsg;
+    if (term && !rsc) ninb = nmsg + total_memory + total_memory % k;
+    int state = 0;
+    int64_t j = 0;
+    for (int64_t i = 0; i < ninb / k; i++) {
+        int cur = 0;
+        for (int q = 0; q < k; q++) {
+            const int64_t pos = i * k + q;
+            cur = (cur << 1) | ((pos < nmsg) ? (m[pos] & 1) : 0);   // bitarray2dec: MSB first (:533)
+        }
+        const int o = ot[state * I + cur];
+        for (int q = 0; q < n; q++)
+            if (j * n + q < nout) c[j * n + q] = (uint8_t)((o >> (n - 1 - q)) & 1);   // dec2bitarray(o, n) (:535)
+        state = nx[state * I + cur];
+        j++;
+    }
+    if (rsc && term) {                                            // (:538-546): feed the register content back, LSB first
+        const int tbits = state;                                  // term_bits = dec2bitarray(state, m)[::-1]
+        for (int i = 0; i < total_memory; i++) {
+            int cur = 0;
+            for (int q = 0; q < k; q++) {
+                const int pos = i * k + q;
+                const int bit = (pos < total_memory) ? ((tbits >> pos) & 1) : 0;
+                if (pos < total_memory) cur = (cur << 1) | bit;
+            }
+            const int o = ot[state * I + cur];
+            for (int q = 0; q < n; q++)
+                if (j * n + q < nout) c[j * n + q] = (uint8_t)((o >> (n - 1 - q)) & 1);
+            state = nx[state * I + cur];
+            j++;
+        }
+    }
+    for (int64_t q = j * n; q < nout; q++) c[q] = 0;
+}
+
+// ---- row-wise gathers: puncturing (u8) and depuncturing (f64, -1 = punctured position -> 0.0) ----------------------
+__global__ __launch_bounds__(LS_BLOCK) void gather_u8_kernel(const uint8_t *__restrict__ in, int64_t B, int64_t nin,
+                                                             const int32_t *__restrict__ idx, int64_t nout,
+                                                             uint8_t *__restrict__ out) {
+    const int64_t total = B * nout;
+    for (int64_t i = (int64_t)blockIdx.x * LS_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * LS_BLOCK) {
+        const int64_t b = i / nout, j = i % nout;
+        out[i] = in[b * nin + idx[j]];
+    }
+}
+
+__global__ __launch_bounds__(LS_BLOCK) void gather_f64_kernel(const double *__restrict__ in, int64_t B, int64_t nin,
+                                                              const int32_t *__restrict__ idx, int64_t nout,
+                                                              double *__restrict__ out) {
+    const int64_t total = B * nout;
+    for (int64_t i = (int64_t)blockIdx.x * LS_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * LS_BLOCK) {
+        const int64_t b = i / nout, j = i % nout;
+        const int32_t src = idx[j];
+        out[i] = (src >= 0) ? in[b * nin + src] : 0.0;
+    }
+}
+
+// ---- modulate: nb bits (MSB first) -> constellation[label]  (modulation.py:93-96) -----------------------------------
+__global__ __launch_bounds__(LS_BLOCK) void modulate_kernel(const uint8_t *__restrict__ bits, int64_t nsym, int nb,
+                                                            const double2 *__restrict__ cst, int M,
+                                                            double2 *__restrict__ sym) {
+    __shared__ double2 c_s[256];
+    for (int m = threadIdx.x; m < M; m += LS_BLOCK) c_s[m] = cst[m];
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * LS_BLOCK + threadIdx.x; i < nsym; i += (int64_t)gridDim.x * LS_BLOCK) {
+        int label = 0;
+        for (int q = 0; q < nb; q++) label = (label << 1) | (bits[i * nb + q] & 1);
+        sym[i] = c_s[label];
+    }
+}
+
+// ---- AWGN: y = x + scale * (n_re + 1j * n_im), n ~ N(0,1) i.i.d. (Box-Muller on Philox) ------------------------------
+__global__ __launch_bounds__(LS_BLOCK) void awgn_kernel(const double2 *__restrict__ x, int64_t n, double scale_re,
+                                                        double scale_im, uint64_t seed, uint64_t stream,
+                                                        double2 *__restrict__ y) {
+    for (int64_t i = (int64_t)blockIdx.x * LS_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * LS_BLOCK) {
+        const Philox r = philox4x32_10((uint64_t)i, stream, seed);
+        const double u1 = u01(r.c[0], r.c[1]), u2 = u01(r.c[2], r.c[3]);
+        const double rad = sqrt(-2.0 * log(u1));
+        double sn, cs;
+        sincos(6.283185307179586476925286766559 * u2, &sn, &cs);
+        double2 v = x[i];
+        v.x += scale_re * rad * cs;
+        v.y += scale_im * rad * sn;
+        y[i] = v;
+    }
+}
+
+// ---- error counting: errs[b][c] = popcount(msg[b, c*chunk:(c+1)*chunk] ^ dec[b, same]) (links.py:252-256) --------------
+__global__ __launch_bounds__(LS_BLOCK) void count_errors_kernel(const uint8_t *__restrict__ msg, int64_t msg_stride,
+                                                                const uint8_t *__restrict__ dec, int64_t dec_stride,
+                                                                int64_t B, int64_t nchunks, int64_t chunk,
+                                                                int32_t *__restrict__ errs) {
+    const int64_t total = B * nchunks;
+    for (int64_t i = (int64_t)blockIdx.x * LS_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * LS_BLOCK) {
+        const int64_t b = i / nchunks, c = i % nchunks;
+        const uint8_t *m = msg + b * msg_stride + c * chunk, *d = dec + b * dec_stride + c * chunk;
+        int32_t e = 0;
+        for (int64_t q = 0; q < chunk; q++) e += (m[q] ^ d[q]) & 1;
+        errs[i] = e;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int cpx_random_bits_dev(uint8_t *d_bits, int64_t n, uint64_t seed, uint64_t stream_id, void *stream) {
+    CPX_REQUIRE(n >= 0, CPX_EINVAL, "random_bits: negative size");
+    if (n == 0) return CPX_OK;
+    hipLaunchKernelGGL(random_bits_kernel, dim3(ls_grid((n + 15) / 16)), dim3(LS_BLOCK), 0, pick_stream(stream), d_bits, n,
+                       seed, stream_id);
+    CPX_HIP(hipGetLastError());
+    return CPX_OK;
+}
+
+int cpx_conv_encode_batch_dev(const cpx_trellis *t, const uint8_t *d_msg, int64_t B, int64_t nmsg, int terminate, int rsc,
+                              uint8_t *d_coded, int64_t nout, void *stream) {
+    CPX_REQUIRE(t, CPX_EINVAL, "conv_encode: null trellis");
+    CPX_REQUIRE(B >= 0 && nmsg >= 0 && nout >= 0, CPX_EINVAL, "conv_encode: negative size");
+    if (B == 0 || nout == 0) return CPX_OK;
+    int total_memory = 0;
+    while ((1 << total_memory) < t->S) total_memory++;
+    const size_t lds = sizeof(int32_t) * 2 * t->S * t->I;
+    hipLaunchKernelGGL(conv_encode_kernel, dim3((unsigned)((B + LS_BLOCK - 1) / LS_BLOCK)), dim3(LS_BLOCK), lds,
+                       pick_stream(stream), d_msg, B, nmsg, t->d_next, t->d_out, t->k, t->n, t->S, t->I, total_memory,
+                       terminate ? 1 : 0, rsc ? 1 : 0, d_coded, nout);
+    CPX_HIP(hipGetLastError());
+    return CPX_OK;
+}
+
+int cpx_gather_u8_dev(const uint8_t *d_in, int64_t B, int64_t nin, const int32_t *d_idx, int64_t nout, uint8_t *d_out,
+                      void *stream) {
+    CPX_REQUIRE(B >= 0 && nin >= 0 && nout >= 0, CPX_EINVAL, "gather: negative size");
+    if (B * nout == 0) return CPX_OK;
+    hipLaunchKernelGGL(gather_u8_kernel, dim3(ls_grid(B * nout)), dim3(LS_BLOCK), 0, pick_stream(stream), d_in, B, nin, d_idx,
+                       nout, d_out);
+    CPX_HIP(hipGetLastError());
+    return CPX_OK;
+}
+
+int cpx_gather_f64_dev(const double *d_in, int64_t B, int64_t nin, const int32_t *d_idx, int64_t nout, double *d_out,
+                       void *stream) {
+    CPX_REQUIRE(B >= 0 && nin >= 0 && nout >= 0, CPX_EINVAL, "gather: negative size");
+    if (B * nout == 0) return CPX_OK;
+    hipLaunchKernelGGL(gather_f64_kernel, dim3(ls_grid(B * nout)), dim3(LS_BLOCK), 0, pick_stream(stream), d_in, B, nin,
+                       d_idx, nout, d_out);
+    CPX_HIP(hipGetLastError());
+    return CPX_OK;
+}
+
+int cpx_modulate_dev(const cpx_modem *m, const uint8_t *d_bits, int64_t nsym, double *d_sym_re_im, void *stream) {
+    CPX_REQUIRE(m, CPX_EINVAL, "modulate: null modem");
+    CPX_REQUIRE(nsym >= 0, CPX_EINVAL, "modulate: negative size");
+    if (nsym == 0) return CPX_OK;
+    hipLaunchKernelGGL(modulate_kernel, dim3(ls_grid(nsym)), dim3(LS_BLOCK), 0, pick_stream(stream), d_bits, nsym, m->nbits,
+                       reinterpret_cast<const double2 *>(m->d_const), m->M, reinterpret_cast<double2 *>(d_sym_re_im));
+    CPX_HIP(hipGetLastError());
+    return CPX_OK;
+}
+
+int cpx_awgn_dev(const double *d_x_re_im, int64_t n, double scale_re, double scale_im, uint64_t seed, uint64_t stream_id,
+                 double *d_y_re_im, void *stream) {
+    CPX_REQUIRE(n >= 0, CPX_EINVAL, "awgn: negative size");
+    if (n == 0) return CPX_OK;
+    hipLaunchKernelGGL(awgn_kernel, dim3(ls_grid(n)), dim3(LS_BLOCK), 0, pick_stream(stream),
+                       reinterpret_cast<const double2 *>(d_x_re_im), n, scale_re, scale_im, seed, stream_id,
+                       reinterpret_cast<double2 *>(d_y_re_im));
+    CPX_HIP(hipGetLastError());
+    return CPX_OK;
+}
+
+int cpx_count_errors_dev(const uint8_t *d_msg, int64_t msg_stride, const uint8_t *d_dec, int64_t dec_stride, int64_t B,
+                         int64_t nchunks, int64_t chunk, int32_t *d_errs, void *stream) {
+    CPX_REQUIRE(B >= 0 && nchunks >= 0 && chunk >= 0, CPX_EINVAL, "count_errors: negative size");
+    if (B * nchunks == 0) return CPX_OK;
+    hipLaunchKernelGGL(count_errors_kernel, dim3(ls_grid(B * nchunks)), dim3(LS_BLOCK), 0, pick_stream(stream), d_msg,
+                       msg_stride, d_dec, dec_stride, B, nchunks, chunk, d_errs);
+    CPX_HIP(hipGetLastError());
+    return CPX_OK;
+}
+
+}  // extern "C"

@@ -163,6 +163,33 @@ int cpx_demod_hard(const cpx_modem *m, const double *y_re_im, int64_t Ns, int8_t
 int cpx_demod_hard_dev(const cpx_modem *m, const double *d_y_re_im, int64_t Ns, int8_t *d_bits,
                        void *stream);
 
+/* ---- link-simulation stages around the decoders ("next" rows) ---------------------------
+ * Device-resident (all pointers are device pointers, asynchronous on `stream`), so that a Monte-Carlo
+ * BER sweep (commpy/links.py:155-267, commpy/wifi80211.py:132-216) never leaves HBM.
+ *   cpx_random_bits_dev       message bits (links.py:229); Philox4x32-10 counter stream (seed, stream_id)
+ *   cpx_conv_encode_batch_dev conv_encode(msg, trellis, termination) convcode.py:475-558 for B rows:
+ *                             msg [B][nmsg] uint8 -> coded [B][nout] uint8 (nout as the reference computes
+ *                             number_outbits; terminate = termination != 'cont'; rsc = code_type == 'rsc')
+ *   cpx_gather_u8_dev         out[b][j] = in[b][idx[j]]: puncturing (convcode.py:752-774) with the kept
+ *                             positions as idx
+ *   cpx_gather_f64_dev        out[b][j] = idx[j] >= 0 ? in[b][idx[j]] : 0: depuncturing (convcode.py:777-804)
+ *   cpx_modulate_dev          Modem.modulate modulation.py:79-98: nb bits MSB-first -> constellation point
+ *   cpx_awgn_dev              y = x + scale_re*n_re + 1j*scale_im*n_im, n ~ N(0,1) (channels.py:37-55)
+ *   cpx_count_errors_dev      errs[b][c] = sum(msg[b, chunk c] ^ dec[b, chunk c]) (links.py:252-256)
+ */
+int cpx_random_bits_dev(uint8_t *d_bits, int64_t n, uint64_t seed, uint64_t stream_id, void *stream);
+int cpx_conv_encode_batch_dev(const cpx_trellis *t, const uint8_t *d_msg, int64_t B, int64_t nmsg, int terminate,
+                              int rsc, uint8_t *d_coded, int64_t nout, void *stream);
+int cpx_gather_u8_dev(const uint8_t *d_in, int64_t B, int64_t nin, const int32_t *d_idx, int64_t nout,
+                      uint8_t *d_out, void *stream);
+int cpx_gather_f64_dev(const double *d_in, int64_t B, int64_t nin, const int32_t *d_idx, int64_t nout,
+                       double *d_out, void *stream);
+int cpx_modulate_dev(const cpx_modem *m, const uint8_t *d_bits, int64_t nsym, double *d_sym_re_im, void *stream);
+int cpx_awgn_dev(const double *d_x_re_im, int64_t n, double scale_re, double scale_im, uint64_t seed,
+                 uint64_t stream_id, double *d_y_re_im, void *stream);
+int cpx_count_errors_dev(const uint8_t *d_msg, int64_t msg_stride, const uint8_t *d_dec, int64_t dec_stride,
+                         int64_t B, int64_t nchunks, int64_t chunk, int32_t *d_errs, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

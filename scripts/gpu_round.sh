@@ -17,6 +17,8 @@ fi
 if [[ $SEC == *b* ]]; then
   timeout 900 python bench.py --gpus 1 --steps 20 --warmup 3 2>&1 | tail -3 | tee $OUT/bench_n1.json
   timeout 1200 python benchmarks/bench_kernels.py 2>&1 | tee $OUT/bench_kernels.jsonl | cut -c1-220
+  timeout 600 python benchmarks/bench_link.py --mcs 5 2>&1 | tail -1 | tee $OUT/bench_link.jsonl | cut -c1-300
+  timeout 600 python benchmarks/bench_link.py --mcs 5 --generators decimal --bits 2e7 2>&1 | tail -1 >> $OUT/bench_link.jsonl
 fi
 if [[ $SEC == *d* ]]; then
   timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 \
