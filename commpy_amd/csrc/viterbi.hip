@@ -42,13 +42,6 @@ struct VitParams {
 };
 
 // ---- cross-lane helpers -------------------------------------------------------------------------
-// ds_bpermute fetch of a float64 from the lane whose BYTE address (lane*4) is `addr4`.
-__device__ __forceinline__ double bperm_f64(double v, int addr4) {
-    const int lo = __builtin_amdgcn_ds_bpermute(addr4, __double2loint(v));
-    const int hi = __builtin_amdgcn_ds_bpermute(addr4, __double2hiint(v));
-    return __hiloint2double(hi, lo);
-}
-
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
     const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
