@@ -97,6 +97,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=65536, help="codewords per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--synth", choices=("device", "host"), default="device",
+                    help="where the synthetic input is generated: on the GPU (Philox bits/noise, device encoder and "
+                         "modulator; fast, no large host arrays) or on the host (NumPy MT19937, SURVEY 8d seeds)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -116,14 +119,23 @@ def main():
     _lib.check(lib.cpx_set_device(local_rank))
 
     B = args.batch
-    tr, md, msgs, y, N0 = synth_inputs(B, 10 + 1000 * rank, 11 + 1000 * rank)
-    nsym = y.shape[1]
+    nsym = (MSG_BITS + 6) * 2 // 2                                 # 1030 QPSK symbols per codeword
     LEN, L, T, TB = 2 * nsym, nsym, nsym + 6 - 1, 30            # 2060 LLRs -> 1030 bits, 1035 steps, tb = min(5m, L)
+    if args.synth == "host":
+        tr, md, msgs, y, N0 = synth_inputs(B, 10 + 1000 * rank, 11 + 1000 * rank)
+        y = np.ascontiguousarray(y)
+    else:
+        from commpy_amd.channelcoding import Trellis
+        from commpy_amd.modulation import QAMModem
+        tr = Trellis(np.array([6]), np.array([[0o133, 0o171]]))
+        md = QAMModem(4)
+        N0 = md.Es / (0.5 * 2 * 10 ** (EBN0_DB / 10.0))
+        msgs = y = None
     h_tr, h_md = tr._device_handle(), md._device_handle()
 
     if distributed:
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        t_y = torch.from_numpy(np.ascontiguousarray(y).view(np.float64)).cuda()
+        t_y = torch.empty((B, nsym, 2), dtype=torch.float64, device="cuda")
         t_llr = torch.empty((B, LEN), dtype=torch.float64, device="cuda")
         t_bits = torch.empty((B, L), dtype=torch.uint8, device="cuda")
         t_all = torch.empty((world * B, L), dtype=torch.uint8, device="cuda")
@@ -133,11 +145,9 @@ def main():
     else:
         stream = None
         d_y, d_llr, d_bits = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
-        _lib.check(lib.cpx_malloc(ctypes.byref(d_y), y.nbytes))
+        _lib.check(lib.cpx_malloc(ctypes.byref(d_y), B * nsym * 16))
         _lib.check(lib.cpx_malloc(ctypes.byref(d_llr), B * LEN * 8))
         _lib.check(lib.cpx_malloc(ctypes.byref(d_bits), B * L))
-        yc = np.ascontiguousarray(y)
-        _lib.check(lib.cpx_memcpy_h2d(d_y, _lib.ptr(yc), yc.nbytes))
 
         def sync():
             _lib.check(lib.cpx_stream_sync(None))
@@ -145,35 +155,60 @@ def main():
         def barrier():
             pass
 
+    if args.synth == "host":
+        _lib.check(lib.cpx_memcpy_h2d(d_y, _lib.ptr(y), y.nbytes))
+    else:
+        # random bits -> conv_encode -> QPSK -> AWGN, all on the device (csrc/linksim.hip)
+        d_msg, d_coded, d_sym = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        _lib.check(lib.cpx_malloc(ctypes.byref(d_msg), B * MSG_BITS))
+        _lib.check(lib.cpx_malloc(ctypes.byref(d_coded), B * LEN))
+        _lib.check(lib.cpx_malloc(ctypes.byref(d_sym), B * nsym * 16))
+        _lib.check(lib.cpx_random_bits_dev(d_msg, B * MSG_BITS, 10 + 1000 * rank, 1, stream))
+        _lib.check(lib.cpx_conv_encode_batch_dev(h_tr, d_msg, B, MSG_BITS, 1, 0, d_coded, LEN, stream))
+        _lib.check(lib.cpx_modulate_dev(h_md, d_coded, B * nsym, d_sym, stream))
+        sc = float(np.sqrt(N0 / 2))
+        _lib.check(lib.cpx_awgn_dev(d_sym, B * nsym, sc, sc, 11 + 1000 * rank, 2, d_y, stream))
+        sync()
+        msgs = np.empty((B, MSG_BITS), dtype=np.uint8)
+        _lib.check(lib.cpx_memcpy_d2h(_lib.ptr(msgs), d_msg, msgs.nbytes))
+        y = np.empty((1, nsym), dtype=np.complex128)              # first codeword's symbols for the demod spot check
+        _lib.check(lib.cpx_memcpy_d2h(_lib.ptr(y), d_y, y.nbytes))
+        for d in (d_msg, d_coded, d_sym):
+            _lib.check(lib.cpx_free(d))
+
     # LLRs are produced on the device by the soft demodulator (same formula as Modem.demodulate) and stay in HBM.
     _lib.check(lib.cpx_demod_soft_dev(h_md, d_y, B * nsym, float(N0), d_llr, stream))
     sync()
 
-    timer = ctypes.c_void_p()
-    _lib.check(lib.cpx_timer_create(ctypes.byref(timer)))
+    # one HIP-event pair per timed step, recorded on the launch stream and read AFTER the timed region
+    timers = []
+    for _ in range(args.steps):
+        tmr = ctypes.c_void_p()
+        _lib.check(lib.cpx_timer_create(ctypes.byref(tmr)))
+        timers.append(tmr)
     kernel_ms = []
 
-    def step(timed):
-        if timed:
-            _lib.check(lib.cpx_timer_start(timer, stream))
+    def step(k):
+        if k is not None:
+            _lib.check(lib.cpx_timer_start(timers[k], stream))
         _lib.check(lib.cpx_viterbi_decode_batch_dev(h_tr, d_llr, B, LEN, L, T, TB, 1, d_bits, stream))
-        if timed:
-            _lib.check(lib.cpx_timer_stop(timer, stream))
+        if k is not None:
+            _lib.check(lib.cpx_timer_stop(timers[k], stream))
         if distributed and world > 1:
             dist.all_gather_into_tensor(t_all, t_bits)               # RCCL all-gather of the decoded bits
-        if timed:
-            ms = ctypes.c_float()
-            _lib.check(lib.cpx_timer_elapsed_ms(timer, ctypes.byref(ms)))
-            kernel_ms.append(ms.value)
 
     for _ in range(args.warmup):
-        step(False)
+        step(None)
     barrier(); sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
+    for k in range(args.steps):
+        step(k)
     barrier(); sync()
     elapsed = time.perf_counter() - t0
+    for tmr in timers:
+        ms = ctypes.c_float()
+        _lib.check(lib.cpx_timer_elapsed_ms(tmr, ctypes.byref(ms)))
+        kernel_ms.append(ms.value)
     if distributed:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -214,7 +249,8 @@ def main():
             "metric": "decoded info-bits/s at fixed Eb/N0 (Viterbi K=7 r=1/2, 1024b); BER match",
             "value": value, "unit": "info-bits/s", "n_gpus": world if distributed else 1, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic (%s-generated: random messages -> conv_encode -> QPSK -> AWGN -> soft demod on device)" % args.synth,
             "config": {"workload": "configs[1]: K=7 (0o133,0o171) r=1/2, 1024-bit blocks, soft Viterbi over "
                                    "AWGN+QPSK at Eb/N0=3 dB, batch=65536 codewords per GPU, tb_depth=30",
                        "batch_per_gpu": B, "block_bits": MSG_BITS, "ebn0_db": EBN0_DB,
