@@ -146,6 +146,41 @@ def bench_ldpc(lib, scale):
         dev.free()
 
 
+def bench_config4(lib, scale):
+    """BASELINE config 4 on one GPU's share: all-zero (1944,1296) codewords -> 64-QAM -> AWGN -> soft demod ->
+    sign flip (quirk B6) -> LDPC BP (<= 50 iterations), every stage on the device."""
+    from commpy_amd.channelcoding.ldpc import _device_code, get_ldpc_code_params
+    from commpy_amd.modulation import QAMModem
+    p = get_ldpc_code_params(os.path.join(ROOT, "commpy_amd/channelcoding/designs/ldpc/ieee80211n/1944.1296.txt"), True)
+    md = QAMModem(64)
+    n, nsym = 1944, 324
+    B = int(32768 * scale)
+    dev = Dev(lib)
+    d_bits = dev.put(np.zeros(B * n, np.uint8))
+    d_sym, d_y = dev.empty(B * nsym * 16), dev.empty(B * nsym * 16)
+    d_llr, d_neg = dev.empty(B * n * 8), dev.empty(B * n * 8)
+    d_dec, d_out, d_it = dev.empty(B * n), dev.empty(B * n * 8), dev.empty(B * 4)
+    code, h_md = _device_code(p), md._device_handle()
+    for ebn0 in (8.0, 10.0):
+        N0 = 42.0 / ((2.0 / 3) * 6 * 10 ** (ebn0 / 10.0))
+        sc = float(np.sqrt(N0 / 2))
+        for alg, name in ((1, "MSA"), (0, "SPA")):
+            def run():
+                _lib.check(lib.cpx_modulate_dev(h_md, d_bits, B * nsym, d_sym, None))
+                _lib.check(lib.cpx_awgn_dev(d_sym, B * nsym, sc, sc, 31, 1, d_y, None))
+                _lib.check(lib.cpx_demod_soft_dev(h_md, d_y, B * nsym, float(N0), d_llr, None))
+                _lib.check(lib.cpx_scale_f64_dev(d_llr, B * n, -1.0, d_neg, None))
+                _lib.check(lib.cpx_ldpc_bp_decode_batch_dev(code, d_neg, B, alg, 50, d_dec, d_out, d_it, None))
+            ms, _ = timeit(lib, run, steps=3, warmup=1)
+            its = dev.get(d_it, (B,), np.int32)
+            dec = dev.get(d_dec, (n, B), np.int8)
+            alg_bytes = B * nsym * 64 + int(its.sum()) * (4 * 7128 + 2 * n) * 8 + B * n * 17
+            emit("config4_pipeline_%s" % name, "64-QAM demod + LDPC (1944,1296) %s, Eb/N0=%.0f dB, B=%d, mean its %.2f" % (
+                name, ebn0, B, its.mean()), B * 1296, "info-bits", ms, alg_bytes, "hbm" if alg else "f64-transcendental",
+                 {"frame_error_rate": float(np.mean(dec.any(axis=0))), "mean_iterations": float(its.mean())})
+    dev.free()
+
+
 def bench_turbo(lib, scale, which):
     import warnings
     from commpy_amd.channelcoding import RandInterlv, Trellis, turbo_encode
@@ -201,7 +236,7 @@ def bench_viterbi_small(lib, scale):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--which", default="demod,ldpc,turbo,map,viterbi_small")
+    ap.add_argument("--which", default="demod,ldpc,config4,turbo,map,viterbi_small")
     ap.add_argument("--scale", type=float, default=1.0)
     a = ap.parse_args()
     lib = _lib.load()
@@ -215,6 +250,8 @@ def main():
         bench_turbo(lib, a.scale, which)
     if "ldpc" in which:
         bench_ldpc(lib, a.scale)
+    if "config4" in which:
+        bench_config4(lib, a.scale)
 
 
 if __name__ == "__main__":

@@ -184,9 +184,23 @@ __global__ __launch_bounds__(LS_BLOCK) void count_errors_kernel(const uint8_t *_
     }
 }
 
+// y = a * x (e.g. the LLR sign flip between Modem.demodulate, log P1/P0, and ldpc_bp_decode, log P0/P1: quirk B6)
+__global__ __launch_bounds__(LS_BLOCK) void scale_f64_kernel(const double *__restrict__ x, int64_t n, double a,
+                                                             double *__restrict__ y) {
+    for (int64_t i = (int64_t)blockIdx.x * LS_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * LS_BLOCK) y[i] = a * x[i];
+}
+
 }  // namespace
 
 extern "C" {
+
+int cpx_scale_f64_dev(const double *d_x, int64_t n, double a, double *d_y, void *stream) {
+    CPX_REQUIRE(n >= 0, CPX_EINVAL, "scale: negative size");
+    if (n == 0) return CPX_OK;
+    hipLaunchKernelGGL(scale_f64_kernel, dim3(ls_grid(n)), dim3(LS_BLOCK), 0, pick_stream(stream), d_x, n, a, d_y);
+    CPX_HIP(hipGetLastError());
+    return CPX_OK;
+}
 
 int cpx_random_bits_dev(uint8_t *d_bits, int64_t n, uint64_t seed, uint64_t stream_id, void *stream) {
     CPX_REQUIRE(n >= 0, CPX_EINVAL, "random_bits: negative size");

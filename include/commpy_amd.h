@@ -176,6 +176,8 @@ int cpx_demod_hard_dev(const cpx_modem *m, const double *d_y_re_im, int64_t Ns, 
  *   cpx_modulate_dev          Modem.modulate modulation.py:79-98: nb bits MSB-first -> constellation point
  *   cpx_awgn_dev              y = x + scale_re*n_re + 1j*scale_im*n_im, n ~ N(0,1) (channels.py:37-55)
  *   cpx_count_errors_dev      errs[b][c] = sum(msg[b, chunk c] ^ dec[b, chunk c]) (links.py:252-256)
+ *   cpx_scale_f64_dev         y = a*x, e.g. the sign flip between Modem.demodulate (log P1/P0) and ldpc_bp_decode
+ *                             (log P0/P1), test_ldpc.py:53-54
  */
 int cpx_random_bits_dev(uint8_t *d_bits, int64_t n, uint64_t seed, uint64_t stream_id, void *stream);
 int cpx_conv_encode_batch_dev(const cpx_trellis *t, const uint8_t *d_msg, int64_t B, int64_t nmsg, int terminate,
@@ -187,6 +189,7 @@ int cpx_gather_f64_dev(const double *d_in, int64_t B, int64_t nin, const int32_t
 int cpx_modulate_dev(const cpx_modem *m, const uint8_t *d_bits, int64_t nsym, double *d_sym_re_im, void *stream);
 int cpx_awgn_dev(const double *d_x_re_im, int64_t n, double scale_re, double scale_im, uint64_t seed,
                  uint64_t stream_id, double *d_y_re_im, void *stream);
+int cpx_scale_f64_dev(const double *d_x, int64_t n, double a, double *d_y, void *stream);
 int cpx_count_errors_dev(const uint8_t *d_msg, int64_t msg_stride, const uint8_t *d_dec, int64_t dec_stride,
                          int64_t B, int64_t nchunks, int64_t chunk, int32_t *d_errs, void *stream);
 

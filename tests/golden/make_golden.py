@@ -481,6 +481,28 @@ def gen_wifi():
 
 GENS["wifi"] = gen_wifi
 
+def gen_viterbi_ber():
+    """BER-vs-Eb/N0 reference points for BASELINE config 2 (K=7 soft Viterbi, 1024-bit blocks, QPSK + AWGN):
+    error counts of the live reference per Eb/N0, for the statistical overlay of the GPU curve."""
+    out = {}
+    ebn0s = [0.0, 1.0, 2.0, 3.0, 4.0]
+    errs, nbits = [], []
+    for i, e in enumerate(ebn0s):
+        B = 20 if e < 3 else 28
+        tr, msg, llr, N0 = c2_inputs(B, e, seed_msg=300 + i, seed_noise=400 + i)
+        t0 = time.time()
+        ne = 0
+        for b in range(B):
+            dec = viterbi_decode(llr[b].copy(), tr, None, "soft")
+            ne += int(np.sum(dec[:1024] != msg[b]))
+        errs.append(ne)
+        nbits.append(B * 1024)
+        print("viterbi_ber Eb/N0=%.1f: %d errors in %d bits (%.0fs)" % (e, ne, B * 1024, time.time() - t0))
+    save("viterbi_ber", ebn0=np.array(ebn0s), errors=np.array(errs), bits=np.array(nbits))
+
+
+GENS["viterbi_ber"] = gen_viterbi_ber
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
