@@ -15,6 +15,10 @@ namespace cpx {
 void set_error(const char *fmt, ...);
 hipStream_t lib_stream();   // lazily created per-process stream of the current device
 int ensure_device();        // CPX_OK if a HIP device is usable
+int device_cus();           // compute units of the current device (256 on MI355X)
+// workgroups of `fn` (block size `threads`, no dynamic LDS) resident on the whole device at once -- the size of a
+// persistent grid; cached per kernel
+int resident_blocks(const void *fn, int threads);
 // Scratch arena keyed by (device, stream, slot): grown with hipMalloc on demand, reused by later calls and
 // released by cpx_release_workspace().  Kernels of one stream serialise, so one arena per stream is safe.
 // (Stream-ordered hipMallocAsync/hipFreeAsync was measured to hand out memory that is still in use on this
@@ -82,6 +86,13 @@ struct cpx_ldpc {
     // variable-major view: for each variable its edges in increasing check order
     int32_t *d_col_ptr = nullptr;     // [n_v+1]
     int32_t *d_col_edge = nullptr;    // [E] edge ids
+    int32_t *d_col_cj = nullptr;      // [E] (check << 5) | position of the edge in its check's row (min-sum records)
+    // padded copies (row/column stride cpad/vpad): their address depends on the node index only, so the
+    // scalar loads of a work item issue together with row_ptr/col_ptr instead of after them
+    int cpad = 0, vpad = 0;
+    int32_t *d_row_pad = nullptr;     // [n_c][cpad] variable of the j-th edge of check c
+    int32_t *d_col_pad_edge = nullptr;  // [n_v][vpad] edge id of the q-th edge of variable v
+    int32_t *d_col_pad_cj = nullptr;    // [n_v][vpad] (check << 5) | position
 };
 
 struct cpx_modem {

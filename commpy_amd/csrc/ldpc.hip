@@ -2,17 +2,41 @@
 //   ldpc_bp_decode  (/root/reference/commpy/channelcoding/ldpc.py:144-254)
 // for a batch of B independent blocks (the reference's sequential `for i_start` loop, ldpc.py:197).
 //
-// Data layout in HBM (codeword index fastest => every access below is coalesced across lanes):
-//   M      [E][B]  float64 edge messages, edges sorted by (check, variable)  -- message_matrix
-//   llrT   [n_v][B] float64 clipped channel LLRs (transposed once from the caller's [B][n_v])
-//   out    [n_v][B] float64 / dec [n_v][B] int8 -- exactly the reference's output layout (:251-253)
-//   unsat  [B] int32 "syndrome not yet zero" flag, recomputed at the start of every iteration
-// One iteration = syndrome pass (early-exit test, :205-206) + check-node pass + variable-node pass;
-// a block whose syndrome is zero is frozen: its threads exit before touching messages, which
-// reproduces the reference's `break` per block.  Lanes = consecutive codewords; a thread owns one
-// (check, codeword) or (variable, codeword) pair and reduces its row/column in registers in the
-// reference's order (row: increasing variable; column: increasing check -- SciPy coo_matvec order).
-// HBM traffic per executed iteration per block = (4E + 2 n_v) * 8 B (algorithmic).
+// Formulation.  The reference keeps ONE message per edge and overwrites it twice per iteration
+// (check pass :209-238, variable pass :243-245).  Its variable pass writes
+//     M[e] = M[e] * -1 + 1.0 * (msg_sum[v] + llr[v])                      (:244-245)
+// and (msg_sum + llr) is exactly the a-posteriori LLR it also stores in out_llrs (:247).  So the engine keeps
+//     R [e]  = check->variable message (the state after the check pass)
+//     Q [v]  = msg_sum + llr            (the a-posteriori LLR, also the decision variable)
+// and the check pass recomputes the variable->check message as R*(-1) + 1.0*Q -- the same two float64
+// operations on the same operands, hence bit-identical -- instead of reading it back from memory.
+// HBM traffic per executed iteration per block falls from (4E + 2n)*8 B to about (3E + 3n)*8 B for SPA
+// (R read+written by the check pass, read by the variable pass; Q, llr: n each; Q re-reads hit L2).
+// Min-sum goes further: the messages a check sends are +-(one of two magnitudes), so its row is kept as a
+// 3-word record (min1, min2, position/sign bits -- see MsaRec) instead of deg_c float64: about
+// (9 n_c + 3n)*8 B per iteration, 2.8x less than the reference formulation for the (1944,1296) code, still
+// bit-identical (the record stores the generating values, not an approximation).
+// The parity of sign(Q) over a check's row is the syndrome bit (:203-206), so the early-termination test
+// rides in the check pass: a pass marks the block "unsatisfied" when it sees an odd row, and the variable pass
+// only commits Q for marked blocks.  A block whose syndrome is zero therefore executes one speculative check
+// pass whose R is never used again, and then freezes -- the reference's `break`.
+//
+// Data layout in HBM: tiles of 64 blocks (one wavefront), tile-major, block index fastest:
+//   R [tile][E][64] (SPA) or [tile][n_c][3][64] (min-sum records), Q [tile][n_v][64], L [tile][n_v][64]
+//   float64;  state/orig [slot] int32
+// Every access is a fully coalesced 512-byte row.  A slot's state is the stamp of the last iteration that
+// found it unsatisfied (+1), -1 for padding/retired slots; orig is the block index in the caller's arrays.
+//
+// Launch geometry: persistent grids sized to what is resident (occupancy x CUs, a multiple of 8 workgroups),
+// wave = one (tile, check) or (tile, variable) item; node tables are padded so that every scalar load of an
+// item depends on the node index only, and the min-sum check pass prefetches the next item's operands.  Workgroups are dealt round-robin to the 8 XCDs, so workgroup id mod 8 selects the tiles it serves:
+// all checks of a tile run on one XCD and the tile's 1 MB of Q (gathered deg_v times) stays in that XCD's L2.
+//
+// Compaction.  Frozen blocks would keep occupying lanes of half-empty wavefronts (partial cache lines cost
+// full transactions).  After every iteration a single-workgroup scan counts the unsatisfied slots; when they are
+// at most half of the live slots, a move pass copies their R/Q/L columns to the front of a second set of
+// buffers and *retires* the frozen ones (out_llrs / dec_word written at their original block index).  All of it
+// is decided and applied on the device (control block in HBM, no host synchronisation).
 #include "cpx_internal.h"
 
 #include <algorithm>
@@ -21,156 +45,574 @@ using namespace cpx;
 
 namespace {
 
-constexpr int LB = 256;     // threads per block (codewords along x)
+constexpr int LB = 256;     // threads per workgroup = 4 wavefronts
 constexpr int MAXDEG = 32;  // max check degree held in registers
+
+struct Ctl { int n_slots, buf, do_move, n_new; };
+
+struct Bufs {
+    double *R[2], *Q[2], *L[2];
+    int32_t *state[2], *orig[2];
+    int32_t *dst;
+    Ctl *ctl;
+};
 
 __device__ __forceinline__ double clip_nan(double v, double lo, double hi) {
     // np.clip propagates NaN
     return (v != v) ? v : fmin(fmax(v, lo), hi);
 }
 
-// llrT[v][b] = clip(llr[b][v]); llr clipped in place (ldpc.py:186); out = llr; dec = signbit (:193-194)
-__global__ __launch_bounds__(LB) void ldpc_init_kernel(double *__restrict__ llr, int64_t B, int n_v,
-                                                       double *__restrict__ llrT, double *__restrict__ out,
-                                                       int8_t *__restrict__ dec, int32_t *__restrict__ iters,
-                                                       int32_t *__restrict__ unsat) {
-    __shared__ double tile[32][33];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
-    const int64_t b0 = (int64_t)blockIdx.x * 32;
-    const int v0 = blockIdx.y * 32;
-    for (int r = ty; r < 32; r += 8) {                            // read rows = codewords, cols = variables
-        const int64_t b = b0 + r;
+// view of the control block for compute passes: a pending move is already in effect for them
+__device__ __forceinline__ void effective(const Ctl *c, int &n_slots, int &buf) {
+    const int mv = c->do_move;
+    n_slots = mv ? c->n_new : c->n_slots;
+    buf = c->buf ^ mv;
+}
+
+// L = Q = clip(llr) tile-major; llr clipped in place (ldpc.py:186); slot table; control block
+__global__ __launch_bounds__(LB) void ldpc_init_kernel(double *__restrict__ llr, int64_t B, int n_v, Bufs bf,
+                                                       int32_t *__restrict__ iters) {
+    __shared__ double ts[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;      // 64 x 4
+    const int64_t tile = blockIdx.x;
+    const int v0 = blockIdx.y * 64;
+    for (int r = ty; r < 64; r += 4) {                            // rows = blocks, columns = variables
+        const int64_t b = tile * 64 + r;
         const int v = v0 + tx;
         double x = 0.0;
         if (b < B && v < n_v) {
             x = clip_nan(llr[b * n_v + v], -500.0, 500.0);
             llr[b * n_v + v] = x;
         }
-        tile[r][tx] = x;
+        ts[r][tx] = x;
     }
     __syncthreads();
-    for (int r = ty; r < 32; r += 8) {                            // write rows = variables, cols = codewords
+    for (int r = ty; r < 64; r += 4) {                            // rows = variables, columns = blocks
         const int v = v0 + r;
-        const int64_t b = b0 + tx;
-        if (b < B && v < n_v) {
-            const double x = tile[tx][r];
-            llrT[(int64_t)v * B + b] = x;
-            out[(int64_t)v * B + b] = x;
-            dec[(int64_t)v * B + b] = (int8_t)(__builtin_signbit(x) ? 1 : 0);
+        if (v < n_v) {
+            const double x = ts[tx][r];
+            const int64_t i = (tile * n_v + v) * 64 + tx;
+            bf.L[0][i] = x;
+            bf.Q[0][i] = x;                                       // out_llrs = llr (:194)
         }
     }
-    if (blockIdx.y == 0) {
-        const int64_t b = b0 + threadIdx.x;
-        if (threadIdx.x < 32 && b < B) {
-            if (iters) iters[b] = 0;
-            unsat[b] = 0;
-        }
+    if (blockIdx.y == 0 && threadIdx.x < 64) {
+        const int64_t slot = tile * 64 + threadIdx.x;
+        bf.state[0][slot] = slot < B ? 0 : -1;
+        bf.orig[0][slot] = (int32_t)slot;
+        if (slot < B && iters) iters[slot] = 0;
+        if (slot == 0) { bf.ctl->n_slots = (int)(gridDim.x * 64); bf.ctl->buf = 0; bf.ctl->do_move = 0; bf.ctl->n_new = 0; }
     }
 }
 
-// message_matrix = H.multiply(llr) (:199): M[e][b] = llr[var(e)][b]
-__global__ __launch_bounds__(LB) void ldpc_msg_init_kernel(const double *__restrict__ llrT, int64_t B,
-                                                           const int32_t *__restrict__ edge_var,
-                                                           int64_t E, double *__restrict__ M) {
-    const int64_t b = (int64_t)blockIdx.x * LB + threadIdx.x;
-    if (b >= B) return;
-    for (int64_t e = blockIdx.y; e < E; e += gridDim.y) M[e * B + b] = 1.0 * llrT[(int64_t)edge_var[e] * B + b];
-}
+// ---------------------------------------------------------------------------------------------------------
+// Work distribution of the compute passes: wave w of workgroup `blockIdx.x` serves group member g*4+w of
+// (tile, group g); tiles are dealt by workgroup id mod 8 so that one XCD owns a tile.
+#define CPX_ITEM_LOOP(N_GROUPS)                                                                      \
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;                                         \
+    const int xcd = blockIdx.x & 7, jstride = gridDim.x >> 3;                                        \
+    for (int idx = blockIdx.x >> 3;; idx += jstride)
 
-// Early-termination test (:205): unsat[b] == stamp <=> some check of block b has odd parity of dec_word.
-__global__ __launch_bounds__(LB) void ldpc_syndrome_kernel(const int8_t *__restrict__ dec, int64_t B,
-                                                           const int32_t *__restrict__ row_ptr,
-                                                           const int32_t *__restrict__ edge_var,
-                                                           int32_t *__restrict__ unsat, int stamp) {
-    const int64_t b = (int64_t)blockIdx.x * LB + threadIdx.x;
-    const int c = blockIdx.y;
-    if (b >= B) return;
-    int par = 0;
-    for (int e = row_ptr[c]; e < row_ptr[c + 1]; e++) par ^= dec[(int64_t)edge_var[e] * B + b];
-    if (par & 1) unsat[b] = stamp;      // stamp = iteration + 1: no per-iteration clearing pass needed
+__device__ __forceinline__ double min_f64(double a, double b) {     // one v_min_f64 (fmin adds two canonicalising v_max)
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
+__device__ __forceinline__ double ntload(const double *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void ntstore(double v, double *p) { __builtin_nontemporal_store(v, p); }
 
-// Check-node update.  SPA (:209-227) / MSA (:229-238).
-template <int ALG, int DEG_CAP>
-__global__ __launch_bounds__(LB) void ldpc_cn_kernel(double *__restrict__ M, int64_t B,
-                                                     const int32_t *__restrict__ row_ptr,
-                                                     const int32_t *__restrict__ unsat, int stamp) {
-    const int64_t b = (int64_t)blockIdx.x * LB + threadIdx.x;
-    const int c = blockIdx.y;
-    if (b >= B || unsat[b] != stamp) return;
-    const int e0 = row_ptr[c];
-    const int deg = row_ptr[c + 1] - e0;
-    double v[DEG_CAP];
+// ---- sum-product (:209-227): R keeps one float64 per edge --------------------------------------------------
+template <int DEG>
+__device__ __forceinline__ void cn_spa_row(double *__restrict__ Rrow, const double *__restrict__ Qt,
+                                           const int32_t *__restrict__ ev, int deg, int k, int32_t *st) {
+    // DEG > 0: exact degree, fully unrolled, row in registers;  DEG == 0: any degree, tanh values parked in R
+    double v[DEG > 0 ? DEG : 1];
+    int sx = 0;
+    double prod = 1.0;
+#define CPX_SPA_IN(j)                                                                                 \
+    {                                                                                                 \
+        const double q = Qt[(int64_t)ev[j] * 64];                                                     \
+        sx ^= __double2hiint(q);                             /* dec_word = out_llrs < 0 (:193, :248) */ \
+        double m = 1.0 * q;                                  /* message_matrix = H.multiply(llr) (:199) */ \
+        if (k > 0) {                                                                                  \
+            m = ntload(&Rrow[(int64_t)(j) * 64]) * -1.0;     /* data *= -1 (:244) */                   \
+            m += 1.0 * q;                                    /* data += H.multiply(msg_sum + llr).data (:245) */ \
+        }                                                                                             \
+        m = tanh(m * 0.5);                                   /* data *= .5; tanh (:210-211) */         \
+        prod *= m;                                           /* row product (reference: exp2(sum(log2)) :217-219) */ \
+        if (DEG > 0) v[DEG > 0 ? (j) : 0] = m; else Rrow[(int64_t)(j) * 64] = m;                       \
+    }
+#define CPX_SPA_OUT(j, t)                                                                             \
+    {                                                                                                 \
+        double x = (1.0 / (t)) * prod;                       /* data = 1/data; multiply(msg_products) (:222-223) */ \
+        x = clip_nan(x, -1.0, 1.0);                          /* (:224) */                              \
+        x = atanh(x) * 2.0;                                  /* (:225-226) */                          \
+        ntstore(clip_nan(x, -500.0, 500.0), &Rrow[(int64_t)(j) * 64]);   /* (:227) */                  \
+    }
+    if (DEG > 0) {
 #pragma unroll
-    for (int j = 0; j < DEG_CAP; j++) v[j] = (j < deg) ? M[(int64_t)(e0 + j) * B + b] : 1.0;
-    if (ALG == CPX_LDPC_SPA) {
-        double prod = 1.0;
+        for (int j = 0; j < DEG; j++) CPX_SPA_IN(j)
+        if (sx < 0) *st = k + 1;                                 // odd row: iteration k is executed (:205)
 #pragma unroll
-        for (int j = 0; j < DEG_CAP; j++) {
-            if (j < deg) {
-                v[j] = tanh(v[j] * 0.5);                 // data *= .5; tanh (:210-211)
-                prod *= v[j];                            // row product (reference: exp2(sum(log2)) :217-219), increasing variable
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < DEG_CAP; j++) {
-            if (j < deg) {
-                double x = (1.0 / v[j]) * prod;          // data = 1/data; multiply(msg_products) (:222-223)
-                x = clip_nan(x, -1.0, 1.0);              // (:224)
-                x = atanh(x) * 2.0;                      // (:225-226)
-                M[(int64_t)(e0 + j) * B + b] = clip_nan(x, -500.0, 500.0);   // (:227)
-            }
-        }
+        for (int j = 0; j < DEG; j++) CPX_SPA_OUT(j, v[DEG > 0 ? j : 0])
     } else {
-        // sign(other).prod() * abs(other).min() over the OTHER edges of the row (:236-237)
-        int nzero = 0, nneg = 0, imin = -1;
-        double min1 = __builtin_huge_val(), min2 = __builtin_huge_val();
+        for (int j = 0; j < deg; j++) CPX_SPA_IN(j)
+        if (sx < 0) *st = k + 1;
+        for (int j = 0; j < deg; j++) CPX_SPA_OUT(j, Rrow[(int64_t)j * 64])
+    }
+#undef CPX_SPA_IN
+#undef CPX_SPA_OUT
+}
+
+// ---- min-sum (:229-238): the messages of a row are (+-) one of TWO magnitudes, so the row is kept as a record
+//   rec[0] = min1 = smallest |v->c message| of the row, rec[1] = min2 = second smallest (ties: a later equal
+//   value), rec[2] = meta: bits 0..7 position of min1, bit 8 parity of the negatives, bits 32..63 negative mask.
+// Edge j receives  (-1)^(negatives among the others) * (j == imin ? min2 : min1)  -- exactly
+// sign(other).prod() * abs(other).min(): a zero among the others makes the minimum zero by itself.
+struct MsaRec { double m1, m2; unsigned neg; int imin, par; };
+
+__device__ __forceinline__ MsaRec msa_load(const double *__restrict__ rec) {
+    MsaRec r;
+    r.m1 = ntload(&rec[0]);
+    r.m2 = ntload(&rec[64]);
+    const double meta = ntload(&rec[128]);
+    const int lo = __double2loint(meta);
+    r.neg = (unsigned)__double2hiint(meta);
+    r.imin = lo & 0xff;
+    r.par = (lo >> 8) & 1;
+    return r;
+}
+// the message edge j of the row received, negated or not (flip = 1 returns -R)
+__device__ __forceinline__ double msa_edge(const MsaRec &r, int j, int flip) {
+    const double mn = (j == r.imin) ? r.m2 : r.m1;
+    const unsigned ng = ((r.neg >> j) ^ (unsigned)r.par ^ (unsigned)flip) & 1u;
+    return __hiloint2double(__double2hiint(mn) | (int)(ng << 31), __double2loint(mn));
+}
+
+template <int DEG>
+__device__ __forceinline__ void cn_msa_row(const MsaRec &o, double *__restrict__ rec, const double *__restrict__ Qt,
+                                           const int32_t *__restrict__ ev, int deg, int k, int32_t *st) {
+    int sx = 0, imin = 0;
+    unsigned neg = 0;
+    double m1 = __builtin_huge_val(), m2 = __builtin_huge_val();
+#define CPX_MSA_EDGE(j)                                                                               \
+    {                                                                                                 \
+        const double q = Qt[(int64_t)ev[j] * 64];                                                     \
+        sx ^= __double2hiint(q);                             /* dec_word = out_llrs < 0 (:193, :248) */ \
+        double m = q;                                        /* 1.0 * llr (:199) */                    \
+        if (k > 0) m = msa_edge(o, (j), 1) + q;              /* data * -1 + 1.0 * (msg_sum + llr) (:244-245) */ \
+        const double a = fabs(m);                                                                     \
+        const bool c1 = a < m1;                                                                       \
+        m2 = min_f64(m2, c1 ? m1 : a);                                                                \
+        m1 = min_f64(m1, a);                                                                          \
+        imin = c1 ? (j) : imin;                                                                       \
+        neg |= (m < 0.0) ? (1u << (j)) : 0u;                                                          \
+    }
+    if (DEG > 0) {
 #pragma unroll
-        for (int j = 0; j < DEG_CAP; j++) {
-            if (j < deg) {
-                const double a = fabs(v[j]);
-                nzero += (v[j] == 0.0);
-                nneg += (v[j] < 0.0);
-                if (a < min1) { min2 = min1; min1 = a; imin = j; }
-                else if (a < min2) { min2 = a; }
+        for (int j = 0; j < DEG; j++) CPX_MSA_EDGE(j)
+    } else {
+        for (int j = 0; j < deg; j++) CPX_MSA_EDGE(j)
+    }
+#undef CPX_MSA_EDGE
+    if (sx < 0) *st = k + 1;                                     // odd row: iteration k is executed (:205)
+    const int lo = imin | ((__popc(neg) & 1) << 8);
+    ntstore(m1, &rec[0]);
+    ntstore(m2, &rec[64]);
+    ntstore(__hiloint2double((int)neg, lo), &rec[128]);
+}
+
+#define CPX_DEG_SWITCH(FN, ...)                                                                      \
+    switch (deg) {                                                                                   \
+    case 2: FN<2>(__VA_ARGS__); break;   case 3: FN<3>(__VA_ARGS__); break;                          \
+    case 4: FN<4>(__VA_ARGS__); break;   case 5: FN<5>(__VA_ARGS__); break;                          \
+    case 6: FN<6>(__VA_ARGS__); break;   case 7: FN<7>(__VA_ARGS__); break;                          \
+    case 8: FN<8>(__VA_ARGS__); break;   case 9: FN<9>(__VA_ARGS__); break;                          \
+    case 10: FN<10>(__VA_ARGS__); break; case 11: FN<11>(__VA_ARGS__); break;                        \
+    case 12: FN<12>(__VA_ARGS__); break;                                                             \
+    default: FN<0>(__VA_ARGS__); break;                                                              \
+    }
+
+// Check pass of iteration k: syndrome bit + check-node update.  RR = rows of R per tile (E or 3 n_c).
+template <int ALG>
+__global__ __launch_bounds__(LB) void ldpc_cn_kernel(Bufs bf, int n_v, int n_c, int64_t RR,
+                                                     const int32_t *__restrict__ row_ptr,
+                                                     const int32_t *__restrict__ row_pad, int cpad, int k) {
+    int n_slots, buf;
+    effective(bf.ctl, n_slots, buf);
+    const int n_tiles = n_slots >> 6;
+    double *__restrict__ R = bf.R[buf];
+    const double *__restrict__ Q = bf.Q[buf];
+    int32_t *__restrict__ state = bf.state[buf];
+    const int nG = (n_c + 3) >> 2;
+    CPX_ITEM_LOOP(nG) {
+        const int tl = idx / nG, cg = idx - tl * nG;
+        const int64_t tile = (int64_t)tl * 8 + xcd;
+        if (tile >= n_tiles) break;
+        const int c = cg * 4 + w;
+        if (c >= n_c) continue;
+        // everything whose address depends on (tile, c) only is requested before the first wait
+        const int64_t slot = tile * 64 + lane;
+        const int st = state[slot];
+        const int e0 = row_ptr[c];
+        const int deg = row_ptr[c + 1] - e0;
+        const int32_t *__restrict__ ev = row_pad + (int64_t)c * cpad;
+        const double *__restrict__ Qt = Q + tile * n_v * 64 + lane;
+        if (ALG == CPX_LDPC_SPA) {
+            if (st < k) continue;                                 // frozen, retired or padding
+            double *__restrict__ Rrow = R + (tile * RR + e0) * 64 + lane;
+            CPX_DEG_SWITCH(cn_spa_row, Rrow, Qt, ev, deg, k, &state[slot])
+        } else {
+            double *__restrict__ rec = R + (tile * RR + (int64_t)c * 3) * 64 + lane;
+            MsaRec o{0.0, 0.0, 0u, 0, 0};
+            if (k > 0) o = msa_load(rec);
+            if (st < k) continue;
+            CPX_DEG_SWITCH(cn_msa_row, o, rec, Qt, ev, deg, k, &state[slot])
+        }
+    }
+}
+
+// Column sum in increasing check order (message_matrix.sum(0), :243).  refs[q]: SPA = edge id; MSA =
+// (check << 5) | position of the edge in the check's row.  DEG > 0: exact degree, all loads of a stage in flight.
+template <int ALG, int DEG>
+__device__ __forceinline__ double vn_sum(const double *__restrict__ Rt, const int32_t *__restrict__ refs, int deg) {
+    constexpr int CH = DEG > 0 ? DEG : 4;
+    double msum = 0.0;
+    for (int q0 = 0; q0 < (DEG > 0 ? 1 : deg); q0 += CH) {
+        double r[CH];
+        if (ALG == CPX_LDPC_SPA) {
+#pragma unroll
+            for (int u = 0; u < CH; u++)
+                if (DEG > 0 || q0 + u < deg) r[u] = ntload(&Rt[(int64_t)refs[q0 + u] * 64]);
+        } else {
+            const double *rec[CH];
+            double meta[CH];
+#pragma unroll
+            for (int u = 0; u < CH; u++) {
+                if (DEG > 0 || q0 + u < deg) {
+                    rec[u] = Rt + (int64_t)(refs[q0 + u] >> 5) * 192;
+                    meta[u] = rec[u][128];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < CH; u++) {
+                if (DEG > 0 || q0 + u < deg) {
+                    const int j = refs[q0 + u] & 31, lo = __double2loint(meta[u]);
+                    const double mn = rec[u][(j == (lo & 0xff)) ? 64 : 0];
+                    const unsigned ng = (((unsigned)__double2hiint(meta[u]) >> j) ^ (unsigned)(lo >> 8)) & 1u;
+                    r[u] = __hiloint2double(__double2hiint(mn) | (int)(ng << 31), __double2loint(mn));
+                }
             }
         }
 #pragma unroll
-        for (int j = 0; j < DEG_CAP; j++) {
-            if (j < deg) {
-                const int oz = nzero - (v[j] == 0.0);
-                const int on = nneg - (v[j] < 0.0);
-                const double sgn = oz ? 0.0 : ((on & 1) ? -1.0 : 1.0);
-                const double mn = (j == imin) ? min2 : min1;
-                M[(int64_t)(e0 + j) * B + b] = sgn * mn;
+        for (int u = 0; u < CH; u++)
+            if (DEG > 0 || q0 + u < deg) msum += r[u];
+    }
+    return msum;
+}
+
+// ---- min-sum passes, software-pipelined: while a wave works on one (tile, node) item, the state word, the old
+// record and the scalar table entries of its NEXT item are already in flight, and the gathers of the current
+// item (Q rows / record words, mostly L2 hits) are issued before the first wait.  The passes were latency-bound
+// with everything requested on demand (four to five dependent round trips per item).
+template <int DEG, int QCAP>
+__device__ __forceinline__ void cn_msa_q(const MsaRec &o, double *__restrict__ rec, const double (&q)[QCAP], int k,
+                                         int32_t *st) {
+    int sx = 0, imin = 0;
+    unsigned neg = 0;
+    double m1 = __builtin_huge_val(), m2 = __builtin_huge_val();
+#pragma unroll
+    for (int j = 0; j < DEG; j++) {
+        sx ^= __double2hiint(q[j]);                              // dec_word = out_llrs < 0 (:193, :248)
+        double m = q[j];                                         // 1.0 * llr (:199)
+        if (k > 0) m = msa_edge(o, j, 1) + q[j];                 // data * -1 + 1.0 * (msg_sum + llr) (:244-245)
+        const double a = fabs(m);
+        const bool c1 = a < m1;
+        m2 = min_f64(m2, c1 ? m1 : a);
+        m1 = min_f64(m1, a);
+        imin = c1 ? j : imin;
+        neg |= (m < 0.0) ? (1u << j) : 0u;
+    }
+    if (sx < 0) *st = k + 1;                                     // odd row: iteration k is executed (:205)
+    const int lo = imin | ((__popc(neg) & 1) << 8);
+    ntstore(m1, &rec[0]);
+    ntstore(m2, &rec[64]);
+    ntstore(__hiloint2double((int)neg, lo), &rec[128]);
+}
+
+template <int QCAP>
+__global__ __launch_bounds__(LB) void ldpc_cn_msa_kernel(Bufs bf, int n_v, int n_c,
+                                                         const int32_t *__restrict__ row_ptr,
+                                                         const int32_t *__restrict__ row_pad, int cpad, int k) {
+    int n_slots, buf;
+    effective(bf.ctl, n_slots, buf);
+    const int n_tiles = n_slots >> 6;
+    double *__restrict__ R = bf.R[buf];
+    const double *__restrict__ Q = bf.Q[buf];
+    int32_t *__restrict__ state = bf.state[buf];
+    const int nG = (n_c + 3) >> 2;
+    const int64_t RR = 3 * (int64_t)n_c;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int xcd = blockIdx.x & 7, jstride = gridDim.x >> 3;
+    struct Pre { int64_t tile; int c, st, deg, live; MsaRec o; int ev[QCAP]; };
+    auto stage_a = [&](int idx, Pre &p) -> bool {
+        const int tl = idx / nG;
+        p.tile = (int64_t)tl * 8 + xcd;
+        if (p.tile >= n_tiles) return false;
+        p.c = (idx - tl * nG) * 4 + w;
+        p.live = p.c < n_c;
+        const int cc = p.live ? p.c : 0;
+        p.st = state[p.tile * 64 + lane];
+        p.deg = row_ptr[cc + 1] - row_ptr[cc];
+#pragma unroll
+        for (int j = 0; j < QCAP; j++) p.ev[j] = row_pad[(int64_t)cc * cpad + j];
+        p.o = MsaRec{0.0, 0.0, 0u, 0, 0};
+        if (k > 0) p.o = msa_load(R + (p.tile * RR + (int64_t)cc * 3) * 64 + lane);
+        return true;
+    };
+    Pre nxt;
+    int idx = blockIdx.x >> 3;
+    bool more = stage_a(idx, nxt);
+    while (more) {
+        const Pre cur = nxt;
+        const double *__restrict__ Qt = Q + cur.tile * n_v * 64 + lane;
+        double q[QCAP];
+#pragma unroll
+        for (int j = 0; j < QCAP; j++) q[j] = Qt[(int64_t)cur.ev[j] * 64];   // entries past deg: valid rows, unused
+        idx += jstride;
+        more = stage_a(idx, nxt);
+        if (cur.live && cur.st >= k) {                            // else frozen, retired or padding
+            double *__restrict__ rec = R + (cur.tile * RR + (int64_t)cur.c * 3) * 64 + lane;
+            int32_t *stp = &state[cur.tile * 64 + lane];
+            switch (cur.deg) {
+#define CPX_CASE(D) case D: if (D <= QCAP) { cn_msa_q<(D <= QCAP ? D : 1), QCAP>(cur.o, rec, q, k, stp); break; }
+            CPX_CASE(2) CPX_CASE(3) CPX_CASE(4) CPX_CASE(5) CPX_CASE(6) CPX_CASE(7) CPX_CASE(8) CPX_CASE(9)
+            CPX_CASE(10) CPX_CASE(11) CPX_CASE(12)
+#undef CPX_CASE
+            default:
+                cn_msa_row<0>(cur.o, rec, Qt, row_pad + (int64_t)cur.c * cpad, cur.deg, k, stp);
+                break;
             }
         }
     }
 }
 
-// Variable-node update (:243-248).
-__global__ __launch_bounds__(LB) void ldpc_vn_kernel(double *__restrict__ M, int64_t B,
-                                                     const int32_t *__restrict__ col_ptr,
-                                                     const int32_t *__restrict__ col_edge,
-                                                     const double *__restrict__ llrT, double *__restrict__ out,
-                                                     int8_t *__restrict__ dec, const int32_t *__restrict__ unsat,
-                                                     int stamp, int32_t *__restrict__ iters) {
-    const int64_t b = (int64_t)blockIdx.x * LB + threadIdx.x;
-    const int v = blockIdx.y;
-    if (b >= B || unsat[b] != stamp) return;
-    const int q0 = col_ptr[v], q1 = col_ptr[v + 1];
-    double msum = 0.0;                                           // message_matrix.sum(0): increasing check
-    for (int q = q0; q < q1; q++) msum += M[(int64_t)col_edge[q] * B + b];
-    const double tot = msum + llrT[(int64_t)v * B + b];          // msg_sum + llr (:245, :247)
-    for (int q = q0; q < q1; q++) {
-        const int64_t idx = (int64_t)col_edge[q] * B + b;
-        double m = M[idx] * -1.0;                                // data *= -1 (:244)
-        m += 1.0 * tot;                                          // data += H.multiply(msg_sum + llr).data (:245)
-        M[idx] = m;
+// Min-sum variable pass: two round trips per item.  (1) state, column descriptor, llr -- addresses depend on the
+// item only; (2) all three words of the records of up to four edges at once (the magnitude is selected in
+// registers: one more L2-hit load per edge instead of a third dependent round trip).
+__device__ __forceinline__ void vn_msa_chunk(const double *__restrict__ Rt, int r0, int r1, int r2, int r3, int n,
+                                             double &msum) {
+    const int ref[4] = {r0, r1, r2, r3};
+    double a[4], b[4], m[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        if (u < n) {
+            const double *__restrict__ rec = Rt + (int64_t)(ref[u] >> 5) * 192;
+            a[u] = rec[0];
+            b[u] = rec[64];
+            m[u] = rec[128];
+        }
     }
-    out[(int64_t)v * B + b] = tot;                               // (:247)
-    dec[(int64_t)v * B + b] = (int8_t)(__builtin_signbit(tot) ? 1 : 0);   // (:248)
-    if (v == 0 && iters) iters[b] += 1;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        if (u < n) {
+            const int j = ref[u] & 31, lo = __double2loint(m[u]);
+            const double mn = (j == (lo & 0xff)) ? b[u] : a[u];
+            const unsigned ng = (((unsigned)__double2hiint(m[u]) >> j) ^ (unsigned)(lo >> 8)) & 1u;
+            msum += __hiloint2double(__double2hiint(mn) | (int)(ng << 31), __double2loint(mn));   // increasing check (:243)
+        }
+    }
+}
+
+__global__ __launch_bounds__(LB) void ldpc_vn_msa_kernel(Bufs bf, int n_v, int n_c,
+                                                         const int32_t *__restrict__ col_ptr,
+                                                         const int32_t *__restrict__ col_pad, int vpad, int k,
+                                                         int32_t *__restrict__ iters) {
+    int n_slots, buf;
+    effective(bf.ctl, n_slots, buf);
+    const int n_tiles = n_slots >> 6;
+    const double *__restrict__ R = bf.R[buf];
+    const double *__restrict__ L = bf.L[buf];
+    double *__restrict__ Q = bf.Q[buf];
+    const int32_t *__restrict__ state = bf.state[buf];
+    const int nG = (n_v + 3) >> 2;
+    const int64_t RR = 3 * (int64_t)n_c;
+    CPX_ITEM_LOOP(nG) {
+        const int tl = idx / nG, vg = idx - tl * nG;
+        const int64_t tile = (int64_t)tl * 8 + xcd;
+        if (tile >= n_tiles) break;
+        const int v = vg * 4 + w;
+        if (v >= n_v) continue;
+        const int64_t slot = tile * 64 + lane;
+        const int st = state[slot];
+        const int deg = col_ptr[v + 1] - col_ptr[v];
+        const int32_t *__restrict__ refs = col_pad + (int64_t)v * vpad;
+        const int r0 = refs[0], r1 = refs[1], r2 = refs[2], r3 = refs[3];
+        const int64_t i = (tile * n_v + v) * 64 + lane;
+        const double l = ntload(&L[i]);
+        if (st <= k) continue;                                    // syndrome was zero at the start of iteration k
+        const double *__restrict__ Rt = R + tile * RR * 64 + lane;
+        double msum = 0.0;
+        vn_msa_chunk(Rt, r0, r1, r2, r3, deg, msum);
+        for (int q0 = 4; q0 < deg; q0 += 4)
+            vn_msa_chunk(Rt, refs[q0], refs[q0 + 1], refs[q0 + 2], refs[q0 + 3], deg - q0, msum);
+        Q[i] = msum + l;                                          // msg_sum + llr (:245, :247)
+        if (v == 0 && iters) iters[bf.orig[buf][slot]] += 1;
+    }
+}
+
+// Variable pass of iteration k (:243-248): Q = column sum + llr.
+template <int ALG>
+__global__ __launch_bounds__(LB) void ldpc_vn_kernel(Bufs bf, int n_v, int64_t RR,
+                                                     const int32_t *__restrict__ col_ptr,
+                                                     const int32_t *__restrict__ col_pad, int vpad, int k,
+                                                     int32_t *__restrict__ iters) {
+    int n_slots, buf;
+    effective(bf.ctl, n_slots, buf);
+    const int n_tiles = n_slots >> 6;
+    const double *__restrict__ R = bf.R[buf];
+    const double *__restrict__ L = bf.L[buf];
+    double *__restrict__ Q = bf.Q[buf];
+    const int32_t *__restrict__ state = bf.state[buf];
+    const int nG = (n_v + 3) >> 2;
+    CPX_ITEM_LOOP(nG) {
+        const int tl = idx / nG, vg = idx - tl * nG;
+        const int64_t tile = (int64_t)tl * 8 + xcd;
+        if (tile >= n_tiles) break;
+        const int v = vg * 4 + w;
+        if (v >= n_v) continue;
+        const int64_t slot = tile * 64 + lane;
+        const int st = state[slot];
+        const int deg = col_ptr[v + 1] - col_ptr[v];
+        const int32_t *__restrict__ refs = col_pad + (int64_t)v * vpad;
+        const int64_t i = (tile * n_v + v) * 64 + lane;
+        const double l = ntload(&L[i]);
+        if (st <= k) continue;                                    // syndrome was zero at the start of iteration k
+        const double *__restrict__ Rt = R + tile * RR * 64 + lane;
+        double msum;
+        switch (deg) {
+        case 2: msum = vn_sum<ALG, 2>(Rt, refs, deg); break;
+        case 3: msum = vn_sum<ALG, 3>(Rt, refs, deg); break;
+        case 4: msum = vn_sum<ALG, 4>(Rt, refs, deg); break;
+        case 5: msum = vn_sum<ALG, 5>(Rt, refs, deg); break;
+        case 6: msum = vn_sum<ALG, 6>(Rt, refs, deg); break;
+        case 7: msum = vn_sum<ALG, 7>(Rt, refs, deg); break;
+        case 8: msum = vn_sum<ALG, 8>(Rt, refs, deg); break;
+        default: msum = vn_sum<ALG, 0>(Rt, refs, deg); break;
+        }
+        Q[i] = msum + l;                                          // msg_sum + llr (:245, :247)
+        if (v == 0 && iters) iters[bf.orig[buf][slot]] += 1;
+    }
+}
+
+// After iteration k: commit a finished move, count the slots that go on (state == k+1) and, when they are at
+// most half of the live slots, number them densely (dst) and request a move.  One workgroup of 1024 threads.
+__global__ __launch_bounds__(1024) void ldpc_scan_kernel(Bufs bf, int k) {
+    __shared__ int part[1024];
+    __shared__ int hdr[2];
+    Ctl *ctl = bf.ctl;
+    if (threadIdx.x == 0) {
+        if (ctl->do_move) { ctl->n_slots = ctl->n_new; ctl->buf ^= 1; ctl->do_move = 0; }
+        hdr[0] = ctl->n_slots; hdr[1] = ctl->buf;
+    }
+    __syncthreads();
+    const int n = hdr[0], buf = hdr[1];
+    if (n <= 64) return;
+    const int32_t *__restrict__ state = bf.state[buf];
+    const int per = (n + 1023) >> 10;
+    const int s0 = threadIdx.x * per, s1 = min(n, s0 + per);
+    int cnt = 0;
+    for (int s = s0; s < s1; s++) cnt += state[s] > k;
+    part[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {                    // inclusive scan of the per-thread counts
+        const int add = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    const int total = part[1023];
+    if (total * 2 > n) return;
+    int run = part[threadIdx.x] - cnt;
+    for (int s = s0; s < s1; s++) bf.dst[s] = state[s] > k ? run++ : -1;
+    const int n_new = (total + 63) & ~63;
+    if (threadIdx.x < 64 && total + (int)threadIdx.x < n_new) bf.state[buf ^ 1][total + threadIdx.x] = -1;   // padding
+    if (threadIdx.x == 0) { ctl->n_new = n_new; ctl->do_move = 1; }
+}
+
+// Move pass (only when requested): columns of continuing slots go to their dense position in the other buffer
+// set; frozen slots are retired to the caller's out_llrs / dec_word ([n_v][B], reference layout :251-253).
+__global__ __launch_bounds__(LB) void ldpc_move_kernel(Bufs bf, int n_v, int64_t E /* rows of R per tile */, int k, int64_t B,
+                                                       double *__restrict__ out, int8_t *__restrict__ dec) {
+    const Ctl *ctl = bf.ctl;
+    if (!ctl->do_move) return;
+    const int buf = ctl->buf, n_tiles = ctl->n_slots >> 6;
+    const int32_t *__restrict__ state = bf.state[buf];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t rows = E + 2 * (int64_t)n_v + 1;
+    constexpr int RPW = 16;                                       // rows per wave and item: 16 row loads in flight
+    const int64_t nRG = (rows + 4 * RPW - 1) / (4 * RPW);
+    const int64_t items = nRG * n_tiles;
+    for (int64_t idx = blockIdx.x; idx < items; idx += gridDim.x) {
+        const int64_t tile = idx / nRG, row0 = ((idx - tile * nRG) * 4 + w) * RPW;
+        if (row0 >= rows) continue;
+        const int64_t slot = tile * 64 + lane;
+        const int st = state[slot];
+        if (st < 0) continue;
+        const bool go = st > k;
+        const int d = go ? bf.dst[slot] : 0;
+        const int64_t dt = d >> 6, dl = d & 63;
+        const int64_t o = go ? 0 : bf.orig[buf][slot];
+        double x[RPW];
+#pragma unroll
+        for (int u = 0; u < RPW; u++) {
+            const int64_t row = row0 + u;
+            if (row < E) x[u] = bf.R[buf][(tile * E + row) * 64 + lane];
+            else if (row < E + n_v) x[u] = bf.Q[buf][(tile * n_v + (row - E)) * 64 + lane];
+            else if (row < E + 2 * (int64_t)n_v) x[u] = bf.L[buf][(tile * n_v + (row - E - n_v)) * 64 + lane];
+        }
+#pragma unroll
+        for (int u = 0; u < RPW; u++) {
+            const int64_t row = row0 + u;
+            if (row < E) {
+                if (go) bf.R[buf ^ 1][(dt * E + row) * 64 + dl] = x[u];
+            } else if (row < E + n_v) {
+                const int64_t v = row - E;
+                if (go) {
+                    bf.Q[buf ^ 1][(dt * n_v + v) * 64 + dl] = x[u];
+                } else {
+                    out[v * B + o] = x[u];                                            // (:247)
+                    dec[v * B + o] = (int8_t)(__builtin_signbit(x[u]) ? 1 : 0);       // (:248)
+                }
+            } else if (row < E + 2 * (int64_t)n_v) {
+                if (go) bf.L[buf ^ 1][(dt * n_v + (row - E - n_v)) * 64 + dl] = x[u];
+            } else if (row < rows && go) {
+                bf.state[buf ^ 1][d] = st;
+                bf.orig[buf ^ 1][d] = bf.orig[buf][slot];
+            }
+        }
+    }
+}
+
+// End of the decode: every slot still in the working set is retired.
+__global__ __launch_bounds__(LB) void ldpc_final_kernel(Bufs bf, int n_v, int64_t B, double *__restrict__ out,
+                                                        int8_t *__restrict__ dec) {
+    int n_slots, buf;
+    effective(bf.ctl, n_slots, buf);
+    const int n_tiles = n_slots >> 6;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t nVG = (n_v + 3) >> 2;
+    const int64_t items = nVG * n_tiles;
+    for (int64_t idx = blockIdx.x; idx < items; idx += gridDim.x) {
+        const int64_t tile = idx / nVG, v = (idx - tile * nVG) * 4 + w;
+        if (v >= n_v) continue;
+        const int64_t slot = tile * 64 + lane;
+        if (bf.state[buf][slot] < 0) continue;
+        const double x = bf.Q[buf][(tile * n_v + v) * 64 + lane];
+        const int64_t o = bf.orig[buf][slot];
+        out[v * B + o] = x;
+        dec[v * B + o] = (int8_t)(__builtin_signbit(x) ? 1 : 0);
+    }
 }
 
 }  // namespace
@@ -200,11 +642,14 @@ int cpx_ldpc_create(int n_vnodes, int n_cnodes, int64_t n_edges, const int32_t *
     int max_cdeg = 0, max_vdeg = 0;
     for (int c = 0; c < n_cnodes; c++) { max_cdeg = std::max(max_cdeg, row_ptr[c + 1]); row_ptr[c + 1] += row_ptr[c]; }
     for (int v = 0; v < n_vnodes; v++) { max_vdeg = std::max(max_vdeg, col_ptr[v + 1]); col_ptr[v + 1] += col_ptr[v]; }
-    CPX_REQUIRE(n_vnodes <= 65535 * 32 && n_cnodes <= 65535, CPX_ELIMIT, "cpx_ldpc_create: code too large (n_c <= 65535)");
-    CPX_REQUIRE(n_vnodes <= 65535, CPX_ELIMIT, "cpx_ldpc_create: code too large (n_v <= 65535)");
+    CPX_REQUIRE(n_vnodes < (1 << 24) && n_cnodes < (1 << 24), CPX_ELIMIT, "cpx_ldpc_create: code too large (n < 2^24)");
     CPX_REQUIRE(max_cdeg <= MAXDEG, CPX_ELIMIT, "cpx_ldpc_create: check degree %d > %d not supported", max_cdeg, MAXDEG);
-    std::vector<int32_t> fill(col_ptr.begin(), col_ptr.end() - 1);
-    for (int64_t e = 0; e < E; e++) col_edge[fill[edge_var[e]]++] = (int32_t)e;   // increasing e == increasing check
+    std::vector<int32_t> fill(col_ptr.begin(), col_ptr.end() - 1), col_cj(E);
+    for (int64_t e = 0; e < E; e++) {                                            // increasing e == increasing check
+        const int32_t q = fill[edge_var[e]]++;
+        col_edge[q] = (int32_t)e;
+        col_cj[q] = (edge_check[e] << 5) | (int32_t)(e - row_ptr[edge_check[e]]);
+    }
     cpx_ldpc *c = new cpx_ldpc;
     c->n_v = n_vnodes; c->n_c = n_cnodes; c->n_edges = E; c->max_cdeg = max_cdeg; c->max_vdeg = max_vdeg;
     (void)hipGetDevice(&c->device);
@@ -212,17 +657,38 @@ int cpx_ldpc_create(int n_vnodes, int n_cnodes, int64_t n_edges, const int32_t *
     CPX_HIP(hipMalloc((void **)&c->d_row_ptr, sizeof(int32_t) * (n_cnodes + 1)));
     CPX_HIP(hipMalloc((void **)&c->d_col_ptr, sizeof(int32_t) * (n_vnodes + 1)));
     CPX_HIP(hipMalloc((void **)&c->d_col_edge, sizeof(int32_t) * E));
+    CPX_HIP(hipMalloc((void **)&c->d_col_cj, sizeof(int32_t) * E));
     CPX_HIP(hipMemcpy(c->d_edge_var, edge_var, sizeof(int32_t) * E, hipMemcpyHostToDevice));
     CPX_HIP(hipMemcpy(c->d_row_ptr, row_ptr.data(), sizeof(int32_t) * (n_cnodes + 1), hipMemcpyHostToDevice));
     CPX_HIP(hipMemcpy(c->d_col_ptr, col_ptr.data(), sizeof(int32_t) * (n_vnodes + 1), hipMemcpyHostToDevice));
     CPX_HIP(hipMemcpy(c->d_col_edge, col_edge.data(), sizeof(int32_t) * E, hipMemcpyHostToDevice));
+    CPX_HIP(hipMemcpy(c->d_col_cj, col_cj.data(), sizeof(int32_t) * E, hipMemcpyHostToDevice));
+    c->cpad = (max_cdeg + 3) & ~3;
+    c->vpad = (max_vdeg + 3) & ~3;
+    // + 16: the pipelined passes read a fixed number of entries per row, past the last row's end
+    std::vector<int32_t> row_pad((size_t)n_cnodes * c->cpad + 16, 0), cpe((size_t)n_vnodes * c->vpad + 16, 0),
+        cpc((size_t)n_vnodes * c->vpad + 16, 0);
+    for (int k = 0; k < n_cnodes; k++)
+        for (int j = 0; j < row_ptr[k + 1] - row_ptr[k]; j++) row_pad[(size_t)k * c->cpad + j] = edge_var[row_ptr[k] + j];
+    for (int v = 0; v < n_vnodes; v++)
+        for (int q = 0; q < col_ptr[v + 1] - col_ptr[v]; q++) {
+            cpe[(size_t)v * c->vpad + q] = col_edge[col_ptr[v] + q];
+            cpc[(size_t)v * c->vpad + q] = col_cj[col_ptr[v] + q];
+        }
+    CPX_HIP(hipMalloc((void **)&c->d_row_pad, sizeof(int32_t) * row_pad.size()));
+    CPX_HIP(hipMalloc((void **)&c->d_col_pad_edge, sizeof(int32_t) * cpe.size()));
+    CPX_HIP(hipMalloc((void **)&c->d_col_pad_cj, sizeof(int32_t) * cpc.size()));
+    CPX_HIP(hipMemcpy(c->d_row_pad, row_pad.data(), sizeof(int32_t) * row_pad.size(), hipMemcpyHostToDevice));
+    CPX_HIP(hipMemcpy(c->d_col_pad_edge, cpe.data(), sizeof(int32_t) * cpe.size(), hipMemcpyHostToDevice));
+    CPX_HIP(hipMemcpy(c->d_col_pad_cj, cpc.data(), sizeof(int32_t) * cpc.size(), hipMemcpyHostToDevice));
     *out = c;
     return CPX_OK;
 }
 
 int cpx_ldpc_destroy(cpx_ldpc *c) {
     if (!c) return CPX_OK;
-    (void)hipFree(c->d_edge_var); (void)hipFree(c->d_row_ptr); (void)hipFree(c->d_col_ptr); (void)hipFree(c->d_col_edge);
+    (void)hipFree(c->d_edge_var); (void)hipFree(c->d_row_ptr); (void)hipFree(c->d_col_ptr); (void)hipFree(c->d_col_edge); (void)hipFree(c->d_col_cj);
+    (void)hipFree(c->d_row_pad); (void)hipFree(c->d_col_pad_edge); (void)hipFree(c->d_col_pad_cj);
     delete c;
     return CPX_OK;
 }
@@ -234,35 +700,67 @@ int cpx_ldpc_bp_decode_batch_dev(const cpx_ldpc *c, double *d_llr, int64_t B, in
                 "Please input a valid decoder_algorithm string (meanning \"SPA\" or \"MSA\").");
     CPX_REQUIRE(B >= 0 && n_iters >= 0, CPX_EINVAL, "ldpc: negative size");
     if (B == 0) return CPX_OK;
+    CPX_REQUIRE(d_llr && d_dec && d_out, CPX_EINVAL, "ldpc: null device pointer");
+    CPX_REQUIRE(B <= (1ll << 30), CPX_ELIMIT, "ldpc: batch too large");
     hipStream_t st = pick_stream(stream);
-    const int64_t E = c->n_edges;
-    double *M = nullptr, *llrT = nullptr;
-    int32_t *unsat = nullptr;
+    const int64_t E = c->n_edges, nv = c->n_v;
+    const int64_t n_tiles = (B + 63) / 64, S = n_tiles * 64;
+    const int64_t RR = alg == CPX_LDPC_MSA ? 3 * (int64_t)c->n_c : E;      // rows of R per tile (records / edges)
+    CPX_REQUIRE((n_tiles / 8 + 1) * ((std::max<int64_t>(nv, c->n_c) + 3) / 4) < (1ll << 31), CPX_ELIMIT,
+                "ldpc: batch x code too large for one launch");
+    // one slab: 2 x (R, Q, L) + slot tables + control block
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t szR = al(sizeof(double) * (size_t)(RR * S)), szV = al(sizeof(double) * (size_t)(nv * S)),
+                 szI = al(sizeof(int32_t) * (size_t)S);
+    char *slab = nullptr;
     int rcw;
-    if ((rcw = workspace(st, 0, sizeof(double) * (size_t)(E * B), (void **)&M))) return rcw;
-    if ((rcw = workspace(st, 1, sizeof(double) * (size_t)((int64_t)c->n_v * B), (void **)&llrT))) return rcw;
-    if ((rcw = workspace(st, 2, sizeof(int32_t) * (size_t)B, (void **)&unsat))) return rcw;
-    const unsigned bx = (unsigned)((B + LB - 1) / LB);
-    {
-        dim3 grid((unsigned)((B + 31) / 32), (unsigned)((c->n_v + 31) / 32));
-        hipLaunchKernelGGL(ldpc_init_kernel, grid, dim3(LB), 0, st, d_llr, B, c->n_v, llrT, d_out, d_dec, d_iters, unsat);
-        hipLaunchKernelGGL(ldpc_msg_init_kernel, dim3(bx, (unsigned)std::min<int64_t>(E, 65535)), dim3(LB), 0, st, llrT, B,
-                           c->d_edge_var, E, M);
-    }
+    if ((rcw = workspace(st, 0, 2 * szR + 4 * szV + 5 * szI + 256, (void **)&slab))) return rcw;
+    Bufs bf;
+    char *p = slab;
+    for (int i = 0; i < 2; i++) { bf.R[i] = (double *)p; p += szR; }
+    for (int i = 0; i < 2; i++) { bf.Q[i] = (double *)p; p += szV; }
+    for (int i = 0; i < 2; i++) { bf.L[i] = (double *)p; p += szV; }
+    for (int i = 0; i < 2; i++) { bf.state[i] = (int32_t *)p; p += szI; }
+    for (int i = 0; i < 2; i++) { bf.orig[i] = (int32_t *)p; p += szI; }
+    bf.dst = (int32_t *)p; p += szI;
+    bf.ctl = (Ctl *)p;
+    hipLaunchKernelGGL(ldpc_init_kernel, dim3((unsigned)n_tiles, (unsigned)((nv + 63) / 64)), dim3(LB), 0, st, d_llr, B,
+                       (int)nv, bf, d_iters);
+    // persistent grids: what is resident at once (occupancy x CUs), no more workgroups than wave items, a
+    // multiple of 8 (one share per XCD)
+    auto pgrid = [&](const void *fn, int64_t items) {
+        const int64_t resident = resident_blocks(fn, LB);
+        return (unsigned)std::max<int64_t>(8, std::min<int64_t>(resident, items) / 8 * 8);
+    };
+    const int qcap = std::min(12, c->cpad);
+    const void *f_cn = alg == CPX_LDPC_SPA ? (const void *)ldpc_cn_kernel<CPX_LDPC_SPA>
+                       : qcap == 4        ? (const void *)ldpc_cn_msa_kernel<4>
+                       : qcap == 8        ? (const void *)ldpc_cn_msa_kernel<8>
+                                          : (const void *)ldpc_cn_msa_kernel<12>;
+    const void *f_vn = alg == CPX_LDPC_SPA ? (const void *)ldpc_vn_kernel<CPX_LDPC_SPA>
+                                          : (const void *)ldpc_vn_msa_kernel;
+    const unsigned g_cn = pgrid(f_cn, n_tiles * ((c->n_c + 3) / 4)), g_vn = pgrid(f_vn, n_tiles * ((nv + 3) / 4));
+    const unsigned g_mv = pgrid((const void *)ldpc_move_kernel, n_tiles * ((RR + 2 * nv + 64) / 64));
     for (int it = 0; it < n_iters; it++) {
-        const int stamp = it + 1;
-        hipLaunchKernelGGL(ldpc_syndrome_kernel, dim3(bx, (unsigned)c->n_c), dim3(LB), 0, st, d_dec, B, c->d_row_ptr,
-                           c->d_edge_var, unsat, stamp);
-        dim3 gc(bx, (unsigned)c->n_c);
-#define LAUNCH_CN(ALG)                                                                                              \
-    if (c->max_cdeg <= 8) hipLaunchKernelGGL((ldpc_cn_kernel<ALG, 8>), gc, dim3(LB), 0, st, M, B, c->d_row_ptr, unsat, stamp); \
-    else if (c->max_cdeg <= 16) hipLaunchKernelGGL((ldpc_cn_kernel<ALG, 16>), gc, dim3(LB), 0, st, M, B, c->d_row_ptr, unsat, stamp); \
-    else hipLaunchKernelGGL((ldpc_cn_kernel<ALG, MAXDEG>), gc, dim3(LB), 0, st, M, B, c->d_row_ptr, unsat, stamp);
-        if (alg == CPX_LDPC_SPA) { LAUNCH_CN(CPX_LDPC_SPA) } else { LAUNCH_CN(CPX_LDPC_MSA) }
-#undef LAUNCH_CN
-        hipLaunchKernelGGL(ldpc_vn_kernel, dim3(bx, (unsigned)c->n_v), dim3(LB), 0, st, M, B, c->d_col_ptr,
-                           c->d_col_edge, llrT, d_out, d_dec, unsat, stamp, d_iters);
+        if (alg == CPX_LDPC_SPA) {
+            hipLaunchKernelGGL((ldpc_cn_kernel<CPX_LDPC_SPA>), dim3(g_cn), dim3(LB), 0, st, bf, (int)nv, c->n_c, RR,
+                               c->d_row_ptr, c->d_row_pad, c->cpad, it);
+            hipLaunchKernelGGL((ldpc_vn_kernel<CPX_LDPC_SPA>), dim3(g_vn), dim3(LB), 0, st, bf, (int)nv, RR, c->d_col_ptr,
+                               c->d_col_pad_edge, c->vpad, it, d_iters);
+        } else {
+#define CN_MSA(QC) hipLaunchKernelGGL((ldpc_cn_msa_kernel<QC>), dim3(g_cn), dim3(LB), 0, st, bf, (int)nv, c->n_c, c->d_row_ptr, c->d_row_pad, c->cpad, it)
+#define VN_MSA() hipLaunchKernelGGL(ldpc_vn_msa_kernel, dim3(g_vn), dim3(LB), 0, st, bf, (int)nv, c->n_c, c->d_col_ptr, c->d_col_pad_cj, c->vpad, it, d_iters)
+            if (qcap == 4) CN_MSA(4); else if (qcap == 8) CN_MSA(8); else CN_MSA(12);
+            VN_MSA();
+#undef CN_MSA
+#undef VN_MSA
+        }
+        if (S > 64 && it + 1 < n_iters) {
+            hipLaunchKernelGGL(ldpc_scan_kernel, dim3(1), dim3(1024), 0, st, bf, it);
+            hipLaunchKernelGGL(ldpc_move_kernel, dim3(g_mv), dim3(LB), 0, st, bf, (int)nv, RR, it, B, d_out, d_dec);
+        }
     }
+    hipLaunchKernelGGL(ldpc_final_kernel, dim3(g_vn), dim3(LB), 0, st, bf, (int)nv, B, d_out, d_dec);
     CPX_HIP(hipGetLastError());
     return CPX_OK;
 }

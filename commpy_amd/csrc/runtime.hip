@@ -2,6 +2,10 @@
 // HIP-event timers.  No compute here.
 #include "cpx_internal.h"
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include <mutex>
 
 namespace cpx {
@@ -93,6 +97,35 @@ int cpx_set_device(int device) {
     CPX_HIP(hipSetDevice(device));
     return CPX_OK;
 }
+
+}  // extern "C"
+
+namespace cpx {
+int device_cus() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
+    return n;
+}
+
+int resident_blocks(const void *fn, int threads) {
+    static std::mutex mu;
+    static std::map<std::pair<const void *, int>, int> cache;
+    std::lock_guard<std::mutex> g(mu);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    auto key = std::make_pair(fn, dev * 4096 + threads);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+    const int r = per_cu * device_cus();
+    cache[key] = r;
+    return r;
+}
+}  // namespace cpx
+
+extern "C" {
 
 int cpx_device_info(char *name, int name_cap, int *compute_units, int64_t *hbm_bytes) {
     int rc = ensure_device();

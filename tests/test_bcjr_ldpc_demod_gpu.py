@@ -139,6 +139,29 @@ def test_ldpc_batch_vs_oracle(gpu):
         assert np.all(np.abs(out - oo) <= TOL + 1e-6 * np.abs(oo)), (alg, np.max(np.abs(out - oo)))
 
 
+def test_ldpc_compaction_mixed_convergence(gpu):
+    """Blocks that converge at very different iterations (noiseless ... undecodable) interleaved in one batch:
+    exercises freezing, on-device compaction of the working set (several moves) and retirement at the
+    original block index.  Min-sum is pure add/compare arithmetic: out_llrs must be bit-identical."""
+    from commpy_amd.channelcoding import ldpc_bp_decode
+    p = ldpc_params("n1944")
+    n, B = 1944, 333
+    rs = np.random.RandomState(77)
+    ebn0 = rs.choice([0.5, 2.0, 2.6, 3.2, 4.5, 30.0], size=B)
+    sig = 1 / np.sqrt(10 ** (ebn0 / 10.0) * (2.0 / 3) * 2)
+    llr = (2.0 * (1.0 + sig[:, None] * rs.randn(B, n)) / sig[:, None] ** 2).reshape(-1)
+    for alg, iters in (("MSA", 25), ("SPA", 9)):
+        dec, out, its = ldpc_bp_decode(llr.copy(), p, alg, iters, return_iterations=True)
+        do, oo, io = oracle.ldpc_bp_decode(llr.copy(), p, alg, iters, True)
+        assert len(set(io.tolist())) >= 5                      # the batch really is staggered
+        assert np.array_equal(its, io), alg
+        assert np.array_equal(dec, do), alg
+        if alg == "MSA":
+            assert np.array_equal(out, oo)
+        else:
+            assert np.all(np.abs(out - oo) <= TOL + 1e-6 * np.abs(oo)), np.max(np.abs(out - oo))
+
+
 def test_ldpc_bad_algorithm(gpu):
     from commpy_amd.channelcoding import ldpc_bp_decode
     with pytest.raises(NameError):
