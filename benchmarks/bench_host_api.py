@@ -1,0 +1,39 @@
+#!/usr/bin/env python
+"""PCIe-inclusive throughput of the drop-in host API (numpy in, numpy out) for BASELINE config 2:
+viterbi_decode(llr[B, 2060] float64 on the host) -> bits[B, 1030].  Never the headline `value` (bench.py times
+HBM-resident inputs); reported so that DESIGN.md can quote what a caller holding host arrays actually gets."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--B", type=int, default=65536)
+    ap.add_argument("--reps", type=int, default=3)
+    a = ap.parse_args()
+    from commpy_amd.channelcoding import Trellis, viterbi_decode
+    tr = Trellis(np.array([6]), np.array([[0o133, 0o171]]))
+    rs = np.random.RandomState(0)
+    llr = rs.randn(a.B, 2060) * 4.0
+    viterbi_decode(llr[:64], tr, None, "soft")            # load library, create handles
+    best = 1e9
+    for _ in range(a.reps):
+        t0 = time.perf_counter()
+        out = viterbi_decode(llr, tr, None, "soft")
+        best = min(best, time.perf_counter() - t0)
+    print(json.dumps({"kernel": "viterbi_decode host API (PCIe inclusive)", "workload": "K=7 soft, 1024-bit, B=%d" % a.B,
+                      "value": a.B * 1024 / best, "unit": "info-bits/s", "ms": best * 1e3,
+                      "host_bytes_in": int(llr.nbytes), "host_bytes_out": int(out.nbytes),
+                      "effective_GBps": (llr.nbytes + out.nbytes) / best / 1e9}))
+
+
+if __name__ == "__main__":
+    main()

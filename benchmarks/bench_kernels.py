@@ -138,11 +138,18 @@ def bench_ldpc(lib, scale):
             lib.cpx_timer_elapsed_ms(tm, ctypes.byref(v))
             its = dev.get(d_it, (B,), np.int32)
             dec = dev.get(d_dec, (n, B), np.int8)
+            # SURVEY 8d figure: the reference formulation moves (4E + 2n) float64 per executed iteration per block.
+            # The engine's own compulsory traffic is smaller (ldpc.hip header): (3E + 3n) for SPA, (9 n_c + 3n)
+            # for min-sum records, plus one speculative check pass per block that converges.
             alg_bytes = int(its.sum()) * (4 * E + 2 * n) * 8 + B * n * 17
+            n_c = n - 1296
+            per_it = (9 * n_c + 3 * n) * 8 if alg else (3 * E + 3 * n) * 8
+            eng_bytes = int(its.sum()) * per_it + B * n * 25
             emit("ldpc_bp_%s" % name, "(1944,1296) Eb/N0=%.1f dB, <=50 its, B=%d, mean executed its %.2f" % (
                 ebn0, B, its.mean()), B * 1296, "info-bits", v.value, alg_bytes, "hbm" if alg else "f64-transcendental",
                  {"frame_error_rate": float(np.mean(dec.any(axis=0))), "mean_iterations": float(its.mean()),
-                  "max_iterations": int(its.max())})
+                  "max_iterations": int(its.max()), "engine_bytes_per_launch": eng_bytes,
+                  "engine_GBps": eng_bytes / (v.value * 1e-3) / 1e9})
         dev.free()
 
 
