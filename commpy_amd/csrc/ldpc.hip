@@ -48,7 +48,7 @@ namespace {
 constexpr int LB = 256;     // threads per workgroup = 4 wavefronts
 constexpr int MAXDEG = 32;  // max check degree held in registers
 
-struct Ctl { int n_slots, buf, do_move, n_new; };
+struct Ctl { int n_slots, buf, do_move, n_new, prev_active; };
 
 struct Bufs {
     double *R[2], *Q[2], *L[2];
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(LB) void ldpc_init_kernel(double *__restrict__ llr,
         bf.state[0][slot] = slot < B ? 0 : -1;
         bf.orig[0][slot] = (int32_t)slot;
         if (slot < B && iters) iters[slot] = 0;
-        if (slot == 0) { bf.ctl->n_slots = (int)(gridDim.x * 64); bf.ctl->buf = 0; bf.ctl->do_move = 0; bf.ctl->n_new = 0; }
+        if (slot == 0) { bf.ctl->n_slots = (int)(gridDim.x * 64); bf.ctl->buf = 0; bf.ctl->do_move = 0; bf.ctl->n_new = 0; bf.ctl->prev_active = (int)(gridDim.x * 64); }
     }
 }
 
@@ -397,29 +397,25 @@ __global__ __launch_bounds__(LB) void ldpc_cn_msa_kernel(Bufs bf, int n_v, int n
     }
 }
 
-// Min-sum variable pass: two round trips per item.  (1) state, column descriptor, llr -- addresses depend on the
-// item only; (2) all three words of the records of up to four edges at once (the magnitude is selected in
-// registers: one more L2-hit load per edge instead of a third dependent round trip).
+// Min-sum variable pass.  (1) state, column descriptor, llr -- addresses depend on the item only; (2) the meta words
+// of up to four edges; (3) the one magnitude each meta word selects.  The pass is bound by L2 gather bandwidth
+// (measured: loading both magnitudes and selecting in registers saves a round trip but costs 0.73 vs 0.60 ms).
 __device__ __forceinline__ void vn_msa_chunk(const double *__restrict__ Rt, int r0, int r1, int r2, int r3, int n,
                                              double &msum) {
     const int ref[4] = {r0, r1, r2, r3};
-    double a[4], b[4], m[4];
+    double mn[4], m[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-        if (u < n) {
-            const double *__restrict__ rec = Rt + (int64_t)(ref[u] >> 5) * 192;
-            a[u] = rec[0];
-            b[u] = rec[64];
-            m[u] = rec[128];
-        }
-    }
+    for (int u = 0; u < 4; u++)
+        if (u < n) m[u] = Rt[(int64_t)(ref[u] >> 5) * 192 + 128];
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+        if (u < n) mn[u] = Rt[(int64_t)(ref[u] >> 5) * 192 + (((ref[u] & 31) == (__double2loint(m[u]) & 0xff)) ? 64 : 0)];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
         if (u < n) {
             const int j = ref[u] & 31, lo = __double2loint(m[u]);
-            const double mn = (j == (lo & 0xff)) ? b[u] : a[u];
             const unsigned ng = (((unsigned)__double2hiint(m[u]) >> j) ^ (unsigned)(lo >> 8)) & 1u;
-            msum += __hiloint2double(__double2hiint(mn) | (int)(ng << 31), __double2loint(mn));   // increasing check (:243)
+            msum += __hiloint2double(__double2hiint(mn[u]) | (int)(ng << 31), __double2loint(mn[u]));   // increasing check (:243)
         }
     }
 }
@@ -507,7 +503,7 @@ __global__ __launch_bounds__(LB) void ldpc_vn_kernel(Bufs bf, int n_v, int64_t R
 
 // After iteration k: commit a finished move, count the slots that go on (state == k+1) and, when they are at
 // most half of the live slots, number them densely (dst) and request a move.  One workgroup of 1024 threads.
-__global__ __launch_bounds__(1024) void ldpc_scan_kernel(Bufs bf, int k) {
+__global__ __launch_bounds__(1024) void ldpc_scan_kernel(Bufs bf, int k, int patient) {
     __shared__ int part[1024];
     __shared__ int hdr[2];
     Ctl *ctl = bf.ctl;
@@ -532,7 +528,15 @@ __global__ __launch_bounds__(1024) void ldpc_scan_kernel(Bufs bf, int k) {
         __syncthreads();
     }
     const int total = part[1023];
+    // A move pays when the live set is at most half full.  For min-sum (`patient`) a move costs about three
+    // iterations of the slots it moves, so it also waits until the set has stopped shrinking quickly (< 20 % since
+    // the last iteration) or is at most a quarter full: while the set is collapsing, a later move is cheaper.
+    // For sum-product an iteration costs more than a move and the move is never delayed.
+    const int prev = ctl->prev_active;
+    __syncthreads();
+    if (threadIdx.x == 0) ctl->prev_active = total;
     if (total * 2 > n) return;
+    if (patient && total * 4 > n && (int64_t)total * 5 < (int64_t)prev * 4) return;
     int run = part[threadIdx.x] - cnt;
     for (int s = s0; s < s1; s++) bf.dst[s] = state[s] > k ? run++ : -1;
     const int n_new = (total + 63) & ~63;
@@ -756,7 +760,7 @@ int cpx_ldpc_bp_decode_batch_dev(const cpx_ldpc *c, double *d_llr, int64_t B, in
 #undef VN_MSA
         }
         if (S > 64 && it + 1 < n_iters) {
-            hipLaunchKernelGGL(ldpc_scan_kernel, dim3(1), dim3(1024), 0, st, bf, it);
+            hipLaunchKernelGGL(ldpc_scan_kernel, dim3(1), dim3(1024), 0, st, bf, it, alg == CPX_LDPC_MSA ? 1 : 0);
             hipLaunchKernelGGL(ldpc_move_kernel, dim3(g_mv), dim3(LB), 0, st, bf, (int)nv, RR, it, B, d_out, d_dec);
         }
     }
