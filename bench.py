@@ -134,7 +134,12 @@ def main():
     h_tr, h_md = tr._device_handle(), md._device_handle()
 
     if distributed:
-        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        # a real (non-null) torch stream made current: the C-ABI launches on it, and the RCCL all-gather issued by
+        # torch.distributed is ordered after the decode of the same step (the null stream handle would make the
+        # library fall back to its own stream, unordered with respect to the collective)
+        tstream = torch.cuda.Stream()
+        torch.cuda.set_stream(tstream)
+        stream = ctypes.c_void_p(tstream.cuda_stream)
         t_y = torch.empty((B, nsym, 2), dtype=torch.float64, device="cuda")
         t_llr = torch.empty((B, LEN), dtype=torch.float64, device="cuda")
         t_bits = torch.empty((B, L), dtype=torch.uint8, device="cuda")
@@ -197,14 +202,33 @@ def main():
         if distributed and world > 1:
             dist.all_gather_into_tensor(t_all, t_bits)               # RCCL all-gather of the decoded bits
 
-    for _ in range(args.warmup):
-        step(None)
+    # warm-up runs exactly what a timed step runs, event records included (the first hipEventRecord of a process
+    # that loaded torch's HIP runtime cost ~70 ms here, which must not land inside the K timed steps)
+    warm = ctypes.c_void_p()
+    _lib.check(lib.cpx_timer_create(ctypes.byref(warm)))
+    timers.append(warm)
+    for _ in range(max(args.warmup, 1)):
+        step(len(timers) - 1)
     barrier(); sync()
+    if distributed:
+        # untimed rehearsal of the whole timed region (same K launches, same closing barrier + synchronize): one-time
+        # host-side costs of the collective path (seen sporadically as a ~70 ms stall in the first closing barrier of
+        # a process on a fresh box) land here, not in the measurement
+        for k in range(args.steps):
+            step(len(timers) - 1)
+        barrier(); sync()
+    timers.pop()
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(k)
-    barrier(); sync()
+    t1 = time.perf_counter()
+    barrier()
+    t2 = time.perf_counter()
+    sync()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("BENCH_DEBUG"):
+        print("debug: enqueue %.3f ms, barrier %.3f ms, sync %.3f ms" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3,
+                                                                           (t0 + elapsed - t2) * 1e3), file=sys.stderr)
     for tmr in timers:
         ms = ctypes.c_float()
         _lib.check(lib.cpx_timer_elapsed_ms(tmr, ctypes.byref(ms)))
