@@ -132,6 +132,7 @@ int cpx_turbo_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const 
  *   dec_word  [n_v][B] int8 and out_llrs [n_v][B] float64: one block per COLUMN, the reference's
  *             output layout (ldpc.py:251-253)
  *   iters_done[B] int32 executed iterations per block (early exit ldpc.py:205-206), may be NULL
+ * Limits (CPX_ELIMIT): check degree <= 32 (a row lives in registers / one 32-bit sign mask), n_v, n_c < 2^24.
  */
 #define CPX_LDPC_SPA 0
 #define CPX_LDPC_MSA 1
