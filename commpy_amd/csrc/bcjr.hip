@@ -185,22 +185,19 @@ __device__ __forceinline__ void stage_chunk(const Ctx<LGS> &c, const RawChunk &r
 }
 
 // Backward recursion over one staged chunk (:78-111): beta of reference time t_lo+tl for tl = len-1 .. 0, starting
-// from `b` = beta at the chunk's upper boundary.  When ROWS, every row is also written to c.bt[tl] (LDS).
-template <int LGS, bool ROWS>
-__device__ __forceinline__ double beta_chunk(const Ctx<LGS> &c, double b, int len) {
-    constexpr int S = Ctx<LGS>::S;
-    const int GW = c.GW, W = GW * S, col = c.g * S + c.s;
+// from `b` = beta at the chunk's upper boundary.  Every row is streamed to `rows` ([CH][64] float64 in HBM, one
+// coalesced 512-byte store per step, off the dependent chain): rows[tl] = beta of time t_lo + tl + 1, the row the
+// forward pass needs at step tl.
+template <int LGS>
+__device__ __forceinline__ double beta_chunk(const Ctx<LGS> &c, double b, int len, double *__restrict__ rows) {
+    const int GW = c.GW;
     if (len <= 0) return b;
-    if (ROWS && c.active) c.bt[(len - 1) * W + col] = b;          // beta[t_lo + len]: row used by the last step of the chunk
-    // operands of step tl are fetched from LDS one step ahead (software pipelining)
-    const double *gm = c.gam + ((len - 1) * GW + c.g) * 4;
-    double g0 = gm[c.code[0]], g1 = gm[c.code[1]], p0 = c.pr0[(len - 1) * GW + c.g];
-    for (int tl = len - 1; tl >= 0; --tl) {
-        double g0n = 0.0, g1n = 0.0, p0n = 0.0;
-        if (tl > 0) {
-            const double *gn = c.gam + ((tl - 1) * GW + c.g) * 4;
-            g0n = gn[c.code[0]]; g1n = gn[c.code[1]]; p0n = c.pr0[(tl - 1) * GW + c.g];
-        }
+    rows[(len - 1) * 64 + c.lane] = b;                            // beta[t_lo + len]: row used by the last step of the chunk
+    // one step; a full chunk is unrolled (compile-time LDS offsets, operand loads hoisted by the scheduler, no
+    // pointer bumps or register rotation on the dependent chain), a partial last chunk runs the same body rolled
+    auto step = [&](int tl) {
+        const double *gm = c.gam + (tl * GW + c.g) * 4;
+        const double g0 = gm[c.code[0]], g1 = gm[c.code[1]], p0 = c.pr0[tl * GW + c.g];
         const double p1 = 1.0 - p0;                               // priors[1] = 1 - priors[0] (:240)
         double bn0, bn1;
         exchange2<LGS>(c, b, c.nxt[0], c.nxt[1], bn0, bn1);
@@ -211,13 +208,18 @@ __device__ __forceinline__ double beta_chunk(const Ctx<LGS> &c, double b, int le
         // (:110-111) every KNORM steps; any positive common factor is a valid normalisation, so the hardware
         // reciprocal (v_rcp_f64) is used instead of a correctly rounded division
         if ((tl & (KNORM - 1)) == 0) b = b * __builtin_amdgcn_rcp(group_sum<LGS>(b));
-        if (ROWS && tl > 0 && c.active) c.bt[(tl - 1) * W + col] = b;   // beta[t_lo + tl]: row used by step tl-1
-        g0 = g0n; g1 = g1n; p0 = p0n;
+        if (tl > 0) rows[(tl - 1) * 64 + c.lane] = b;            // beta[t_lo + tl]: row used by step tl-1
+    };
+    if (len == Ctx<LGS>::CH) {
+#pragma unroll
+        for (int tl = Ctx<LGS>::CH - 1; tl >= 0; --tl) step(tl);
+    } else {
+        for (int tl = len - 1; tl >= 0; --tl) step(tl);
     }
     return b;
 }
 
-// One MAP pass over the GW codewords of this wavefront.  ckpt: [nchunks + 1][64] beta checkpoints of this wave.
+// One MAP pass over the GW codewords of this wavefront.  ckpt: [nchunks][CH][64] beta rows of this wave (HBM).
 // Lout (stride lstride per codeword) receives L_int + log(app1/app0).
 template <int LGS>
 __device__ void map_pass(const Ctx<LGS> &c, int64_t cw0, int64_t B, int64_t N, double nv2, const double *sys,
@@ -228,9 +230,8 @@ __device__ void map_pass(const Ctx<LGS> &c, int64_t cw0, int64_t B, int64_t N, d
     const int nx0 = c.nxt[0] & (W - 1), nx1 = c.nxt[1] & (W - 1);   // next-state columns inside the bt rows
     const int64_t nchunks = (N + CH - 1) / CH;
     RawChunk cur, nxt;
-    // ---------------- backward pass: chunks from the end, checkpoints only ----------------
+    // ---------------- backward pass: chunks from the end, beta rows streamed to HBM ----------------
     double b = 1.0;                                               // b_state_metrics[:, N] = 1 (:225)
-    ckpt[nchunks * 64 + c.lane] = b;
     {
         const int64_t t_lo = (nchunks - 1) * CH;
         load_raw<LGS>(c, cur, cw0, B, N, t_lo, (int)(N - t_lo), sys, sys_perm, par, Lin, lstride);
@@ -242,41 +243,39 @@ __device__ void map_pass(const Ctx<LGS> &c, int64_t cw0, int64_t B, int64_t N, d
         stage_chunk<LGS>(c, cur, nv2);
         if (k > 0) load_raw<LGS>(c, nxt, cw0, B, N, t_lo - CH, CH, sys, sys_perm, par, Lin, lstride);   // prefetch
         __syncthreads();
-        b = beta_chunk<LGS, false>(c, b, len);
-        ckpt[k * 64 + c.lane] = b;                                // beta at the chunk's lower boundary (time t_lo)
+        b = beta_chunk<LGS>(c, b, len, ckpt + k * CH * 64);
         cur = nxt;
     }
     __syncthreads();
-    // ---------------- forward pass: recompute the chunk's beta rows, then alpha + LLR (:114-158) ----------------
+    // ---------------- forward pass: the chunk's beta rows come back from HBM (prefetched one chunk ahead),
+    // then alpha + LLR (:114-158) ----------------
     double a = (c.s == 0) ? 1.0 : 0.0;                            // f_state_metrics[0][0] = 1 (:221)
     load_raw<LGS>(c, cur, cw0, B, N, 0, (int)((N < CH) ? N : CH), sys, sys_perm, par, Lin, lstride);
+    double brow[CH], brown[CH];
+#pragma unroll
+    for (int tl = 0; tl < CH; tl++) brow[tl] = ckpt[tl * 64 + c.lane];
     for (int64_t k = 0; k < nchunks; ++k) {
         const int64_t t_lo = k * CH;
         const int len = (int)((N - t_lo < CH) ? (N - t_lo) : CH);
         __syncthreads();
         stage_chunk<LGS>(c, cur, nv2);
-        const double bhi = ckpt[(k + 1) * 64 + c.lane];
+        if (c.active) {
+#pragma unroll
+            for (int tl = 0; tl < CH; tl++) c.bt[tl * W + col] = brow[tl];   // bt[tl] = beta[t_lo + tl + 1]
+        }
         if (k + 1 < nchunks) {
             const int64_t t2 = t_lo + CH;
             load_raw<LGS>(c, nxt, cw0, B, N, t2, (int)((N - t2 < CH) ? (N - t2) : CH), sys, sys_perm, par, Lin, lstride);
+#pragma unroll
+            for (int tl = 0; tl < CH; tl++) brown[tl] = ckpt[((k + 1) * CH + tl) * 64 + c.lane];
         }
         __syncthreads();
-        (void)beta_chunk<LGS, true>(c, bhi, len);                 // bt[tl] = beta[t_lo + tl + 1], bit-identical to the backward pass
-        __syncthreads();
         {
-            const double *gm = c.gam + c.g * 4;
-            double go0 = gm[c.code[0]], go1 = gm[c.code[1]], gi0 = gm[c.pcode[0]], gi1 = gm[c.pcode[1]];
-            double p0 = c.pr0[c.g], bt0 = c.bt[(c.g * S) + (nx0 & (S - 1))], bt1 = c.bt[(c.g * S) + (nx1 & (S - 1))];
-            for (int tl = 0; tl < len; tl++) {
-                double go0n = 0, go1n = 0, gi0n = 0, gi1n = 0, p0n = 0, bt0n = 0, bt1n = 0;   // operands of step tl+1
-                if (tl + 1 < len) {
-                    const double *gn = c.gam + ((tl + 1) * GW + c.g) * 4;
-                    go0n = gn[c.code[0]]; go1n = gn[c.code[1]]; gi0n = gn[c.pcode[0]]; gi1n = gn[c.pcode[1]];
-                    p0n = c.pr0[(tl + 1) * GW + c.g];
-                    bt0n = c.bt[(tl + 1) * W + c.g * S + (nx0 & (S - 1))];
-                    bt1n = c.bt[(tl + 1) * W + c.g * S + (nx1 & (S - 1))];
-                }
-                const double p1 = 1.0 - p0;
+            auto step = [&](int tl) {
+                const double *gm = c.gam + (tl * GW + c.g) * 4;
+                const double go0 = gm[c.code[0]], go1 = gm[c.code[1]], gi0 = gm[c.pcode[0]], gi1 = gm[c.pcode[1]];
+                const double p0 = c.pr0[tl * GW + c.g], p1 = 1.0 - p0;
+                const double bt0 = c.bt[tl * W + c.g * S + (nx0 & (S - 1))], bt1 = c.bt[tl * W + c.g * S + (nx1 & (S - 1))];
                 // app[i] += f[cs,0] * branch_prob * b[next_state, t]   (:141-143): products parked, summed in the epilogue
                 double2 xv;
                 xv.x = a * go0 * bt0;
@@ -290,7 +289,12 @@ __device__ void map_pass(const Ctx<LGS> &c, int64_t cw0, int64_t B, int64_t N, d
                 na += (ap1 * gi1 * (c.pin[1] ? p1 : p0));
                 a = na;
                 if ((tl & (KNORM - 1)) == KNORM - 1) a = a * __builtin_amdgcn_rcp(group_sum<LGS>(a));   // (:155-158), every KNORM steps
-                go0 = go0n; go1 = go1n; gi0 = gi0n; gi1 = gi1n; p0 = p0n; bt0 = bt0n; bt1 = bt1n;
+            };
+            if (len == CH) {
+#pragma unroll
+                for (int tl = 0; tl < CH; tl++) step(tl);
+            } else {
+                for (int tl = 0; tl < len; tl++) step(tl);
             }
         }
         __syncthreads();
@@ -308,6 +312,8 @@ __device__ void map_pass(const Ctx<LGS> &c, int64_t cw0, int64_t B, int64_t N, d
             }
         }
         cur = nxt;
+#pragma unroll
+        for (int tl = 0; tl < CH; tl++) brow[tl] = brown[tl];
     }
     __syncthreads();
 }
@@ -317,7 +323,7 @@ struct MapParams {
     const double *sys, *par, *Lin;     // [B][N]
     double *Lout;                      // [B][N]
     uint8_t *bits;                     // [B][N]
-    double *scratch;                   // per wave: beta checkpoints [nchunks + 1][64]
+    double *scratch;                   // per wave: beta rows [nchunks][CH][64]
     int64_t B, N;
     double nv2;
     int want_bits, GW;
@@ -329,7 +335,7 @@ __global__ __launch_bounds__(64) void map_decode_kernel(MapParams p) {
     Ctx<LGS> c;
     init_ctx<LGS>(c, p.tb, smem, p.GW);
     const int64_t cw0 = (int64_t)blockIdx.x * p.GW;
-    const int64_t wslab = ((p.N + Ctx<LGS>::CH - 1) / Ctx<LGS>::CH + 1) * 64;
+    const int64_t wslab = ((p.N + Ctx<LGS>::CH - 1) / Ctx<LGS>::CH) * Ctx<LGS>::CH * 64;
     double *ckpt = p.scratch + (int64_t)blockIdx.x * wslab;
     map_pass<LGS>(c, cw0, p.B, p.N, p.nv2, p.sys, nullptr, p.par, p.Lin, p.N, ckpt, p.Lout);
     const int64_t cw = cw0 + c.g;
@@ -343,7 +349,7 @@ struct TurboParams {
     const double *sys, *p1, *p2, *Lint;   // [B][N], Lint may be null
     const int32_t *perm;                  // [N]
     uint8_t *bits;                        // [B][N]
-    double *beta;                         // per wave: beta checkpoints [nchunks + 1][64]
+    double *beta;                         // per wave: beta rows [nchunks][CH][64]
     double *larr;                         // per codeword: A[N] B[N] C[N]
     int64_t B, N;
     double nv2;
@@ -359,7 +365,7 @@ __global__ __launch_bounds__(64) void turbo_decode_kernel(TurboParams p) {
     const int64_t cw0 = (int64_t)blockIdx.x * p.GW, N = p.N;
     const int64_t cw = cw0 + c.g;
     const bool valid = c.active && cw < p.B;
-    const int64_t wslab = ((N + Ctx<LGS>::CH - 1) / Ctx<LGS>::CH + 1) * 64;
+    const int64_t wslab = ((N + Ctx<LGS>::CH - 1) / Ctx<LGS>::CH) * Ctx<LGS>::CH * 64;
     double *beta = p.beta + (int64_t)blockIdx.x * wslab;
     // L arrays of all codewords: [B][3][N] -> per-codeword stride 3N; A at +0, B at +N, C at +2N
     double *A0 = p.larr, *B0 = p.larr + N, *C0 = p.larr + 2 * N;
@@ -434,7 +440,7 @@ int cpx_map_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const do
     p.GW = GW;
     p.sys = d_sys; p.par = d_par; p.Lin = d_L_int; p.Lout = d_L_ext; p.bits = d_bits;
     p.B = B; p.N = N; p.nv2 = 2 * noise_variance; p.want_bits = want_bits;
-    if ((rc = workspace(st, 0, sizeof(double) * (size_t)(nblocks * (N / 8 + 2) * 64), (void **)&p.scratch))) return rc;
+    if ((rc = workspace(st, 0, sizeof(double) * (size_t)(nblocks * ((N + MAXCH - 1) / MAXCH) * MAXCH * 64), (void **)&p.scratch))) return rc;
     dim3 grid((unsigned)nblocks), block(64);
     switch (p.tb.lgS) {
 #define CASE(LG) case LG: hipLaunchKernelGGL(map_decode_kernel<LG>, grid, block, lds_bytes<LG>(GW), st, p); break;
@@ -460,7 +466,7 @@ int cpx_turbo_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const 
     p.GW = GW;
     p.sys = d_sys; p.p1 = d_p1; p.p2 = d_p2; p.Lint = d_L_int_or_null; p.perm = d_perm; p.bits = d_bits;
     p.B = B; p.N = N; p.nv2 = 2 * noise_variance; p.n_iter = n_iter;
-    if ((rc = workspace(st, 0, sizeof(double) * (size_t)(nblocks * (N / 8 + 2) * 64), (void **)&p.beta))) return rc;
+    if ((rc = workspace(st, 0, sizeof(double) * (size_t)(nblocks * ((N + MAXCH - 1) / MAXCH) * MAXCH * 64), (void **)&p.beta))) return rc;
     if ((rc = workspace(st, 1, sizeof(double) * (size_t)(B * 3 * N), (void **)&p.larr))) return rc;
     dim3 grid((unsigned)nblocks), block(64);
     switch (p.tb.lgS) {
