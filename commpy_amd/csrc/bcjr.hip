@@ -42,7 +42,7 @@ constexpr int MAXCH = 16;      // steps per chunk (upper bound; keeps LDS <= 37 
 struct MapTables {
     const int32_t *next_state, *output;                       // [S][2]
     const int32_t *pred_state, *pred_input, *pred_code;       // [S][2]
-    int lgS, n;
+    int lgS, n, sr4;
 };
 
 template <int CTRL>
@@ -71,6 +71,8 @@ struct Ctx {
     static constexpr int CH = MAXCH;                                   // steps per chunk
     static constexpr int NI = 4;                                       // max (codeword, step) items per lane (CH*GW <= 256)
     int lane, g, s, GW;
+    bool sr4;                                                          // 4-state shift-register trellis: static DPP exchange
+    int sb[2];                                                         // sr4: MSB of next_state[s][i] (which successor input i leads to)
     bool active;                                                       // lane belongs to one of the GW decoded slots
     int nxt[2], code[2];              // outgoing branches of state s: next-state lane, 2-bit code (sys, parity)
     int plane[2], pin[2], pcode[2];   // incoming branches in np.where order: predecessor lane, input, code
@@ -91,9 +93,11 @@ __device__ __forceinline__ void init_ctx(Ctx<LGS> &c, const MapTables &tb, unsig
     c.active = (c.lane >> LGS) < GW;
     c.g = c.active ? (c.lane >> LGS) : 0;                         // idle lanes shadow slot 0 (reads only)
     c.s = c.lane & (S - 1);
+    c.sr4 = (LGS == 2) && tb.sr4;
     const int gbase = (c.lane >> LGS) << LGS, sh = tb.n - 2;      // exchanges stay inside the lane's own group
     for (int i = 0; i < 2; i++) {
         c.nxt[i] = gbase + tb.next_state[c.s * 2 + i];
+        c.sb[i] = (tb.next_state[c.s * 2 + i] >> (LGS - 1)) & 1;
         c.code[i] = (tb.output[c.s * 2 + i] >> sh) & 3;       // [msg_bit, parity_bit] = codeword_array[0:2] (:96-98)
         c.plane[i] = gbase + tb.pred_state[c.s * 2 + i];
         c.pin[i] = tb.pred_input[c.s * 2 + i];
@@ -134,6 +138,33 @@ __device__ __forceinline__ void exchange2(const Ctx<LGS> &c, double v, int la, i
         va = c.xch[la];
         vb = c.xch[lb];
         asm volatile("" ::: "memory");
+    }
+}
+
+// beta of the two successors of this lane's state, ordered by INPUT (0, 1).  4-state shift-register trellises:
+// the successors of state s are (s>>1) and 2|(s>>1) -- two constant quad permutes + a per-lane select instead of
+// four quad broadcasts and a select tree.
+template <int LGS>
+__device__ __forceinline__ void exchange_succ(const Ctx<LGS> &c, double v, double &v0, double &v1) {
+    if (LGS == 2 && c.sr4) {
+        const double lo = dppd<0x50>(v);                          // quad_perm [0,0,1,1]: lane s <- lane s>>1
+        const double hi = dppd<0xFA>(v);                          // quad_perm [2,2,3,3]: lane s <- lane 2|(s>>1)
+        v0 = c.sb[0] ? hi : lo;
+        v1 = c.sb[1] ? hi : lo;
+    } else {
+        exchange2<LGS>(c, v, c.nxt[0], c.nxt[1], v0, v1);
+    }
+}
+
+// alpha of the two predecessors of this lane's state in np.where order (increasing predecessor state).
+// 4-state shift-register trellises: predecessors of ns are 2(ns&1) and 2(ns&1)+1.
+template <int LGS>
+__device__ __forceinline__ void exchange_pred(const Ctx<LGS> &c, double v, double &v0, double &v1) {
+    if (LGS == 2 && c.sr4) {
+        v0 = dppd<0x88>(v);                                       // quad_perm [0,2,0,2]
+        v1 = dppd<0xDD>(v);                                       // quad_perm [1,3,1,3]
+    } else {
+        exchange2<LGS>(c, v, c.plane[0], c.plane[1], v0, v1);
     }
 }
 
@@ -200,7 +231,7 @@ __device__ __forceinline__ double beta_chunk(const Ctx<LGS> &c, double b, int le
         const double g0 = gm[c.code[0]], g1 = gm[c.code[1]], p0 = c.pr0[tl * GW + c.g];
         const double p1 = 1.0 - p0;                               // priors[1] = 1 - priors[0] (:240)
         double bn0, bn1;
-        exchange2<LGS>(c, b, c.nxt[0], c.nxt[1], bn0, bn1);
+        exchange_succ<LGS>(c, b, bn0, bn1);
         double nb = 0.0;
         nb += (bn0 * g0 * p0);                                    // (:106-108), input 0 then input 1
         nb += (bn1 * g1 * p1);
@@ -283,7 +314,7 @@ __device__ void map_pass(const Ctx<LGS> &c, int64_t cw0, int64_t B, int64_t N, d
                 if (c.active) *reinterpret_cast<double2 *>(c.xs + (tl * W + col) * 2) = xv;
                 // f[next,1] += f[cs,0] * branch_prob * priors[input]     (:136-138), accumulation in (cs, input) order
                 double ap0, ap1;
-                exchange2<LGS>(c, a, c.plane[0], c.plane[1], ap0, ap1);
+                exchange_pred<LGS>(c, a, ap0, ap1);
                 double na = 0.0;
                 na += (ap0 * gi0 * (c.pin[0] ? p1 : p0));
                 na += (ap1 * gi1 * (c.pin[1] ? p1 : p0));
@@ -419,6 +450,13 @@ int fill_tables(const cpx_trellis *t, MapTables &tb) {
     tb.n = t->n;
     tb.lgS = 0;
     while ((1 << tb.lgS) < t->S) tb.lgS++;
+    // 4-state shift-register structure (everything commpy's Trellis builds with memory 2, k = 1)
+    tb.sr4 = (t->S == 4);
+    for (int s2 = 0; s2 < 4 && tb.sr4; s2++) {
+        const int a = t->next_state[s2 * 2], b2 = t->next_state[s2 * 2 + 1];
+        if (!((a == (s2 >> 1) && b2 == (2 | (s2 >> 1))) || (b2 == (s2 >> 1) && a == (2 | (s2 >> 1))))) tb.sr4 = 0;
+        if (t->pred_state[s2 * 2] != 2 * (s2 & 1) || t->pred_state[s2 * 2 + 1] != 2 * (s2 & 1) + 1) tb.sr4 = 0;
+    }
     return CPX_OK;
 }
 
