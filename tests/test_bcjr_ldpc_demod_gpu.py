@@ -227,3 +227,25 @@ def test_demod_bad_type(gpu):
     from commpy_amd.modulation import QAMModem
     with pytest.raises(ValueError):
         QAMModem(4).demodulate(np.zeros(3, complex), "fuzzy")
+
+
+@pytest.mark.parametrize("B", [1, 64, 65])
+@pytest.mark.parametrize("iters", [0, 1, 2])
+def test_ldpc_edge_sizes(gpu, B, iters):
+    """Tile boundaries (one block, exactly one wavefront tile, one block more) and the iteration-count edge cases
+    (0: hard decision of the clipped input; 1: no compaction scan at all) against the oracle, both algorithms."""
+    from commpy_amd.channelcoding import ldpc_bp_decode
+    p = ldpc_params("gallager96")
+    n = int(p["n_vnodes"])
+    rs = np.random.RandomState(B * 10 + iters)
+    llr = rs.randn(B * n) * 2.0 + 1.0
+    llr[::17] *= 400.0                                             # some values beyond the +-500 clip
+    for alg in ("MSA", "SPA"):
+        x = llr.copy()
+        dec, out, its = ldpc_bp_decode(x, p, alg, iters, return_iterations=True)
+        y = llr.copy()
+        do, oo, io = oracle.ldpc_bp_decode(y, p, alg, iters, True)
+        assert np.array_equal(x, y)                                # in-place clip of the caller's array (ldpc.py:186)
+        assert np.array_equal(np.atleast_1d(its), np.atleast_1d(io))
+        assert np.array_equal(dec, do)
+        assert np.all(np.abs(out - oo) <= TOL + 1e-6 * np.abs(oo))
