@@ -6,8 +6,9 @@ QPSK + AWGN at Eb/N0 = 3 dB, batch 65536 codewords per GPU (BASELINE.json config
 
 A "step" is one pass of the HIP Viterbi decoder over the whole per-GPU batch with the float64 LLRs
 already resident in HBM.  N > 1 (launched by torch.distributed.run, one process per GPU): weak
-scaling, every rank decodes its own 65536-codeword batch and one RCCL all-gather reassembles the
-decoded bits on every rank inside the timed step.  Rank 0 prints ONE JSON line with the contract
+scaling, every rank decodes and keeps its own 65536-codeword batch -- the path shards by codeword and has no
+exchange step, so the timed region contains no collective (barrier + max over ranks only; the error counts of the
+shards are all-reduced once, after the measurement).  Rank 0 prints ONE JSON line with the contract
 fields plus `roofline` (dominant kernel, HIP-event timed on its own stream) and `cpu_baseline`
 (the C oracle -- a port of the reference's algorithm -- timed on the host cores on a bounded sample;
 the unmodified Python reference is not available on the GPU box).
@@ -134,16 +135,15 @@ def main():
     h_tr, h_md = tr._device_handle(), md._device_handle()
 
     if distributed:
-        # a real (non-null) torch stream made current: the C-ABI launches on it, and the RCCL all-gather issued by
-        # torch.distributed is ordered after the decode of the same step (the null stream handle would make the
-        # library fall back to its own stream, unordered with respect to the collective)
+        # a real (non-null) torch stream made current: the C-ABI launches on it and torch.distributed's collectives
+        # (closing barrier, error-count all-reduce) are ordered after the decodes (the null stream handle would make
+        # the library fall back to its own stream, unordered with respect to them)
         tstream = torch.cuda.Stream()
         torch.cuda.set_stream(tstream)
         stream = ctypes.c_void_p(tstream.cuda_stream)
         t_y = torch.empty((B, nsym, 2), dtype=torch.float64, device="cuda")
         t_llr = torch.empty((B, LEN), dtype=torch.float64, device="cuda")
         t_bits = torch.empty((B, L), dtype=torch.uint8, device="cuda")
-        t_all = torch.empty((world * B, L), dtype=torch.uint8, device="cuda")
         d_y, d_llr, d_bits = (ctypes.c_void_p(t.data_ptr()) for t in (t_y, t_llr, t_bits))
         sync = torch.cuda.synchronize
         barrier = dist.barrier
@@ -199,8 +199,6 @@ def main():
         _lib.check(lib.cpx_viterbi_decode_batch_dev(h_tr, d_llr, B, LEN, L, T, TB, 1, d_bits, stream))
         if k is not None:
             _lib.check(lib.cpx_timer_stop(timers[k], stream))
-        if distributed and world > 1:
-            dist.all_gather_into_tensor(t_all, t_bits)               # RCCL all-gather of the decoded bits
 
     # warm-up runs exactly what a timed step runs, event records included (the first hipEventRecord of a process
     # that loaded torch's HIP runtime cost ~70 ms here, which must not land inside the K timed steps)
@@ -244,7 +242,14 @@ def main():
         bits[...] = t_bits.cpu().numpy()
     else:
         _lib.check(lib.cpx_memcpy_d2h(_lib.ptr(bits), d_bits, bits.nbytes))
-    ber = float(np.mean(bits[:, :MSG_BITS] != msgs))
+    nerr = int(np.sum(bits[:, :MSG_BITS] != msgs))
+    if distributed and world > 1:
+        # the only collective of the job, outside the timed region: error counts of all shards (RCCL all-reduce).
+        # The decode path itself has no exchange step -- every rank decodes and keeps its own codewords.
+        terr = torch.tensor([nerr], dtype=torch.int64, device="cuda")
+        dist.all_reduce(terr, op=dist.ReduceOp.SUM)
+        nerr = int(terr.item())
+    ber = nerr / float(world * B * MSG_BITS)
     out = None
     if rank == 0:
         import oracle
@@ -278,7 +283,7 @@ def main():
             "config": {"workload": "configs[1]: K=7 (0o133,0o171) r=1/2, 1024-bit blocks, soft Viterbi over "
                                    "AWGN+QPSK at Eb/N0=3 dB, batch=65536 codewords per GPU, tb_depth=30",
                        "batch_per_gpu": B, "block_bits": MSG_BITS, "ebn0_db": EBN0_DB,
-                       "parallelism": "batch-sharded x%d, all-gather of bits" % (world if distributed else 1)},
+                       "parallelism": "codewords sharded x%d, no data-path collective" % (world if distributed else 1)},
             "ber": ber, "oracle_mismatched_bits": mism, "oracle_sample_codewords": ns,
             "demod_max_abs_err_vs_oracle": demod_err,
             "roofline": {"bound": "hbm", "kernel": "viterbi_wave_kernel<6,2,true,2>", "achieved": achieved,

@@ -59,13 +59,16 @@ def all_gather_rows(local, n_total, group=None):
     return full.numpy() if is_np else full
 
 
-def sharded_decode(decode_fn, batch_inputs, n_total=None, group=None):
-    """Decode a batch sharded over the ranks of the process group and reassemble the bits.
+def sharded_decode(decode_fn, batch_inputs, n_total=None, group=None, gather=True):
+    """Decode a batch sharded over the ranks of the process group.
+
+    The decode path has no exchange step: with ``gather=False`` every rank returns only the rows
+    ``shard_bounds(n_total, rank, world)`` it decoded (no collective at all).  ``gather=True`` (default, the
+    convenient form for scripts that continue on every rank) reassembles the full result with one all-gather.
 
     ``decode_fn(*shard_inputs) -> ndarray [rows, ...]`` is any of the batched decoders (e.g.
     ``lambda x: viterbi_decode(x, trellis, None, 'soft')``); ``batch_inputs`` are arrays whose first
     axis is the codeword index (every rank passes the same full arrays, or arrays it can slice).
-    Returns the full result on every rank.
     """
     dist = _dist()
     n_total = int(batch_inputs[0].shape[0]) if n_total is None else int(n_total)
@@ -75,4 +78,6 @@ def sharded_decode(decode_fn, batch_inputs, n_total=None, group=None):
         rank, world = 0, 1
     lo, hi = shard_bounds(n_total, rank, world)
     local = np.asarray(decode_fn(*[a[lo:hi] for a in batch_inputs]))
+    if not gather:
+        return local
     return all_gather_rows(local, n_total, group)

@@ -44,6 +44,11 @@ def _worker(rank, world, port, q):
         full = sharded_decode(lambda x: oracle.viterbi_decode(x, tr, None, "hard").astype(np.uint8), [rx])
         want = oracle.viterbi_decode(rx, tr, None, "hard").astype(np.uint8)
         ok = full.shape == want.shape and np.array_equal(full, want)
+        # collective-free form: every rank keeps exactly its own rows
+        from commpy_amd.parallel import shard_bounds
+        mine = sharded_decode(lambda x: oracle.viterbi_decode(x, tr, None, "hard").astype(np.uint8), [rx], gather=False)
+        a, b = shard_bounds(B, rank, world)
+        ok = ok and mine.shape[0] == b - a and np.array_equal(mine, want[a:b])
         # equal shards (no padding branch) + float payload
         lo, hi = B // world * rank, B // world * (rank + 1)
         even = all_gather_rows(np.arange(40, dtype=np.float64).reshape(10, 4)[rank * 5:(rank + 1) * 5], 10)
