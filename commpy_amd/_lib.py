@@ -45,6 +45,8 @@ SYMBOLS = {
                                          c_void_p]),
     "cpx_viterbi_decode_batch_dev": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int,
                                              c_void_p, c_void_p]),
+    "cpx_viterbi_decode_batch_i64": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int,
+                                     c_void_p]),
     "cpx_map_decode_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_double, c_int,
                                      c_void_p, c_void_p]),
     "cpx_map_decode_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_double, c_int,

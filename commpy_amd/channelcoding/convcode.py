@@ -325,11 +325,12 @@ def viterbi_decode(coded_bits, trellis, tb_depth=None, decoding_type='hard'):
         raise ValueError('coded_bits must be 1-D or 2-D [batch, len]')
     B, length = x.shape
     L, n_steps, tb = _viterbi_sizes(length, trellis, tb_depth)
-    out = np.zeros((B, L), dtype=np.uint8)
+    # int64 like the reference's `decoded_bits`; widened on the device (doing it with astype on the host costs more
+    # than the decode for large batches)
+    res = np.empty((B, L), dtype=np.int64)                   # every element is written by the library
     if B and L:
         if tb < 2:
             raise ValueError('tb_depth must be >= 2')
-        _lib.check(lib.cpx_viterbi_decode_batch(trellis._device_handle(), _lib.ptr(x), B, length, L, n_steps, tb,
-                                                _VIT_TYPES[decoding_type], _lib.ptr(out)))
-    res = out.astype(np.int64)
+        _lib.check(lib.cpx_viterbi_decode_batch_i64(trellis._device_handle(), _lib.ptr(x), B, length, L, n_steps, tb,
+                                                    _VIT_TYPES[decoding_type], _lib.ptr(res)))
     return res[0] if single else res

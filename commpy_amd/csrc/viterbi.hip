@@ -29,6 +29,11 @@
 // -ffp-contract=off so sums round like NumPy's.
 #include "cpx_internal.h"
 
+#include <algorithm>
+#include <mutex>
+#include <thread>
+#include <vector>
+
 using namespace cpx;
 
 namespace {
@@ -646,6 +651,52 @@ int cpx_viterbi_decode_batch(const cpx_trellis *t, const double *coded, int64_t 
     if (rc) return rc;
     CPX_HIP(hipMemcpyAsync(bits, dout.p, (size_t)(B * L), hipMemcpyDeviceToHost, st));
     CPX_HIP(hipStreamSynchronize(st));
+    return CPX_OK;
+}
+
+int cpx_viterbi_decode_batch_i64(const cpx_trellis *t, const double *coded, int64_t B, int64_t len, int64_t L,
+                                 int64_t n_steps, int tb_depth, int decoding_type, int64_t *bits64) {
+    CPX_REQUIRE(t && (coded || B * len == 0) && (bits64 || B * L == 0), CPX_EINVAL, "viterbi: null pointer");
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (B == 0 || L == 0) return CPX_OK;
+    const size_t nout = (size_t)(B * L);
+    // compact bits cross PCIe into a pinned staging block and are widened by host threads straight into the caller's
+    // array (first touch of its pages included): 8x less PCIe traffic than widening on the device, and the page
+    // faults of a fresh 8-byte-per-bit result array are spread over the cores
+    static std::mutex mu;
+    static uint8_t *stage = nullptr;
+    static size_t stage_cap = 0;
+    std::lock_guard<std::mutex> lk(mu);
+    if (stage_cap < nout) {
+        if (stage) (void)hipHostFree(stage);
+        stage = nullptr; stage_cap = 0;
+        CPX_HIP(hipHostMalloc((void **)&stage, nout, hipHostMallocDefault));
+        stage_cap = nout;
+    }
+    DevBuf din, dout;
+    if ((rc = din.alloc(sizeof(double) * (size_t)(B * len)))) return rc;
+    if ((rc = dout.alloc(nout))) return rc;
+    hipStream_t st = lib_stream();
+    // (cutting the batch into chunks on two streams to overlap upload and decode was measured: 44.7 ms against
+    // 39.2 ms for B = 65536 -- smaller pageable uploads lose more than the 3 ms of decode they hide)
+    CPX_HIP(hipMemcpyAsync(din.p, coded, sizeof(double) * (size_t)(B * len), hipMemcpyHostToDevice, st));
+    rc = cpx_viterbi_decode_batch_dev(t, din.as<double>(), B, len, L, n_steps, tb_depth, decoding_type,
+                                      dout.as<uint8_t>(), st);
+    if (rc) return rc;
+    CPX_HIP(hipMemcpyAsync(stage, dout.p, nout, hipMemcpyDeviceToHost, st));
+    CPX_HIP(hipStreamSynchronize(st));
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt > 16) nt = 16;
+    if (nt < 1 || nout < (1u << 20)) nt = 1;
+    auto work = [&](unsigned i) {
+        const size_t lo = nout * i / nt, hi = nout * (i + 1) / nt;
+        for (size_t j = lo; j < hi; j++) bits64[j] = stage[j];
+    };
+    std::vector<std::thread> th;
+    for (unsigned i = 1; i < nt; i++) th.emplace_back(work, i);
+    work(0);
+    for (auto &x : th) x.join();
     return CPX_OK;
 }
 

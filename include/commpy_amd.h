@@ -95,6 +95,11 @@ int cpx_viterbi_decode_batch(const cpx_trellis *t, const double *coded, int64_t 
 int cpx_viterbi_decode_batch_dev(const cpx_trellis *t, const double *d_coded, int64_t B, int64_t len,
                                  int64_t L, int64_t n_steps, int tb_depth, int decoding_type,
                                  uint8_t *d_bits, void *stream);
+/* Same as cpx_viterbi_decode_batch with the result widened to the reference's return type (`decoded_bits` is an
+ * int array, convcode.py:711/749): bits64 [B][L] int64.  The compact bits cross PCIe, host threads widen them
+ * straight into the caller's array: a single-threaded astype of 67 M bits costs more than decoding them. */
+int cpx_viterbi_decode_batch_i64(const cpx_trellis *t, const double *coded, int64_t B, int64_t len,
+                                 int64_t L, int64_t n_steps, int tb_depth, int decoding_type, int64_t *bits64);
 
 /* ---- turbo codes: BCJR / MAP ---------------------------------------------------------------------
  * cpx_map_decode_batch replaces map_decode(sys, non_sys, trellis, noise_variance, L_int, mode)
