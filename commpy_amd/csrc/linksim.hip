@@ -116,6 +116,35 @@ __global__ __launch_bounds__(LS_BLOCK) void conv_encode_kernel(const uint8_t *__
     for (int64_t q = j * n; q < nout; q++) c[q] = 0;
 }
 
+// Feed-forward shift-register codes (k = 1, next state = (b << (m-1)) | (state >> 1), the trellises commpy builds
+// for non-recursive codes): the state at step j is just the previous m message bits, so every trellis step is
+// independent -- one thread per (codeword, step) instead of one per codeword (the sequential walk above took longer
+// than the Viterbi decoder of the same batch in the link benchmark).
+__global__ __launch_bounds__(LS_BLOCK) void conv_encode_ff_kernel(const uint8_t *__restrict__ msg, int64_t B, int64_t nmsg,
+                                                                  const int32_t *__restrict__ output, int n, int m,
+                                                                  int64_t nsteps, uint8_t *__restrict__ coded,
+                                                                  int64_t nout) {
+    const int64_t spc = (nout + n - 1) / n;                        // step slots per codeword (zero fill past nsteps)
+    for (int64_t idx = (int64_t)blockIdx.x * LS_BLOCK + threadIdx.x; idx < B * spc; idx += (int64_t)gridDim.x * LS_BLOCK) {
+        const int64_t b = idx / spc, j = idx - b * spc;
+        int o = 0;
+        if (j < nsteps) {
+            const uint8_t *mb = msg + b * nmsg;
+            int state = 0;
+            for (int i = 1; i <= m; i++) {                         // most recent bit = MSB of the state
+                const int64_t pos = j - i;
+                const int bit = (pos >= 0 && pos < nmsg) ? (mb[pos] & 1) : 0;
+                state |= bit << (m - i);
+            }
+            const int cur = (j < nmsg) ? (mb[j] & 1) : 0;          // zero tail of 'term' (:505-520)
+            o = output[state * 2 + cur];
+        }
+        uint8_t *c = coded + b * nout + j * n;
+        for (int q = 0; q < n; q++)
+            if (j * n + q < nout) c[q] = (uint8_t)((o >> (n - 1 - q)) & 1);   // dec2bitarray(o, n) (:535)
+    }
+}
+
 // ---- row-wise gathers: puncturing (u8) and depuncturing (f64, -1 = punctured position -> 0.0) ----------------------
 __global__ __launch_bounds__(LS_BLOCK) void gather_u8_kernel(const uint8_t *__restrict__ in, int64_t B, int64_t nin,
                                                              const int32_t *__restrict__ idx, int64_t nout,
@@ -218,6 +247,18 @@ int cpx_conv_encode_batch_dev(const cpx_trellis *t, const uint8_t *d_msg, int64_
     if (B == 0 || nout == 0) return CPX_OK;
     int total_memory = 0;
     while ((1 << total_memory) < t->S) total_memory++;
+    bool ff = (t->k == 1 && t->I == 2 && !rsc && total_memory >= 1);
+    for (int s2 = 0; s2 < t->S && ff; s2++)
+        for (int b2 = 0; b2 < 2; b2++)
+            if (t->next_state[s2 * 2 + b2] != ((b2 << (total_memory - 1)) | (s2 >> 1))) ff = false;
+    if (ff) {
+        const int64_t nsteps = nmsg + (terminate ? total_memory : 0);
+        const int64_t spc = (nout + t->n - 1) / t->n;
+        hipLaunchKernelGGL(conv_encode_ff_kernel, dim3(ls_grid(B * spc)), dim3(LS_BLOCK), 0, pick_stream(stream), d_msg, B,
+                           nmsg, t->d_out, t->n, total_memory, nsteps, d_coded, nout);
+        CPX_HIP(hipGetLastError());
+        return CPX_OK;
+    }
     const size_t lds = sizeof(int32_t) * 2 * t->S * t->I;
     hipLaunchKernelGGL(conv_encode_kernel, dim3((unsigned)((B + LS_BLOCK - 1) / LS_BLOCK)), dim3(LS_BLOCK), lds,
                        pick_stream(stream), d_msg, B, nmsg, t->d_next, t->d_out, t->k, t->n, t->S, t->I, total_memory,
