@@ -203,13 +203,18 @@ __global__ __launch_bounds__(LS_BLOCK) void count_errors_kernel(const uint8_t *_
                                                                 const uint8_t *__restrict__ dec, int64_t dec_stride,
                                                                 int64_t B, int64_t nchunks, int64_t chunk,
                                                                 int32_t *__restrict__ errs) {
-    const int64_t total = B * nchunks;
-    for (int64_t i = (int64_t)blockIdx.x * LS_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * LS_BLOCK) {
+    // one wavefront per (block, chunk): coalesced byte reads, butterfly sum (a thread per chunk walked its bytes
+    // alone and took 12 % of the link benchmark)
+    const int lane = threadIdx.x & 63;
+    const int64_t total = B * nchunks, nwaves = (int64_t)gridDim.x * (LS_BLOCK / 64);
+    for (int64_t i = (int64_t)blockIdx.x * (LS_BLOCK / 64) + (threadIdx.x >> 6); i < total; i += nwaves) {
         const int64_t b = i / nchunks, c = i % nchunks;
         const uint8_t *m = msg + b * msg_stride + c * chunk, *d = dec + b * dec_stride + c * chunk;
         int32_t e = 0;
-        for (int64_t q = 0; q < chunk; q++) e += (m[q] ^ d[q]) & 1;
-        errs[i] = e;
+        for (int64_t q = lane; q < chunk; q += 64) e += (m[q] ^ d[q]) & 1;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) e += __shfl_xor(e, off);
+        if (lane == 0) errs[i] = e;
     }
 }
 
@@ -312,7 +317,7 @@ int cpx_count_errors_dev(const uint8_t *d_msg, int64_t msg_stride, const uint8_t
                          int64_t nchunks, int64_t chunk, int32_t *d_errs, void *stream) {
     CPX_REQUIRE(B >= 0 && nchunks >= 0 && chunk >= 0, CPX_EINVAL, "count_errors: negative size");
     if (B * nchunks == 0) return CPX_OK;
-    hipLaunchKernelGGL(count_errors_kernel, dim3(ls_grid(B * nchunks)), dim3(LS_BLOCK), 0, pick_stream(stream), d_msg,
+    hipLaunchKernelGGL(count_errors_kernel, dim3(ls_grid(B * nchunks * 64)), dim3(LS_BLOCK), 0, pick_stream(stream), d_msg,
                        msg_stride, d_dec, dec_stride, B, nchunks, chunk, d_errs);
     CPX_HIP(hipGetLastError());
     return CPX_OK;
