@@ -34,7 +34,7 @@ def main():
     ebn0 = np.arange(0.0, 10.5, 1.0)
     snrs = ebn0 + 10 * math.log10(link.rate * link.modem.num_bits_symbol)
     per_point = int(a.bits / len(snrs))
-    link.run_batch(float(snrs[0]), 4096)                    # warm-up (allocations, code objects)
+    link.run_batch(float(snrs[0]), int(min(8192, math.ceil(per_point / link.nbits))))   # warm-up: same batch size as the sweep (allocations, code objects)
     t0 = time.perf_counter()
     bers = link.ber_sweep(snrs, per_point, tx_batch=8192)
     dt = time.perf_counter() - t0
