@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/ldpc_pmc
 mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
-for C in "FETCH_SIZE WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
+for C in "FETCH_SIZE WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   N=$(echo $C | tr ' ' '_' | cut -c1-30)
   timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$N -- python $R/benchmarks/bench_kernels.py --which ldpc --scale ${SCALE:-1.0} > $OUT/$N.log 2>&1
   F=$(find $OUT/$N -name '*counter_collection.csv' | head -1)
