@@ -291,9 +291,9 @@ def main():
                          "traffic_source": "profiles/r01_viterbi_c2_traffic.json (rocprofv3 FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KiB)",
                          "kernel_ms_avg": kavg,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_CW * B,
-                         "note": "serial ACS recursion: VALU/ds_bpermute bound, not HBM bound (SURVEY 8d)"},
+                         "note": "serial float64 add-compare-select recursion: VALU-issue bound, not HBM bound (DESIGN 4.1)"},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:                # reported at N = 1 only; the other ranks would idle
             out["cpu_baseline"] = cpu_baseline(tr, llr_s)
         else:
             out["cpu_baseline"] = None
