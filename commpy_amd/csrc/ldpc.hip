@@ -233,11 +233,10 @@ __device__ __forceinline__ void cn_msa_row(const MsaRec &o, double *__restrict__
     default: FN<0>(__VA_ARGS__); break;                                                              \
     }
 
-// Check pass of iteration k: syndrome bit + check-node update.  RR = rows of R per tile (E or 3 n_c).
-template <int ALG>
-__global__ __launch_bounds__(LB) void ldpc_cn_kernel(Bufs bf, int n_v, int n_c, int64_t RR,
-                                                     const int32_t *__restrict__ row_ptr,
-                                                     const int32_t *__restrict__ row_pad, int cpad, int k) {
+// Sum-product check pass of iteration k: syndrome bit + check-node update.  RR = E rows of R per tile.
+__global__ __launch_bounds__(LB) void ldpc_cn_spa_kernel(Bufs bf, int n_v, int n_c, int64_t RR,
+                                                         const int32_t *__restrict__ row_ptr,
+                                                         const int32_t *__restrict__ row_pad, int cpad, int k) {
     int n_slots, buf;
     effective(bf.ctl, n_slots, buf);
     const int n_tiles = n_slots >> 6;
@@ -258,52 +257,23 @@ __global__ __launch_bounds__(LB) void ldpc_cn_kernel(Bufs bf, int n_v, int n_c, 
         const int deg = row_ptr[c + 1] - e0;
         const int32_t *__restrict__ ev = row_pad + (int64_t)c * cpad;
         const double *__restrict__ Qt = Q + tile * n_v * 64 + lane;
-        if (ALG == CPX_LDPC_SPA) {
-            if (st < k) continue;                                 // frozen, retired or padding
-            double *__restrict__ Rrow = R + (tile * RR + e0) * 64 + lane;
-            CPX_DEG_SWITCH(cn_spa_row, Rrow, Qt, ev, deg, k, &state[slot])
-        } else {
-            double *__restrict__ rec = R + (tile * RR + (int64_t)c * 3) * 64 + lane;
-            MsaRec o{0.0, 0.0, 0u, 0, 0};
-            if (k > 0) o = msa_load(rec);
-            if (st < k) continue;
-            CPX_DEG_SWITCH(cn_msa_row, o, rec, Qt, ev, deg, k, &state[slot])
-        }
+        if (st < k) continue;                                     // frozen, retired or padding
+        double *__restrict__ Rrow = R + (tile * RR + e0) * 64 + lane;
+        CPX_DEG_SWITCH(cn_spa_row, Rrow, Qt, ev, deg, k, &state[slot])
     }
 }
 
-// Column sum in increasing check order (message_matrix.sum(0), :243).  refs[q]: SPA = edge id; MSA =
-// (check << 5) | position of the edge in the check's row.  DEG > 0: exact degree, all loads of a stage in flight.
-template <int ALG, int DEG>
+// Sum-product column sum in increasing check order (message_matrix.sum(0), :243); refs[q] = edge id.
+// DEG > 0: exact degree, all loads in flight; DEG == 0: any degree, four at a time.
+template <int DEG>
 __device__ __forceinline__ double vn_sum(const double *__restrict__ Rt, const int32_t *__restrict__ refs, int deg) {
     constexpr int CH = DEG > 0 ? DEG : 4;
     double msum = 0.0;
     for (int q0 = 0; q0 < (DEG > 0 ? 1 : deg); q0 += CH) {
         double r[CH];
-        if (ALG == CPX_LDPC_SPA) {
 #pragma unroll
-            for (int u = 0; u < CH; u++)
-                if (DEG > 0 || q0 + u < deg) r[u] = ntload(&Rt[(int64_t)refs[q0 + u] * 64]);
-        } else {
-            const double *rec[CH];
-            double meta[CH];
-#pragma unroll
-            for (int u = 0; u < CH; u++) {
-                if (DEG > 0 || q0 + u < deg) {
-                    rec[u] = Rt + (int64_t)(refs[q0 + u] >> 5) * 192;
-                    meta[u] = rec[u][128];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < CH; u++) {
-                if (DEG > 0 || q0 + u < deg) {
-                    const int j = refs[q0 + u] & 31, lo = __double2loint(meta[u]);
-                    const double mn = rec[u][(j == (lo & 0xff)) ? 64 : 0];
-                    const unsigned ng = (((unsigned)__double2hiint(meta[u]) >> j) ^ (unsigned)(lo >> 8)) & 1u;
-                    r[u] = __hiloint2double(__double2hiint(mn) | (int)(ng << 31), __double2loint(mn));
-                }
-            }
-        }
+        for (int u = 0; u < CH; u++)
+            if (DEG > 0 || q0 + u < deg) r[u] = ntload(&Rt[(int64_t)refs[q0 + u] * 64]);
 #pragma unroll
         for (int u = 0; u < CH; u++)
             if (DEG > 0 || q0 + u < deg) msum += r[u];
@@ -457,9 +427,8 @@ __global__ __launch_bounds__(LB) void ldpc_vn_msa_kernel(Bufs bf, int n_v, int n
     }
 }
 
-// Variable pass of iteration k (:243-248): Q = column sum + llr.
-template <int ALG>
-__global__ __launch_bounds__(LB) void ldpc_vn_kernel(Bufs bf, int n_v, int64_t RR,
+// Sum-product variable pass of iteration k (:243-248): Q = column sum + llr.
+__global__ __launch_bounds__(LB) void ldpc_vn_spa_kernel(Bufs bf, int n_v, int64_t RR,
                                                      const int32_t *__restrict__ col_ptr,
                                                      const int32_t *__restrict__ col_pad, int vpad, int k,
                                                      int32_t *__restrict__ iters) {
@@ -487,14 +456,14 @@ __global__ __launch_bounds__(LB) void ldpc_vn_kernel(Bufs bf, int n_v, int64_t R
         const double *__restrict__ Rt = R + tile * RR * 64 + lane;
         double msum;
         switch (deg) {
-        case 2: msum = vn_sum<ALG, 2>(Rt, refs, deg); break;
-        case 3: msum = vn_sum<ALG, 3>(Rt, refs, deg); break;
-        case 4: msum = vn_sum<ALG, 4>(Rt, refs, deg); break;
-        case 5: msum = vn_sum<ALG, 5>(Rt, refs, deg); break;
-        case 6: msum = vn_sum<ALG, 6>(Rt, refs, deg); break;
-        case 7: msum = vn_sum<ALG, 7>(Rt, refs, deg); break;
-        case 8: msum = vn_sum<ALG, 8>(Rt, refs, deg); break;
-        default: msum = vn_sum<ALG, 0>(Rt, refs, deg); break;
+        case 2: msum = vn_sum<2>(Rt, refs, deg); break;
+        case 3: msum = vn_sum<3>(Rt, refs, deg); break;
+        case 4: msum = vn_sum<4>(Rt, refs, deg); break;
+        case 5: msum = vn_sum<5>(Rt, refs, deg); break;
+        case 6: msum = vn_sum<6>(Rt, refs, deg); break;
+        case 7: msum = vn_sum<7>(Rt, refs, deg); break;
+        case 8: msum = vn_sum<8>(Rt, refs, deg); break;
+        default: msum = vn_sum<0>(Rt, refs, deg); break;
         }
         Q[i] = msum + l;                                          // msg_sum + llr (:245, :247)
         if (v == 0 && iters) iters[bf.orig[buf][slot]] += 1;
@@ -737,19 +706,19 @@ int cpx_ldpc_bp_decode_batch_dev(const cpx_ldpc *c, double *d_llr, int64_t B, in
         return (unsigned)std::max<int64_t>(8, std::min<int64_t>(resident, items) / 8 * 8);
     };
     const int qcap = std::min(12, c->cpad);
-    const void *f_cn = alg == CPX_LDPC_SPA ? (const void *)ldpc_cn_kernel<CPX_LDPC_SPA>
+    const void *f_cn = alg == CPX_LDPC_SPA ? (const void *)ldpc_cn_spa_kernel
                        : qcap == 4        ? (const void *)ldpc_cn_msa_kernel<4>
                        : qcap == 8        ? (const void *)ldpc_cn_msa_kernel<8>
                                           : (const void *)ldpc_cn_msa_kernel<12>;
-    const void *f_vn = alg == CPX_LDPC_SPA ? (const void *)ldpc_vn_kernel<CPX_LDPC_SPA>
+    const void *f_vn = alg == CPX_LDPC_SPA ? (const void *)ldpc_vn_spa_kernel
                                           : (const void *)ldpc_vn_msa_kernel;
     const unsigned g_cn = pgrid(f_cn, n_tiles * ((c->n_c + 3) / 4)), g_vn = pgrid(f_vn, n_tiles * ((nv + 3) / 4));
     const unsigned g_mv = pgrid((const void *)ldpc_move_kernel, n_tiles * ((RR + 2 * nv + 64) / 64));
     for (int it = 0; it < n_iters; it++) {
         if (alg == CPX_LDPC_SPA) {
-            hipLaunchKernelGGL((ldpc_cn_kernel<CPX_LDPC_SPA>), dim3(g_cn), dim3(LB), 0, st, bf, (int)nv, c->n_c, RR,
+            hipLaunchKernelGGL(ldpc_cn_spa_kernel, dim3(g_cn), dim3(LB), 0, st, bf, (int)nv, c->n_c, RR,
                                c->d_row_ptr, c->d_row_pad, c->cpad, it);
-            hipLaunchKernelGGL((ldpc_vn_kernel<CPX_LDPC_SPA>), dim3(g_vn), dim3(LB), 0, st, bf, (int)nv, RR, c->d_col_ptr,
+            hipLaunchKernelGGL(ldpc_vn_spa_kernel, dim3(g_vn), dim3(LB), 0, st, bf, (int)nv, RR, c->d_col_ptr,
                                c->d_col_pad_edge, c->vpad, it, d_iters);
         } else {
 #define CN_MSA(QC) hipLaunchKernelGGL((ldpc_cn_msa_kernel<QC>), dim3(g_cn), dim3(LB), 0, st, bf, (int)nv, c->n_c, c->d_row_ptr, c->d_row_pad, c->cpad, it)
