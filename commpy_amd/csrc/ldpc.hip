@@ -121,6 +121,20 @@ __device__ __forceinline__ double min_f64(double a, double b) {     // one v_min
 __device__ __forceinline__ double ntload(const double *p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ void ntstore(double v, double *p) { __builtin_nontemporal_store(v, p); }
 
+// tanh(v/2) and 2*atanh(x) for the sum-product pass.  ocml's tanh/atanh are correctly rounded to < 1 ulp through
+// double-double arithmetic (~300 VALU instructions per edge for the pair, which bounded the check pass); these
+// evaluate the same functions through one exp / one log with an ABSOLUTE error of a few 1e-16:
+//   tanh(v/2) = sign(v) (1 - e) / (1 + e),  e = exp(-|v|)        (cancellation in 1 - e only costs relative accuracy
+//                                                                  of results that are themselves ~|v|/2 << 1)
+//   2 atanh(x) = log((1 + x) / (1 - x))                            (1 - x is exact for x > 1/2; x = +-1 gives +-inf)
+// The decoder's sensitivity to the last ulp of these functions is the same either way ("LDPC-SPA note").
+__device__ __forceinline__ double tanh_half(double v) {
+    const double e = exp(-fabs(v));
+    const double t = (1.0 - e) / (1.0 + e);
+    return __builtin_copysign(t, v);                              // NaN propagates through exp
+}
+__device__ __forceinline__ double atanh_twice(double x) { return log((1.0 + x) / (1.0 - x)); }
+
 // ---- sum-product (:209-227): R keeps one float64 per edge --------------------------------------------------
 template <int DEG>
 __device__ __forceinline__ void cn_spa_row(double *__restrict__ Rrow, const double *__restrict__ Qt,
@@ -138,7 +152,7 @@ __device__ __forceinline__ void cn_spa_row(double *__restrict__ Rrow, const doub
             m = ntload(&Rrow[(int64_t)(j) * 64]) * -1.0;     /* data *= -1 (:244) */                   \
             m += 1.0 * q;                                    /* data += H.multiply(msg_sum + llr).data (:245) */ \
         }                                                                                             \
-        m = tanh(m * 0.5);                                   /* data *= .5; tanh (:210-211) */         \
+        m = tanh_half(m);                                    /* data *= .5; tanh (:210-211) */         \
         prod *= m;                                           /* row product (reference: exp2(sum(log2)) :217-219) */ \
         if (DEG > 0) v[DEG > 0 ? (j) : 0] = m; else Rrow[(int64_t)(j) * 64] = m;                       \
     }
@@ -146,7 +160,7 @@ __device__ __forceinline__ void cn_spa_row(double *__restrict__ Rrow, const doub
     {                                                                                                 \
         double x = (1.0 / (t)) * prod;                       /* data = 1/data; multiply(msg_products) (:222-223) */ \
         x = clip_nan(x, -1.0, 1.0);                          /* (:224) */                              \
-        x = atanh(x) * 2.0;                                  /* (:225-226) */                          \
+        x = atanh_twice(x);                                  /* (:225-226) */                          \
         ntstore(clip_nan(x, -500.0, 500.0), &Rrow[(int64_t)(j) * 64]);   /* (:227) */                  \
     }
     if (DEG > 0) {

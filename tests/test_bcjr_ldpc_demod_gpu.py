@@ -159,7 +159,12 @@ def test_ldpc_compaction_mixed_convergence(gpu):
         if alg == "MSA":
             assert np.array_equal(out, oo)
         else:
-            assert np.all(np.abs(out - oo) <= TOL + 1e-6 * np.abs(oo)), np.max(np.abs(out - oo))
+            # 2*atanh amplifies a last-ulp difference of its argument by 1/(1 - |x|): 1e-5 absolute is the bar up to
+            # |LLR| = 26 (DESIGN.md "LDPC-SPA note"), relative 1e-5 above it -- no implementation, the reference's
+            # own NumPy builds included, agrees more closely there
+            dev, mag = np.abs(out - oo), np.abs(oo)
+            assert np.all(dev[mag <= 26.0] <= TOL), np.max(dev[mag <= 26.0])
+            assert np.all(dev[mag > 26.0] <= 1e-5 * mag[mag > 26.0]), np.max(dev[mag > 26.0])
 
 
 def test_ldpc_bad_algorithm(gpu):
