@@ -28,7 +28,7 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     mt = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "cpx_internal.h"),
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "cpx_internal.h"), os.path.join(CSRC, "cpx_math.h"),
                                                        os.path.join(INCLUDE, "commpy_amd.h")]
     return any(os.path.exists(d) and os.path.getmtime(d) > mt for d in deps)
 

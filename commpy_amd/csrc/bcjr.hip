@@ -32,6 +32,7 @@
 // LLRs of a chunk are staged in LDS, log() evaluated time-parallel, and written back as coalesced segments.  turbo_decode runs its whole iteration loop inside ONE launch; the
 // interleaver is a gather/scatter through per-codeword L arrays in the slab.
 #include "cpx_internal.h"
+#include "cpx_math.h"
 
 using namespace cpx;
 
@@ -339,7 +340,7 @@ __device__ void map_pass(const Ctx<LGS> &c, int64_t cw0, int64_t B, int64_t N, d
                 double app0 = 0.0, app1 = 0.0;
 #pragma unroll
                 for (int st = 0; st < S; st++) { app0 += x[2 * st]; app1 += x[2 * st + 1]; }
-                Lout[cw * lstride + t_lo + tl] = c.lin[tl * GW + gg] + log(app1 / app0);
+                Lout[cw * lstride + t_lo + tl] = c.lin[tl * GW + gg] + fast_log(app1 / app0);
             }
         }
         cur = nxt;

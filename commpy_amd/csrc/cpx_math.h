@@ -1,0 +1,40 @@
+// Device math shared by the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace cpx {
+
+// Natural logarithm, float64, error < 1 ulp: the classic argument reduction x = 2^k * m, m in [sqrt(1/2), sqrt(2)),
+// s = f / (2 + f) with f = m - 1, and a degree-14 odd series in s evaluated as two interleaved polynomials in s^4
+// (the construction of Sun's fdlibm e_log.c, coefficients from a Remez fit on [0, 0.1716]).  About 45 VALU
+// instructions on gfx950; ocml's log (double-double, 98 instructions) bounded the soft demodulator, the
+// sum-product check pass and the branch-metric stage.  Special values as libm: log(0) = -inf, log(x < 0) = NaN,
+// log(inf) = inf, a NaN argument is returned unchanged (its sign decides dec_word in
+// the LDPC passes exactly as it does through libm); denormals are handled by v_frexp.
+__device__ __forceinline__ double fast_log(double x) {
+    constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    constexpr double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                     Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                     Lg7 = 1.479819860511658591e-01;
+    double m = __builtin_amdgcn_frexp_mant(x);                    // [0.5, 1)
+    int e = __builtin_amdgcn_frexp_exp(x);
+    const bool lo = m < 7.07106781186547524401e-01;
+    m = lo ? m + m : m;                                           // [sqrt(1/2), sqrt(2))
+    e = lo ? e - 1 : e;
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double z = s * s, w = z * z;
+    const double t1 = w * __builtin_fma(w, __builtin_fma(w, Lg6, Lg4), Lg2);
+    const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, Lg7, Lg5), Lg3), Lg1);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)e;
+    double r = dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+    r = (x == 0.0) ? -__builtin_huge_val() : r;
+    r = (x == __builtin_huge_val()) ? x : r;
+    r = (x < 0.0) ? __builtin_nan("") : r;
+    r = (x != x) ? x : r;                                         // a NaN argument is returned as is (sign and payload)
+    return r;
+}
+
+}  // namespace cpx

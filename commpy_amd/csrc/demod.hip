@@ -20,6 +20,7 @@
 //     exactly (nearest grid point, first minimum = lowest label); symbols whose two best axis
 //     distances are closer than 1e-12 relative are re-decided with the reference's full hypot scan.
 #include "cpx_internal.h"
+#include "cpx_math.h"
 
 #include <cmath>
 
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(DEMOD_BLOCK) void demod_soft_kernel(const double2 *
             }
         }
 #pragma unroll
-        for (int b = 0; b < NB; b++) llr[i * NB + NB - 1 - b] = log(num[b] / den[b]);   // (:137)
+        for (int b = 0; b < NB; b++) llr[i * NB + NB - 1 - b] = fast_log(num[b] / den[b]);   // (:137)
     }
 }
 
@@ -83,8 +84,8 @@ __global__ __launch_bounds__(DEMOD_BLOCK) void demod_soft_sep_kernel(const doubl
             for (int a = 0; a < R; a++) {
                 if ((a >> b) & 1) { nx += ex[a]; ny += ey[a]; } else { qx += ex[a]; qy += ey[a]; }
             }
-            out[NH + b] = log((nx * sy) / (qx * sy));    // label bit NH+b = bit b of the real-axis index a
-            out[b] = log((ny * sx) / (qy * sx));         // label bit b    = bit b of the imag-axis index b
+            out[NH + b] = fast_log((nx * sy) / (qx * sy));    // label bit NH+b = bit b of the real-axis index a
+            out[b] = fast_log((ny * sx) / (qy * sx));         // label bit b    = bit b of the imag-axis index b
         }
 #pragma unroll
         for (int b = 0; b < NB; b++) llr[i * NB + NB - 1 - b] = out[b];   // (:137)

@@ -38,6 +38,7 @@
 // buffers and *retires* the frozen ones (out_llrs / dec_word written at their original block index).  All of it
 // is decided and applied on the device (control block in HBM, no host synchronisation).
 #include "cpx_internal.h"
+#include "cpx_math.h"
 
 #include <algorithm>
 
@@ -133,7 +134,7 @@ __device__ __forceinline__ double tanh_half(double v) {
     const double t = (1.0 - e) / (1.0 + e);
     return __builtin_copysign(t, v);                              // NaN propagates through exp
 }
-__device__ __forceinline__ double atanh_twice(double x) { return log((1.0 + x) / (1.0 - x)); }
+__device__ __forceinline__ double atanh_twice(double x) { return fast_log((1.0 + x) / (1.0 - x)); }
 
 // ---- sum-product (:209-227): R keeps one float64 per edge --------------------------------------------------
 template <int DEG>

@@ -28,6 +28,7 @@
 // bit written once.  float64 throughout (the reference's arithmetic); compiled with
 // -ffp-contract=off so sums round like NumPy's.
 #include "cpx_internal.h"
+#include "cpx_math.h"
 
 #include <algorithm>
 #include <mutex>
@@ -148,7 +149,7 @@ __device__ __forceinline__ void bit_metrics(int type, double r, double &m0, doub
         m0 = (double)(ri ^ 0ll);                // hamming_dist = sum of xor (utilities.py:130)
         m1 = (double)(ri ^ 1ll);
     } else if (type == CPX_VIT_SOFT) {
-        double nll0 = log(exp(r) + 1.0);        // :582
+        double nll0 = fast_log(exp(r) + 1.0);   // :582
         m0 = nll0;
         m1 = nll0 - r;                          // :583
     } else {
