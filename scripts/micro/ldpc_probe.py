@@ -1,4 +1,5 @@
-"""Timing probe for the LDPC passes: fixed 8 iterations at an SNR where nothing converges, debug flag sweep."""
+"""Timing probe for the LDPC passes: fixed 8 iterations at an SNR where nothing converges (full working set, no
+compaction).  The CPX_LDPC_DBG flag sweep belonged to ablation builds of csrc/ldpc.hip and is ignored by the shipped library."""
 import ctypes, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
