@@ -82,8 +82,9 @@ __global__ __launch_bounds__(LB) void ldpc_init_kernel(double *__restrict__ llr,
         const int v = v0 + tx;
         double x = 0.0;
         if (b < B && v < n_v) {
-            x = clip_nan(llr[b * n_v + v], -500.0, 500.0);
-            llr[b * n_v + v] = x;
+            const double raw = llr[b * n_v + v];
+            x = clip_nan(raw, -500.0, 500.0);
+            if (x != raw) llr[b * n_v + v] = x;                   // in-place clip (:186); untouched values are not rewritten
         }
         ts[r][tx] = x;
     }
