@@ -254,3 +254,28 @@ def test_ldpc_edge_sizes(gpu, B, iters):
         assert np.array_equal(np.atleast_1d(its), np.atleast_1d(io))
         assert np.array_equal(dec, do)
         assert np.all(np.abs(out - oo) <= TOL + 1e-6 * np.abs(oo))
+
+
+def test_ldpc_full_size_syndrome_property(gpu):
+    """BASELINE config-4 per-GPU share (B = 32768 blocks of the (1944,1296) code, min-sum, <= 50 iterations):
+    size-independent properties instead of an oracle run -- every block that stopped early satisfies all parity
+    checks (H . dec = 0), a block that ran all iterations does not, out_llrs signs agree with dec_word, and a
+    noiseless all-zero block is returned untouched after 0 iterations."""
+    from commpy_amd.channelcoding import ldpc_bp_decode
+    p = ldpc_params("n1944")
+    n, B, iters = 1944, 32768, 50
+    rs = np.random.RandomState(2024)
+    sigma = 1 / np.sqrt(10 ** (3.0 / 10.0) * (2.0 / 3) * 2)
+    llr = (2.0 * (1.0 + sigma * rs.standard_normal((B, n))) / sigma ** 2)
+    llr[7] = 25.0                                                  # noiseless all-zero codeword
+    dec, out, its = ldpc_bp_decode(llr.reshape(-1), p, "MSA", iters, return_iterations=True)
+    assert dec.shape == (n, B) and out.shape == (n, B) and its.shape == (B,)
+    assert its[7] == 0 and not dec[:, 7].any() and np.array_equal(out[:, 7], np.full(n, 25.0))
+    ec, ev = oracle.ldpc_edges(p)
+    syn = np.zeros((int(p["n_cnodes"]), B), np.int32)
+    np.add.at(syn, ec, dec[ev].astype(np.int32))                   # H . dec over the integers, then mod 2
+    unsat = (syn & 1).any(axis=0)
+    assert not unsat[its < iters].any()                            # early exit <=> zero syndrome (ldpc.py:205)
+    assert unsat[its == iters].sum() >= 0.5 * (its == iters).sum() # blocks that used every iteration mostly failed
+    assert np.array_equal(dec == 1, np.signbit(out))               # dec_word = out_llrs < 0 (ldpc.py:248)
+    assert 5.5 < its.mean() < 7.5 and (its < iters).mean() > 0.999
