@@ -279,3 +279,21 @@ def test_ldpc_full_size_syndrome_property(gpu):
     assert unsat[its == iters].sum() >= 0.5 * (its == iters).sum() # blocks that used every iteration mostly failed
     assert np.array_equal(dec == 1, np.signbit(out))               # dec_word = out_llrs < 0 (ldpc.py:248)
     assert 5.5 < its.mean() < 7.5 and (its < iters).mean() > 0.999
+
+
+def test_demod_full_size_identity(gpu):
+    """BASELINE config-4 demodulator size (32768 x 324 64-QAM symbols): modulate -> AWGN at high SNR -> hard
+    demodulation returns the bits, and the sign of every soft LLR (log P1/P0) agrees with them."""
+    from commpy_amd.modulation import QAMModem
+    md = QAMModem(64)
+    rs = np.random.RandomState(64)
+    nsym = 32768 * 324
+    bits = rs.randint(0, 2, nsym * 6).astype(np.int8)
+    N0 = md.Es / 10 ** (32 / 10.0)
+    y = md.modulate(bits)
+    y = y + np.sqrt(N0 / 2) * (rs.standard_normal(nsym) + 1j * rs.standard_normal(nsym))
+    hard = md.demodulate(y, "hard")
+    assert hard.dtype == np.int8 and np.array_equal(hard, bits)
+    soft = md.demodulate(y, "soft", N0)
+    assert soft.shape == (nsym * 6,) and np.all(np.isfinite(soft) | np.isinf(soft))
+    assert np.array_equal(soft > 0, bits == 1)
