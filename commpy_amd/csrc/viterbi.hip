@@ -136,12 +136,6 @@ __device__ __forceinline__ double min8_transposed(const double (&h)[8]) {
     return e;
 }
 
-__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
-    return __hiloint2double(hi, lo);
-}
-
 // Per-bit metrics of one received value (convcode.py:575-587): m0 = cost of code bit 0, m1 = of bit 1.
 __device__ __forceinline__ void bit_metrics(int type, double r, double &m0, double &m1) {
     if (type == CPX_VIT_HARD) {
@@ -175,7 +169,8 @@ __global__ __launch_bounds__(64) void viterbi_wave_kernel(VitParams p) {
 
     double *bm = reinterpret_cast<double *>(smem);                              // [64][NC]
     double *pmbuf = bm + 64 * NC;                                               // [64] path metrics of the previous step
-    unsigned long long *dring = reinterpret_cast<unsigned long long *>(pmbuf + 64);    // [RS][PL]
+    double *mnbuf = pmbuf + 64;                                                 // [8] minima of the eight steps of a block (S = 64)
+    unsigned long long *dring = reinterpret_cast<unsigned long long *>(mnbuf + 8);     // [RS][PL]
     unsigned short *ptab = reinterpret_cast<unsigned short *>(dring + (size_t)p.RS * PL);  // [S*I]
     unsigned char *bring = reinterpret_cast<unsigned char *>(ptab + S * I_T);   // [RS][G]
 
@@ -294,14 +289,27 @@ __global__ __launch_bounds__(64) void viterbi_wave_kernel(VitParams p) {
                     hist[u] = pm;
                 }
                 const double e = min8_transposed(hist);
+                // The minimum of step u sits in lanes 8*bitrev3(u)..+7.  All eight are handed to every lane through 64 bytes
+                // of LDS (one masked store, four broadcast reads) instead of sixteen v_readlane; the eight first-argmin
+                // states are found with scalar ballots / s_ff1, packed one byte each into an SGPR pair and dropped into
+                // the lanes that own the steps with a single variable shift (a section profile showed this extraction,
+                // done step by step, costing as much as the add-compare-select itself).
+                if ((lane & 7) == 0) mnbuf[lane >> 3] = e;
+                asm volatile("" ::: "memory");                 // in-order LDS: the reads below see the eight stores
+                const double2 m01 = *reinterpret_cast<const double2 *>(mnbuf + 0), m23 = *reinterpret_cast<const double2 *>(mnbuf + 2);
+                const double2 m45 = *reinterpret_cast<const double2 *>(mnbuf + 4), m67 = *reinterpret_cast<const double2 *>(mnbuf + 6);
+                asm volatile("" ::: "memory");
+                const double seg[8] = {m01.x, m01.y, m23.x, m23.y, m45.x, m45.y, m67.x, m67.y};
+                unsigned long long pack = 0;                   // wave-uniform: first-argmin state of step i0+u in byte u
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
                     constexpr int SEG[8] = {0, 4, 2, 6, 1, 5, 3, 7};          // bitrev3(u): segment holding min(hist[u])
-                    const double mn = readlane_f64(e, 8 * SEG[u]);
-                    const unsigned long long eq = __ballot(hist[u] == mn);
-                    const int bst = eq ? (__ffsll((long long)eq) - 1) : 0;
-                    mybest = (s == i0 + u) ? bst : mybest;
+                    const unsigned long long eq = __ballot(hist[u] == seg[SEG[u]]);
+                    const unsigned long long bst = eq ? (unsigned long long)(__ffsll((long long)eq) - 1) : 0ull;
+                    pack |= bst << (8 * u);
                 }
+                const unsigned rel = (unsigned)(s - i0);       // this lane owns step i0 + rel when rel < 8
+                mybest = (rel < 8u) ? (int)((pack >> ((rel & 7u) * 8u)) & 0xffull) : mybest;
             }
         } else {
             for (int i = 0; i < nsteps; i++) {
@@ -602,7 +610,7 @@ int cpx_viterbi_decode_batch_dev(const cpx_trellis *t, const double *d_coded, in
     }
     const int S = t->S, G = 64 / S, CH = S;
     p.RS = next_pow2(CH + tb_depth);
-    size_t lds = sizeof(double) * 64 * p.NC + sizeof(double) * 64 + sizeof(unsigned long long) * p.RS * PL +
+    size_t lds = sizeof(double) * 64 * p.NC + sizeof(double) * (64 + 8) + sizeof(unsigned long long) * p.RS * PL +
                  sizeof(unsigned short) * S * t->I + (size_t)p.RS * G;
     CPX_REQUIRE(lds <= 64 * 1024, CPX_ELIMIT, "viterbi: tb_depth %d needs %zu B of LDS (> 64 KiB)", tb_depth, lds);
     const int64_t nblocks = (B + G - 1) / G;
