@@ -9,6 +9,7 @@
   turbo   rate-1/3, N = 1024, 6 iterations, random interleaver, B = 16384 (config 3)
   map     one MAP pass of the same
   viterbi_small  config 1 (K=3, 64-bit, hard) scaled to B = 1M codewords
+  encoders  device turbo_encode (config 3) and systematic LDPC encode (config 4)
 bench.py (repo root) stays the headline Viterbi benchmark.
 """
 import argparse
@@ -75,10 +76,10 @@ def timeit(lib, fn, steps=5, warmup=1):
     return float(np.mean(ms)), float(np.min(ms))
 
 
-def emit(name, workload, units, unit_name, ms, alg_bytes, bound, extra=None):
+def emit(name, workload, units, unit_name, ms, alg_bytes, bound, extra=None, dtype="f64"):
     ach = alg_bytes / (ms * 1e-3) / 1e9
     d = {"kernel": name, "workload": workload, "value": units / (ms * 1e-3), "unit": unit_name + "/s", "ms": ms,
-         "dtype": "f64", "roofline": {"bound": bound, "achieved": ach, "peak": HBM_PEAK, "unit": "GB/s",
+         "dtype": dtype, "roofline": {"bound": bound, "achieved": ach, "peak": HBM_PEAK, "unit": "GB/s",
                                       "frac": ach / HBM_PEAK, "algorithmic_bytes_per_launch": alg_bytes}}
     if extra:
         d.update(extra)
@@ -154,8 +155,9 @@ def bench_ldpc(lib, scale):
 
 
 def bench_config4(lib, scale):
-    """BASELINE config 4 on one GPU's share: all-zero (1944,1296) codewords -> 64-QAM -> AWGN -> soft demod ->
-    sign flip (quirk B6) -> LDPC BP (<= 50 iterations), every stage on the device."""
+    """BASELINE config 4 on one GPU's share: random messages -> systematic (1944,1296) encoder -> 64-QAM -> AWGN ->
+    soft demod -> sign flip (quirk B6) -> LDPC BP (<= 50 iterations), every stage on the device."""
+    from commpy_amd.devicelink import LdpcEncoder
     from commpy_amd.channelcoding.ldpc import _device_code, get_ldpc_code_params
     from commpy_amd.modulation import QAMModem
     p = get_ldpc_code_params(os.path.join(ROOT, "commpy_amd/channelcoding/designs/ldpc/ieee80211n/1944.1296.txt"), True)
@@ -163,7 +165,8 @@ def bench_config4(lib, scale):
     n, nsym = 1944, 324
     B = int(32768 * scale)
     dev = Dev(lib)
-    d_bits = dev.put(np.zeros(B * n, np.uint8))
+    enc = LdpcEncoder(p, "gf2")
+    d_msg, d_bits = dev.empty(B * enc.k), dev.empty(B * n)
     d_sym, d_y = dev.empty(B * nsym * 16), dev.empty(B * nsym * 16)
     d_llr, d_neg = dev.empty(B * n * 8), dev.empty(B * n * 8)
     d_dec, d_out, d_it = dev.empty(B * n), dev.empty(B * n * 8), dev.empty(B * 4)
@@ -173,6 +176,8 @@ def bench_config4(lib, scale):
         sc = float(np.sqrt(N0 / 2))
         for alg, name in ((1, "MSA"), (0, "SPA")):
             def run():
+                _lib.check(lib.cpx_random_bits_dev(d_msg, B * enc.k, 30, 0, None))
+                enc.encode_dev(d_msg, B, d_bits)
                 _lib.check(lib.cpx_modulate_dev(h_md, d_bits, B * nsym, d_sym, None))
                 _lib.check(lib.cpx_awgn_dev(d_sym, B * nsym, sc, sc, 31, 1, d_y, None))
                 _lib.check(lib.cpx_demod_soft_dev(h_md, d_y, B * nsym, float(N0), d_llr, None))
@@ -181,26 +186,29 @@ def bench_config4(lib, scale):
             ms, _ = timeit(lib, run, steps=3, warmup=1)
             its = dev.get(d_it, (B,), np.int32)
             dec = dev.get(d_dec, (n, B), np.int8)
+            sent = dev.get(d_bits, (B, n), np.int8)
             alg_bytes = B * nsym * 64 + int(its.sum()) * (4 * 7128 + 2 * n) * 8 + B * n * 17
-            emit("config4_pipeline_%s" % name, "64-QAM demod + LDPC (1944,1296) %s, Eb/N0=%.0f dB, B=%d, mean its %.2f" % (
-                name, ebn0, B, its.mean()), B * 1296, "info-bits", ms, alg_bytes, "hbm" if alg else "f64-transcendental",
-                 {"frame_error_rate": float(np.mean(dec.any(axis=0))), "mean_iterations": float(its.mean())})
+            emit("config4_pipeline_%s" % name, "encode + 64-QAM + AWGN + demod + LDPC (1944,1296) %s, Eb/N0=%.0f dB, B=%d, "
+                 "mean its %.2f" % (name, ebn0, B, its.mean()), B * 1296, "info-bits", ms, alg_bytes,
+                 "hbm" if alg else "f64-transcendental",
+                 {"frame_error_rate": float(np.mean((dec.T != sent).any(axis=1))),
+                  "bit_error_rate": float(np.mean(dec.T[:, :1296] != sent[:, :1296])),
+                  "mean_iterations": float(its.mean())})
     dev.free()
 
 
 def bench_turbo(lib, scale, which):
     import warnings
-    from commpy_amd.channelcoding import RandInterlv, Trellis, turbo_encode
+    from commpy_amd.channelcoding import RandInterlv, Trellis
+    from commpy_amd.devicelink import turbo_encode_gpu
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         tr = Trellis(np.array([2]), np.array([[1, 7]]), 5, "rsc")
     N, B = 1024, int(16384 * scale)
     il = RandInterlv(N, 1234)
     rs = np.random.RandomState(20)
-    msgs = rs.randint(0, 2, (16, N))
-    enc = [turbo_encode(m, tr, tr, il) for m in msgs]
-    rep = B // 16
-    s, p1, p2 = (np.tile(np.stack([e[i][:N] for e in enc]), (rep, 1)) * 2.0 - 1 for i in range(3))
+    msgs = rs.randint(0, 2, (B, N))
+    s, p1, p2 = (a[:, :N] * 2.0 - 1 for a in turbo_encode_gpu(msgs, tr, tr, il))   # B distinct codewords (device encoder)
     nv = 1 / (2 * (1.0 / 3) * 10 ** (1.5 / 10.0))
     nrs = np.random.RandomState(21)
     s, p1, p2 = (a + np.sqrt(nv) * nrs.randn(B, N) for a in (s, p1, p2))
@@ -216,7 +224,7 @@ def bench_turbo(lib, scale, which):
                                                                              d_bits, None)), steps=3)
         bits = dev.get(d_bits, (B, N), np.uint8)
         emit("turbo_decode_kernel", "rate-1/3 4-state RSC, N=1024, 6 iterations, Eb/N0=1.5 dB, B=%d" % B, B * N,
-             "info-bits", ms, B * 25600, "latency/valu", {"ber": float(np.mean(bits != np.tile(msgs, (rep, 1))))})
+             "info-bits", ms, B * 25600, "latency/valu", {"ber": float(np.mean(bits != msgs))})
     if "map" in which:
         ms, _ = timeit(lib, lambda: _lib.check(lib.cpx_map_decode_batch_dev(h, d_s, d_p1, d_zero, B, N, nv, 1, d_L, d_bits,
                                                                            None)), steps=3)
@@ -241,9 +249,42 @@ def bench_viterbi_small(lib, scale):
     dev.free()
 
 
+def bench_encoders(lib, scale):
+    """the device encoders of configs 3 and 4 (byte streams: HBM roofline)."""
+    import warnings
+    from commpy_amd.channelcoding import RandInterlv, Trellis
+    from commpy_amd.channelcoding.ldpc import get_ldpc_code_params
+    from commpy_amd.devicelink import LdpcEncoder
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tr = Trellis(np.array([2]), np.array([[1, 7]]), 5, "rsc")
+    N, B = 1024, int(16384 * scale)
+    il = RandInterlv(N, 1234)
+    dev = Dev(lib)
+    d_msg = dev.put(np.random.RandomState(20).randint(0, 2, (B, N)).astype(np.uint8))
+    d_perm = dev.put(np.asarray(il.p_array, dtype=np.int32))
+    d_s, d_p1, d_p2 = dev.empty(B * N), dev.empty(B * N), dev.empty(B * N)
+    h = tr._device_handle()
+    for mode, name in ((2, "turbo_encode_wave_kernel<4>"), (1, "turbo_encode_seq_kernel")):
+        ms, _ = timeit(lib, lambda: _lib.check(lib.cpx_turbo_encode_batch_dev(h, h, d_msg, B, N, d_perm, d_s, d_p1, d_p2, N,
+                                                                             mode, None)))
+        emit(name, "turbo_encode, 4-state RSC, N=1024, B=%d" % B, B * N, "info-bits", ms, B * 4 * N, "hbm", dtype="u8")
+    dev.free()
+    design = os.path.join(ROOT, "commpy_amd", "channelcoding", "designs", "ldpc", "ieee80211n", "1944.1296.txt")
+    enc = LdpcEncoder(get_ldpc_code_params(design), "gf2")
+    B = int(32768 * scale)
+    dev = Dev(lib)
+    d_msg = dev.put(np.random.RandomState(31).randint(0, 2, (B, enc.k)).astype(np.uint8))
+    d_code = dev.empty(B * enc.n)
+    ms, _ = timeit(lib, lambda: enc.encode_dev(d_msg, B, d_code))
+    emit("ldpc_pack_kernel+ldpc_parity_kernel", "systematic LDPC encode (1944,1296), B=%d" % B, B * enc.k, "info-bits", ms,
+         B * (enc.k + enc.n), "hbm", dtype="u8")
+    dev.free()
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--which", default="demod,ldpc,config4,turbo,map,viterbi_small")
+    ap.add_argument("--which", default="demod,ldpc,config4,turbo,map,viterbi_small,encoders")
     ap.add_argument("--scale", type=float, default=1.0)
     a = ap.parse_args()
     lib = _lib.load()
@@ -259,6 +300,8 @@ def main():
         bench_ldpc(lib, a.scale)
     if "config4" in which:
         bench_config4(lib, a.scale)
+    if "encoders" in which:
+        bench_encoders(lib, a.scale)
 
 
 if __name__ == "__main__":

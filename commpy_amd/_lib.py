@@ -74,6 +74,11 @@ SYMBOLS = {
     "cpx_awgn_dev": (c_int, [c_void_p, c_int64, c_double, c_double, c_uint64, c_uint64, c_void_p, c_void_p]),
     "cpx_scale_f64_dev": (c_int, [c_void_p, c_int64, c_double, c_void_p, c_void_p]),
     "cpx_count_errors_dev": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
+    "cpx_turbo_encode_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_int64, c_int, c_void_p]),
+    "cpx_ldpc_encoder_create": (c_int, [c_void_p, c_int64, c_int64, POINTER(c_void_p)]),
+    "cpx_ldpc_encoder_destroy": (c_int, [c_void_p]),
+    "cpx_ldpc_encode_batch_dev": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
 }
 
 

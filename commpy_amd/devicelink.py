@@ -22,7 +22,8 @@ import numpy as np
 from commpy_amd import _lib
 from commpy_amd.wifi80211 import Wifi80211
 
-__all__ = ['DeviceBuf', 'DeviceWifiLink', 'conv_encode_gpu', 'modulate_gpu']
+__all__ = ['DeviceBuf', 'DeviceWifiLink', 'conv_encode_gpu', 'modulate_gpu', 'turbo_encode_gpu', 'LdpcEncoder',
+           'gf2_generator', 'triang_ldpc_systematic_encode_gpu']
 
 
 class DeviceBuf:
@@ -93,6 +94,143 @@ def modulate_gpu(modem, input_bits):
     _lib.check(lib.cpx_modulate_dev(modem._device_handle(), d_bits.ptr, nsym, d_sym.ptr, None))
     _lib.check(lib.cpx_stream_sync(None))
     return d_sym.to_array((nsym,), np.complex128)
+
+
+def turbo_encode_gpu(msg_bits, trellis1, trellis2, interleaver, mode=0):
+    """``turbo_encode`` (turbo.py:14-59) for a batch ``[B, N]`` of messages on the GPU.
+
+    Returns ``[sys, p1, p2]`` as int64 arrays ``[B, N]``, ``[B, N]`` and ``[B, 2(N+m2)-m2]``: row ``b`` of each equals
+    what the reference returns for ``msg_bits[b]`` (the second parity stream keeps ``conv_encode``'s
+    unpunctured length with a zero tail -- use ``p2[:, :N]``).  ``mode``: 0 auto, 1 walk, 2 scan kernel.
+    """
+    lib = _lib.load()
+    msgs = np.ascontiguousarray(np.atleast_2d(msg_bits), dtype=np.uint8)
+    B, N = msgs.shape
+    if trellis1.code_type != 'rsc' or trellis2.code_type != 'rsc':
+        # a non-recursive trellis makes conv_encode clock a zero tail (convcode.py:516-520) whose outputs the
+        # reference leaves in the second parity stream; only the recursive-systematic case is built
+        raise ValueError("turbo_encode_gpu needs recursive systematic component codes (code_type='rsc')")
+    perm = np.ascontiguousarray(interleaver.p_array, dtype=np.int32)
+    if perm.size != N:
+        raise ValueError('interleaver length must equal the message length')
+    np2 = 2 * (N + trellis2.total_memory) - trellis2.total_memory     # conv_encode's length minus turbo.py:57's cut
+    d_msg, d_perm = DeviceBuf.from_array(msgs), DeviceBuf.from_array(perm)
+    d_sys, d_p1, d_p2 = DeviceBuf(B * N), DeviceBuf(B * N), DeviceBuf(B * np2)
+    _lib.check(lib.cpx_turbo_encode_batch_dev(trellis1._device_handle(), trellis2._device_handle(), d_msg.ptr, B, N,
+                                              d_perm.ptr, d_sys.ptr, d_p1.ptr, d_p2.ptr, np2, int(mode), None))
+    _lib.check(lib.cpx_stream_sync(None))
+    return [d_sys.to_array((B, N), np.uint8).astype(np.int64), d_p1.to_array((B, N), np.uint8).astype(np.int64),
+            d_p2.to_array((B, np2), np.uint8).astype(np.int64)]
+
+
+def gf2_generator(ldpc_code_params):
+    """Systematic generator over GF(2): ``P`` (uint8 ``[m, k]``) with ``H[:, k:] @ P = H[:, :k] (mod 2)``.
+
+    ``build_matrix`` (ldpc.py:44-48) inverts the last ``m`` columns of H over the *reals*, which is only a valid GF(2)
+    inverse for (approximately) triangular codes; this is the same construction done in GF(2) arithmetic, so it
+    also covers codes like the 802.11n (1944,1296) matrix of BASELINE config 4 whose real inverse is not integral.
+    """
+    from commpy_amd.channelcoding.ldpc import build_matrix
+    if ldpc_code_params.get('parity_check_matrix') is None:
+        try:
+            build_matrix(ldpc_code_params)
+        except Exception:       # the real-valued inverse may not exist; H itself is all that is needed here
+            pass
+    H = ldpc_code_params.get('parity_check_matrix')
+    if H is None:
+        n_c, deg = ldpc_code_params['n_cnodes'], ldpc_code_params['max_cnode_deg']
+        adj = np.asarray(ldpc_code_params['cnode_adj_list']).reshape(n_c, deg)
+        Hd = np.zeros((n_c, ldpc_code_params['n_vnodes']), np.uint8)
+        for c in range(n_c):
+            Hd[c, adj[c, :ldpc_code_params['cnode_deg_list'][c]]] = 1
+    else:
+        Hd = (np.asarray(H.todense() if hasattr(H, 'todense') else H) != 0).astype(np.uint8)
+    m, n = Hd.shape
+    k = n - m
+    A = np.concatenate([Hd[:, k:], Hd[:, :k]], axis=1)               # [H_sys | H_par], reduce the left block to I
+    for col in range(m):
+        piv = col + np.flatnonzero(A[col:, col])
+        if piv.size == 0:
+            raise ValueError('the last n_cnodes columns of H are singular over GF(2)')
+        if piv[0] != col:
+            A[[col, piv[0]]] = A[[piv[0], col]]
+        rows = np.flatnonzero(A[:, col])
+        rows = rows[rows != col]
+        A[rows] ^= A[col]
+    return np.ascontiguousarray(A[:, m:])
+
+
+class LdpcEncoder:
+    """Device-resident systematic LDPC encoder: ``code = [msg, G2 @ msg mod 2]`` per block (ldpc.py:302-354).
+
+    ``generator='reference'`` uses ``ldpc_code_params['generator_matrix']`` exactly as
+    ``triang_ldpc_systematic_encode`` does (built by ``build_matrix`` if absent) and requires its entries to be
+    integers, so that ``G.dot(msg) % 2`` (ldpc.py:353) is GF(2) arithmetic; ``generator='gf2'`` uses
+    :func:`gf2_generator`.
+    """
+
+    def __init__(self, ldpc_code_params, generator='reference'):
+        from commpy_amd.channelcoding.ldpc import build_matrix
+        self.lib = _lib.load()
+        if generator == 'gf2':
+            G2 = gf2_generator(ldpc_code_params)
+        elif generator == 'reference':
+            if ldpc_code_params.get('generator_matrix') is None or ldpc_code_params.get('parity_check_matrix') is None:
+                build_matrix(ldpc_code_params)
+            G = ldpc_code_params['generator_matrix']
+            G = np.asarray(G.todense() if hasattr(G, 'todense') else G, dtype=np.float64)
+            if not np.all(np.abs(G - np.rint(G)) < 1e-9):
+                raise ValueError("generator_matrix is not integer valued (the code is not triangular); "
+                                 "use generator='gf2'")
+            G2 = (np.rint(G).astype(np.int64) % 2).astype(np.uint8)
+        else:
+            raise ValueError("generator must be 'reference' or 'gf2'")
+        self.G2 = np.ascontiguousarray(G2, dtype=np.uint8)
+        self.m, self.k = self.G2.shape
+        self.n = self.m + self.k
+        self.h = ctypes.c_void_p()
+        _lib.require_device()
+        _lib.check(self.lib.cpx_ldpc_encoder_create(_lib.ptr(self.G2), self.m, self.k, ctypes.byref(self.h)))
+
+    def encode_dev(self, d_msg, B, d_code, stream=None):
+        """msg ``[B][k]`` uint8 (device) -> code ``[B][n]`` uint8 (device); asynchronous on ``stream``."""
+        _lib.check(self.lib.cpx_ldpc_encode_batch_dev(self.h, d_msg, int(B), d_code, stream))
+
+    def encode(self, msgs):
+        """Host convenience: uint8/int ``[B, k]`` -> int8 ``[B, n]``."""
+        msgs = np.ascontiguousarray(np.atleast_2d(msgs), dtype=np.uint8)
+        B, k = msgs.shape
+        if k != self.k:
+            raise ValueError('messages must have %d bits' % self.k)
+        d_msg, d_code = DeviceBuf.from_array(msgs), DeviceBuf(B * self.n)
+        self.encode_dev(d_msg.ptr, B, d_code.ptr)
+        _lib.check(self.lib.cpx_stream_sync(None))
+        return d_code.to_array((B, self.n), np.int8)
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.lib.cpx_ldpc_encoder_destroy(self.h)
+                self.h = ctypes.c_void_p()
+        except Exception:
+            pass
+
+
+def triang_ldpc_systematic_encode_gpu(message_bits, ldpc_code_params, pad=True, generator='reference'):
+    """``triang_ldpc_systematic_encode`` (ldpc.py:302-354) on the GPU: same arguments, padding rule, ``ValueError``
+    and return layout (int8 ``(n, n_blocks)``, squeezed; block ``j`` = ``message_bits[j*k:(j+1)*k]``)."""
+    enc = ldpc_code_params.get('_cpx_ldpc_enc_' + generator)
+    if enc is None:
+        enc = LdpcEncoder(ldpc_code_params, generator)
+        ldpc_code_params['_cpx_ldpc_enc_' + generator] = enc
+    message_bits = np.asarray(message_bits)
+    modulo = len(message_bits) % enc.k
+    if modulo:
+        if pad:
+            message_bits = np.concatenate((message_bits, np.zeros(enc.k - modulo, message_bits.dtype)))
+        else:
+            raise ValueError('Padding is disable but message length is not a multiple of block length.')
+    return enc.encode(message_bits.reshape(-1, enc.k)).T.squeeze().astype(np.int8)
 
 
 class DeviceWifiLink:

@@ -199,6 +199,29 @@ int cpx_scale_f64_dev(const double *d_x, int64_t n, double a, double *d_y, void 
 int cpx_count_errors_dev(const uint8_t *d_msg, int64_t msg_stride, const uint8_t *d_dec, int64_t dec_stride,
                          int64_t B, int64_t nchunks, int64_t chunk, int32_t *d_errs, void *stream);
 
+/* ---- channel encoders on the device ("next" rows) --------------------------------
+ * Device pointers, asynchronous on `stream`; bit-exact integer work.
+ *   cpx_turbo_encode_batch_dev  turbo_encode(msg, trellis1, trellis2, interleaver) commpy/channelcoding/turbo.py:14-59
+ *       for B rows: msg [B][N] uint8 -> sys [B][N], p1 [B][N], p2 [B][np2] (np2 >= N; entries past N are 0:
+ *       turbo.py:47,53 pass 'rsc' as the termination argument, so conv_encode (convcode.py:538) clocks no
+ *       tail and leaves the tail of its output zero; the reference returns len(p2) = 2(N+m2)-m2).
+ *       Component codes must be rate 1/2 (the [::2] / [1::2] split of turbo.py:48-49).  perm = the
+ *       interleaver's p_array (interleavers.py:45: out[i] = in[p[i]]), int32 [N], 16-byte aligned.
+ *       mode: 0 auto, 1 one-codeword-per-lane walk, 2 wave-per-codeword state-map scan (<= 16 states).
+ *   cpx_ldpc_encoder_create     packs a GF(2) generator: gen_bits [m][k] uint8 (0/1), parity = gen . msg mod 2 --
+ *       `generator_matrix` of build_matrix (ldpc.py:44-48) reduced mod 2; k <= 8192.
+ *   cpx_ldpc_encode_batch_dev   triang_ldpc_systematic_encode (ldpc.py:302-354) for B blocks: msg [B][k] uint8 ->
+ *       code [B][k+m] uint8, systematic part first (:354); row b is column b of the reference's result.
+ */
+typedef struct cpx_ldpc_encoder cpx_ldpc_encoder;
+int cpx_turbo_encode_batch_dev(const cpx_trellis *t1, const cpx_trellis *t2, const uint8_t *d_msg, int64_t B, int64_t N,
+                               const int32_t *d_perm, uint8_t *d_sys, uint8_t *d_p1, uint8_t *d_p2, int64_t np2,
+                               int mode, void *stream);
+int cpx_ldpc_encoder_create(const uint8_t *gen_bits, int64_t m, int64_t k, cpx_ldpc_encoder **out);
+int cpx_ldpc_encoder_destroy(cpx_ldpc_encoder *e);
+int cpx_ldpc_encode_batch_dev(const cpx_ldpc_encoder *e, const uint8_t *d_msg, int64_t B, uint8_t *d_code,
+                              void *stream);
+
 #ifdef __cplusplus
 }
 #endif
