@@ -171,7 +171,7 @@ def bench_config4(lib, scale):
     d_llr, d_neg = dev.empty(B * n * 8), dev.empty(B * n * 8)
     d_dec, d_out, d_it = dev.empty(B * n), dev.empty(B * n * 8), dev.empty(B * 4)
     code, h_md = _device_code(p), md._device_handle()
-    for ebn0 in (8.0, 10.0):
+    for ebn0 in (8.0, 9.0, 10.0):
         N0 = 42.0 / ((2.0 / 3) * 6 * 10 ** (ebn0 / 10.0))
         sc = float(np.sqrt(N0 / 2))
         for alg, name in ((1, "MSA"), (0, "SPA")):
