@@ -266,12 +266,21 @@ def main():
         kavg = float(np.mean(kernel_ms))
         achieved = ALG_BYTES_PER_CW * B / (kavg * 1e-3) / 1e9
         value = world * B * MSG_BITS * args.steps / elapsed
-        traffic = None                       # HBM bytes per launch from the committed PMC passes (same workload only)
+        # which kernels ran: the library takes the codeword-per-lane path (csrc/viterbi_cw.hip) for batches that give every
+        # SIMD a wavefront of 64 codewords (B >= 3/4 * CUs * 4 * 64) unless CPX_VITERBI_PATH=wave
+        cus = ctypes.c_int(0)
+        lib.cpx_device_info(None, 0, ctypes.byref(cus), None)
+        forced = os.environ.get("CPX_VITERBI_PATH", "")
+        cw_path = (not forced.startswith("w")) and (forced.startswith("c") or B >= 3 * cus.value * 4 * 64 // 4)
+        kernel_name = ("viterbi_cw_acs_kernel<6,0155,0117,soft> + viterbi_cw_tb_kernel<6>" if cw_path
+                       else "viterbi_wave_kernel<6,2,true,2>")
+        traffic, traffic_src = None, None    # HBM bytes per launch from the committed PMC passes (same workload and kernels only)
         try:
             with open(os.path.join(ROOT, "profiles", "r01_viterbi_c2_traffic.json")) as f:
                 tj = json.load(f)
-            if B == 65536:
+            if B == 65536 and tj.get("path") == ("cw" if cw_path else "wave"):
                 traffic = tj["traffic_bytes_per_launch"]
+                traffic_src = "profiles/r01_viterbi_c2_traffic.json (rocprofv3 FETCH_SIZE / WRITE_SIZE passes, KiB; see the file for the gfx950 correction)"
         except (OSError, ValueError, KeyError):
             pass
         out = {
@@ -286,9 +295,9 @@ def main():
                        "parallelism": "codewords sharded x%d, no data-path collective" % (world if distributed else 1)},
             "ber": ber, "oracle_mismatched_bits": mism, "oracle_sample_codewords": ns,
             "demod_max_abs_err_vs_oracle": demod_err,
-            "roofline": {"bound": "hbm", "kernel": "viterbi_wave_kernel<6,2,true,2>", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": "profiles/r01_viterbi_c2_traffic.json (rocprofv3 FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KiB)",
+                         "traffic_source": traffic_src,
                          "kernel_ms_avg": kavg,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_CW * B,
                          "note": "serial float64 add-compare-select recursion: VALU-issue bound, not HBM bound (DESIGN 4.1)"},

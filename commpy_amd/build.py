@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(CSRC, "libcommpy_amd.so")
-SOURCES = ["runtime.hip", "viterbi.hip", "bcjr.hip", "ldpc.hip", "demod.hip", "linksim.hip", "encoders.hip"]
+SOURCES = ["runtime.hip", "viterbi.hip", "viterbi_cw.hip", "bcjr.hip", "ldpc.hip", "demod.hip", "linksim.hip", "encoders.hip"]
 
 
 def _hipcc():

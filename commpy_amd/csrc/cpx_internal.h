@@ -42,6 +42,10 @@ int workspace(hipStream_t stream, int slot, size_t bytes, void **out);
         }                                       \
     } while (0)
 
+// codeword-per-lane Viterbi path (viterbi_cw.hip): true when it handled the call (*rc = status)
+bool viterbi_codeword_path(const ::cpx_trellis *t, const double *d_coded, int64_t B, int64_t len, int64_t L, int64_t T,
+                           int tb, int type, uint8_t *d_bits, hipStream_t st, int *rc);
+
 inline hipStream_t pick_stream(void *s) { return s ? reinterpret_cast<hipStream_t>(s) : lib_stream(); }
 
 // RAII device buffer for the host-buffer entry points.

@@ -586,6 +586,10 @@ int cpx_viterbi_decode_batch_dev(const cpx_trellis *t, const double *d_coded, in
     hipStream_t st = pick_stream(stream);
     if (n_steps <= 0 || n_steps * t->k < L) CPX_HIP(hipMemsetAsync(d_bits, 0, (size_t)(B * L), st));
     if (n_steps <= 0) return CPX_OK;
+    {   // large batches of the standard rate-1/2 codes: one codeword per lane (viterbi_cw.hip)
+        int rc_cw = CPX_OK;
+        if (viterbi_codeword_path(t, d_coded, B, len, L, n_steps, tb_depth, decoding_type, d_bits, st, &rc_cw)) return rc_cw;
+    }
 
     VitParams p;
     p.coded = d_coded; p.bits = d_bits;

@@ -1,0 +1,357 @@
+// Viterbi decoder, "codeword per lane" path for large batches of the standard rate-1/2 feed-forward codes.
+// Same contract and decision rule as viterbi.hip (/root/reference/commpy/channelcoding/convcode.py:661-749,
+// :590-657, :575-587) and the same float64 operations in the same order: bit-identical output.
+//
+// viterbi.hip maps one trellis STATE to a lane: every step pays a cross-lane exchange of the path metrics, an
+// all-lane float64 minimum (first-argmin rule) and a ballot -- 26 VALU instructions per trellis step per codeword,
+// VALU-issue bound.  When the batch gives every SIMD of the chip a wavefront of 64 codewords, a lane can own a
+// whole CODEWORD instead:
+//   * the S path metrics live in the lane's registers and are updated IN PLACE.  The radix-2 butterfly of a
+//     shift-register trellis reads states (2j, 2j+1) and writes (j, j+S/2); leaving the results where the inputs
+//     were rotates the logical->physical register map by one bit per step, so log2(S) unrolled steps return to the
+//     identity: 2S VGPRs hold the metrics and the add-compare-select of all states is straight-line code with NO
+//     cross-lane traffic (2 v_add_f64, v_cmp_lt_f64, 2 v_cndmask, v_addc per state);
+//   * WHICH of the four branch metrics a branch uses depends on the generator polynomials; they are template
+//     parameters (the branch code is a constexpr function), instantiated for the standard codes below and checked
+//     against the trellis tables the caller built -- any other trellis takes the state-per-lane kernels;
+//   * the first-argmin state of a step is an in-lane v_min_f64 tree + an in-lane first-equal scan;
+//   * decision words and first-argmin states go to a workspace in HBM, [group of 64 codewords][step][lane] so that
+//     every store is one coalesced line per wave (9 B per codeword-step), and a second kernel runs the sliding
+//     traceback: one workgroup per group stages a window of 64 + tb - 2 steps in LDS (row stride 65 words: the
+//     lanes of a wave walk consecutive rows of one column without bank conflicts) and every wave traces two
+//     codewords at a time, lane-parallel over output steps.
+// Measured on MI355X for BASELINE config 2 (B = 65536, K = 7, soft): see DESIGN.md 4.1.
+#include "cpx_internal.h"
+#include "cpx_math.h"
+
+#include <cstdlib>
+
+using namespace cpx;
+
+namespace {
+
+template <int LGS, unsigned G0, unsigned G1>
+struct SrCode {
+    static constexpr int S = 1 << LGS;
+    static constexpr int parity(unsigned v) { return __builtin_popcount(v) & 1; }
+    // 2-bit output (MSB = first generator) of the branch into state s from its j-th predecessor:
+    // register = [input bit | predecessor state], convcode.py:166-175 (generator MSB taps the input)
+    static constexpr int code(int s, int j) {
+        const unsigned p = (unsigned)(((s << 1) & (S - 1)) | j), b = (unsigned)(s >> (LGS - 1));
+        const unsigned reg = (b << LGS) | p;
+        return (parity(reg & G0) << 1) | parity(reg & G1);
+    }
+};
+
+template <int LGS>
+constexpr int rotl(int s, int r) {
+    r %= LGS;
+    return r == 0 ? s : (((s << r) | (s >> (LGS - r))) & ((1 << LGS) - 1));
+}
+
+__device__ __forceinline__ double vmin(double a, double b) {      // one v_min_f64 (fmin adds canonicalising v_max)
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// One add-compare-select decision: d = (y < x); result = d ? y : x (first minimum wins, convcode.py:633-642);
+// acc = 2*acc + d shifts the decision bit in.  Two forms:
+//  * acs_min: v_cmp + v_addc + v_min_f64 -- equal to the select whenever neither operand is NaN, which holds for
+//    'hard' (integer metrics) and 'soft' (the clip maps a NaN input to -500, metrics are >= 0 or +inf, only added);
+//  * acs_select: v_cmp + 2 v_cndmask + v_addc, the select of viterbi.hip itself -- used for 'unquantized', where a NaN
+//    input reaches the metrics and v_min_f64's NaN rule (return the other operand) would differ.
+__device__ __forceinline__ double acs_min(unsigned &acc, double x, double y) {
+    double r;
+    asm("v_cmp_lt_f64 vcc, %3, %2\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc\n\tv_min_f64 %0, %2, %3"
+        : "=&v"(r), "+v"(acc) : "v"(x), "v"(y) : "vcc");
+    return r;
+}
+
+__device__ __forceinline__ double acs_select(unsigned &acc, double x, double y) {
+    int rlo, rhi;
+    asm("v_cmp_lt_f64 vcc, %4, %3\n\tv_cndmask_b32 %0, %5, %7, vcc\n\tv_cndmask_b32 %1, %6, %8, vcc\n\t"
+        "v_addc_co_u32 %2, vcc, %2, %2, vcc"
+        : "=&v"(rlo), "=&v"(rhi), "+v"(acc)
+        : "v"(x), "v"(y), "v"(__double2loint(x)), "v"(__double2hiint(x)), "v"(__double2loint(y)), "v"(__double2hiint(y))
+        : "vcc");
+    return __hiloint2double(rhi, rlo);
+}
+
+struct CwParams {
+    const double *coded;          // [B][len]
+    unsigned long long *dec;      // [groups][T][64]  decision word of step t of the lane's codeword
+    unsigned char *best;          // [groups][T][64]  first-argmin state
+    uint8_t *bits;                // [B][L]
+    int64_t B, len, L, T, Lk, Tp;   // Tp: T rounded up to whole groups of log2(S) steps (row count of dec/best)
+    int type, tb;
+};
+
+// Per-bit metrics of one received value (convcode.py:575-587) -- identical to viterbi.hip
+__device__ __forceinline__ void bit_metrics_cw(int type, double r, double &m0, double &m1) {
+    if (type == CPX_VIT_HARD) {
+        long long ri = (long long)r;
+        m0 = (double)(ri ^ 0ll);
+        m1 = (double)(ri ^ 1ll);
+    } else if (type == CPX_VIT_SOFT) {
+        double nll0 = fast_log(exp(r) + 1.0);
+        m0 = nll0;
+        m1 = nll0 - r;
+    } else {
+        double d0 = r - (-1.0), d1 = r - 1.0;
+        m0 = d0 * d0;
+        m1 = d1 * d1;
+    }
+}
+
+// Decision bit of state s inside the word of a step: the states of each half are shifted in in increasing order,
+// the upper half sits S/2 bits higher  ->  bit (s ^ (S/2 - 1)).
+template <int LGS>
+__device__ __forceinline__ int dec_bit(unsigned long long w, int st) {
+    constexpr int S = 1 << LGS;
+    return (int)((w >> (st ^ (S / 2 - 1))) & 1ull);
+}
+
+// One trellis step with the logical->physical map rotated by R: physical register rotl(s, R) holds state s before the
+// step and rotl(s, R + 1) after it.
+// The hot loop is kept free of branches (decoding type as a template parameter, unconditional loads and stores): with
+// control flow between the prefetch and its use the compiler waits for vmcnt(0) right after issuing the loads and the
+// memory latency of every group is exposed (measured: 3.26 ms instead of 1.75 ms for BASELINE config 2).
+template <int LGS, unsigned G0, unsigned G1, int TYPE, int R>
+__device__ __forceinline__ void cw_step(double (&pm)[1 << LGS], double r0, double r1, unsigned long long *dec,
+                                        unsigned char *best) {
+    constexpr int type = TYPE;
+    using C = SrCode<LGS, G0, G1>;
+    constexpr int S = 1 << LGS, H = S / 2;
+    if (type == CPX_VIT_SOFT) {                                    // coded_bits.clip(-500, 500) (:719)
+        r0 = fmin(fmax(r0, -500.0), 500.0);
+        r1 = fmin(fmax(r1, -500.0), 500.0);
+    }
+    double m00, m01, m10, m11;
+    bit_metrics_cw(type, r0, m00, m01);
+    bit_metrics_cw(type, r1, m10, m11);
+    double bmv[4];                                                 // NumPy add.reduce, n < 8: sequential from 0
+    bmv[0] = (0.0 + m00) + m10; bmv[1] = (0.0 + m00) + m11;
+    bmv[2] = (0.0 + m01) + m10; bmv[3] = (0.0 + m01) + m11;
+    unsigned da = 0, db = 0;                                       // decisions of states 0..H-1 / H..S-1
+#pragma unroll
+    for (int j = 0; j < H; j++) {
+        constexpr int dummy = 0; (void)dummy;
+        const int x = rotl<LGS>(2 * j, R), y = rotl<LGS>(2 * j + 1, R);
+        const double a = pm[x], b = pm[y];                         // metrics of the predecessors 2j, 2j+1
+        const double a0 = a + bmv[C::code(j, 0)], a1 = b + bmv[C::code(j, 1)];          // into state j      (:629)
+        const double b0 = a + bmv[C::code(j + H, 0)], b1 = b + bmv[C::code(j + H, 1)];  // into state j + S/2
+        if (TYPE == CPX_VIT_UNQUANTIZED) {
+            pm[x] = acs_select(da, a0, a1);                        // state j     now lives in register rotl(j, R+1) = x
+            pm[y] = acs_select(db, b0, b1);                        // state j+S/2 now lives in register y
+        } else {
+            pm[x] = acs_min(da, a0, a1);
+            pm[y] = acs_min(db, b0, b1);
+        }
+    }
+    // first-argmin state (:645): the minimum (v_min_f64 tree, as viterbi.hip's cross-lane tree) and the first state equal to it
+    double m0 = pm[0], m1 = pm[1 % S], m2 = pm[2 % S], m3 = pm[3 % S];
+#pragma unroll
+    for (int s = 4; s < S; s += 4) {
+        m0 = vmin(m0, pm[s]); m1 = vmin(m1, pm[s + 1]); m2 = vmin(m2, pm[s + 2]); m3 = vmin(m3, pm[s + 3]);
+    }
+    const double mn = vmin(vmin(m0, m1), vmin(m2, m3));
+    int bst = 0;
+#pragma unroll
+    for (int s = S - 1; s >= 0; s--) bst = (pm[rotl<LGS>(s, R + 1)] == mn) ? s : bst;
+    *dec = (S == 64) ? (((unsigned long long)db << 32) | da) : (unsigned long long)(da | (db << (H & 31)));
+    *best = (unsigned char)bst;
+}
+
+// Workgroups of four wavefronts (one group of 64 codewords each): the four waves of a workgroup land on the four SIMDs
+// of one CU, so 256 workgroups put exactly one wave on every SIMD of the chip.  (With single-wave workgroups the
+// dispatcher packed two waves per SIMD on half of the CUs for B = 65536: 2.98 ms instead of 1.75 ms.)
+constexpr int ACS_WAVES = 4;
+
+template <int LGS, unsigned G0, unsigned G1, int TYPE>
+__global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_acs_kernel(CwParams p) {
+    constexpr int S = 1 << LGS;
+    const int lane = threadIdx.x & 63;
+    const int64_t grp = (int64_t)blockIdx.x * ACS_WAVES + (threadIdx.x >> 6);
+    const int64_t cw = grp * 64 + lane;
+    if (grp * 64 >= p.B) return;                                                   // whole wave beyond the batch
+    const bool valid = cw < p.B;
+    const double *x = p.coded + (valid ? cw : 0) * p.len;
+    unsigned long long *dec = p.dec + grp * p.Tp * 64 + lane;                      // rows of steps T+1..Tp: never read
+    unsigned char *best = p.best + grp * p.Tp * 64 + lane;
+
+    double pm[S];
+#pragma unroll
+    for (int s = 0; s < S; s++) pm[s] = (s == 0) ? 0.0 : __builtin_huge_val();   // path_metrics[:,0] = inf, [0][0] = 0 (:705-706)
+
+    const double pad = (TYPE == CPX_VIT_UNQUANTIZED) ? -1.0 : 0.0;                // t > L//k -> padding (:722-734)
+    const int64_t tmax = (p.Lk < p.T) ? p.Lk : p.T;                               // last step with received values (>= 1)
+    auto load = [&](int64_t t) {                                                  // always a valid address; padded below
+        const int64_t tc = (t < tmax) ? t : tmax;
+        return *reinterpret_cast<const double2 *>(x + (tc - 1) * 2);
+    };
+    double2 cur[LGS], nxt[LGS];
+#pragma unroll
+    for (int u = 0; u < LGS; u++) cur[u] = load(1 + u);
+    // groups of LGS steps; a partial last group simply runs on (steps > T see padding, their rows are never read)
+    for (int64_t t = 1; t <= p.T; t += LGS) {
+#pragma unroll
+        for (int u = 0; u < LGS; u++) nxt[u] = load(t + LGS + u);                // prefetch: lands during this group
+#pragma unroll
+        for (int u = 0; u < LGS; u++) {
+            const bool have = t + u <= tmax;
+            cur[u].x = have ? cur[u].x : pad;
+            cur[u].y = have ? cur[u].y : pad;
+        }
+        unsigned long long *d = dec + (t - 1) * 64;
+        unsigned char *b = best + (t - 1) * 64;
+        if constexpr (LGS >= 1) cw_step<LGS, G0, G1, TYPE, 0>(pm, cur[0].x, cur[0].y, d + 0 * 64, b + 0 * 64);
+        if constexpr (LGS >= 2) cw_step<LGS, G0, G1, TYPE, 1>(pm, cur[1 % LGS].x, cur[1 % LGS].y, d + 1 * 64, b + 1 * 64);
+        if constexpr (LGS >= 3) cw_step<LGS, G0, G1, TYPE, 2>(pm, cur[2 % LGS].x, cur[2 % LGS].y, d + 2 * 64, b + 2 * 64);
+        if constexpr (LGS >= 4) cw_step<LGS, G0, G1, TYPE, 3>(pm, cur[3 % LGS].x, cur[3 % LGS].y, d + 3 * 64, b + 3 * 64);
+        if constexpr (LGS >= 5) cw_step<LGS, G0, G1, TYPE, 4>(pm, cur[4 % LGS].x, cur[4 % LGS].y, d + 4 * 64, b + 4 * 64);
+        if constexpr (LGS >= 6) cw_step<LGS, G0, G1, TYPE, 5>(pm, cur[5 % LGS].x, cur[5 % LGS].y, d + 5 * 64, b + 5 * 64);
+#pragma unroll
+        for (int u = 0; u < LGS; u++) cur[u] = nxt[u];
+    }
+}
+
+// Sliding traceback: bit of output step s = input bit of the state at step s on the path traced back from
+// best[min(s + tb - 2, T)] (the rule of viterbi.hip).  One workgroup per group of 64 codewords; per pass of 64 output
+// steps the rows of steps base .. base + 63 + tb - 2 are staged in LDS; wave w traces codewords w, w+8, ... two at a
+// time (two independent dependent-load chains), lane i = output step base + i.
+constexpr int TB_THREADS = 512, TB_WAVES = TB_THREADS / 64, TB_STRIDE = 65;
+
+template <int LGS>
+__global__ __launch_bounds__(TB_THREADS) void viterbi_cw_tb_kernel(CwParams p) {
+    constexpr int S = 1 << LGS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int H = p.tb - 2, rows = 64 + H;
+    unsigned long long *win = reinterpret_cast<unsigned long long *>(smem);        // [rows][65]
+    unsigned char *bwin = reinterpret_cast<unsigned char *>(win + (size_t)rows * TB_STRIDE);   // [rows][64]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t grp = blockIdx.x;
+    const unsigned long long *dec = p.dec + grp * p.Tp * 64;
+    const unsigned char *best = p.best + grp * p.Tp * 64;
+    for (int64_t base = 1; base <= p.T; base += 64) {
+        int64_t need = base + 63 + H;
+        if (need > p.T) need = p.T;
+        __syncthreads();                                                          // readers of the previous window are done
+        for (int64_t tt = base + w; tt <= need; tt += TB_WAVES) {                 // row of step tt -> window row tt - base
+            win[(tt - base) * TB_STRIDE + lane] = dec[(tt - 1) * 64 + lane];
+            bwin[(tt - base) * 64 + lane] = best[(tt - 1) * 64 + lane];
+        }
+        __syncthreads();
+        const int64_t so = base + lane;                                           // output step of this lane
+        const bool full = base + 63 + H <= p.T;                                   // every lane of the pass walks all H hops
+        int64_t t0 = so + H;
+        if (t0 > p.T) t0 = p.T;
+        for (int c0 = w; c0 < 64; c0 += 2 * TB_WAVES) {
+            const int c1 = c0 + TB_WAVES;
+            int st0 = 0, st1 = 0;
+            if (so <= p.T) {
+                st0 = bwin[(t0 - base) * 64 + c0];
+                st1 = bwin[(t0 - base) * 64 + c1];
+            }
+            // hop h uses the decision word of step so + H - h (clipped lanes wait until that step is <= T)
+            int idx = (lane + H) * TB_STRIDE;                                     // window row of step so + H
+            if (full) {
+                for (int h = 0; h < H; h++) {
+                    const int j0 = dec_bit<LGS>(win[idx + c0], st0), j1 = dec_bit<LGS>(win[idx + c1], st1);
+                    st0 = ((st0 << 1) & (S - 1)) | j0;
+                    st1 = ((st1 << 1) & (S - 1)) | j1;
+                    idx -= TB_STRIDE;
+                }
+            } else {
+                for (int h = 0; h < H; h++) {
+                    const bool go = so + H - h <= p.T;                            // rows past `need` hold stale words: skipped
+                    const int j0 = dec_bit<LGS>(win[idx + c0], st0), j1 = dec_bit<LGS>(win[idx + c1], st1);
+                    st0 = go ? (((st0 << 1) & (S - 1)) | j0) : st0;
+                    st1 = go ? (((st1 << 1) & (S - 1)) | j1) : st1;
+                    idx -= TB_STRIDE;
+                }
+            }
+            const int64_t pos = so - 1;
+            if (so <= p.T && pos < p.L) {
+                const int64_t cwa = grp * 64 + c0, cwb = grp * 64 + c1;
+                if (cwa < p.B) p.bits[cwa * p.L + pos] = (uint8_t)(st0 >> (LGS - 1));   // input bit of the branch into st
+                if (cwb < p.B) p.bits[cwb * p.L + pos] = (uint8_t)(st1 >> (LGS - 1));
+            }
+        }
+    }
+}
+
+template <int LGS, unsigned G0, unsigned G1>
+bool tables_match(const cpx_trellis *t) {
+    using C = SrCode<LGS, G0, G1>;
+    if (t->S != (1 << LGS) || t->I != 2 || t->k != 1 || t->n != 2) return false;
+    for (int s = 0; s < t->S; s++)
+        for (int j = 0; j < 2; j++) {
+            if (t->pred_state[s * 2 + j] != (((s << 1) & (t->S - 1)) | j)) return false;
+            if (t->pred_input[s * 2 + j] != (s >> (LGS - 1))) return false;
+            if (t->pred_code[s * 2 + j] != C::code(s, j)) return false;
+        }
+    return true;
+}
+
+template <int LGS, unsigned G0, unsigned G1>
+void launch(const CwParams &p, size_t tb_lds, hipStream_t st) {
+    const unsigned groups = (unsigned)((p.B + 63) / 64), ablocks = (groups + ACS_WAVES - 1) / ACS_WAVES;
+    const dim3 ab(64 * ACS_WAVES);
+    if (p.type == CPX_VIT_HARD) hipLaunchKernelGGL((viterbi_cw_acs_kernel<LGS, G0, G1, CPX_VIT_HARD>), dim3(ablocks), ab, 0, st, p);
+    else if (p.type == CPX_VIT_SOFT) hipLaunchKernelGGL((viterbi_cw_acs_kernel<LGS, G0, G1, CPX_VIT_SOFT>), dim3(ablocks), ab, 0, st, p);
+    else hipLaunchKernelGGL((viterbi_cw_acs_kernel<LGS, G0, G1, CPX_VIT_UNQUANTIZED>), dim3(ablocks), ab, 0, st, p);
+    hipLaunchKernelGGL((viterbi_cw_tb_kernel<LGS>), dim3(groups), dim3(TB_THREADS), tb_lds, st, p);
+}
+
+}  // namespace
+
+namespace cpx {
+
+// Returns true when the call was handled here (*rc = status); false -> the caller uses the state-per-lane kernels.
+bool viterbi_codeword_path(const cpx_trellis *t, const double *d_coded, int64_t B, int64_t len, int64_t L, int64_t T,
+                           int tb, int type, uint8_t *d_bits, hipStream_t st, int *rc) {
+    *rc = CPX_OK;
+    const char *e = getenv("CPX_VITERBI_PATH");                   // "wave" / "cw" / "cw!" force a path (tests, benchmarks)
+    if (e && e[0] == 'w') return false;
+    const bool forced = e && e[0] == 'c';
+    const bool strict = forced && e[1] == 'w' && e[2] == '!';     // "cw!": fail instead of falling back
+    auto reject = [&](const char *why) {
+        if (!strict) return false;
+        set_error("viterbi (codeword path): %s", why);
+        *rc = CPX_ELIMIT;
+        return true;
+    };
+    // one wavefront of 64 codewords per SIMD needs 65536 codewords on 256 CUs; below ~3/4 of that the wave kernels win
+    if (!forced && B < 3 * (int64_t)device_cus() * 4 * 64 / 4) return false;
+    if (t->I != 2 || t->k != 1 || t->n != 2 || T < 1) return reject("needs a rate-1/2, k = 1 trellis");
+    if ((len & 1) || ((uintptr_t)d_coded & 15)) return reject("rows must be 16-byte aligned");
+    const size_t tb_lds = (size_t)(64 + tb - 2) * (TB_STRIDE * 8 + 64);
+    if (tb_lds > 64 * 1024) return reject("traceback window exceeds 64 KiB of LDS");
+    const int64_t groups = (B + 63) / 64;
+    if (groups >= (1ll << 31)) return reject("batch too large");
+    CwParams p;
+    p.coded = d_coded; p.bits = d_bits; p.B = B; p.len = len; p.L = L; p.T = T; p.Lk = L;   // k = 1
+    p.type = type; p.tb = tb;
+#define CPX_TRY(LG, GA, GB)                                                                                         \
+    if (tables_match<LG, GA, GB>(t)) {                                                                              \
+        void *w0 = nullptr, *w1 = nullptr;                                                                          \
+        p.Tp = (T + LG - 1) / LG * LG;                                                                              \
+        if ((*rc = workspace(st, 0, sizeof(unsigned long long) * (size_t)(groups * p.Tp * 64), &w0))) return true;  \
+        if ((*rc = workspace(st, 1, (size_t)(groups * p.Tp * 64), &w1))) return true;                               \
+        p.dec = static_cast<unsigned long long *>(w0);                                                              \
+        p.best = static_cast<unsigned char *>(w1);                                                                  \
+        launch<LG, GA, GB>(p, tb_lds, st);                                                                          \
+        if (hipGetLastError() != hipSuccess) { set_error("viterbi (codeword path): launch failed"); *rc = CPX_EHIP; } \
+        return true;                                                                                                \
+    }
+    // Template generators are in "MSB taps the input" order.  commpy's default polynomial_format='MSB' makes the
+    // LEAST significant bit of the octal number the D^0 tap (convcode.py:211-222), i.e. the bit-reversed number here:
+    // (133,171) -> (155,117).
+    CPX_TRY(6, 0155u, 0117u)      // K = 7 (133,171), commpy default format: 802.11 / BASELINE configs 2 and 5
+    CPX_TRY(6, 0117u, 0155u)      // K = 7 (171,133)
+#undef CPX_TRY
+    return reject("no instantiation for this trellis");
+}
+
+}  // namespace cpx

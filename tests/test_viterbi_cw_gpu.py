@@ -1,0 +1,140 @@
+"""The codeword-per-lane Viterbi path (csrc/viterbi_cw.hip) against the reference goldens, the CPU oracle and the
+state-per-lane kernels -- bit-exact for every decoding type.  CPX_VITERBI_PATH forces a path: "cw!" fails instead of
+falling back, "wave" disables the codeword path."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from helpers import golden, make_trellis
+
+pytestmark = pytest.mark.gpu
+
+
+class _path:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        self.old = os.environ.get("CPX_VITERBI_PATH")
+        os.environ["CPX_VITERBI_PATH"] = self.name
+
+    def __exit__(self, *a):
+        if self.old is None:
+            os.environ.pop("CPX_VITERBI_PATH", None)
+        else:
+            os.environ["CPX_VITERBI_PATH"] = self.old
+
+
+def _decode(x, tr, tb, dtype, path):
+    from commpy_amd.channelcoding import viterbi_decode
+    with _path(path):
+        return viterbi_decode(x, tr, tb, dtype)
+
+
+def test_forced_path_is_really_taken(gpu):
+    """"cw!" must refuse a trellis it has no instantiation for instead of silently using the wave kernels."""
+    tr = make_trellis("k8_247_371")
+    with pytest.raises(ValueError):
+        _decode(np.zeros((2, 60)), tr, None, "hard", "cw!")
+    tr = make_trellis("k7_133_171")
+    with pytest.raises(ValueError):
+        _decode(np.zeros((2, 61)), tr, None, "hard", "cw!")          # odd row length: rows not 16-byte aligned
+    assert _decode(np.zeros((2, 60)), tr, None, "hard", "cw!").shape == (2, 30)
+
+
+def test_golden_k7_cases_through_the_codeword_path(gpu):
+    """Every K=7 (133,171) case of the reference grid (hard/soft/unquantized x term/cont x tb x noise, +-inf LLRs)."""
+    g = golden("viterbi_small")
+    done, bad = 0, []
+    for nm in g["names"]:
+        key, tname, term, dtype, tb, noisy = str(nm).split("|")
+        if tname != "k7_133_171" or len(g[key + "__in"]) % 2:
+            continue
+        tr = make_trellis(tname)
+        tb = None if tb == "None" else int(tb)
+        dec = _decode(g[key + "__in"], tr, tb, dtype, "cw!")
+        done += 1
+        if dec.dtype != np.int64 or not np.array_equal(dec, g[key + "__out"]):
+            bad.append(str(nm))
+    assert done >= 24, done
+    assert not bad, bad[:10]
+    c2 = golden("viterbi_c2")
+    tr = make_trellis("k7_133_171")
+    for tag in ("e3", "e1"):
+        assert np.array_equal(_decode(c2[tag + "__llr"], tr, None, "soft", "cw!"), c2[tag + "__dec"]), tag
+
+
+@pytest.mark.parametrize("dtype", ["hard", "soft", "unquantized"])
+@pytest.mark.parametrize("B,nbits,tb", [(1, 1, None), (3, 2, 2), (63, 5, None), (64, 30, None), (65, 31, 15), (130, 96, 40),
+                                        (37, 120, 48), (200, 64, 3), (5, 333, None), (70, 1024, None)])
+def test_random_batches_vs_oracle(gpu, dtype, B, nbits, tb):
+    """Seeded batches, ragged groups, window edges (tb = 2, 3, window = 64 KiB limit), ties (hard) -- vs the CPU oracle."""
+    from commpy_amd.channelcoding import conv_encode_batch
+    tr = make_trellis("k7_133_171")
+    rs = np.random.RandomState(1000 * B + nbits)
+    coded = conv_encode_batch(rs.randint(0, 2, (B, nbits)), tr).astype(float)
+    if dtype == "hard":
+        rx = np.where(rs.rand(*coded.shape) < 0.08, 1 - coded, coded)
+    elif dtype == "soft":
+        rx = 4.0 * coded - 2 + rs.randn(*coded.shape) * 2.0
+        rx[rs.rand(*rx.shape) < 0.01] = np.inf
+        rx[rs.rand(*rx.shape) < 0.01] = -np.inf
+        rx[rs.rand(*rx.shape) < 0.01] = 0.0
+    else:
+        rx = 2.0 * coded - 1 + rs.randn(*coded.shape) * 0.8
+    got = _decode(rx, tr, tb, dtype, "cw!")
+    want = oracle.viterbi_decode(rx, tr, tb, dtype)
+    assert np.array_equal(got, want), (dtype, B, nbits, tb)
+    assert np.array_equal(got, _decode(rx, tr, tb, dtype, "wave"))
+
+
+@pytest.mark.parametrize("gm,fmt", [([[0o133, 0o171]], "MSB"), ([[0o171, 0o133]], "MSB")])
+def test_all_instantiated_generators(gpu, gm, fmt):
+    from commpy_amd.channelcoding import Trellis, conv_encode_batch
+    try:
+        tr = Trellis(np.array([6]), np.array(gm), polynomial_format=fmt)
+    except Exception:
+        pytest.skip("polynomial format not supported by the host Trellis")
+    rs = np.random.RandomState(7)
+    coded = conv_encode_batch(rs.randint(0, 2, (150, 200)), tr).astype(float)
+    rx = 4.0 * coded - 2 + rs.randn(*coded.shape) * 2.2
+    got = _decode(rx, tr, None, "soft", "cw!")
+    assert np.array_equal(got, oracle.viterbi_decode(rx, tr, None, "soft"))
+
+
+def test_continuous_termination_and_short_windows(gpu):
+    """'cont' streams (no tail), tb_depth larger than the block, L smaller than the window."""
+    from commpy_amd.channelcoding import conv_encode
+    tr = make_trellis("k7_133_171")
+    rs = np.random.RandomState(3)
+    for nbits, tb in ((40, None), (12, 30), (100, 10), (64, 35)):
+        msgs = rs.randint(0, 2, (9, nbits))
+        coded = np.stack([conv_encode(m, tr, "cont") for m in msgs]).astype(float)
+        rx = 4.0 * coded - 2 + rs.randn(*coded.shape) * 1.5
+        got = _decode(rx, tr, tb, "soft", "cw!")
+        assert np.array_equal(got, _decode(rx, tr, tb, "soft", "wave")), (nbits, tb)
+        steps = nbits + 6 - 1
+        if (tb or min(30, nbits)) - 1 <= steps:      # otherwise the reference never traces back (deviations)
+            assert np.array_equal(got, oracle.viterbi_decode(rx, tr, tb, "soft")), (nbits, tb)
+
+
+def test_full_size_default_dispatch_equals_wave_kernels(gpu):
+    """BASELINE config-2 size: the default dispatch (codeword path at this batch) and the wave kernels return the same
+    bits for all 65536 codewords; a slice is checked against the oracle; the noiseless batch decodes to the messages."""
+    from commpy_amd.channelcoding import conv_encode_batch
+    tr = make_trellis("k7_133_171")
+    rs = np.random.RandomState(10)
+    B = 65536
+    msgs = rs.randint(0, 2, (B, 1024))
+    coded = conv_encode_batch(msgs, tr).astype(np.float64)
+    clean = _decode(4.0 * coded - 2, tr, None, "soft", "cw!")
+    assert np.array_equal(clean[:, :1024], msgs)
+    rx = 4.0 * coded - 2 + rs.randn(*coded.shape) * 1.6
+    auto = _decode(rx, tr, None, "soft", "auto")
+    assert np.array_equal(auto, _decode(rx, tr, None, "soft", "cw!"))
+    assert np.array_equal(auto, _decode(rx, tr, None, "soft", "wave"))
+    sel = np.r_[0:48, B - 48:B]
+    assert np.array_equal(auto[sel], oracle.viterbi_decode(rx[sel], tr, None, "soft"))
+    assert 0 < np.mean(auto[:, :1024] != msgs) < 0.05
