@@ -104,12 +104,12 @@ __device__ __forceinline__ void bit_metrics_cw(int type, double r, double &m0, d
     }
 }
 
-// Decision bit of state s inside the word of a step: the states of each half are shifted in in increasing order,
-// the upper half sits S/2 bits higher  ->  bit (s ^ (S/2 - 1)).
-template <int LGS>
-__device__ __forceinline__ int dec_bit(unsigned long long w, int st) {
-    constexpr int S = 1 << LGS;
-    return (int)((w >> (st ^ (S / 2 - 1))) & 1ull);
+// One traceback hop: the decision bit of state st is bit 63 - st of the step's word, i.e. the top bit of (w << st)
+// (v_lshlrev_b64 uses the low 6 bits of st only); st' = (st << 1) | bit in one v_alignbit_b32.  The high bits of st are
+// never masked on the way -- only st mod S is meaningful.
+__device__ __forceinline__ unsigned tb_hop(unsigned long long w, unsigned st) {
+    const unsigned hi = (unsigned)((w << (st & 63u)) >> 32);
+    return __builtin_amdgcn_alignbit(st, hi, 31);
 }
 
 // One trellis step with the logical->physical map rotated by R: physical register rotl(s, R) holds state s before the
@@ -159,7 +159,9 @@ __device__ __forceinline__ void cw_step(double (&pm)[1 << LGS], double r0, doubl
     int bst = 0;
 #pragma unroll
     for (int s = S - 1; s >= 0; s--) bst = (pm[rotl<LGS>(s, R + 1)] == mn) ? s : bst;
-    *dec = (S == 64) ? (((unsigned long long)db << 32) | da) : (unsigned long long)(da | (db << (H & 31)));
+    // shifting the decisions in in increasing state order leaves state j of a half at bit H-1-j of its word; placing the
+    // lower half on top puts state s at bit 63 - s of the 64-bit word: the traceback reads it as the top bit of (w << s)
+    *dec = ((unsigned long long)da << (64 - H)) | ((unsigned long long)db << (64 - S));
     *best = (unsigned char)bst;
 }
 
@@ -224,7 +226,7 @@ constexpr int TB_THREADS = 512, TB_WAVES = TB_THREADS / 64, TB_STRIDE = 65;
 
 template <int LGS>
 __global__ __launch_bounds__(TB_THREADS) void viterbi_cw_tb_kernel(CwParams p) {
-    constexpr int S = 1 << LGS;
+    (void)LGS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int H = p.tb - 2, rows = 64 + H;
     unsigned long long *win = reinterpret_cast<unsigned long long *>(smem);        // [rows][65]
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(TB_THREADS) void viterbi_cw_tb_kernel(CwParams p) {
         if (t0 > p.T) t0 = p.T;
         for (int c0 = w; c0 < 64; c0 += 2 * TB_WAVES) {
             const int c1 = c0 + TB_WAVES;
-            int st0 = 0, st1 = 0;
+            unsigned st0 = 0, st1 = 0;
             if (so <= p.T) {
                 st0 = bwin[(t0 - base) * 64 + c0];
                 st1 = bwin[(t0 - base) * 64 + c1];
@@ -256,26 +258,27 @@ __global__ __launch_bounds__(TB_THREADS) void viterbi_cw_tb_kernel(CwParams p) {
             // hop h uses the decision word of step so + H - h (clipped lanes wait until that step is <= T)
             int idx = (lane + H) * TB_STRIDE;                                     // window row of step so + H
             if (full) {
+                // the addresses do not depend on the states: unrolled, the reads of four hops are in flight together
+#pragma unroll 4
                 for (int h = 0; h < H; h++) {
-                    const int j0 = dec_bit<LGS>(win[idx + c0], st0), j1 = dec_bit<LGS>(win[idx + c1], st1);
-                    st0 = ((st0 << 1) & (S - 1)) | j0;
-                    st1 = ((st1 << 1) & (S - 1)) | j1;
+                    st0 = tb_hop(win[idx + c0], st0);
+                    st1 = tb_hop(win[idx + c1], st1);
                     idx -= TB_STRIDE;
                 }
             } else {
                 for (int h = 0; h < H; h++) {
                     const bool go = so + H - h <= p.T;                            // rows past `need` hold stale words: skipped
-                    const int j0 = dec_bit<LGS>(win[idx + c0], st0), j1 = dec_bit<LGS>(win[idx + c1], st1);
-                    st0 = go ? (((st0 << 1) & (S - 1)) | j0) : st0;
-                    st1 = go ? (((st1 << 1) & (S - 1)) | j1) : st1;
+                    const unsigned n0 = tb_hop(win[idx + c0], st0), n1 = tb_hop(win[idx + c1], st1);
+                    st0 = go ? n0 : st0;
+                    st1 = go ? n1 : st1;
                     idx -= TB_STRIDE;
                 }
             }
             const int64_t pos = so - 1;
             if (so <= p.T && pos < p.L) {
                 const int64_t cwa = grp * 64 + c0, cwb = grp * 64 + c1;
-                if (cwa < p.B) p.bits[cwa * p.L + pos] = (uint8_t)(st0 >> (LGS - 1));   // input bit of the branch into st
-                if (cwb < p.B) p.bits[cwb * p.L + pos] = (uint8_t)(st1 >> (LGS - 1));
+                if (cwa < p.B) p.bits[cwa * p.L + pos] = (uint8_t)((st0 >> (LGS - 1)) & 1u);   // input bit of the branch into st
+                if (cwb < p.B) p.bits[cwb * p.L + pos] = (uint8_t)((st1 >> (LGS - 1)) & 1u);
             }
         }
     }
