@@ -272,13 +272,15 @@ def main():
         lib.cpx_device_info(None, 0, ctypes.byref(cus), None)
         forced = os.environ.get("CPX_VITERBI_PATH", "")
         cw_path = (not forced.startswith("w")) and (forced.startswith("c") or B >= 3 * cus.value * 4 * 64 // 4)
-        kernel_name = ("viterbi_cw_acs_kernel<6,0155,0117,soft> + viterbi_cw_tb_kernel<6>" if cw_path
-                       else "viterbi_wave_kernel<6,2,true,2>")
+        two = "2" in forced                                    # "cw2": ACS + traceback kernels instead of the fused kernel
+        kernel_name = ("viterbi_wave_kernel<6,2,true,2>" if not cw_path else
+                       "viterbi_cw_acs_kernel<6,0155,0117,soft> + viterbi_cw_tb_kernel<6>" if two else
+                       "viterbi_cw_fused_kernel<6,0155,0117,soft,28>")
         traffic, traffic_src = None, None    # HBM bytes per launch from the committed PMC passes (same workload and kernels only)
         try:
             with open(os.path.join(ROOT, "profiles", "r01_viterbi_c2_traffic.json")) as f:
                 tj = json.load(f)
-            if B == 65536 and tj.get("path") == ("cw" if cw_path else "wave"):
+            if B == 65536 and tj.get("path") == (("cw2" if two else "fused") if cw_path else "wave"):
                 traffic = tj["traffic_bytes_per_launch"]
                 traffic_src = "profiles/r01_viterbi_c2_traffic.json (rocprofv3 FETCH_SIZE / WRITE_SIZE passes, KiB; see the file for the gfx950 correction)"
         except (OSError, ValueError, KeyError):

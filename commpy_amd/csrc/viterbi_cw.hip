@@ -25,6 +25,8 @@
 #include "cpx_math.h"
 
 #include <cstdlib>
+#include <cstring>
+#include <type_traits>
 
 using namespace cpx;
 
@@ -117,9 +119,15 @@ __device__ __forceinline__ unsigned tb_hop(unsigned long long w, unsigned st) {
 // The hot loop is kept free of branches (decoding type as a template parameter, unconditional loads and stores): with
 // control flow between the prefetch and its use the compiler waits for vmcnt(0) right after issuing the loads and the
 // memory latency of every group is exposed (measured: 3.26 ms instead of 1.75 ms for BASELINE config 2).
-template <int LGS, unsigned G0, unsigned G1, int TYPE, int R>
-__device__ __forceinline__ void cw_step(double (&pm)[1 << LGS], double r0, double r1, unsigned long long *dec,
-                                        unsigned char *best) {
+struct NoHook {
+    template <int P> __device__ __forceinline__ void at() const {}
+};
+
+// `hook.at<P>()` is called at four fixed points of the step (after the branch metrics, after each half of the butterflies,
+// after the minimum tree): the fused kernel slots the traceback of the previous step in there.
+template <int LGS, unsigned G0, unsigned G1, int TYPE, int R, class Hook = NoHook>
+__device__ __forceinline__ void cw_step(double (&pm)[1 << LGS], double r0, double r1, unsigned long long &word, int &best,
+                                        const Hook &hook = Hook()) {
     constexpr int type = TYPE;
     using C = SrCode<LGS, G0, G1>;
     constexpr int S = 1 << LGS, H = S / 2;
@@ -134,9 +142,10 @@ __device__ __forceinline__ void cw_step(double (&pm)[1 << LGS], double r0, doubl
     bmv[0] = (0.0 + m00) + m10; bmv[1] = (0.0 + m00) + m11;
     bmv[2] = (0.0 + m01) + m10; bmv[3] = (0.0 + m01) + m11;
     unsigned da = 0, db = 0;                                       // decisions of states 0..H-1 / H..S-1
+    hook.template at<0>();
 #pragma unroll
     for (int j = 0; j < H; j++) {
-        constexpr int dummy = 0; (void)dummy;
+        if (j == H / 2) hook.template at<1>();
         const int x = rotl<LGS>(2 * j, R), y = rotl<LGS>(2 * j + 1, R);
         const double a = pm[x], b = pm[y];                         // metrics of the predecessors 2j, 2j+1
         const double a0 = a + bmv[C::code(j, 0)], a1 = b + bmv[C::code(j, 1)];          // into state j      (:629)
@@ -149,6 +158,7 @@ __device__ __forceinline__ void cw_step(double (&pm)[1 << LGS], double r0, doubl
             pm[y] = acs_min(db, b0, b1);
         }
     }
+    hook.template at<2>();
     // first-argmin state (:645): the minimum (v_min_f64 tree, as viterbi.hip's cross-lane tree) and the first state equal to it
     double m0 = pm[0], m1 = pm[1 % S], m2 = pm[2 % S], m3 = pm[3 % S];
 #pragma unroll
@@ -156,13 +166,14 @@ __device__ __forceinline__ void cw_step(double (&pm)[1 << LGS], double r0, doubl
         m0 = vmin(m0, pm[s]); m1 = vmin(m1, pm[s + 1]); m2 = vmin(m2, pm[s + 2]); m3 = vmin(m3, pm[s + 3]);
     }
     const double mn = vmin(vmin(m0, m1), vmin(m2, m3));
+    hook.template at<3>();
     int bst = 0;
 #pragma unroll
     for (int s = S - 1; s >= 0; s--) bst = (pm[rotl<LGS>(s, R + 1)] == mn) ? s : bst;
     // shifting the decisions in in increasing state order leaves state j of a half at bit H-1-j of its word; placing the
     // lower half on top puts state s at bit 63 - s of the 64-bit word: the traceback reads it as the top bit of (w << s)
-    *dec = ((unsigned long long)da << (64 - H)) | ((unsigned long long)db << (64 - S));
-    *best = (unsigned char)bst;
+    word = ((unsigned long long)da << (64 - H)) | ((unsigned long long)db << (64 - S));
+    best = bst;
 }
 
 // Workgroups of four wavefronts (one group of 64 codewords each): the four waves of a workgroup land on the four SIMDs
@@ -207,14 +218,183 @@ __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_acs_kernel(CwParams
         }
         unsigned long long *d = dec + (t - 1) * 64;
         unsigned char *b = best + (t - 1) * 64;
-        if constexpr (LGS >= 1) cw_step<LGS, G0, G1, TYPE, 0>(pm, cur[0].x, cur[0].y, d + 0 * 64, b + 0 * 64);
-        if constexpr (LGS >= 2) cw_step<LGS, G0, G1, TYPE, 1>(pm, cur[1 % LGS].x, cur[1 % LGS].y, d + 1 * 64, b + 1 * 64);
-        if constexpr (LGS >= 3) cw_step<LGS, G0, G1, TYPE, 2>(pm, cur[2 % LGS].x, cur[2 % LGS].y, d + 2 * 64, b + 2 * 64);
-        if constexpr (LGS >= 4) cw_step<LGS, G0, G1, TYPE, 3>(pm, cur[3 % LGS].x, cur[3 % LGS].y, d + 3 * 64, b + 3 * 64);
-        if constexpr (LGS >= 5) cw_step<LGS, G0, G1, TYPE, 4>(pm, cur[4 % LGS].x, cur[4 % LGS].y, d + 4 * 64, b + 4 * 64);
-        if constexpr (LGS >= 6) cw_step<LGS, G0, G1, TYPE, 5>(pm, cur[5 % LGS].x, cur[5 % LGS].y, d + 5 * 64, b + 5 * 64);
+        auto one = [&](auto rtag, const double2 &v) {
+            constexpr int R = decltype(rtag)::value;
+            unsigned long long word;
+            int bst;
+            cw_step<LGS, G0, G1, TYPE, R>(pm, v.x, v.y, word, bst);
+            d[R * 64] = word;
+            b[R * 64] = (unsigned char)bst;
+        };
+        if constexpr (LGS >= 1) one(std::integral_constant<int, 0>{}, cur[0]);
+        if constexpr (LGS >= 2) one(std::integral_constant<int, 1>{}, cur[1 % LGS]);
+        if constexpr (LGS >= 3) one(std::integral_constant<int, 2>{}, cur[2 % LGS]);
+        if constexpr (LGS >= 4) one(std::integral_constant<int, 3>{}, cur[3 % LGS]);
+        if constexpr (LGS >= 5) one(std::integral_constant<int, 4>{}, cur[4 % LGS]);
+        if constexpr (LGS >= 6) one(std::integral_constant<int, 5>{}, cur[5 % LGS]);
 #pragma unroll
         for (int u = 0; u < LGS; u++) cur[u] = nxt[u];
+    }
+}
+
+// ---- fused variant: add-compare-select AND sliding traceback in one kernel, no workspace in HBM -------------------------
+// For the default traceback depth of the K = 7 code (tb_depth = 5 m = 30, H = tb - 2 = 28 hops) the decision words never
+// leave the CU: every wave keeps the last 32 words of its 64 codewords in an LDS ring [slot][lane] (conflict-free, each
+// lane reads only its own column) and, right after the add-compare-select of step t, walks the H hops back from the
+// step's first-argmin state -- 2 VALU instructions per hop (tb_hop), LDS addresses that do not depend on the states, the
+// whole walk straight-line code that the scheduler interleaves with the next step's arithmetic.  The ring is stored
+// twice, 32 slots apart, so that the H + 1 words of a walk sit at constant offsets below one base address.  The decoded
+// bit of step t - H goes to a staging tile in LDS and the tile is written out every 96 steps, one coalesced 64-byte
+// store per codeword and half-tile.  HBM traffic is the algorithmic one again (the two-kernel path moves 9 B per
+// codeword-step through a workspace and back).
+constexpr int FR_RING = 32, FR_GROUPS = 16, FR_OBPAD = 100;     // ring slots (mirrored), groups of LGS steps per flush, tile row bytes
+
+template <int LGS>
+constexpr size_t fused_wave_lds() {
+    return (size_t)(2 * FR_RING + 2) * 64 * 8 + (size_t)64 * FR_OBPAD;   // ring + two dummy slots for steps > T, staging tile
+}
+
+// The traceback walk of one step, cut into four batches of hops that cw_step's hook runs between the phases of the NEXT
+// step: the LDS reads of a batch are issued one phase before their hops, so their latency hides behind the
+// add-compare-select arithmetic (left to itself the compiler emits the walk as 14 read -> wait -> 2-hop rounds at the end
+// of the step: +0.5 ms).  sched_barrier pins the batches where they are put.
+template <int H>
+struct WalkHook {
+    static constexpr int NB = 4, PER = (H + NB - 1) / NB;
+    const unsigned long long *pw;           // ring pointer of the walked step t': word of step t' - h at pw[(FR_RING - h) * 64]
+    mutable unsigned st;                    // state of the walk
+    mutable unsigned long long buf[PER];
+    template <int B> __device__ __forceinline__ void issue() const {
+#pragma unroll
+        for (int i = 0; i < PER; i++)
+            if (B * PER + i < H) buf[i] = pw[(FR_RING - (B * PER + i)) * 64];
+    }
+    template <int B> __device__ __forceinline__ void hops() const {
+#pragma unroll
+        for (int i = 0; i < PER; i++)
+            if (B * PER + i < H) st = tb_hop(buf[i], st);
+    }
+    template <int P> __device__ __forceinline__ void at() const {
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (P == 0) {
+            issue<0>();
+        } else {
+            hops<P - 1>();
+            issue<P>();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __device__ __forceinline__ void finish() const {
+        __builtin_amdgcn_sched_barrier(0);
+        hops<NB - 1>();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+};
+
+template <int LGS, unsigned G0, unsigned G1, int TYPE, int H>
+__global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_fused_kernel(CwParams p) {
+    constexpr int S = 1 << LGS, CHUNK = FR_GROUPS * LGS;
+    static_assert(H + 1 <= FR_RING && CHUNK + 1 <= FR_OBPAD, "ring / tile too small");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t grp = (int64_t)blockIdx.x * ACS_WAVES + wv;
+    const int64_t cw = grp * 64 + lane;
+    if (grp * 64 >= p.B) return;                                                   // whole wave beyond the batch
+    const bool valid = cw < p.B;
+    const double *x = p.coded + (valid ? cw : 0) * p.len;
+    unsigned long long *ring = reinterpret_cast<unsigned long long *>(smem + (size_t)wv * fused_wave_lds<LGS>());
+    unsigned char *obuf = reinterpret_cast<unsigned char *>(ring + (2 * FR_RING + 2) * 64);
+    unsigned long long *mycol = ring + lane;                                       // slot s of this lane's codeword: mycol[s * 64]
+    unsigned char *myrow = obuf + lane * FR_OBPAD;
+
+    double pm[S];
+#pragma unroll
+    for (int s = 0; s < S; s++) pm[s] = (s == 0) ? 0.0 : __builtin_huge_val();   // path_metrics[:,0] = inf, [0][0] = 0 (:705-706)
+
+    const double pad = (TYPE == CPX_VIT_UNQUANTIZED) ? -1.0 : 0.0;                // t > L//k -> padding (:722-734)
+    const int64_t tmax = (p.Lk < p.T) ? p.Lk : p.T;                               // last step with received values (>= 1)
+    auto load = [&](int64_t t) {                                                  // always a valid address; padded at use
+        const int64_t tc = (t < tmax) ? t : tmax;
+        return *reinterpret_cast<const double2 *>(x + (tc - 1) * 2);
+    };
+    double2 cur[LGS];
+#pragma unroll
+    for (int u = 0; u < LGS; u++) cur[u] = load(1 + u);
+    int best_T = 0;                                                               // first-argmin state of step T
+    WalkHook<H> walk;                                                             // walk of the previous step (step 0: a dummy)
+    walk.pw = mycol;
+    walk.st = 0;
+
+    // writes the decoded bits staged in tile entries 0 .. n-1: entry li holds the result of the walk of step tc0 + li - 1,
+    // i.e. output step tc0 + li - 1 - H
+    auto flush = [&](int64_t tc0, int n) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                         // the tile rows are complete (same wave wrote them)
+        for (int c = 0; c < 64; c++) {
+            const int64_t cwc = grp * 64 + c;
+            if (cwc >= p.B) break;
+            for (int li = lane; li < n; li += 64) {
+                const int64_t so = tc0 + li - 1 - H;
+                if (so >= 1 && so <= p.T - H && so - 1 < p.L) p.bits[cwc * p.L + so - 1] = obuf[c * FR_OBPAD + li];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                         // tile read before the next chunk overwrites it
+    };
+
+    for (int64_t tc0 = 1; tc0 <= p.T; tc0 += CHUNK) {
+        int64_t left = (p.T - tc0) / LGS + 1;                                      // groups that start at a step <= T
+        const int ngroups = (int)(left < FR_GROUPS ? left : FR_GROUPS);
+        for (int g = 0; g < ngroups; g++) {
+            const int64_t t = tc0 + (int64_t)g * LGS;
+            auto one = [&](auto rtag) {
+                constexpr int R = decltype(rtag)::value;
+                const int64_t tt = t + R;
+                const bool have = tt <= tmax;
+                const double r0 = have ? cur[R].x : pad, r1 = have ? cur[R].y : pad;
+                cur[R] = load(tt + LGS);                                          // prefetch: needed one group later
+                unsigned long long word;
+                int bst;
+                cw_step<LGS, G0, G1, TYPE, R>(pm, r0, r1, word, bst, walk);      // + hops 0 .. 3/4 H of the walk of step tt - 1
+                walk.finish();
+                myrow[g * LGS + R] = (unsigned char)((walk.st >> (LGS - 1)) & 1u);   // input bit of the branch into the state at step tt - 1 - H
+                // ring slot of step tt and its mirror FR_RING slots above; the (at most LGS - 1) steps > T of the last group
+                // write to two dummy slots instead: the ring must keep the words of steps T-H+1 .. T for the final walk
+                const bool live = tt <= p.T;
+                const int q = (int)(tt & (FR_RING - 1));
+                unsigned long long *wb = mycol + q * 64;
+                unsigned long long *w0 = live ? wb : mycol + (2 * FR_RING) * 64;
+                unsigned long long *w1 = live ? wb + FR_RING * 64 : mycol + (2 * FR_RING + 1) * 64;
+                *w0 = word;
+                *w1 = word;
+                best_T = (tt == p.T) ? bst : best_T;
+                walk.pw = wb;                                                     // next: the walk of this step
+                walk.st = (unsigned)bst;
+            };
+            if constexpr (LGS >= 1) one(std::integral_constant<int, 0>{});
+            if constexpr (LGS >= 2) one(std::integral_constant<int, 1 % LGS>{});
+            if constexpr (LGS >= 3) one(std::integral_constant<int, 2 % LGS>{});
+            if constexpr (LGS >= 4) one(std::integral_constant<int, 3 % LGS>{});
+            if constexpr (LGS >= 5) one(std::integral_constant<int, 4 % LGS>{});
+            if constexpr (LGS >= 6) one(std::integral_constant<int, 5 % LGS>{});
+        }
+        int n = ngroups * LGS;
+        if (tc0 + CHUNK > p.T) {                                                   // last chunk: finish the pending walk (of its last step)
+            unsigned st = walk.st;
+            for (int h = 0; h < H; h++) st = tb_hop(walk.pw[(FR_RING - h) * 64], st);
+            myrow[n] = (unsigned char)((st >> (LGS - 1)) & 1u);
+            n++;
+        }
+        flush(tc0, n);
+    }
+    // the last H output steps: one walk from best[T]; the state before hop h is the state of step T - h
+    if (valid) {
+        const int qT = (int)(p.T & (FR_RING - 1));
+        unsigned st = (unsigned)best_T;
+        for (int h = 0; h < H; h++) {
+            const int64_t so = p.T - h;
+            if (so < 1) break;
+            if (so - 1 < p.L) p.bits[cw * p.L + so - 1] = (uint8_t)((st >> (LGS - 1)) & 1u);
+            st = tb_hop(mycol[(qT + FR_RING - h) * 64], st);
+        }
     }
 }
 
@@ -307,6 +487,33 @@ void launch(const CwParams &p, size_t tb_lds, hipStream_t st) {
     hipLaunchKernelGGL((viterbi_cw_tb_kernel<LGS>), dim3(groups), dim3(TB_THREADS), tb_lds, st, p);
 }
 
+// fused kernel: instantiated for the default traceback depth of the K = 7 code (tb_depth = 30)
+constexpr int FUSED_TB = 30;
+
+template <int LGS, unsigned G0, unsigned G1, int TYPE>
+int launch_fused_typed(const CwParams &p, hipStream_t st) {
+    auto *fn = viterbi_cw_fused_kernel<LGS, G0, G1, TYPE, FUSED_TB - 2>;
+    const size_t lds = ACS_WAVES * fused_wave_lds<LGS>();
+    static bool raised = false;                                  // > 64 KiB of dynamic LDS is opt-in, once per kernel
+    if (!raised) {
+        if (hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            (void)hipGetLastError();
+            return 0;
+        }
+        raised = true;
+    }
+    const unsigned groups = (unsigned)((p.B + 63) / 64), blocks = (groups + ACS_WAVES - 1) / ACS_WAVES;
+    hipLaunchKernelGGL(fn, dim3(blocks), dim3(64 * ACS_WAVES), lds, st, p);
+    return 1;
+}
+
+template <int LGS, unsigned G0, unsigned G1>
+int launch_fused(const CwParams &p, hipStream_t st) {
+    if (p.type == CPX_VIT_HARD) return launch_fused_typed<LGS, G0, G1, CPX_VIT_HARD>(p, st);
+    if (p.type == CPX_VIT_SOFT) return launch_fused_typed<LGS, G0, G1, CPX_VIT_SOFT>(p, st);
+    return launch_fused_typed<LGS, G0, G1, CPX_VIT_UNQUANTIZED>(p, st);
+}
+
 }  // namespace
 
 namespace cpx {
@@ -315,10 +522,14 @@ namespace cpx {
 bool viterbi_codeword_path(const cpx_trellis *t, const double *d_coded, int64_t B, int64_t len, int64_t L, int64_t T,
                            int tb, int type, uint8_t *d_bits, hipStream_t st, int *rc) {
     *rc = CPX_OK;
-    const char *e = getenv("CPX_VITERBI_PATH");                   // "wave" / "cw" / "cw!" force a path (tests, benchmarks)
+    // CPX_VITERBI_PATH (tests, benchmarks): "wave" = state-per-lane kernels; "cw" = this path whatever the batch size;
+    // "cw!" = fail instead of falling back; a '2' anywhere ("cw2", "cw2!") = the two-kernel form even where the fused
+    // kernel applies
+    const char *e = getenv("CPX_VITERBI_PATH");
     if (e && e[0] == 'w') return false;
     const bool forced = e && e[0] == 'c';
-    const bool strict = forced && e[1] == 'w' && e[2] == '!';     // "cw!": fail instead of falling back
+    const bool strict = forced && strchr(e, '!') != nullptr;
+    const bool two_kernels = forced && strchr(e, '2') != nullptr;
     auto reject = [&](const char *why) {
         if (!strict) return false;
         set_error("viterbi (codeword path): %s", why);
@@ -338,6 +549,10 @@ bool viterbi_codeword_path(const cpx_trellis *t, const double *d_coded, int64_t 
     p.type = type; p.tb = tb;
 #define CPX_TRY(LG, GA, GB)                                                                                         \
     if (tables_match<LG, GA, GB>(t)) {                                                                              \
+        if (tb == FUSED_TB && !two_kernels && launch_fused<LG, GA, GB>(p, st)) {                                    \
+            if (hipGetLastError() != hipSuccess) { set_error("viterbi (fused codeword path): launch failed"); *rc = CPX_EHIP; } \
+            return true;                                                                                            \
+        }                                                                                                           \
         void *w0 = nullptr, *w1 = nullptr;                                                                          \
         p.Tp = (T + LG - 1) / LG * LG;                                                                              \
         if ((*rc = workspace(st, 0, sizeof(unsigned long long) * (size_t)(groups * p.Tp * 64), &w0))) return true;  \

@@ -1,6 +1,7 @@
 """The codeword-per-lane Viterbi path (csrc/viterbi_cw.hip) against the reference goldens, the CPU oracle and the
-state-per-lane kernels -- bit-exact for every decoding type.  CPX_VITERBI_PATH forces a path: "cw!" fails instead of
-falling back, "wave" disables the codeword path."""
+state-per-lane kernels -- bit-exact for every decoding type.  CPX_VITERBI_PATH forces a path: "cw!" = codeword path or
+fail (the fused single kernel when tb_depth = 30, else ACS + traceback kernels), "cw2!" = always the two-kernel form,
+"wave" = state-per-lane kernels."""
 import os
 
 import numpy as np
@@ -54,21 +55,24 @@ def test_golden_k7_cases_through_the_codeword_path(gpu):
             continue
         tr = make_trellis(tname)
         tb = None if tb == "None" else int(tb)
-        dec = _decode(g[key + "__in"], tr, tb, dtype, "cw!")
         done += 1
-        if dec.dtype != np.int64 or not np.array_equal(dec, g[key + "__out"]):
-            bad.append(str(nm))
+        for path in ("cw!", "cw2!"):
+            dec = _decode(g[key + "__in"], tr, tb, dtype, path)
+            if dec.dtype != np.int64 or not np.array_equal(dec, g[key + "__out"]):
+                bad.append(str(nm) + path)
     assert done >= 24, done
     assert not bad, bad[:10]
     c2 = golden("viterbi_c2")
     tr = make_trellis("k7_133_171")
     for tag in ("e3", "e1"):
-        assert np.array_equal(_decode(c2[tag + "__llr"], tr, None, "soft", "cw!"), c2[tag + "__dec"]), tag
+        for path in ("cw!", "cw2!"):
+            assert np.array_equal(_decode(c2[tag + "__llr"], tr, None, "soft", path), c2[tag + "__dec"]), (tag, path)
 
 
 @pytest.mark.parametrize("dtype", ["hard", "soft", "unquantized"])
 @pytest.mark.parametrize("B,nbits,tb", [(1, 1, None), (3, 2, 2), (63, 5, None), (64, 30, None), (65, 31, 15), (130, 96, 40),
-                                        (37, 120, 48), (200, 64, 3), (5, 333, None), (70, 1024, None)])
+                                        (37, 120, 48), (200, 64, 3), (5, 333, None), (70, 1024, None), (257, 24, 30),
+                                        (100, 25, 30), (300, 95, None), (64, 96, 30), (129, 97, 30), (9, 191, 30)])
 def test_random_batches_vs_oracle(gpu, dtype, B, nbits, tb):
     """Seeded batches, ragged groups, window edges (tb = 2, 3, window = 64 KiB limit), ties (hard) -- vs the CPU oracle."""
     from commpy_amd.channelcoding import conv_encode_batch
@@ -84,10 +88,9 @@ def test_random_batches_vs_oracle(gpu, dtype, B, nbits, tb):
         rx[rs.rand(*rx.shape) < 0.01] = 0.0
     else:
         rx = 2.0 * coded - 1 + rs.randn(*coded.shape) * 0.8
-    got = _decode(rx, tr, tb, dtype, "cw!")
     want = oracle.viterbi_decode(rx, tr, tb, dtype)
-    assert np.array_equal(got, want), (dtype, B, nbits, tb)
-    assert np.array_equal(got, _decode(rx, tr, tb, dtype, "wave"))
+    for path in ("cw!", "cw2!", "wave"):
+        assert np.array_equal(_decode(rx, tr, tb, dtype, path), want), (dtype, B, nbits, tb, path)
 
 
 @pytest.mark.parametrize("gm,fmt", [([[0o133, 0o171]], "MSB"), ([[0o171, 0o133]], "MSB")])
@@ -134,6 +137,7 @@ def test_full_size_default_dispatch_equals_wave_kernels(gpu):
     rx = 4.0 * coded - 2 + rs.randn(*coded.shape) * 1.6
     auto = _decode(rx, tr, None, "soft", "auto")
     assert np.array_equal(auto, _decode(rx, tr, None, "soft", "cw!"))
+    assert np.array_equal(auto, _decode(rx, tr, None, "soft", "cw2!"))
     assert np.array_equal(auto, _decode(rx, tr, None, "soft", "wave"))
     sel = np.r_[0:48, B - 48:B]
     assert np.array_equal(auto[sel], oracle.viterbi_decode(rx[sel], tr, None, "soft"))
