@@ -108,9 +108,10 @@ __device__ __forceinline__ void bit_metrics_cw(int type, double r, double &m0, d
 
 // One traceback hop: the decision bit of state st is bit 63 - st of the step's word, i.e. the top bit of (w << st)
 // (v_lshlrev_b64 uses the low 6 bits of st only); st' = (st << 1) | bit in one v_alignbit_b32.  The high bits of st are
-// never masked on the way -- only st mod S is meaningful.
+// never masked on the way -- only st mod S is meaningful (for S < 64 the shift amount is masked explicitly).
+template <int LGS>
 __device__ __forceinline__ unsigned tb_hop(unsigned long long w, unsigned st) {
-    const unsigned hi = (unsigned)((w << (st & 63u)) >> 32);
+    const unsigned hi = (unsigned)((w << (st & ((1u << LGS) - 1u))) >> 32);       // LGS = 6: the mask is the hardware's own
     return __builtin_amdgcn_alignbit(st, hi, 31);
 }
 
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_acs_kernel(CwParams
 // bit of step t - H goes to a staging tile in LDS and the tile is written out every 96 steps, one coalesced 64-byte
 // store per codeword and half-tile.  HBM traffic is the algorithmic one again (the two-kernel path moves 9 B per
 // codeword-step through a workspace and back).
-constexpr int FR_RING = 32, FR_GROUPS = 16, FR_OBPAD = 100;     // ring slots (mirrored), groups of LGS steps per flush, tile row bytes
+constexpr int FR_RING = 32, FR_CHUNK = 96, FR_OBPAD = 100;     // ring slots (mirrored), steps per flush (a multiple of LGS), tile row bytes
 
 template <int LGS>
 constexpr size_t fused_wave_lds() {
@@ -258,7 +259,7 @@ constexpr size_t fused_wave_lds() {
 // step: the LDS reads of a batch are issued one phase before their hops, so their latency hides behind the
 // add-compare-select arithmetic (left to itself the compiler emits the walk as 14 read -> wait -> 2-hop rounds at the end
 // of the step: +0.5 ms).  sched_barrier pins the batches where they are put.
-template <int H>
+template <int LGS, int H>
 struct WalkHook {
     static constexpr int NB = 4, PER = (H + NB - 1) / NB;
     const unsigned long long *pw;           // ring pointer of the walked step t': word of step t' - h at pw[(FR_RING - h) * 64]
@@ -272,7 +273,7 @@ struct WalkHook {
     template <int B> __device__ __forceinline__ void hops() const {
 #pragma unroll
         for (int i = 0; i < PER; i++)
-            if (B * PER + i < H) st = tb_hop(buf[i], st);
+            if (B * PER + i < H) st = tb_hop<LGS>(buf[i], st);
     }
     template <int P> __device__ __forceinline__ void at() const {
         __builtin_amdgcn_sched_barrier(0);
@@ -293,8 +294,8 @@ struct WalkHook {
 
 template <int LGS, unsigned G0, unsigned G1, int TYPE, int H>
 __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_fused_kernel(CwParams p) {
-    constexpr int S = 1 << LGS, CHUNK = FR_GROUPS * LGS;
-    static_assert(H + 1 <= FR_RING && CHUNK + 1 <= FR_OBPAD, "ring / tile too small");
+    constexpr int S = 1 << LGS, FR_GROUPS = FR_CHUNK / LGS, CHUNK = FR_GROUPS * LGS;
+    static_assert(H >= 0 && H + 1 <= FR_RING && CHUNK + 1 <= FR_OBPAD, "ring / tile too small");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t grp = (int64_t)blockIdx.x * ACS_WAVES + wv;
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_fused_kernel(CwPara
 #pragma unroll
     for (int u = 0; u < LGS; u++) cur[u] = load(1 + u);
     int best_T = 0;                                                               // first-argmin state of step T
-    WalkHook<H> walk;                                                             // walk of the previous step (step 0: a dummy)
+    WalkHook<LGS, H> walk;                                                             // walk of the previous step (step 0: a dummy)
     walk.pw = mycol;
     walk.st = 0;
 
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_fused_kernel(CwPara
         int n = ngroups * LGS;
         if (tc0 + CHUNK > p.T) {                                                   // last chunk: finish the pending walk (of its last step)
             unsigned st = walk.st;
-            for (int h = 0; h < H; h++) st = tb_hop(walk.pw[(FR_RING - h) * 64], st);
+            for (int h = 0; h < H; h++) st = tb_hop<LGS>(walk.pw[(FR_RING - h) * 64], st);
             myrow[n] = (unsigned char)((st >> (LGS - 1)) & 1u);
             n++;
         }
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_fused_kernel(CwPara
             const int64_t so = p.T - h;
             if (so < 1) break;
             if (so - 1 < p.L) p.bits[cw * p.L + so - 1] = (uint8_t)((st >> (LGS - 1)) & 1u);
-            st = tb_hop(mycol[(qT + FR_RING - h) * 64], st);
+            st = tb_hop<LGS>(mycol[(qT + FR_RING - h) * 64], st);
         }
     }
 }
@@ -441,14 +442,14 @@ __global__ __launch_bounds__(TB_THREADS) void viterbi_cw_tb_kernel(CwParams p) {
                 // the addresses do not depend on the states: unrolled, the reads of four hops are in flight together
 #pragma unroll 4
                 for (int h = 0; h < H; h++) {
-                    st0 = tb_hop(win[idx + c0], st0);
-                    st1 = tb_hop(win[idx + c1], st1);
+                    st0 = tb_hop<LGS>(win[idx + c0], st0);
+                    st1 = tb_hop<LGS>(win[idx + c1], st1);
                     idx -= TB_STRIDE;
                 }
             } else {
                 for (int h = 0; h < H; h++) {
                     const bool go = so + H - h <= p.T;                            // rows past `need` hold stale words: skipped
-                    const unsigned n0 = tb_hop(win[idx + c0], st0), n1 = tb_hop(win[idx + c1], st1);
+                    const unsigned n0 = tb_hop<LGS>(win[idx + c0], st0), n1 = tb_hop<LGS>(win[idx + c1], st1);
                     st0 = go ? n0 : st0;
                     st1 = go ? n1 : st1;
                     idx -= TB_STRIDE;
@@ -487,12 +488,12 @@ void launch(const CwParams &p, size_t tb_lds, hipStream_t st) {
     hipLaunchKernelGGL((viterbi_cw_tb_kernel<LGS>), dim3(groups), dim3(TB_THREADS), tb_lds, st, p);
 }
 
-// fused kernel: instantiated for the default traceback depth of the K = 7 code (tb_depth = 30)
-constexpr int FUSED_TB = 30;
+// fused kernel: instantiated for the reference's default traceback depth, tb_depth = 5 * total_memory (convcode.py:701)
+template <int LGS> constexpr int fused_tb() { return 5 * LGS; }
 
 template <int LGS, unsigned G0, unsigned G1, int TYPE>
 int launch_fused_typed(const CwParams &p, hipStream_t st) {
-    auto *fn = viterbi_cw_fused_kernel<LGS, G0, G1, TYPE, FUSED_TB - 2>;
+    auto *fn = viterbi_cw_fused_kernel<LGS, G0, G1, TYPE, fused_tb<LGS>() - 2>;
     const size_t lds = ACS_WAVES * fused_wave_lds<LGS>();
     static bool raised = false;                                  // > 64 KiB of dynamic LDS is opt-in, once per kernel
     if (!raised) {
@@ -549,7 +550,7 @@ bool viterbi_codeword_path(const cpx_trellis *t, const double *d_coded, int64_t 
     p.type = type; p.tb = tb;
 #define CPX_TRY(LG, GA, GB)                                                                                         \
     if (tables_match<LG, GA, GB>(t)) {                                                                              \
-        if (tb == FUSED_TB && !two_kernels && launch_fused<LG, GA, GB>(p, st)) {                                    \
+        if (tb == fused_tb<LG>() && !two_kernels && launch_fused<LG, GA, GB>(p, st)) {                                    \
             if (hipGetLastError() != hipSuccess) { set_error("viterbi (fused codeword path): launch failed"); *rc = CPX_EHIP; } \
             return true;                                                                                            \
         }                                                                                                           \
@@ -568,6 +569,9 @@ bool viterbi_codeword_path(const cpx_trellis *t, const double *d_coded, int64_t 
     // (133,171) -> (155,117).
     CPX_TRY(6, 0155u, 0117u)      // K = 7 (133,171), commpy default format: 802.11 / BASELINE configs 2 and 5
     CPX_TRY(6, 0117u, 0155u)      // K = 7 (171,133)
+    // (K = 3 (5,7) and K = 5 (23,35) instantiate and pass the same tests -- CPX_TRY(2, 05u, 07u), CPX_TRY(4, 031u, 027u) --
+    //  but are not built: with 4 or 16 states the wave kernels already pack 16 / 4 codewords into a wavefront and the
+    //  one-wave-per-SIMD structure of this path loses -- BASELINE config 1, 2^20 codewords: 0.77 ms here, 0.56 ms there.)
 #undef CPX_TRY
     return reject("no instantiation for this trellis");
 }

@@ -39,19 +39,25 @@ def test_forced_path_is_really_taken(gpu):
     tr = make_trellis("k8_247_371")
     with pytest.raises(ValueError):
         _decode(np.zeros((2, 60)), tr, None, "hard", "cw!")
+    with pytest.raises(ValueError):
+        _decode(np.zeros((2, 60)), make_trellis("rsc_legacy_4"), None, "hard", "cw!")   # recursive: not a shift register
     tr = make_trellis("k7_133_171")
     with pytest.raises(ValueError):
         _decode(np.zeros((2, 61)), tr, None, "hard", "cw!")          # odd row length: rows not 16-byte aligned
     assert _decode(np.zeros((2, 60)), tr, None, "hard", "cw!").shape == (2, 30)
 
 
-def test_golden_k7_cases_through_the_codeword_path(gpu):
-    """Every K=7 (133,171) case of the reference grid (hard/soft/unquantized x term/cont x tb x noise, +-inf LLRs)."""
+CW_TRELLISES = ("k7_133_171",)     # the instantiated code: K = 7 (133,171)
+
+
+def test_golden_cases_through_the_codeword_path(gpu):
+    """Every case of the reference grid for the instantiated codes (hard/soft/unquantized x term/cont x tb x noise,
+    +-inf LLRs)."""
     g = golden("viterbi_small")
     done, bad = 0, []
     for nm in g["names"]:
         key, tname, term, dtype, tb, noisy = str(nm).split("|")
-        if tname != "k7_133_171" or len(g[key + "__in"]) % 2:
+        if tname not in CW_TRELLISES or len(g[key + "__in"]) % 2:
             continue
         tr = make_trellis(tname)
         tb = None if tb == "None" else int(tb)
