@@ -89,6 +89,11 @@ int cpx_trellis_destroy(cpx_trellis *t);
  *   bits       [B][L] uint8 decoded bits, tail included (convcode.py:749)
  * Decision rule: the bit(s) of step s come from the survivor of the
  * first-minimum state at step min(s+tb_depth-2, n_steps), ties -> lowest index.
+ * Kernel selection is internal and does not change a single output bit: batches of >= 3/4 * (SIMDs of the device) * 64
+ * codewords of the K = 7 (133,171) code run one codeword per lane (csrc/viterbi_cw.hip: a single fused kernel when
+ * tb_depth is the default 5*m = 30, an add-compare-select + a traceback kernel with a 9 B per codeword-step device
+ * workspace otherwise, tb_depth <= 48); everything else runs one trellis state per lane (csrc/viterbi.hip).  The
+ * environment variable CPX_VITERBI_PATH = wave | cw | cw! | cw2 | cw2! overrides the choice (tests, benchmarks).
  */
 int cpx_viterbi_decode_batch(const cpx_trellis *t, const double *coded, int64_t B, int64_t len,
                              int64_t L, int64_t n_steps, int tb_depth, int decoding_type, uint8_t *bits);
