@@ -348,3 +348,67 @@ class DeviceWifiLink:
                 done += T * self.nbits
             out.append(errs / done)
         return np.array(out)
+
+    def ber_sweep_batched(self, snrs_db, n_bits):
+        """Same result statistics as :meth:`ber_sweep`, with ONE Viterbi call for the whole sweep.
+
+        The element-wise stages (bits, encode, puncture, modulate, AWGN, demod, depuncture) run per SNR point on their
+        slice of sweep-sized buffers; the decoder and the error counter then see all ``len(snrs) * T`` frames at once,
+        which is what gives the large-batch Viterbi kernel (one codeword per lane, csrc/viterbi_cw.hip) its batch.
+        """
+        lib, ck = self.lib, _lib.check
+        nb = self.modem.num_bits_symbol
+        T = int(math.ceil(n_bits / self.nbits))
+        P = len(snrs_db)
+        R = P * T
+        key = ('sweep', R)
+        if self._bufs.get('T') != key:
+            for b in self._bufs.values():
+                if isinstance(b, DeviceBuf):
+                    b.free()
+            bufs = {'T': key,
+                    'msg': DeviceBuf(R * self.nbits), 'coded': DeviceBuf(T * self.ncoded),
+                    'sym': DeviceBuf(T * self.nsym * 16), 'llr': DeviceBuf(T * self.nsym * nb * 8),
+                    'llr_all': DeviceBuf(R * self.nde * 8), 'dec': DeviceBuf(R * self.nbits),
+                    'errs': DeviceBuf(R * self.agg * 4)}
+            if self.keep_idx is not None:
+                bufs['tx'] = DeviceBuf(T * self.ntx)
+                bufs['keep_idx'] = DeviceBuf.from_array(self.keep_idx)
+                bufs['de_idx'] = DeviceBuf.from_array(self.de_idx)
+            self._bufs = bufs
+        bufs = self._bufs
+        h_tr, h_md = self.trellis._device_handle(), self.modem._device_handle()
+
+        def at(buf, nbytes):
+            return ctypes.c_void_p(buf.ptr.value + nbytes)
+
+        for i, snr_db in enumerate(snrs_db):
+            noise_std = math.sqrt(2.0 * self.modem.Es / (self.rate * 10 ** (float(snr_db) / 10.0)))   # channels.py:74
+            self._calls += 1
+            msg = at(bufs['msg'], i * T * self.nbits)
+            llr_out = at(bufs['llr_all'], i * T * self.nde * 8)
+            ck(lib.cpx_random_bits_dev(msg, T * self.nbits, self.seed, 2 * self._calls, None))
+            ck(lib.cpx_conv_encode_batch_dev(h_tr, msg, T, self.nbits, 0, 0, bufs['coded'].ptr, self.ncoded, None))
+            tx = bufs['coded']
+            if self.keep_idx is not None:
+                ck(lib.cpx_gather_u8_dev(bufs['coded'].ptr, T, self.ncoded, bufs['keep_idx'].ptr, self.ntx, bufs['tx'].ptr, None))
+                tx = bufs['tx']
+            ck(lib.cpx_modulate_dev(h_md, tx.ptr, T * self.nsym, bufs['sym'].ptr, None))
+            ck(lib.cpx_awgn_dev(bufs['sym'].ptr, T * self.nsym, noise_std * 0.5, noise_std * 0.5, self.seed,
+                                2 * self._calls + 1, bufs['sym'].ptr, None))
+            if self.keep_idx is not None:
+                ck(lib.cpx_demod_soft_dev(h_md, bufs['sym'].ptr, T * self.nsym, noise_std ** 2, bufs['llr'].ptr, None))
+                ck(lib.cpx_gather_f64_dev(bufs['llr'].ptr, T, self.ntx, bufs['de_idx'].ptr, self.nde, llr_out, None))
+            else:
+                ck(lib.cpx_demod_soft_dev(h_md, bufs['sym'].ptr, T * self.nsym, noise_std ** 2, llr_out, None))
+        m = self.trellis.total_memory
+        length = self.nde
+        L = int(length * 0.5)
+        n_steps = int((L + m) / 1) - 1
+        ck(lib.cpx_viterbi_decode_batch_dev(h_tr, bufs['llr_all'].ptr, R, length, L, n_steps, min(5 * m, L), 1,
+                                            bufs['dec'].ptr, None))
+        ck(lib.cpx_count_errors_dev(bufs['msg'].ptr, self.nbits, bufs['dec'].ptr, L, R, self.agg, self.send_chunk,
+                                    bufs['errs'].ptr, None))
+        ck(lib.cpx_stream_sync(None))
+        errs = bufs['errs'].to_array((P, T * self.agg), np.int32)
+        return errs.sum(axis=1) / float(T * self.nbits)

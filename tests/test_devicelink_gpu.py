@@ -69,16 +69,17 @@ def test_device_wifi_link_overlays_reference(gpu, gname, mcs):
     key = "w_%s_mcs%d" % (gname, mcs)
     snrs, ref = g[key + "__snrs"], g[key + "__ber"]
     link = DeviceWifiLink(mcs, 600, generator_matrix=[[0o133, 0o171]] if gname == "octal" else None, seed=11 + mcs)
-    bers = link.ber_sweep(snrs, 600 * 2048)
     ref_bits = int(g[key + "__tx"]) * 600
-    for s, b, r in zip(snrs, bers, ref):
-        ref_errors = r * ref_bits
-        if ref_errors >= 100:
-            assert r / 2 <= b <= 2 * r, (key, s, b, r)
-        elif ref_errors >= 10:
-            assert r / 4 <= b <= 4 * r, (key, s, b, r)
-        else:
-            assert b <= max(8 * r, 100.0 / ref_bits), (key, s, b, r)
+    # per-point calls, and the whole sweep through one Viterbi call (the large-batch kernel when 49152+ frames)
+    for bers in (link.ber_sweep(snrs, 600 * 2048), link.ber_sweep_batched(snrs, 600 * 8192)):
+        for s, b, r in zip(snrs, bers, ref):
+            ref_errors = r * ref_bits
+            if ref_errors >= 100:
+                assert r / 2 <= b <= 2 * r, (key, s, b, r)
+            elif ref_errors >= 10:
+                assert r / 4 <= b <= 4 * r, (key, s, b, r)
+            else:
+                assert b <= max(8 * r, 100.0 / ref_bits), (key, s, b, r)
 
 
 def test_device_wifi_link_matches_host_pipeline(gpu):
@@ -93,6 +94,24 @@ def test_device_wifi_link_matches_host_pipeline(gpu):
     dev = DeviceWifiLink(1, 600, generator_matrix=[[0o133, 0o171]], seed=3).ber_sweep(snrs, 600 * 6000)
     assert np.all(dev > 0) and np.all(host > 0)
     assert np.all(np.abs(np.log(dev / host)) < np.log(1.6)), (dev, host)
+
+
+def test_device_wifi_link_batched_sweep_noiseless_and_equal_paths(gpu):
+    """The batched sweep decodes every frame of every point (very high SNR -> zero errors), and its BER does not depend
+    on which Viterbi kernels decode it (same random streams, CPX_VITERBI_PATH = wave vs default)."""
+    import os
+    from commpy_amd.devicelink import DeviceWifiLink
+    snrs = np.array([40.0, 41.0, 42.0])
+    assert not DeviceWifiLink(5, 1200, generator_matrix=[[0o133, 0o171]], seed=9).ber_sweep_batched(snrs, 1200 * 20000).any()
+    snrs = np.array([14.0, 15.0, 16.0])
+    res = {}
+    for path in ("wave", "auto"):
+        os.environ["CPX_VITERBI_PATH"] = path
+        try:
+            res[path] = DeviceWifiLink(5, 1200, generator_matrix=[[0o133, 0o171]], seed=9).ber_sweep_batched(snrs, 1200 * 20000)
+        finally:
+            os.environ.pop("CPX_VITERBI_PATH", None)
+    assert np.array_equal(res["wave"], res["auto"]) and res["auto"][0] > 0
 
 
 def test_device_wifi_link_noiseless(gpu):
