@@ -130,12 +130,13 @@ def test_continuous_termination_and_short_windows(gpu):
 
 
 def test_full_size_default_dispatch_equals_wave_kernels(gpu):
-    """BASELINE config-2 size: the default dispatch (codeword path at this batch) and the wave kernels return the same
-    bits for all 65536 codewords; a slice is checked against the oracle; the noiseless batch decodes to the messages."""
+    """BASELINE config-2 size plus a partial round (the default dispatch sends one full round of 65536 codewords through
+    the fused kernel and the last 5000 through the wave kernels): same bits as every forced path for all codewords; slices
+    against the oracle; the noiseless batch decodes to the messages."""
     from commpy_amd.channelcoding import conv_encode_batch
     tr = make_trellis("k7_133_171")
     rs = np.random.RandomState(10)
-    B = 65536
+    B = 65536 + 5000
     msgs = rs.randint(0, 2, (B, 1024))
     coded = conv_encode_batch(msgs, tr).astype(np.float64)
     clean = _decode(4.0 * coded - 2, tr, None, "soft", "cw!")
@@ -145,6 +146,6 @@ def test_full_size_default_dispatch_equals_wave_kernels(gpu):
     assert np.array_equal(auto, _decode(rx, tr, None, "soft", "cw!"))
     assert np.array_equal(auto, _decode(rx, tr, None, "soft", "cw2!"))
     assert np.array_equal(auto, _decode(rx, tr, None, "soft", "wave"))
-    sel = np.r_[0:48, B - 48:B]
+    sel = np.r_[0:48, 65536 - 24:65536 + 24, B - 48:B]
     assert np.array_equal(auto[sel], oracle.viterbi_decode(rx[sel], tr, None, "soft"))
     assert 0 < np.mean(auto[:, :1024] != msgs) < 0.05
