@@ -402,31 +402,59 @@ __global__ __launch_bounds__(64) void turbo_decode_kernel(TurboParams p) {
     // L arrays of all codewords: [B][3][N] -> per-codeword stride 3N; A at +0, B at +N, C at +2N
     double *A0 = p.larr, *B0 = p.larr + N, *C0 = p.larr + 2 * N;
     const int64_t ls = 3 * N;
-    double *A = A0 + (valid ? cw : 0) * ls, *Bb = B0 + (valid ? cw : 0) * ls, *C = C0 + (valid ? cw : 0) * ls;
-    if (valid)
-        for (int64_t t = c.s; t < N; t += S) A[t] = p.Lint ? p.Lint[cw * N + t] : 0.0;     // L_int_1 (:305-308)
+    // The element-wise stages between the MAP passes are done by the whole wave, one codeword after the other, 64
+    // consecutive elements per instruction and four independent rounds in flight.  (The first version gave every
+    // codeword to its own S lanes: N/S dependent load -> store rounds per stage, 3.9 of the 14.0 ms of config 3.)
+    const int lane = c.lane, GW = p.GW;
+    (void)cw; (void)valid; (void)S;
+    for (int g = 0; g < GW; g++) {
+        const int64_t cwg = cw0 + g;
+        if (cwg >= p.B) break;
+        double *A = A0 + cwg * ls;
+#pragma unroll 4
+        for (int64_t t = lane; t < N; t += 64) A[t] = p.Lint ? p.Lint[cwg * N + t] : 0.0;      // L_int_1 (:305-308)
+    }
     __syncthreads();
     for (int it = 0; it < p.n_iter; it++) {
         // [L_ext_1, _] = map_decode(sys, non_sys_1, trellis, nv, L_int_1, 'compute')   (:315)
         map_pass<LGS>(c, cw0, p.B, N, p.nv2, p.sys, nullptr, p.p1, A0, ls, beta, B0);
-        // L_ext_1 -= L_int_1 ; L_int_2 = interlv(L_ext_1)                               (:318-319)
-        if (valid)
-            for (int64_t t = c.s; t < N; t += S) Bb[t] = Bb[t] - A[t];
         __syncthreads();
-        if (valid)
-            for (int64_t t = c.s; t < N; t += S) C[t] = Bb[p.perm[t]];
+        // L_ext_1 -= L_int_1 ; L_int_2 = interlv(L_ext_1)                               (:318-319), one pass: same subtraction
+        for (int g = 0; g < GW; g++) {
+            const int64_t cwg = cw0 + g;
+            if (cwg >= p.B) break;
+            const double *A = A0 + cwg * ls, *Bb = B0 + cwg * ls;
+            double *C = C0 + cwg * ls;
+#pragma unroll 4
+            for (int64_t t = lane; t < N; t += 64) {
+                const int32_t q = p.perm[t];
+                C[t] = Bb[q] - A[q];
+            }
+        }
         __syncthreads();
         // [L_2, bits] = map_decode(sys_i, non_sys_2, trellis, nv, L_int_2, mode)          (:326)
         map_pass<LGS>(c, cw0, p.B, N, p.nv2, p.sys, p.perm, p.p2, C0, ls, beta, B0);
+        __syncthreads();
         // L_ext_2 = L_2 - L_int_2 ; L_int_1 = deinterlv(L_ext_2)                          (:328-329)
-        if (valid)
-            for (int64_t t = c.s; t < N; t += S) A[p.perm[t]] = Bb[t] - C[t];
+        for (int g = 0; g < GW; g++) {
+            const int64_t cwg = cw0 + g;
+            if (cwg >= p.B) break;
+            const double *Bb = B0 + cwg * ls, *C = C0 + cwg * ls;
+            double *A = A0 + cwg * ls;
+#pragma unroll 4
+            for (int64_t t = lane; t < N; t += 64) A[p.perm[t]] = Bb[t] - C[t];
+        }
         __syncthreads();
     }
     // decoded_bits = deinterlv(decoded_bits of the last MAP2)                              (:331)
-    if (valid)
-        for (int64_t t = c.s; t < N; t += S)
-            p.bits[cw * N + p.perm[t]] = (uint8_t)((p.n_iter > 0 && Bb[t] > 0) ? 1 : 0);
+    for (int g = 0; g < GW; g++) {
+        const int64_t cwg = cw0 + g;
+        if (cwg >= p.B) break;
+        const double *Bb = B0 + cwg * ls;
+#pragma unroll 4
+        for (int64_t t = lane; t < N; t += 64)
+            p.bits[cwg * N + p.perm[t]] = (uint8_t)((p.n_iter > 0 && Bb[t] > 0) ? 1 : 0);
+    }
 }
 
 // codewords per wavefront: full wavefronts as soon as the batch gives every SIMD of the chip one of them; for
