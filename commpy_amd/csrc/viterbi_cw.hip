@@ -495,13 +495,15 @@ template <int LGS, unsigned G0, unsigned G1, int TYPE>
 int launch_fused_typed(const CwParams &p, hipStream_t st) {
     auto *fn = viterbi_cw_fused_kernel<LGS, G0, G1, TYPE, fused_tb<LGS>() - 2>;
     const size_t lds = ACS_WAVES * fused_wave_lds<LGS>();
-    static bool raised = false;                                  // > 64 KiB of dynamic LDS is opt-in, once per kernel
-    if (!raised) {
+    static bool raised[64] = {};                                 // > 64 KiB of dynamic LDS is opt-in, once per kernel and device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (!raised[dev]) {
         if (hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            (void)hipGetLastError();
+            (void)hipGetLastError();                             // a device with less LDS: the two-kernel form is used
             return 0;
         }
-        raised = true;
+        raised[dev] = true;
     }
     const unsigned groups = (unsigned)((p.B + 63) / 64), blocks = (groups + ACS_WAVES - 1) / ACS_WAVES;
     hipLaunchKernelGGL(fn, dim3(blocks), dim3(64 * ACS_WAVES), lds, st, p);
