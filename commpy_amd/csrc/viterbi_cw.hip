@@ -169,8 +169,24 @@ __device__ __forceinline__ void cw_step(double (&pm)[1 << LGS], double r0, doubl
     const double mn = vmin(vmin(m0, m1), vmin(m2, m3));
     hook.template at<3>();
     int bst = 0;
+    if constexpr (S % 4 == 0) {
+        // first state equal to the minimum, scanned downwards four states at a time: four compares into four SGPR pairs,
+        // then the four selects.  A select right behind its float64 compare needs two wait states on gfx950 (the compiler
+        // pads every pair with s_nop 1); here three instructions always sit between a compare and its select (-4 %).
 #pragma unroll
-    for (int s = S - 1; s >= 0; s--) bst = (pm[rotl<LGS>(s, R + 1)] == mn) ? s : bst;
+        for (int s = S - 4; s >= 0; s -= 4) {
+            unsigned long long k0, k1, k2, k3;
+            asm("v_cmp_eq_f64 %1, %5, %9\n\tv_cmp_eq_f64 %2, %6, %9\n\tv_cmp_eq_f64 %3, %7, %9\n\tv_cmp_eq_f64 %4, %8, %9\n\t"
+                "v_cndmask_b32 %0, %0, %10, %1\n\tv_cndmask_b32 %0, %0, %11, %2\n\tv_cndmask_b32 %0, %0, %12, %3\n\t"
+                "v_cndmask_b32 %0, %0, %13, %4"
+                : "+v"(bst), "=&s"(k0), "=&s"(k1), "=&s"(k2), "=&s"(k3)
+                : "v"(pm[rotl<LGS>(s + 3, R + 1)]), "v"(pm[rotl<LGS>(s + 2, R + 1)]), "v"(pm[rotl<LGS>(s + 1, R + 1)]),
+                  "v"(pm[rotl<LGS>(s, R + 1)]), "v"(mn), "v"(s + 3), "v"(s + 2), "v"(s + 1), "v"(s));
+        }
+    } else {
+#pragma unroll
+        for (int s = S - 1; s >= 0; s--) bst = (pm[rotl<LGS>(s, R + 1)] == mn) ? s : bst;
+    }
     // shifting the decisions in in increasing state order leaves state j of a half at bit H-1-j of its word; placing the
     // lower half on top puts state s at bit 63 - s of the 64-bit word: the traceback reads it as the top bit of (w << s)
     word = ((unsigned long long)da << (64 - H)) | ((unsigned long long)db << (64 - S));
