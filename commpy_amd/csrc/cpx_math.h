@@ -11,6 +11,9 @@ namespace cpx {
 // sum-product check pass and the branch-metric stage.  Special values as libm: log(0) = -inf, log(x < 0) = NaN,
 // log(inf) = inf, a NaN argument is returned unchanged (its sign decides dec_word in
 // the LDPC passes exactly as it does through libm); denormals are handled by v_frexp.
+// SPECIAL = false drops the four special-value selects: for arguments known to be finite and >= 1 (the Viterbi branch
+// metrics take log(exp(r) + 1) with |r| <= 500) the result is bit-identical and 4 compares + 8 selects shorter.
+template <bool SPECIAL = true>
 __device__ __forceinline__ double fast_log(double x) {
     constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
     constexpr double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
@@ -30,10 +33,12 @@ __device__ __forceinline__ double fast_log(double x) {
     const double hfsq = 0.5 * f * f;
     const double dk = (double)e;
     double r = dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
-    r = (x == 0.0) ? -__builtin_huge_val() : r;
-    r = (x == __builtin_huge_val()) ? x : r;
-    r = (x < 0.0) ? __builtin_nan("") : r;
-    r = (x != x) ? x : r;                                         // a NaN argument is returned as is (sign and payload)
+    if (SPECIAL) {
+        r = (x == 0.0) ? -__builtin_huge_val() : r;
+        r = (x == __builtin_huge_val()) ? x : r;
+        r = (x < 0.0) ? __builtin_nan("") : r;
+        r = (x != x) ? x : r;                                     // a NaN argument is returned as is (sign and payload)
+    }
     return r;
 }
 

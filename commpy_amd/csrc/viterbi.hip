@@ -143,7 +143,7 @@ __device__ __forceinline__ void bit_metrics(int type, double r, double &m0, doub
         m0 = (double)(ri ^ 0ll);                // hamming_dist = sum of xor (utilities.py:130)
         m1 = (double)(ri ^ 1ll);
     } else if (type == CPX_VIT_SOFT) {
-        double nll0 = fast_log(exp(r) + 1.0);   // :582
+        double nll0 = fast_log<false>(exp(r) + 1.0);   // :582 (r is clipped to +-500: the argument is finite and >= 1)
         m0 = nll0;
         m1 = nll0 - r;                          // :583
     } else {

@@ -96,7 +96,7 @@ __device__ __forceinline__ void bit_metrics_cw(int type, double r, double &m0, d
         m0 = (double)(ri ^ 0ll);
         m1 = (double)(ri ^ 1ll);
     } else if (type == CPX_VIT_SOFT) {
-        double nll0 = fast_log(exp(r) + 1.0);
+        double nll0 = fast_log<false>(exp(r) + 1.0);   // r is clipped to +-500: the argument is finite and >= 1
         m0 = nll0;
         m1 = nll0 - r;
     } else {
