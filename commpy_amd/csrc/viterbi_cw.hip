@@ -181,7 +181,7 @@ __device__ __forceinline__ void cw_step(double (&pm)[1 << LGS], double r0, doubl
                 "v_cndmask_b32 %0, %0, %13, %4"
                 : "+v"(bst), "=&s"(k0), "=&s"(k1), "=&s"(k2), "=&s"(k3)
                 : "v"(pm[rotl<LGS>(s + 3, R + 1)]), "v"(pm[rotl<LGS>(s + 2, R + 1)]), "v"(pm[rotl<LGS>(s + 1, R + 1)]),
-                  "v"(pm[rotl<LGS>(s, R + 1)]), "v"(mn), "v"(s + 3), "v"(s + 2), "v"(s + 1), "v"(s));
+                  "v"(pm[rotl<LGS>(s, R + 1)]), "v"(mn), "n"(s + 3), "n"(s + 2), "n"(s + 1), "n"(s));   // inline constants
         }
     } else {
 #pragma unroll
@@ -215,16 +215,18 @@ __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_acs_kernel(CwParams
     for (int s = 0; s < S; s++) pm[s] = (s == 0) ? 0.0 : __builtin_huge_val();   // path_metrics[:,0] = inf, [0][0] = 0 (:705-706)
 
     const double pad = (TYPE == CPX_VIT_UNQUANTIZED) ? -1.0 : 0.0;                // t > L//k -> padding (:722-734)
-    const int64_t tmax = (p.Lk < p.T) ? p.Lk : p.T;                               // last step with received values (>= 1)
-    auto load = [&](int64_t t) {                                                  // always a valid address; padded below
-        const int64_t tc = (t < tmax) ? t : tmax;
-        return *reinterpret_cast<const double2 *>(x + (tc - 1) * 2);
+    // step indices are 32-bit (the dispatcher guarantees T < 2^31): the scalar unit has no signed 64-bit compare, and
+    // 64-bit step arithmetic put ~20 VALU instructions per step of purely wave-uniform work into the hot loop
+    const int T = (int)p.T, tmax = (int)((p.Lk < p.T) ? p.Lk : p.T);              // tmax: last step with received values (>= 1)
+    auto load = [&](int t) {                                                      // always a valid address; padded below
+        const int tc = (t < tmax) ? t : tmax;
+        return *reinterpret_cast<const double2 *>(x + (int64_t)(tc - 1) * 2);
     };
     double2 cur[LGS], nxt[LGS];
 #pragma unroll
     for (int u = 0; u < LGS; u++) cur[u] = load(1 + u);
     // groups of LGS steps; a partial last group simply runs on (steps > T see padding, their rows are never read)
-    for (int64_t t = 1; t <= p.T; t += LGS) {
+    for (int t = 1; t <= T; t += LGS) {
 #pragma unroll
         for (int u = 0; u < LGS; u++) nxt[u] = load(t + LGS + u);                // prefetch: lands during this group
 #pragma unroll
@@ -233,8 +235,8 @@ __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_acs_kernel(CwParams
             cur[u].x = have ? cur[u].x : pad;
             cur[u].y = have ? cur[u].y : pad;
         }
-        unsigned long long *d = dec + (t - 1) * 64;
-        unsigned char *b = best + (t - 1) * 64;
+        unsigned long long *d = dec + (int64_t)(t - 1) * 64;
+        unsigned char *b = best + (int64_t)(t - 1) * 64;
         auto one = [&](auto rtag, const double2 &v) {
             constexpr int R = decltype(rtag)::value;
             unsigned long long word;
@@ -329,10 +331,10 @@ __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_fused_kernel(CwPara
     for (int s = 0; s < S; s++) pm[s] = (s == 0) ? 0.0 : __builtin_huge_val();   // path_metrics[:,0] = inf, [0][0] = 0 (:705-706)
 
     const double pad = (TYPE == CPX_VIT_UNQUANTIZED) ? -1.0 : 0.0;                // t > L//k -> padding (:722-734)
-    const int64_t tmax = (p.Lk < p.T) ? p.Lk : p.T;                               // last step with received values (>= 1)
-    auto load = [&](int64_t t) {                                                  // always a valid address; padded at use
-        const int64_t tc = (t < tmax) ? t : tmax;
-        return *reinterpret_cast<const double2 *>(x + (tc - 1) * 2);
+    const int T = (int)p.T, tmax = (int)((p.Lk < p.T) ? p.Lk : p.T);              // 32-bit step indices, see the ACS kernel
+    auto load = [&](int t) {                                                      // always a valid address; padded at use
+        const int tc = (t < tmax) ? t : tmax;
+        return *reinterpret_cast<const double2 *>(x + (int64_t)(tc - 1) * 2);
     };
     double2 cur[LGS];
 #pragma unroll
@@ -344,27 +346,27 @@ __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_fused_kernel(CwPara
 
     // writes the decoded bits staged in tile entries 0 .. n-1: entry li holds the result of the walk of step tc0 + li - 1,
     // i.e. output step tc0 + li - 1 - H
-    auto flush = [&](int64_t tc0, int n) {
+    auto flush = [&](int tc0, int n) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                         // the tile rows are complete (same wave wrote them)
         for (int c = 0; c < 64; c++) {
             const int64_t cwc = grp * 64 + c;
             if (cwc >= p.B) break;
             for (int li = lane; li < n; li += 64) {
-                const int64_t so = tc0 + li - 1 - H;
-                if (so >= 1 && so <= p.T - H && so - 1 < p.L) p.bits[cwc * p.L + so - 1] = obuf[c * FR_OBPAD + li];
+                const int so = tc0 + li - 1 - H;
+                if (so >= 1 && so <= T - H && so - 1 < p.L) p.bits[cwc * p.L + so - 1] = obuf[c * FR_OBPAD + li];
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                         // tile read before the next chunk overwrites it
     };
 
-    for (int64_t tc0 = 1; tc0 <= p.T; tc0 += CHUNK) {
-        int64_t left = (p.T - tc0) / LGS + 1;                                      // groups that start at a step <= T
-        const int ngroups = (int)(left < FR_GROUPS ? left : FR_GROUPS);
+    for (int tc0 = 1; tc0 <= T; tc0 += CHUNK) {
+        const int left = (T - tc0) / LGS + 1;                                      // groups that start at a step <= T
+        const int ngroups = left < FR_GROUPS ? left : FR_GROUPS;
         for (int g = 0; g < ngroups; g++) {
-            const int64_t t = tc0 + (int64_t)g * LGS;
+            const int t = tc0 + g * LGS;
             auto one = [&](auto rtag) {
                 constexpr int R = decltype(rtag)::value;
-                const int64_t tt = t + R;
+                const int tt = t + R;
                 const bool have = tt <= tmax;
                 const double r0 = have ? cur[R].x : pad, r1 = have ? cur[R].y : pad;
                 cur[R] = load(tt + LGS);                                          // prefetch: needed one group later
@@ -375,14 +377,14 @@ __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_fused_kernel(CwPara
                 myrow[g * LGS + R] = (unsigned char)((walk.st >> (LGS - 1)) & 1u);   // input bit of the branch into the state at step tt - 1 - H
                 // ring slot of step tt and its mirror FR_RING slots above; the (at most LGS - 1) steps > T of the last group
                 // write to two dummy slots instead: the ring must keep the words of steps T-H+1 .. T for the final walk
-                const bool live = tt <= p.T;
-                const int q = (int)(tt & (FR_RING - 1));
+                const bool live = tt <= T;
+                const int q = tt & (FR_RING - 1);
                 unsigned long long *wb = mycol + q * 64;
                 unsigned long long *w0 = live ? wb : mycol + (2 * FR_RING) * 64;
                 unsigned long long *w1 = live ? wb + FR_RING * 64 : mycol + (2 * FR_RING + 1) * 64;
                 *w0 = word;
                 *w1 = word;
-                best_T = (tt == p.T) ? bst : best_T;
+                best_T = (tt == T) ? bst : best_T;
                 walk.pw = wb;                                                     // next: the walk of this step
                 walk.st = (unsigned)bst;
             };
@@ -394,7 +396,7 @@ __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_fused_kernel(CwPara
             if constexpr (LGS >= 6) one(std::integral_constant<int, 5 % LGS>{});
         }
         int n = ngroups * LGS;
-        if (tc0 + CHUNK > p.T) {                                                   // last chunk: finish the pending walk (of its last step)
+        if (tc0 + CHUNK > T) {                                                     // last chunk: finish the pending walk (of its last step)
             unsigned st = walk.st;
             for (int h = 0; h < H; h++) st = tb_hop<LGS>(walk.pw[(FR_RING - h) * 64], st);
             myrow[n] = (unsigned char)((st >> (LGS - 1)) & 1u);
@@ -404,10 +406,10 @@ __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_fused_kernel(CwPara
     }
     // the last H output steps: one walk from best[T]; the state before hop h is the state of step T - h
     if (valid) {
-        const int qT = (int)(p.T & (FR_RING - 1));
+        const int qT = T & (FR_RING - 1);
         unsigned st = (unsigned)best_T;
         for (int h = 0; h < H; h++) {
-            const int64_t so = p.T - h;
+            const int so = T - h;
             if (so < 1) break;
             if (so - 1 < p.L) p.bits[cw * p.L + so - 1] = (uint8_t)((st >> (LGS - 1)) & 1u);
             st = tb_hop<LGS>(mycol[(qT + FR_RING - h) * 64], st);
@@ -562,7 +564,7 @@ bool viterbi_codeword_path(const cpx_trellis *t, const double *d_coded, int64_t 
     const size_t tb_lds = (size_t)(64 + tb - 2) * (TB_STRIDE * 8 + 64);
     if (tb_lds > 64 * 1024) return reject("traceback window exceeds 64 KiB of LDS");
     const int64_t groups = (B + 63) / 64;
-    if (groups >= (1ll << 31)) return reject("batch too large");
+    if (groups >= (1ll << 31) || T >= (1ll << 31) - 64) return reject("batch too large / block too long");
     CwParams p;
     p.coded = d_coded; p.bits = d_bits; p.B = B; p.len = len; p.L = L; p.T = T; p.Lk = L;   // k = 1
     p.type = type; p.tb = tb;
