@@ -10,16 +10,20 @@
 //     shift-register trellis reads states (2j, 2j+1) and writes (j, j+S/2); leaving the results where the inputs
 //     were rotates the logical->physical register map by one bit per step, so log2(S) unrolled steps return to the
 //     identity: 2S VGPRs hold the metrics and the add-compare-select of all states is straight-line code with NO
-//     cross-lane traffic (2 v_add_f64, v_cmp_lt_f64, 2 v_cndmask, v_addc per state);
+//     cross-lane traffic (2 v_add_f64, v_cmp_lt_f64, v_min_f64 or 2 v_cndmask, v_addc per state);
 //   * WHICH of the four branch metrics a branch uses depends on the generator polynomials; they are template
 //     parameters (the branch code is a constexpr function), instantiated for the standard codes below and checked
 //     against the trellis tables the caller built -- any other trellis takes the state-per-lane kernels;
 //   * the first-argmin state of a step is an in-lane v_min_f64 tree + an in-lane first-equal scan;
-//   * decision words and first-argmin states go to a workspace in HBM, [group of 64 codewords][step][lane] so that
-//     every store is one coalesced line per wave (9 B per codeword-step), and a second kernel runs the sliding
-//     traceback: one workgroup per group stages a window of 64 + tb - 2 steps in LDS (row stride 65 words: the
-//     lanes of a wave walk consecutive rows of one column without bank conflicts) and every wave traces two
-//     codewords at a time, lane-parallel over output steps.
+//   * traceback, two forms:
+//       - fused (viterbi_cw_fused_kernel, default traceback depth 5 m): the decision words stay in an LDS ring per
+//         wave, the walk of step t-1 is pipelined through the arithmetic of step t, decoded bits leave through an
+//         LDS tile -- one kernel, HBM traffic = LLRs in + bits out;
+//       - two kernels (any depth <= 48): decision words and first-argmin states go to a workspace in HBM,
+//         [group of 64 codewords][step][lane] so that every store is one coalesced line per wave (9 B per
+//         codeword-step), and viterbi_cw_tb_kernel runs the sliding traceback: one workgroup per group stages a
+//         window of 64 + tb - 2 steps in LDS (row stride 65 words: the lanes of a wave walk consecutive rows of one
+//         column without bank conflicts) and every wave traces two codewords at a time, lane = output step.
 // Measured on MI355X for BASELINE config 2 (B = 65536, K = 7, soft): see DESIGN.md 4.1.
 #include "cpx_internal.h"
 #include "cpx_math.h"
