@@ -14,6 +14,13 @@ KERNEL(k_add_f64, asm volatile("v_add_f64 %0, %0, %2\n v_add_f64 %1, %1, %3" : "
 KERNEL(k_min_f64, asm volatile("v_min_f64 %0, %0, %2\n v_min_f64 %1, %1, %3" : "+v"(a), "+v"(b) : "v"(c), "v"(d));)
 KERNEL(k_cmp_f64, asm volatile("v_cmp_lt_f64 vcc, %0, %2\n v_cmp_lt_f64 vcc, %1, %3" : "+v"(a), "+v"(b) : "v"(c), "v"(d) : "vcc");)
 KERNEL(k_cndmask, asm volatile("v_cndmask_b32 %0, %0, %2, vcc\n v_cndmask_b32 %1, %1, %3, vcc" : "+v"(x), "+v"(y) : "v"(z), "v"(w) : "vcc");)
+KERNEL(k_cndmask_sgpr, asm volatile("v_cndmask_b32 %0, %0, %2, s[20:21]\n v_cndmask_b32 %1, %1, %3, s[20:21]" : "+v"(x), "+v"(y) : "v"(z), "v"(w) : "s20", "s21");)
+KERNEL(k_cndmask_indep, asm volatile("v_cndmask_b32 %0, %2, %3, vcc\n v_cndmask_b32 %1, %3, %2, vcc" : "=v"(x), "=v"(y) : "v"(z), "v"(w) : "vcc");)
+KERNEL(k_cndmask_init, asm volatile("v_cndmask_b32 %0, %0, %2, vcc\n v_cndmask_b32 %1, %1, %3, vcc" : "+v"(x), "+v"(y) : "v"(z + 1), "v"(w + 1));)
+KERNEL(k_cmp_cnd_vcc, asm volatile("v_cmp_eq_u32 vcc, %0, %2\n v_cndmask_b32 %1, %1, %3, vcc" : "+v"(x), "+v"(y) : "v"(z), "v"(w) : "vcc");)
+KERNEL(k_cmp_cnd_sgpr, asm volatile("v_cmp_eq_u32 s[20:21], %0, %2\n v_cndmask_b32 %1, %1, %3, s[20:21]" : "+v"(x), "+v"(y) : "v"(z), "v"(w) : "s20", "s21");)
+KERNEL(k_cmp64_cnd_vcc, asm volatile("v_cmp_lt_f64 vcc, %0, %2\n s_nop 1\n v_cndmask_b32 %1, %1, %3, vcc" : "+v"(a), "+v"(y) : "v"(c), "v"(w) : "vcc");)
+KERNEL(k_cmp64_cnd_sgpr, asm volatile("v_cmp_lt_f64 s[20:21], %0, %2\n s_nop 1\n v_cndmask_b32 %1, %1, %3, s[20:21]" : "+v"(a), "+v"(y) : "v"(c), "v"(w) : "s20", "s21");)
 KERNEL(k_mov, asm volatile("v_mov_b32 %0, %2\n v_mov_b32 %1, %3" : "+v"(x), "+v"(y) : "v"(z), "v"(w));)
 KERNEL(k_add_u32, asm volatile("v_add_u32 %0, %0, %2\n v_add_u32 %1, %1, %3" : "+v"(x), "+v"(y) : "v"(z), "v"(w));)
 KERNEL(k_dpp, asm volatile("v_mov_b32_dpp %0, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %3 row_mirror row_mask:0xf bank_mask:0xf" : "+v"(x), "+v"(y) : "v"(z), "v"(w));)
@@ -32,7 +39,7 @@ int main() {
     CHECK(hipMalloc(&d_out, sizeof(double) * nblocks * 256));
     struct { const char *name; void (*k)(double *, int); double per_iter; } ks[] = {
         {"v_add_f64", k_add_f64, 32}, {"v_min_f64", k_min_f64, 32}, {"v_fma_f64", k_fma_f64, 32}, {"v_cmp_lt_f64", k_cmp_f64, 32},
-        {"v_cndmask_b32", k_cndmask, 32}, {"v_mov_b32", k_mov, 32}, {"v_add_u32", k_add_u32, 32}, {"v_cmp_eq_u32", k_cmp_u32, 32},
+        {"v_cndmask_b32", k_cndmask, 32}, {"v_cndmask_b32 sgpr mask", k_cndmask_sgpr, 32}, {"v_cndmask_b32 independent", k_cndmask_indep, 32}, {"v_cndmask_b32 z+1 operands", k_cndmask_init, 32}, {"cmp_u32->vcc + cndmask vcc (pair)", k_cmp_cnd_vcc, 16}, {"cmp_u32->sgpr + cndmask sgpr (pair)", k_cmp_cnd_sgpr, 16}, {"cmp_f64->vcc,nop,cndmask vcc (pair)", k_cmp64_cnd_vcc, 16}, {"cmp_f64->sgpr,nop,cndmask sgpr (pair)", k_cmp64_cnd_sgpr, 16}, {"v_mov_b32", k_mov, 32}, {"v_add_u32", k_add_u32, 32}, {"v_cmp_eq_u32", k_cmp_u32, 32},
         {"v_mov_b32_dpp", k_dpp, 32}, {"v_permlane32_swap", k_swap32, 32}, {"v_permlane16_swap", k_swap16, 32},
         {"v_readlane_b32", k_readlane, 32}, {"v_writelane_b32", k_writelane, 32}, {"v_lshrrev_b64", k_lshr64, 32},
         {"exp+log f64 pair (ocml)", k_exp_pipe, 16},
