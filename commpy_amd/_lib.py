@@ -25,12 +25,19 @@ SYMBOLS = {
     "cpx_version": (c_int, []),
     "cpx_device_count": (c_int, [POINTER(c_int)]),
     "cpx_set_device": (c_int, [c_int]),
+    "cpx_get_device": (c_int, [POINTER(c_int)]),
+    "cpx_last_kernel": (c_int, [c_char_p, c_int]),
     "cpx_device_info": (c_int, [c_char_p, c_int, POINTER(c_int), POINTER(c_int64)]),
     "cpx_malloc": (c_int, [POINTER(c_void_p), c_size_t]),
     "cpx_free": (c_int, [c_void_p]),
     "cpx_memset": (c_int, [c_void_p, c_int, c_size_t]),
     "cpx_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_size_t]),
     "cpx_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "cpx_memcpy_h2d_async": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "cpx_memcpy_d2h_async": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "cpx_memcpy_d2d_async": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "cpx_stream_create": (c_int, [POINTER(c_void_p)]),
+    "cpx_stream_destroy": (c_int, [c_void_p]),
     "cpx_stream_sync": (c_int, [c_void_p]),
     "cpx_release_workspace": (c_int, []),
     "cpx_default_stream": (c_void_p, []),
@@ -47,6 +54,11 @@ SYMBOLS = {
                                              c_void_p, c_void_p]),
     "cpx_viterbi_decode_batch_i64": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int,
                                      c_void_p]),
+    "cpx_viterbi_set_path": (c_int, [c_char_p]),
+    "cpx_demod_hard_viterbi_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int,
+                                             c_void_p]),
+    "cpx_demod_hard_viterbi_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int,
+                                                 c_void_p, c_void_p]),
     "cpx_map_decode_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_double, c_int,
                                      c_void_p, c_void_p]),
     "cpx_map_decode_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_double, c_int,
@@ -57,6 +69,10 @@ SYMBOLS = {
                                            c_int64, c_double, c_int, c_void_p, c_void_p]),
     "cpx_ldpc_create": (c_int, [c_int, c_int, c_int64, _i32p, _i32p, POINTER(c_void_p)]),
     "cpx_ldpc_destroy": (c_int, [c_void_p]),
+    "cpx_ldpc_blob_build": (c_int, [c_int, c_int, c_int64, _i32p, _i32p, c_void_p, c_size_t, POINTER(c_size_t)]),
+    "cpx_ldpc_blob_info": (c_int, [c_void_p, c_size_t, POINTER(c_int), POINTER(c_int), POINTER(c_int64), POINTER(c_int),
+                                   POINTER(c_int)]),
+    "cpx_ldpc_create_from_blob": (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
     "cpx_ldpc_bp_decode_batch": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "cpx_ldpc_bp_decode_batch_dev": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                              c_void_p]),
@@ -79,6 +95,14 @@ SYMBOLS = {
     "cpx_ldpc_encoder_create": (c_int, [c_void_p, c_int64, c_int64, POINTER(c_void_p)]),
     "cpx_ldpc_encoder_destroy": (c_int, [c_void_p]),
     "cpx_ldpc_encode_batch_dev": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "cpx_comm_unique_id": (c_int, [c_void_p]),
+    "cpx_comm_init_rank": (c_int, [c_void_p, c_int, c_int, POINTER(c_void_p)]),
+    "cpx_comm_init_all": (c_int, [POINTER(c_int), c_int, POINTER(c_void_p)]),
+    "cpx_comm_info": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+    "cpx_comm_destroy": (c_int, [c_void_p]),
+    "cpx_comm_allgather_u8": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_size_t, POINTER(c_void_p)]),
+    "cpx_comm_allreduce_i64": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_size_t, c_int, POINTER(c_void_p)]),
+    "cpx_comm_allreduce_f64": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_size_t, c_int, POINTER(c_void_p)]),
 }
 
 
@@ -149,3 +173,36 @@ def as_f64(a):
 
 def as_i32(a):
     return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def current_device():
+    d = c_int(0)
+    check(load().cpx_get_device(ctypes.byref(d)))
+    return d.value
+
+
+def last_kernel():
+    """Name of the kernel the last decoder call of this thread launched (cpx_last_kernel)."""
+    buf = ctypes.create_string_buffer(200)
+    check(load().cpx_last_kernel(buf, 200))
+    return buf.value.decode()
+
+
+def viterbi_last_path():
+    """'fused' | 'cw2' | 'wave' | 'wide' | 'fused+wave' ...: the Viterbi kernel path of the last call, from cpx_last_kernel."""
+    k = last_kernel()
+    parts = []
+    if "viterbi_cw_fused_kernel" in k:
+        parts.append("fused")
+    if "viterbi_cw_acs_kernel" in k:
+        parts.append("cw2")
+    if "viterbi_wave_kernel" in k:
+        parts.append("wave")
+    if "viterbi_wide_kernel" in k:
+        parts.append("wide")
+    return "+".join(parts)
+
+
+def viterbi_set_path(mode):
+    """Force a Viterbi kernel path: None/'auto', 'wave', 'cw', 'cw!', 'cw2', 'cw2!' (tests and benchmarks)."""
+    check(load().cpx_viterbi_set_path(None if mode is None else mode.encode()))

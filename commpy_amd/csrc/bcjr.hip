@@ -471,6 +471,7 @@ int pick_gw(int S, int64_t B) {
 
 int fill_tables(const cpx_trellis *t, MapTables &tb) {
     CPX_REQUIRE(t, CPX_EINVAL, "map_decode: null trellis");
+    if (int rcd = check_handle_device(t->device, "map_decode")) return rcd;
     CPX_REQUIRE(t->I == 2 && t->k == 1, CPX_ELIMIT, "map_decode: only k = 1 (two inputs per step) trellises are supported, like the reference's priors[2]");
     CPX_REQUIRE(t->n >= 2, CPX_EINVAL, "map_decode: needs a rate-1/2 trellis (n >= 2)");
     CPX_REQUIRE(t->S >= 2 && t->S <= 16, CPX_ELIMIT, "map_decode: 2..16 states supported (got %d)", t->S);

@@ -14,6 +14,12 @@ namespace cpx {
 
 void set_error(const char *fmt, ...);
 hipStream_t lib_stream();   // lazily created per-process stream of the current device
+// name of the (dominant) kernel the last decoder call of this thread launched -- read back by cpx_last_kernel(), so
+// that benchmarks and tests report what really ran instead of re-deriving the dispatch rules
+void note_kernel(const char *fmt, ...);
+const char *last_kernel_name();
+// CPX_EINVAL unless the current device is the one the handle's tables were created on
+int check_handle_device(int handle_device, const char *what);
 int ensure_device();        // CPX_OK if a HIP device is usable
 int device_cus();           // compute units of the current device (256 on MI355X)
 // workgroups of `fn` (block size `threads`, no dynamic LDS) resident on the whole device at once -- the size of a
@@ -45,6 +51,8 @@ int workspace(hipStream_t stream, int slot, size_t bytes, void **out);
 // codeword-per-lane Viterbi path (viterbi_cw.hip): true when it handled the call (*rc = status)
 bool viterbi_codeword_path(const ::cpx_trellis *t, const double *d_coded, int64_t B, int64_t len, int64_t L, int64_t T,
                            int tb, int type, uint8_t *d_bits, hipStream_t st, int *rc);
+
+int viterbi_path_flags();   // bit 0 wave only, bit 1 codeword path forced, bit 2 strict, bit 3 two-kernel form
 
 inline hipStream_t pick_stream(void *s) { return s ? reinterpret_cast<hipStream_t>(s) : lib_stream(); }
 

@@ -21,6 +21,7 @@
 //     distances are closer than 1e-12 relative are re-decided with the reference's full hypot scan.
 #include "cpx_internal.h"
 #include "cpx_math.h"
+#include "demod_dev.h"
 
 #include <cmath>
 
@@ -92,16 +93,6 @@ __global__ __launch_bounds__(DEMOD_BLOCK) void demod_soft_sep_kernel(const doubl
     }
 }
 
-__device__ __forceinline__ int hard_scan(const double2 *c_s, int M, double2 cur) {
-    int best = 0;
-    double bd = hypot(cur.x - c_s[0].x, cur.y - c_s[0].y);
-    for (int m = 1; m < M; m++) {                                 // abs(y - c[:, None]).argmin(0): first minimum (:122)
-        const double a = hypot(cur.x - c_s[m].x, cur.y - c_s[m].y);
-        if (a < bd) { bd = a; best = m; }
-    }
-    return best;
-}
-
 __global__ __launch_bounds__(DEMOD_BLOCK) void demod_hard_kernel(const double2 *__restrict__ y, int64_t Ns,
                                                                  const double2 *__restrict__ cst, int M, int nb,
                                                                  int8_t *__restrict__ bits) {
@@ -126,18 +117,7 @@ __global__ __launch_bounds__(DEMOD_BLOCK) void demod_hard_sep_kernel(const doubl
     for (int m = threadIdx.x; m < 2 * R; m += DEMOD_BLOCK) ax_s[m] = axes[m];
     __syncthreads();
     for (int64_t i = (int64_t)blockIdx.x * DEMOD_BLOCK + threadIdx.x; i < Ns; i += (int64_t)gridDim.x * DEMOD_BLOCK) {
-        const double2 cur = y[i];
-        int ia = 0, ib = 0;
-        double da = fabs(cur.x - ax_s[0]), db = fabs(cur.y - ax_s[R]), da2 = __builtin_huge_val(), db2 = da2;
-#pragma unroll
-        for (int a = 1; a < R; a++) {
-            const double dx = fabs(cur.x - ax_s[a]), dy = fabs(cur.y - ax_s[R + a]);
-            if (dx < da) { da2 = da; da = dx; ia = a; } else if (dx < da2) da2 = dx;
-            if (dy < db) { db2 = db; db = dy; ib = a; } else if (dy < db2) db2 = dy;
-        }
-        int best = (ia << NH) | ib;
-        // near-tie between the two closest grid lines on either axis: decide like the reference (full hypot scan)
-        if (da2 - da <= 1e-12 * da2 || db2 - db <= 1e-12 * db2) best = hard_scan(c_s, M, cur);
+        const int best = hard_sep<NH>(c_s, ax_s, y[i]);
 #pragma unroll
         for (int b = 0; b < NB; b++) bits[i * NB + b] = (int8_t)((best >> (NB - 1 - b)) & 1);   // dec2bitarray (:123)
     }
@@ -201,6 +181,7 @@ int cpx_modem_destroy(cpx_modem *m) {
 
 int cpx_demod_soft_dev(const cpx_modem *m, const double *d_y, int64_t Ns, double noise_var, double *d_llr, void *stream) {
     CPX_REQUIRE(m, CPX_EINVAL, "demod: null modem");
+    if (int rcd = check_handle_device(m->device, "demod")) return rcd;
     CPX_REQUIRE(Ns >= 0, CPX_EINVAL, "demod: negative size");
     if (Ns == 0) return CPX_OK;
     hipStream_t st = pick_stream(stream);
@@ -228,6 +209,7 @@ int cpx_demod_soft_dev(const cpx_modem *m, const double *d_y, int64_t Ns, double
 
 int cpx_demod_hard_dev(const cpx_modem *m, const double *d_y, int64_t Ns, int8_t *d_bits, void *stream) {
     CPX_REQUIRE(m, CPX_EINVAL, "demod: null modem");
+    if (int rcd = check_handle_device(m->device, "demod")) return rcd;
     CPX_REQUIRE(Ns >= 0, CPX_EINVAL, "demod: negative size");
     if (Ns == 0) return CPX_OK;
     hipStream_t st = pick_stream(stream);

@@ -608,15 +608,100 @@ __global__ __launch_bounds__(LB) void ldpc_final_kernel(Bufs bf, int n_v, int64_
 
 extern "C" {
 
-int cpx_ldpc_create(int n_vnodes, int n_cnodes, int64_t n_edges, const int32_t *edge_check, const int32_t *edge_var,
-                    cpx_ldpc **out) {
-    CPX_REQUIRE(out && edge_check && edge_var, CPX_EINVAL, "cpx_ldpc_create: null pointer");
+// ---- compiled design ("blob"): everything the device needs about a Tanner graph, position-independent ------------------
+// Layout (little endian, int32 words after the header):
+//   header   magic "CPXLDPC1", version, n_v, n_c, max_cdeg, max_vdeg, cpad, vpad, n_edges, payload words, FNV-1a of the payload
+//   payload  edge_check[E] edge_var[E] row_ptr[n_c+1] col_ptr[n_v+1] col_edge[E] col_cj[E]
+//            row_pad[n_c*cpad+16] col_pad_edge[n_v*vpad+16] col_pad_cj[n_v*vpad+16]
+// Built on the host without a device (cpx_ldpc_blob_build), so a design file can be compiled once and the blob cached
+// next to it, keyed by the file's hash (commpy_amd/channelcoding/ldpc.py); cpx_ldpc_create_from_blob validates and uploads.
+struct LdpcBlobHeader {
+    char magic[8];
+    uint32_t version;
+    int32_t n_v, n_c, max_cdeg, max_vdeg, cpad, vpad;
+    int32_t reserved;
+    int64_t n_edges;
+    uint64_t payload_words;
+    uint64_t checksum;
+};
+static_assert(sizeof(LdpcBlobHeader) == 64, "blob header layout");
+static const char LDPC_BLOB_MAGIC[8] = {'C', 'P', 'X', 'L', 'D', 'P', 'C', '1'};
+
+static uint64_t fnv1a(const void *data, size_t n) {
+    const unsigned char *p = static_cast<const unsigned char *>(data);
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 1099511628211ull; }
+    return h;
+}
+
+struct LdpcBlobView {                       // pointers into a validated blob
+    const LdpcBlobHeader *h;
+    const int32_t *edge_check, *edge_var, *row_ptr, *col_ptr, *col_edge, *col_cj, *row_pad, *col_pad_edge, *col_pad_cj;
+    size_t n_row_pad, n_col_pad;
+};
+
+static size_t blob_payload_words(int64_t E, int n_v, int n_c, int cpad, int vpad) {
+    return (size_t)(4 * E + (n_c + 1) + (n_v + 1)) + ((size_t)n_c * cpad + 16) + 2 * ((size_t)n_v * vpad + 16);
+}
+
+static int blob_view(const void *blob, size_t nbytes, LdpcBlobView &v) {
+    CPX_REQUIRE(blob && nbytes >= sizeof(LdpcBlobHeader), CPX_EINVAL, "ldpc blob: too short");
+    CPX_REQUIRE(((uintptr_t)blob & 3) == 0, CPX_EINVAL, "ldpc blob: buffer must be 4-byte aligned");
+    const LdpcBlobHeader *h = static_cast<const LdpcBlobHeader *>(blob);
+    CPX_REQUIRE(memcmp(h->magic, LDPC_BLOB_MAGIC, 8) == 0 && h->version == 1, CPX_EINVAL, "ldpc blob: bad magic / version");
+    CPX_REQUIRE(h->n_v > 0 && h->n_c > 0 && h->n_edges > 0 && h->n_edges < (1ll << 30) && h->n_v < (1 << 24) && h->n_c < (1 << 24),
+                CPX_EINVAL, "ldpc blob: bad dimensions");
+    CPX_REQUIRE(h->max_cdeg >= 1 && h->max_cdeg <= MAXDEG && h->max_vdeg >= 1 && h->cpad == ((h->max_cdeg + 3) & ~3) &&
+                h->vpad == ((h->max_vdeg + 3) & ~3), CPX_EINVAL, "ldpc blob: bad degrees");
+    const size_t words = blob_payload_words(h->n_edges, h->n_v, h->n_c, h->cpad, h->vpad);
+    CPX_REQUIRE(h->payload_words == words && nbytes == sizeof(LdpcBlobHeader) + 4 * words, CPX_EINVAL, "ldpc blob: size mismatch");
+    const int32_t *w = reinterpret_cast<const int32_t *>(h + 1);
+    CPX_REQUIRE(fnv1a(w, 4 * words) == h->checksum, CPX_EINVAL, "ldpc blob: checksum mismatch (corrupted cache file?)");
+    const int64_t E = h->n_edges;
+    v.h = h;
+    v.edge_check = w; w += E;
+    v.edge_var = w; w += E;
+    v.row_ptr = w; w += h->n_c + 1;
+    v.col_ptr = w; w += h->n_v + 1;
+    v.col_edge = w; w += E;
+    v.col_cj = w; w += E;
+    v.n_row_pad = (size_t)h->n_c * h->cpad + 16;
+    v.n_col_pad = (size_t)h->n_v * h->vpad + 16;
+    v.row_pad = w; w += v.n_row_pad;
+    v.col_pad_edge = w; w += v.n_col_pad;
+    v.col_pad_cj = w;
+    // the kernels index device memory with these tables: range-check all of them
+    CPX_REQUIRE(v.row_ptr[0] == 0 && v.row_ptr[h->n_c] == E && v.col_ptr[0] == 0 && v.col_ptr[h->n_v] == E, CPX_EINVAL,
+                "ldpc blob: bad row/column pointers");
+    for (int c = 0; c < h->n_c; c++) {
+        const int d = v.row_ptr[c + 1] - v.row_ptr[c];
+        CPX_REQUIRE(d >= 0 && d <= h->max_cdeg, CPX_EINVAL, "ldpc blob: bad check degree");
+    }
+    for (int q = 0; q < h->n_v; q++) {
+        const int d = v.col_ptr[q + 1] - v.col_ptr[q];
+        CPX_REQUIRE(d >= 0 && d <= h->max_vdeg, CPX_EINVAL, "ldpc blob: bad variable degree");
+    }
+    for (int64_t e = 0; e < E; e++) {
+        CPX_REQUIRE(v.edge_check[e] >= 0 && v.edge_check[e] < h->n_c && v.edge_var[e] >= 0 && v.edge_var[e] < h->n_v &&
+                    v.col_edge[e] >= 0 && v.col_edge[e] < E && (v.col_cj[e] >> 5) >= 0 && (v.col_cj[e] >> 5) < h->n_c &&
+                    (v.col_cj[e] & 31) < h->max_cdeg, CPX_EINVAL, "ldpc blob: index out of range");
+    }
+    for (size_t i = 0; i < v.n_row_pad; i++)
+        CPX_REQUIRE(v.row_pad[i] >= 0 && v.row_pad[i] < h->n_v, CPX_EINVAL, "ldpc blob: padded row entry out of range");
+    for (size_t i = 0; i < v.n_col_pad; i++)
+        CPX_REQUIRE(v.col_pad_edge[i] >= 0 && v.col_pad_edge[i] < E && (v.col_pad_cj[i] >> 5) >= 0 &&
+                    (v.col_pad_cj[i] >> 5) < h->n_c, CPX_EINVAL, "ldpc blob: padded column entry out of range");
+    return CPX_OK;
+}
+
+int cpx_ldpc_blob_build(int n_vnodes, int n_cnodes, int64_t n_edges, const int32_t *edge_check, const int32_t *edge_var,
+                        void *blob, size_t cap, size_t *need) {
+    CPX_REQUIRE(edge_check && edge_var && need, CPX_EINVAL, "cpx_ldpc_blob_build: null pointer");
     CPX_REQUIRE(n_vnodes > 0 && n_cnodes > 0 && n_edges > 0, CPX_EINVAL, "cpx_ldpc_create: empty code");
     CPX_REQUIRE(n_edges < (1ll << 30), CPX_ELIMIT, "cpx_ldpc_create: too many edges");
-    int rc = ensure_device();
-    if (rc) return rc;
+    CPX_REQUIRE(n_vnodes < (1 << 24) && n_cnodes < (1 << 24), CPX_ELIMIT, "cpx_ldpc_create: code too large (n < 2^24)");
     const int64_t E = n_edges;
-    std::vector<int32_t> row_ptr(n_cnodes + 1, 0), col_ptr(n_vnodes + 1, 0), col_edge(E);
+    std::vector<int32_t> row_ptr(n_cnodes + 1, 0), col_ptr(n_vnodes + 1, 0);
     for (int64_t e = 0; e < E; e++) {
         CPX_REQUIRE(edge_check[e] >= 0 && edge_check[e] < n_cnodes && edge_var[e] >= 0 && edge_var[e] < n_vnodes,
                     CPX_EINVAL, "cpx_ldpc_create: edge %lld out of range", (long long)e);
@@ -631,47 +716,103 @@ int cpx_ldpc_create(int n_vnodes, int n_cnodes, int64_t n_edges, const int32_t *
     int max_cdeg = 0, max_vdeg = 0;
     for (int c = 0; c < n_cnodes; c++) { max_cdeg = std::max(max_cdeg, row_ptr[c + 1]); row_ptr[c + 1] += row_ptr[c]; }
     for (int v = 0; v < n_vnodes; v++) { max_vdeg = std::max(max_vdeg, col_ptr[v + 1]); col_ptr[v + 1] += col_ptr[v]; }
-    CPX_REQUIRE(n_vnodes < (1 << 24) && n_cnodes < (1 << 24), CPX_ELIMIT, "cpx_ldpc_create: code too large (n < 2^24)");
     CPX_REQUIRE(max_cdeg <= MAXDEG, CPX_ELIMIT, "cpx_ldpc_create: check degree %d > %d not supported", max_cdeg, MAXDEG);
-    std::vector<int32_t> fill(col_ptr.begin(), col_ptr.end() - 1), col_cj(E);
+    const int cpad = (max_cdeg + 3) & ~3, vpad = (max_vdeg + 3) & ~3;
+    const size_t words = blob_payload_words(E, n_vnodes, n_cnodes, cpad, vpad);
+    *need = sizeof(LdpcBlobHeader) + 4 * words;
+    if (!blob) return CPX_OK;                                                    // size query
+    CPX_REQUIRE(cap >= *need, CPX_EINVAL, "cpx_ldpc_blob_build: buffer too small (%zu < %zu)", cap, *need);
+    CPX_REQUIRE(((uintptr_t)blob & 7) == 0, CPX_EINVAL, "cpx_ldpc_blob_build: buffer must be 8-byte aligned");
+    LdpcBlobHeader *h = static_cast<LdpcBlobHeader *>(blob);
+    memset(h, 0, sizeof(*h));
+    memcpy(h->magic, LDPC_BLOB_MAGIC, 8);
+    h->version = 1; h->n_v = n_vnodes; h->n_c = n_cnodes; h->max_cdeg = max_cdeg; h->max_vdeg = max_vdeg;
+    h->cpad = cpad; h->vpad = vpad; h->n_edges = E; h->payload_words = words;
+    int32_t *w = reinterpret_cast<int32_t *>(h + 1);
+    memset(w, 0, 4 * words);
+    int32_t *b_ec = w; w += E;
+    int32_t *b_ev = w; w += E;
+    int32_t *b_rp = w; w += n_cnodes + 1;
+    int32_t *b_cp = w; w += n_vnodes + 1;
+    int32_t *b_ce = w; w += E;
+    int32_t *b_cj = w; w += E;
+    int32_t *b_rpad = w; w += (size_t)n_cnodes * cpad + 16;       // + 16: the pipelined passes read a fixed number of
+    int32_t *b_cpe = w; w += (size_t)n_vnodes * vpad + 16;         // entries per row, past the last row's end
+    int32_t *b_cpc = w;
+    memcpy(b_ec, edge_check, 4 * (size_t)E);
+    memcpy(b_ev, edge_var, 4 * (size_t)E);
+    memcpy(b_rp, row_ptr.data(), 4 * (size_t)(n_cnodes + 1));
+    memcpy(b_cp, col_ptr.data(), 4 * (size_t)(n_vnodes + 1));
+    std::vector<int32_t> fill(col_ptr.begin(), col_ptr.end() - 1);
     for (int64_t e = 0; e < E; e++) {                                            // increasing e == increasing check
         const int32_t q = fill[edge_var[e]]++;
-        col_edge[q] = (int32_t)e;
-        col_cj[q] = (edge_check[e] << 5) | (int32_t)(e - row_ptr[edge_check[e]]);
+        b_ce[q] = (int32_t)e;
+        b_cj[q] = (edge_check[e] << 5) | (int32_t)(e - row_ptr[edge_check[e]]);
     }
-    cpx_ldpc *c = new cpx_ldpc;
-    c->n_v = n_vnodes; c->n_c = n_cnodes; c->n_edges = E; c->max_cdeg = max_cdeg; c->max_vdeg = max_vdeg;
-    (void)hipGetDevice(&c->device);
-    CPX_HIP(hipMalloc((void **)&c->d_edge_var, sizeof(int32_t) * E));
-    CPX_HIP(hipMalloc((void **)&c->d_row_ptr, sizeof(int32_t) * (n_cnodes + 1)));
-    CPX_HIP(hipMalloc((void **)&c->d_col_ptr, sizeof(int32_t) * (n_vnodes + 1)));
-    CPX_HIP(hipMalloc((void **)&c->d_col_edge, sizeof(int32_t) * E));
-    CPX_HIP(hipMalloc((void **)&c->d_col_cj, sizeof(int32_t) * E));
-    CPX_HIP(hipMemcpy(c->d_edge_var, edge_var, sizeof(int32_t) * E, hipMemcpyHostToDevice));
-    CPX_HIP(hipMemcpy(c->d_row_ptr, row_ptr.data(), sizeof(int32_t) * (n_cnodes + 1), hipMemcpyHostToDevice));
-    CPX_HIP(hipMemcpy(c->d_col_ptr, col_ptr.data(), sizeof(int32_t) * (n_vnodes + 1), hipMemcpyHostToDevice));
-    CPX_HIP(hipMemcpy(c->d_col_edge, col_edge.data(), sizeof(int32_t) * E, hipMemcpyHostToDevice));
-    CPX_HIP(hipMemcpy(c->d_col_cj, col_cj.data(), sizeof(int32_t) * E, hipMemcpyHostToDevice));
-    c->cpad = (max_cdeg + 3) & ~3;
-    c->vpad = (max_vdeg + 3) & ~3;
-    // + 16: the pipelined passes read a fixed number of entries per row, past the last row's end
-    std::vector<int32_t> row_pad((size_t)n_cnodes * c->cpad + 16, 0), cpe((size_t)n_vnodes * c->vpad + 16, 0),
-        cpc((size_t)n_vnodes * c->vpad + 16, 0);
     for (int k = 0; k < n_cnodes; k++)
-        for (int j = 0; j < row_ptr[k + 1] - row_ptr[k]; j++) row_pad[(size_t)k * c->cpad + j] = edge_var[row_ptr[k] + j];
+        for (int j = 0; j < row_ptr[k + 1] - row_ptr[k]; j++) b_rpad[(size_t)k * cpad + j] = edge_var[row_ptr[k] + j];
     for (int v = 0; v < n_vnodes; v++)
         for (int q = 0; q < col_ptr[v + 1] - col_ptr[v]; q++) {
-            cpe[(size_t)v * c->vpad + q] = col_edge[col_ptr[v] + q];
-            cpc[(size_t)v * c->vpad + q] = col_cj[col_ptr[v] + q];
+            b_cpe[(size_t)v * vpad + q] = b_ce[col_ptr[v] + q];
+            b_cpc[(size_t)v * vpad + q] = b_cj[col_ptr[v] + q];
         }
-    CPX_HIP(hipMalloc((void **)&c->d_row_pad, sizeof(int32_t) * row_pad.size()));
-    CPX_HIP(hipMalloc((void **)&c->d_col_pad_edge, sizeof(int32_t) * cpe.size()));
-    CPX_HIP(hipMalloc((void **)&c->d_col_pad_cj, sizeof(int32_t) * cpc.size()));
-    CPX_HIP(hipMemcpy(c->d_row_pad, row_pad.data(), sizeof(int32_t) * row_pad.size(), hipMemcpyHostToDevice));
-    CPX_HIP(hipMemcpy(c->d_col_pad_edge, cpe.data(), sizeof(int32_t) * cpe.size(), hipMemcpyHostToDevice));
-    CPX_HIP(hipMemcpy(c->d_col_pad_cj, cpc.data(), sizeof(int32_t) * cpc.size(), hipMemcpyHostToDevice));
+    h->checksum = fnv1a(h + 1, 4 * words);
+    return CPX_OK;
+}
+
+int cpx_ldpc_blob_info(const void *blob, size_t nbytes, int *n_vnodes, int *n_cnodes, int64_t *n_edges, int *max_cnode_deg,
+                       int *max_vnode_deg) {
+    LdpcBlobView v;
+    int rc = blob_view(blob, nbytes, v);
+    if (rc) return rc;
+    if (n_vnodes) *n_vnodes = v.h->n_v;
+    if (n_cnodes) *n_cnodes = v.h->n_c;
+    if (n_edges) *n_edges = v.h->n_edges;
+    if (max_cnode_deg) *max_cnode_deg = v.h->max_cdeg;
+    if (max_vnode_deg) *max_vnode_deg = v.h->max_vdeg;
+    return CPX_OK;
+}
+
+int cpx_ldpc_create_from_blob(const void *blob, size_t nbytes, cpx_ldpc **out) {
+    CPX_REQUIRE(out, CPX_EINVAL, "cpx_ldpc_create_from_blob: null pointer");
+    LdpcBlobView v;
+    int rc = blob_view(blob, nbytes, v);
+    if (rc) return rc;
+    if ((rc = ensure_device())) return rc;
+    const LdpcBlobHeader *h = v.h;
+    const int64_t E = h->n_edges;
+    cpx_ldpc *c = new cpx_ldpc;
+    c->n_v = h->n_v; c->n_c = h->n_c; c->n_edges = E; c->max_cdeg = h->max_cdeg; c->max_vdeg = h->max_vdeg;
+    c->cpad = h->cpad; c->vpad = h->vpad;
+    (void)hipGetDevice(&c->device);
+    struct Up { int32_t **dst; const int32_t *src; size_t n; } ups[] = {
+        {&c->d_edge_var, v.edge_var, (size_t)E}, {&c->d_row_ptr, v.row_ptr, (size_t)h->n_c + 1},
+        {&c->d_col_ptr, v.col_ptr, (size_t)h->n_v + 1}, {&c->d_col_edge, v.col_edge, (size_t)E},
+        {&c->d_col_cj, v.col_cj, (size_t)E}, {&c->d_row_pad, v.row_pad, v.n_row_pad},
+        {&c->d_col_pad_edge, v.col_pad_edge, v.n_col_pad}, {&c->d_col_pad_cj, v.col_pad_cj, v.n_col_pad}};
+    for (auto &u : ups) {
+        hipError_t e1 = hipMalloc((void **)u.dst, sizeof(int32_t) * u.n);
+        hipError_t e2 = e1 == hipSuccess ? hipMemcpy(*u.dst, u.src, sizeof(int32_t) * u.n, hipMemcpyHostToDevice) : e1;
+        if (e2 != hipSuccess) {
+            set_error("cpx_ldpc_create: device upload failed: %s", hipGetErrorString(e2));
+            cpx_ldpc_destroy(c);
+            return CPX_EHIP;
+        }
+    }
     *out = c;
     return CPX_OK;
+}
+
+int cpx_ldpc_create(int n_vnodes, int n_cnodes, int64_t n_edges, const int32_t *edge_check, const int32_t *edge_var,
+                    cpx_ldpc **out) {
+    CPX_REQUIRE(out && edge_check && edge_var, CPX_EINVAL, "cpx_ldpc_create: null pointer");
+    size_t need = 0;
+    int rc = cpx_ldpc_blob_build(n_vnodes, n_cnodes, n_edges, edge_check, edge_var, nullptr, 0, &need);
+    if (rc) return rc;
+    if ((rc = ensure_device())) return rc;
+    std::vector<uint64_t> buf((need + 7) / 8);
+    if ((rc = cpx_ldpc_blob_build(n_vnodes, n_cnodes, n_edges, edge_check, edge_var, buf.data(), buf.size() * 8, &need))) return rc;
+    return cpx_ldpc_create_from_blob(buf.data(), need, out);
 }
 
 int cpx_ldpc_destroy(cpx_ldpc *c) {
@@ -685,6 +826,7 @@ int cpx_ldpc_destroy(cpx_ldpc *c) {
 int cpx_ldpc_bp_decode_batch_dev(const cpx_ldpc *c, double *d_llr, int64_t B, int alg, int n_iters, int8_t *d_dec,
                                  double *d_out, int32_t *d_iters, void *stream) {
     CPX_REQUIRE(c, CPX_EINVAL, "ldpc: null code");
+    if (int rcd = check_handle_device(c->device, "ldpc")) return rcd;
     CPX_REQUIRE(alg == CPX_LDPC_SPA || alg == CPX_LDPC_MSA, CPX_EINVAL,
                 "Please input a valid decoder_algorithm string (meanning \"SPA\" or \"MSA\").");
     CPX_REQUIRE(B >= 0 && n_iters >= 0, CPX_EINVAL, "ldpc: negative size");

@@ -248,6 +248,7 @@ int cpx_random_bits_dev(uint8_t *d_bits, int64_t n, uint64_t seed, uint64_t stre
 int cpx_conv_encode_batch_dev(const cpx_trellis *t, const uint8_t *d_msg, int64_t B, int64_t nmsg, int terminate, int rsc,
                               uint8_t *d_coded, int64_t nout, void *stream) {
     CPX_REQUIRE(t, CPX_EINVAL, "conv_encode: null trellis");
+    if (int rcd = check_handle_device(t->device, "conv_encode")) return rcd;
     CPX_REQUIRE(B >= 0 && nmsg >= 0 && nout >= 0, CPX_EINVAL, "conv_encode: negative size");
     if (B == 0 || nout == 0) return CPX_OK;
     int total_memory = 0;
@@ -294,6 +295,7 @@ int cpx_gather_f64_dev(const double *d_in, int64_t B, int64_t nin, const int32_t
 
 int cpx_modulate_dev(const cpx_modem *m, const uint8_t *d_bits, int64_t nsym, double *d_sym_re_im, void *stream) {
     CPX_REQUIRE(m, CPX_EINVAL, "modulate: null modem");
+    if (int rcd = check_handle_device(m->device, "modulate")) return rcd;
     CPX_REQUIRE(nsym >= 0, CPX_EINVAL, "modulate: negative size");
     if (nsym == 0) return CPX_OK;
     hipLaunchKernelGGL(modulate_kernel, dim3(ls_grid(nsym)), dim3(LS_BLOCK), 0, pick_stream(stream), d_bits, nsym, m->nbits,

@@ -6,8 +6,6 @@
 #include <mutex>
 #include <utility>
 
-#include <mutex>
-
 namespace cpx {
 
 static thread_local char g_err[1024] = "";
@@ -20,14 +18,36 @@ void set_error(const char *fmt, ...) {
 }
 
 static hipStream_t g_streams[64] = {};
+static std::mutex g_streams_mu;
 
 hipStream_t lib_stream() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lk(g_streams_mu);              // two host threads may meet here (ctypes drops the GIL)
     if (!g_streams[dev]) {
         if (hipStreamCreateWithFlags(&g_streams[dev], hipStreamNonBlocking) != hipSuccess) g_streams[dev] = nullptr;
     }
     return g_streams[dev];
+}
+
+static thread_local char g_kernel[160] = "";
+
+void note_kernel(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap);
+    va_end(ap);
+}
+
+const char *last_kernel_name() { return g_kernel; }
+
+int check_handle_device(int handle_device, const char *what) {
+    int dev = -1;
+    CPX_HIP(hipGetDevice(&dev));
+    CPX_REQUIRE(dev == handle_device, CPX_EINVAL,
+                "%s: the handle's tables live on device %d but device %d is current (handles belong to the device "
+                "that was current when they were created)", what, handle_device, dev);
+    return CPX_OK;
 }
 
 struct WsEntry { int dev; hipStream_t st; int slot; void *p; size_t cap; };
@@ -80,7 +100,7 @@ extern "C" {
 
 const char *cpx_last_error(void) { return g_err; }
 
-int cpx_version(void) { return 100; }  // 0.1.0
+int cpx_version(void) { return 200; }  // 0.2.0
 
 int cpx_device_count(int *n) {
     CPX_REQUIRE(n, CPX_EINVAL, "cpx_device_count: null pointer");
@@ -95,6 +115,20 @@ int cpx_set_device(int device) {
     int rc = ensure_device();
     if (rc) return rc;
     CPX_HIP(hipSetDevice(device));
+    return CPX_OK;
+}
+
+int cpx_get_device(int *device) {
+    CPX_REQUIRE(device, CPX_EINVAL, "cpx_get_device: null pointer");
+    int rc = ensure_device();
+    if (rc) return rc;
+    CPX_HIP(hipGetDevice(device));
+    return CPX_OK;
+}
+
+int cpx_last_kernel(char *name, int cap) {
+    CPX_REQUIRE(name && cap > 0, CPX_EINVAL, "cpx_last_kernel: null buffer");
+    snprintf(name, (size_t)cap, "%s", g_kernel);
     return CPX_OK;
 }
 
@@ -167,6 +201,36 @@ int cpx_memcpy_h2d(void *dst, const void *src, size_t bytes) {
 
 int cpx_memcpy_d2h(void *dst, const void *src, size_t bytes) {
     CPX_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return CPX_OK;
+}
+
+int cpx_memcpy_h2d_async(void *dst, const void *src, size_t bytes, void *stream) {
+    CPX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, pick_stream(stream)));
+    return CPX_OK;
+}
+
+int cpx_memcpy_d2h_async(void *dst, const void *src, size_t bytes, void *stream) {
+    CPX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, pick_stream(stream)));
+    return CPX_OK;
+}
+
+int cpx_memcpy_d2d_async(void *dst, const void *src, size_t bytes, void *stream) {
+    CPX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, pick_stream(stream)));
+    return CPX_OK;
+}
+
+int cpx_stream_create(void **stream) {
+    CPX_REQUIRE(stream, CPX_EINVAL, "cpx_stream_create: null pointer");
+    int rc = ensure_device();
+    if (rc) return rc;
+    hipStream_t st = nullptr;
+    CPX_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    *stream = (void *)st;
+    return CPX_OK;
+}
+
+int cpx_stream_destroy(void *stream) {
+    if (stream) CPX_HIP(hipStreamDestroy((hipStream_t)stream));
     return CPX_OK;
 }
 

@@ -29,6 +29,7 @@
 // -ffp-contract=off so sums round like NumPy's.
 #include "cpx_internal.h"
 #include "cpx_math.h"
+#include "demod_dev.h"
 
 #include <algorithm>
 #include <mutex>
@@ -45,6 +46,13 @@ struct VitParams {
     const int32_t *pred_state, *pred_input, *pred_code;  // [S][I]
     int64_t B, len, L, T, Lk;
     int k, n, lgS, I, NC, type, tb, RS;
+    // fused hard demodulation (cpx_demod_hard_viterbi_batch_dev): the kernel reads received SYMBOLS and takes the
+    // hard decisions itself -- the int8 bits of Modem.demodulate(y, 'hard') never exist in HBM
+    const double2 *ysym;   // [B][nsym] complex128, or null = `coded` holds the decoder input
+    const double2 *cst;    // [M] constellation
+    const double *axes;    // separable constellations: [2][sqrt(M)], else null
+    int64_t nsym;
+    int M, nb, nh;         // nh: log2(sqrt(M)) for separable constellations, 0 = generic scan
 };
 
 // ---- cross-lane helpers -------------------------------------------------------------------------
@@ -157,7 +165,8 @@ __device__ __forceinline__ void bit_metrics(int type, double r, double &m0, doub
 // SR: shift-register trellis (feed-forward, k = 1): predecessor j of state s is ((s << 1) & (S-1)) | j
 //     and the input on every branch into s is s >> (LGS-1), so the traceback needs no table lookups;
 // N_T: outputs per trellis step when known at compile time (2, 3), 0 = run-time n <= CPX_MAX_N.
-template <int LGS, int I_T, bool SR, int N_T>
+// DM: the input is symbols to be hard-demodulated in the kernel (run-time n only, 'hard' metrics).
+template <int LGS, int I_T, bool SR, int N_T, bool DM = false>
 __global__ __launch_bounds__(64) void viterbi_wave_kernel(VitParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int PL = (I_T == 2) ? 1 : 2;          // decision bit planes
@@ -200,9 +209,26 @@ __global__ __launch_bounds__(64) void viterbi_wave_kernel(VitParams p) {
 
     // received values of the chunk being prepared (software prefetch one chunk ahead)
     double rcur[NMAX];
+    const double2 *ys = DM ? p.ysym + (valid_cw ? cw : 0) * p.nsym : nullptr;
     auto load_chunk = [&](int64_t t_base, double *r) {
         const int64_t t = t_base + s;                        // lane (g, s) prepares step t of codeword g
         const bool have = valid_cw && (t <= p.Lk) && (t <= p.T);   // t > L//k -> padding (:722-734)
+        if constexpr (DM) {
+            // coded bit q of the codeword is bit q % nb (MSB first) of the label of symbol q / nb (modulation.py:121-123)
+            unsigned last = ~0u;
+            int label = 0;
+#pragma unroll
+            for (int j = 0; j < NMAX; j++) {
+                double v = 0.0;
+                if (have && j < n) {
+                    const unsigned q = (unsigned)((t - 1) * n + j), sy = q / (unsigned)p.nb;
+                    if (sy != last) { label = hard_label(p.cst, p.axes, p.M, p.nh, ys[sy]); last = sy; }
+                    v = (double)((label >> (p.nb - 1 - (int)(q - sy * (unsigned)p.nb))) & 1);
+                }
+                r[j] = v;
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < NMAX; j++) {
             double v = (p.type == CPX_VIT_UNQUANTIZED) ? -1.0 : 0.0;
@@ -571,9 +597,16 @@ int cpx_trellis_destroy(cpx_trellis *t) {
     return CPX_OK;
 }
 
-int cpx_viterbi_decode_batch_dev(const cpx_trellis *t, const double *d_coded, int64_t B, int64_t len, int64_t L,
-                                 int64_t n_steps, int tb_depth, int decoding_type, uint8_t *d_bits, void *stream) {
+struct DemodSrc {                  // fused hard demodulation: symbols instead of decoder input
+    const cpx_modem *m;
+    const double *d_y;             // [B][nsym][2]
+    int64_t nsym;
+};
+
+static int viterbi_dispatch(const cpx_trellis *t, const double *d_coded, const DemodSrc *dm, int64_t B, int64_t len, int64_t L,
+                            int64_t n_steps, int tb_depth, int decoding_type, uint8_t *d_bits, void *stream) {
     CPX_REQUIRE(t, CPX_EINVAL, "viterbi: null trellis");
+    if (int rcd = check_handle_device(t->device, "viterbi")) return rcd;
     CPX_REQUIRE(decoding_type >= 0 && decoding_type <= 2, CPX_EINVAL,
                 "The available decoding types are \"hard\", \"soft\" and \"unquantized");
     CPX_REQUIRE(B >= 0 && len >= 0 && L >= 0, CPX_EINVAL, "viterbi: negative size");
@@ -586,13 +619,13 @@ int cpx_viterbi_decode_batch_dev(const cpx_trellis *t, const double *d_coded, in
     hipStream_t st = pick_stream(stream);
     if (n_steps <= 0 || n_steps * t->k < L) CPX_HIP(hipMemsetAsync(d_bits, 0, (size_t)(B * L), st));
     if (n_steps <= 0) return CPX_OK;
-    {   // large batches of the standard rate-1/2 codes: one codeword per lane (viterbi_cw.hip).  That path runs in rounds
+    note_kernel("");
+    if (!dm) {   // large batches of the standard rate-1/2 codes: one codeword per lane (viterbi_cw.hip).  That path runs in rounds
         // of one wavefront of 64 codewords per SIMD; a last round that would fill less than 3/4 of the chip is cheaper on
         // the wave kernels below (83 k codewords: 4.5 ms as two rounds, 3.2 ms as one round + wave kernels)
-        const char *e = getenv("CPX_VITERBI_PATH");
         const int64_t round = (int64_t)device_cus() * 4 * 64;
         int64_t Bcw = B;
-        if (!(e && e[0] == 'c') && B > round && 4 * (B % round) < 3 * round) Bcw = B / round * round;
+        if (!(viterbi_path_flags() & 2) && B > round && 4 * (B % round) < 3 * round) Bcw = B / round * round;
         int rc_cw = CPX_OK;
         if (viterbi_codeword_path(t, d_coded, Bcw, len, L, n_steps, tb_depth, decoding_type, d_bits, st, &rc_cw)) {
             if (rc_cw != CPX_OK || Bcw == B) return rc_cw;
@@ -607,6 +640,14 @@ int cpx_viterbi_decode_batch_dev(const cpx_trellis *t, const double *d_coded, in
     p.pred_state = t->d_pred_state; p.pred_input = t->d_pred_input; p.pred_code = t->d_pred_code;
     p.B = B; p.len = len; p.L = L; p.T = n_steps; p.Lk = L / t->k;
     p.k = t->k; p.n = t->n; p.I = t->I; p.NC = 1 << t->n; p.type = decoding_type; p.tb = tb_depth;
+    p.ysym = nullptr; p.cst = nullptr; p.axes = nullptr; p.nsym = 0; p.M = 0; p.nb = 1; p.nh = 0;
+    if (dm) {
+        p.ysym = reinterpret_cast<const double2 *>(dm->d_y);
+        p.cst = reinterpret_cast<const double2 *>(dm->m->d_const);
+        p.axes = dm->m->separable ? dm->m->d_axes : nullptr;
+        p.nsym = dm->nsym; p.M = dm->m->M; p.nb = dm->m->nbits; p.nh = dm->m->separable ? dm->m->nbits / 2 : 0;
+        CPX_REQUIRE(t->S <= 64, CPX_ELIMIT, "demod_hard_viterbi: trellises above 64 states take the two-call path");
+    }
     int lgS = 0;
     while ((1 << lgS) < t->S) lgS++;
     p.lgS = lgS;
@@ -621,6 +662,7 @@ int cpx_viterbi_decode_batch_dev(const cpx_trellis *t, const double *d_coded, in
         if (t->I == 2) hipLaunchKernelGGL((viterbi_wide_kernel<2, 2>), dim3((unsigned)B), dim3(64), ldsw, st, p);
         else hipLaunchKernelGGL((viterbi_wide_kernel<2, 4>), dim3((unsigned)B), dim3(64), ldsw, st, p);
         CPX_HIP(hipGetLastError());
+        note_kernel("viterbi_wide_kernel<2,%d>", t->I);
         return CPX_OK;
     }
     const int S = t->S, G = 64 / S, CH = S;
@@ -639,7 +681,8 @@ int cpx_viterbi_decode_batch_dev(const cpx_trellis *t, const double *d_coded, in
                 sr = false;
 #define VIT_LAUNCH(LG, IT, SRV)                                                                             \
     do {                                                                                                    \
-        if (t->n == 2) hipLaunchKernelGGL((viterbi_wave_kernel<LG, IT, SRV, 2>), grid, block, lds, st, p);    \
+        if (dm) hipLaunchKernelGGL((viterbi_wave_kernel<LG, IT, SRV, 0, true>), grid, block, lds, st, p);    \
+        else if (t->n == 2) hipLaunchKernelGGL((viterbi_wave_kernel<LG, IT, SRV, 2>), grid, block, lds, st, p);    \
         else if (t->n == 3) hipLaunchKernelGGL((viterbi_wave_kernel<LG, IT, SRV, 3>), grid, block, lds, st, p); \
         else hipLaunchKernelGGL((viterbi_wave_kernel<LG, IT, SRV, 0>), grid, block, lds, st, p);             \
     } while (0)
@@ -656,6 +699,46 @@ int cpx_viterbi_decode_batch_dev(const cpx_trellis *t, const double *d_coded, in
 #undef VIT_CASE
 #undef VIT_LAUNCH
     CPX_HIP(hipGetLastError());
+    {
+        char first[160];                                         // a leading round on the codeword path, if any
+        snprintf(first, sizeof(first), "%s", last_kernel_name());
+        note_kernel("%s%sviterbi_wave_kernel<%d,%d,%s,%d%s>", first, first[0] ? " + " : "", lgS, t->I,
+                    (t->I == 2 && sr) ? "true" : "false", (!dm && (t->n == 2 || t->n == 3)) ? t->n : 0, dm ? ",demod" : "");
+    }
+    return CPX_OK;
+}
+
+int cpx_viterbi_decode_batch_dev(const cpx_trellis *t, const double *d_coded, int64_t B, int64_t len, int64_t L,
+                                 int64_t n_steps, int tb_depth, int decoding_type, uint8_t *d_bits, void *stream) {
+    return viterbi_dispatch(t, d_coded, nullptr, B, len, L, n_steps, tb_depth, decoding_type, d_bits, stream);
+}
+
+int cpx_demod_hard_viterbi_batch_dev(const cpx_modem *m, const cpx_trellis *t, const double *d_y_re_im, int64_t B,
+                                     int64_t nsym, int64_t L, int64_t n_steps, int tb_depth, uint8_t *d_bits, void *stream) {
+    CPX_REQUIRE(m && t, CPX_EINVAL, "demod_hard_viterbi: null handle");
+    if (int rcd = check_handle_device(m->device, "demod_hard_viterbi")) return rcd;
+    CPX_REQUIRE(B >= 0 && nsym >= 0, CPX_EINVAL, "demod_hard_viterbi: negative size");
+    CPX_REQUIRE(nsym * (int64_t)m->nbits < (1ll << 31), CPX_ELIMIT, "demod_hard_viterbi: codeword too long");
+    DemodSrc dm{m, d_y_re_im, nsym};
+    // len = the coded bits one codeword's symbols carry, exactly what demodulate(y, 'hard') would have returned
+    return viterbi_dispatch(t, nullptr, &dm, B, nsym * m->nbits, L, n_steps, tb_depth, CPX_VIT_HARD, d_bits, stream);
+}
+
+int cpx_demod_hard_viterbi_batch(const cpx_modem *m, const cpx_trellis *t, const double *y_re_im, int64_t B, int64_t nsym,
+                                 int64_t L, int64_t n_steps, int tb_depth, uint8_t *bits) {
+    CPX_REQUIRE(m && t && (y_re_im || B * nsym == 0) && (bits || B * L == 0), CPX_EINVAL, "demod_hard_viterbi: null pointer");
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (B == 0 || L == 0) return CPX_OK;
+    DevBuf din, dout;
+    if ((rc = din.alloc(sizeof(double) * 2 * (size_t)(B * nsym)))) return rc;
+    if ((rc = dout.alloc((size_t)(B * L)))) return rc;
+    hipStream_t st = lib_stream();
+    CPX_HIP(hipMemcpyAsync(din.p, y_re_im, sizeof(double) * 2 * (size_t)(B * nsym), hipMemcpyHostToDevice, st));
+    rc = cpx_demod_hard_viterbi_batch_dev(m, t, din.as<double>(), B, nsym, L, n_steps, tb_depth, dout.as<uint8_t>(), st);
+    if (rc) return rc;
+    CPX_HIP(hipMemcpyAsync(bits, dout.p, (size_t)(B * L), hipMemcpyDeviceToHost, st));
+    CPX_HIP(hipStreamSynchronize(st));
     return CPX_OK;
 }
 

@@ -28,8 +28,10 @@
 #include "cpx_internal.h"
 #include "cpx_math.h"
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <type_traits>
 
 using namespace cpx;
@@ -518,8 +520,10 @@ int launch_fused_typed(const CwParams &p, hipStream_t st) {
     auto *fn = viterbi_cw_fused_kernel<LGS, G0, G1, TYPE, fused_tb<LGS>() - 2>;
     const size_t lds = ACS_WAVES * fused_wave_lds<LGS>();
     static bool raised[64] = {};                                 // > 64 KiB of dynamic LDS is opt-in, once per kernel and device
+    static std::mutex raised_mu;                                 // host threads may launch concurrently (ctypes drops the GIL)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    std::lock_guard<std::mutex> lk(raised_mu);
     if (!raised[dev]) {
         if (hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             (void)hipGetLastError();                             // a device with less LDS: the two-kernel form is used
@@ -543,18 +547,40 @@ int launch_fused(const CwParams &p, hipStream_t st) {
 
 namespace cpx {
 
+// Kernel-path override (tests, benchmarks): bit 0 = "wave" (state-per-lane kernels only), bit 1 = forced codeword path,
+// bit 2 = strict ("!": fail instead of falling back), bit 3 = two-kernel form even where the fused kernel applies.
+// Initialised once from the environment variable CPX_VITERBI_PATH, changed at run time through cpx_viterbi_set_path().
+static std::atomic<int> g_vit_path{-1};
+
+static int parse_path(const char *e) {
+    if (!e || !e[0]) return 0;
+    if (e[0] == 'w') return 1;
+    if (e[0] != 'c') return 0;
+    return 2 | (strchr(e, '!') ? 4 : 0) | (strchr(e, '2') ? 8 : 0);
+}
+
+int viterbi_path_flags() {
+    int v = g_vit_path.load(std::memory_order_relaxed);
+    if (v < 0) {
+        static std::once_flag once;
+        std::call_once(once, [] { g_vit_path.store(parse_path(getenv("CPX_VITERBI_PATH")), std::memory_order_relaxed); });
+        v = g_vit_path.load(std::memory_order_relaxed);
+    }
+    return v;
+}
+
+static const char *type_name(int type) { return type == CPX_VIT_HARD ? "hard" : type == CPX_VIT_SOFT ? "soft" : "unquantized"; }
+
 // Returns true when the call was handled here (*rc = status); false -> the caller uses the state-per-lane kernels.
 bool viterbi_codeword_path(const cpx_trellis *t, const double *d_coded, int64_t B, int64_t len, int64_t L, int64_t T,
                            int tb, int type, uint8_t *d_bits, hipStream_t st, int *rc) {
     *rc = CPX_OK;
-    // CPX_VITERBI_PATH (tests, benchmarks): "wave" = state-per-lane kernels; "cw" = this path whatever the batch size;
-    // "cw!" = fail instead of falling back; a '2' anywhere ("cw2", "cw2!") = the two-kernel form even where the fused
-    // kernel applies
-    const char *e = getenv("CPX_VITERBI_PATH");
-    if (e && e[0] == 'w') return false;
-    const bool forced = e && e[0] == 'c';
-    const bool strict = forced && strchr(e, '!') != nullptr;
-    const bool two_kernels = forced && strchr(e, '2') != nullptr;
+    // path override (cpx_viterbi_set_path / CPX_VITERBI_PATH): "wave" = state-per-lane kernels; "cw" = this path whatever
+    // the batch size; "cw!" = fail instead of falling back; a '2' anywhere ("cw2", "cw2!") = the two-kernel form even
+    // where the fused kernel applies
+    const int pf = viterbi_path_flags();
+    if (pf & 1) return false;
+    const bool forced = pf & 2, strict = pf & 4, two_kernels = pf & 8;
     auto reject = [&](const char *why) {
         if (!strict) return false;
         set_error("viterbi (codeword path): %s", why);
@@ -576,6 +602,7 @@ bool viterbi_codeword_path(const cpx_trellis *t, const double *d_coded, int64_t 
     if (tables_match<LG, GA, GB>(t)) {                                                                              \
         if (tb == fused_tb<LG>() && !two_kernels && launch_fused<LG, GA, GB>(p, st)) {                                    \
             if (hipGetLastError() != hipSuccess) { set_error("viterbi (fused codeword path): launch failed"); *rc = CPX_EHIP; } \
+            note_kernel("viterbi_cw_fused_kernel<%d,0%o,0%o,%s,%d>", LG, GA, GB, type_name(type), tb - 2);             \
             return true;                                                                                            \
         }                                                                                                           \
         void *w0 = nullptr, *w1 = nullptr;                                                                          \
@@ -586,6 +613,7 @@ bool viterbi_codeword_path(const cpx_trellis *t, const double *d_coded, int64_t 
         p.best = static_cast<unsigned char *>(w1);                                                                  \
         launch<LG, GA, GB>(p, tb_lds, st);                                                                          \
         if (hipGetLastError() != hipSuccess) { set_error("viterbi (codeword path): launch failed"); *rc = CPX_EHIP; } \
+        note_kernel("viterbi_cw_acs_kernel<%d,0%o,0%o,%s> + viterbi_cw_tb_kernel<%d>", LG, GA, GB, type_name(type), LG); \
         return true;                                                                                                \
     }
     // Template generators are in "MSB taps the input" order.  commpy's default polynomial_format='MSB' makes the
@@ -601,3 +629,12 @@ bool viterbi_codeword_path(const cpx_trellis *t, const double *d_coded, int64_t 
 }
 
 }  // namespace cpx
+
+extern "C" int cpx_viterbi_set_path(const char *mode) {
+    if (mode && mode[0] && mode[0] != 'w' && mode[0] != 'c' && strcmp(mode, "auto") != 0) {
+        cpx::set_error("cpx_viterbi_set_path: unknown mode '%s' (auto | wave | cw | cw! | cw2 | cw2!)", mode);
+        return CPX_EINVAL;
+    }
+    cpx::g_vit_path.store((mode && strcmp(mode, "auto") != 0) ? cpx::parse_path(mode) : 0, std::memory_order_relaxed);
+    return CPX_OK;
+}

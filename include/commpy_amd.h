@@ -46,12 +46,21 @@ const char *cpx_last_error(void);
 int cpx_version(void);
 int cpx_device_count(int *n);
 int cpx_set_device(int device);
+int cpx_get_device(int *device);
+/* Name of the (dominant) kernel the last decoder call of the calling thread launched, e.g.
+ * "viterbi_cw_fused_kernel<6,0155,0117,soft,28>": benchmarks and tests report what really ran. */
+int cpx_last_kernel(char *name, int cap);
 int cpx_device_info(char *name, int name_cap, int *compute_units, int64_t *hbm_bytes);
 int cpx_malloc(void **dptr, size_t bytes);
 int cpx_free(void *dptr);
 int cpx_memset(void *dptr, int value, size_t bytes);
 int cpx_memcpy_h2d(void *dst, const void *src, size_t bytes);
 int cpx_memcpy_d2h(void *dst, const void *src, size_t bytes);
+int cpx_memcpy_h2d_async(void *dst, const void *src, size_t bytes, void *stream);
+int cpx_memcpy_d2h_async(void *dst, const void *src, size_t bytes, void *stream);
+int cpx_memcpy_d2d_async(void *dst, const void *src, size_t bytes, void *stream);
+int cpx_stream_create(void **stream);       /* a non-blocking hipStream_t on the current device */
+int cpx_stream_destroy(void *stream);
 int cpx_stream_sync(void *stream);          /* NULL = the library's stream */
 int cpx_release_workspace(void);            /* free the per-stream scratch arenas the decoders keep between calls */
 void *cpx_default_stream(void);             /* the library's own hipStream_t */
@@ -92,14 +101,30 @@ int cpx_trellis_destroy(cpx_trellis *t);
  * Kernel selection is internal and does not change a single output bit: batches of >= 3/4 * (SIMDs of the device) * 64
  * codewords of the K = 7 (133,171) code run one codeword per lane (csrc/viterbi_cw.hip: a single fused kernel when
  * tb_depth is the default 5*m = 30, an add-compare-select + a traceback kernel with a 9 B per codeword-step device
- * workspace otherwise, tb_depth <= 48); everything else runs one trellis state per lane (csrc/viterbi.hip).  The
- * environment variable CPX_VITERBI_PATH = wave | cw | cw! | cw2 | cw2! overrides the choice (tests, benchmarks).
+ * workspace otherwise, tb_depth <= 48); everything else runs one trellis state per lane (csrc/viterbi.hip).
+ * cpx_viterbi_set_path (or the environment variable CPX_VITERBI_PATH = wave | cw | cw! | cw2 | cw2! at load time)
+ * overrides the choice (tests, benchmarks); cpx_last_kernel reports which kernel ran.
  */
 int cpx_viterbi_decode_batch(const cpx_trellis *t, const double *coded, int64_t B, int64_t len,
                              int64_t L, int64_t n_steps, int tb_depth, int decoding_type, uint8_t *bits);
 int cpx_viterbi_decode_batch_dev(const cpx_trellis *t, const double *d_coded, int64_t B, int64_t len,
                                  int64_t L, int64_t n_steps, int tb_depth, int decoding_type,
                                  uint8_t *d_bits, void *stream);
+/* Kernel-path override for tests and benchmarks (initial value: environment variable CPX_VITERBI_PATH):
+ * NULL / "" / "auto" = automatic, "wave", "cw", "cw!", "cw2", "cw2!" as described above. */
+int cpx_viterbi_set_path(const char *mode);
+/* Fused hard demodulation + hard-decision Viterbi: replaces the pair
+ *   bits = modem.demodulate(y, 'hard')            commpy/modulation.py:121-123
+ *   viterbi_decode(bits, trellis, tb_depth, 'hard')  commpy/channelcoding/convcode.py:578-580, 661-749
+ * for B codewords of nsym symbols each (y [B][nsym][2] float64 = complex128).  The kernel takes the hard decisions
+ * itself while it prepares the branch metrics: the int8 bits are never written to (or re-read from) HBM -- 16 B in per
+ * symbol instead of 16 B in + nb B out + 8 nb B in.  Output identical to the two calls.  len = nsym * bits-per-symbol
+ * takes the place of len(coded_bits); trellises above 64 states return CPX_ELIMIT (use the two calls). */
+int cpx_demod_hard_viterbi_batch(const cpx_modem *m, const cpx_trellis *t, const double *y_re_im, int64_t B,
+                                 int64_t nsym, int64_t L, int64_t n_steps, int tb_depth, uint8_t *bits);
+int cpx_demod_hard_viterbi_batch_dev(const cpx_modem *m, const cpx_trellis *t, const double *d_y_re_im, int64_t B,
+                                     int64_t nsym, int64_t L, int64_t n_steps, int tb_depth, uint8_t *d_bits,
+                                     void *stream);
 /* Same as cpx_viterbi_decode_batch with the result widened to the reference's return type (`decoded_bits` is an
  * int array, convcode.py:711/749): bits64 [B][L] int64.  The compact bits cross PCIe, host threads widen them
  * straight into the caller's array: a single-threaded astype of 67 M bits costs more than decoding them. */
@@ -149,6 +174,19 @@ int cpx_turbo_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const 
 int cpx_ldpc_create(int n_vnodes, int n_cnodes, int64_t n_edges, const int32_t *edge_check,
                     const int32_t *edge_var, cpx_ldpc **out);
 int cpx_ldpc_destroy(cpx_ldpc *c);
+/* Compiled design ("blob"): the device tables of a Tanner graph -- sorted edge list, row / column
+ * pointers, the variable-major view and the padded node tables the passes read -- in one position-independent,
+ * checksummed byte string, so that a design file (ldpc.py:51-141 / write_ldpc_params :257-299) is compiled ONCE and the
+ * result cached under the file's hash instead of being re-derived per code object.
+ *   cpx_ldpc_blob_build        host only (no device needed); blob == NULL queries the size into *need;
+ *                              blob must be 8-byte aligned
+ *   cpx_ldpc_blob_info         validates a blob (magic, sizes, checksum, every index in range) and returns its dimensions
+ *   cpx_ldpc_create_from_blob  validates, then uploads; cpx_ldpc_create == blob_build + create_from_blob */
+int cpx_ldpc_blob_build(int n_vnodes, int n_cnodes, int64_t n_edges, const int32_t *edge_check, const int32_t *edge_var,
+                        void *blob, size_t cap, size_t *need);
+int cpx_ldpc_blob_info(const void *blob, size_t nbytes, int *n_vnodes, int *n_cnodes, int64_t *n_edges,
+                       int *max_cnode_deg, int *max_vnode_deg);
+int cpx_ldpc_create_from_blob(const void *blob, size_t nbytes, cpx_ldpc **out);
 int cpx_ldpc_bp_decode_batch(const cpx_ldpc *c, double *llr, int64_t B, int alg, int n_iters,
                              int8_t *dec_word, double *out_llrs, int32_t *iters_done);
 int cpx_ldpc_bp_decode_batch_dev(const cpx_ldpc *c, double *d_llr, int64_t B, int alg, int n_iters,
@@ -226,6 +264,35 @@ int cpx_ldpc_encoder_create(const uint8_t *gen_bits, int64_t m, int64_t k, cpx_l
 int cpx_ldpc_encoder_destroy(cpx_ldpc_encoder *e);
 int cpx_ldpc_encode_batch_dev(const cpx_ldpc_encoder *e, const uint8_t *d_msg, int64_t B, uint8_t *d_code,
                               void *stream);
+
+/* ---- multi-GPU: RCCL collectives of the sharded decode ------------------------------------
+ * The path shards by codeword (contiguous blocks of B/G codewords per GPU, tables replicated) and has no exchange
+ * step inside a decoder.  Two collectives exist around it:
+ *   all-gather of decoded bits (uint8)   -- every GPU ends with the whole [B][L] result, the array the reference
+ *                                           returns from viterbi_decode / ldpc_bp_decode (convcode.py:749, ldpc.py:251-254)
+ *   all-reduce (sum / max) of int64 / float64 counters -- the error and bit counters of a Monte-Carlo sweep,
+ *                                           commpy/links.py:252-260
+ * A communicator is formed either by ONE process for several devices (cpx_comm_init_all = ncclCommInitAll; every
+ * collective then takes one buffer per local device, in the order of `devices`, issued inside one ncclGroup) or by one
+ * process per GPU (cpx_comm_unique_id on rank 0, the 128-byte id handed to the others by the launcher plumbing,
+ * cpx_comm_init_rank on every rank with its device current).  librccl.so.1 is dlopen()ed at the first communicator.
+ * d_send / d_recv / streams are arrays of nlocal pointers (nlocal = 1 for init_rank); streams == NULL or a NULL entry =
+ * the library's stream of that device.  All calls are asynchronous on those streams.
+ *   cpx_comm_allgather_u8: d_recv[i] holds nranks * bytes_per_rank bytes, rank r's block at r * bytes_per_rank
+ *                          (ragged shards: the caller pads to the largest shard, commpy_amd/parallel.py)
+ *   op: 0 = sum, 1 = max */
+typedef struct cpx_comm cpx_comm;
+int cpx_comm_unique_id(void *id128);
+int cpx_comm_init_rank(const void *id128, int nranks, int rank, cpx_comm **out);
+int cpx_comm_init_all(const int *devices, int ndev, cpx_comm **out);
+int cpx_comm_info(const cpx_comm *c, int *nranks, int *nlocal, int *first_rank);
+int cpx_comm_destroy(cpx_comm *c);
+int cpx_comm_allgather_u8(cpx_comm *c, const void *const *d_send, void *const *d_recv, size_t bytes_per_rank,
+                          void *const *streams);
+int cpx_comm_allreduce_i64(cpx_comm *c, const void *const *d_send, void *const *d_recv, size_t count, int op,
+                           void *const *streams);
+int cpx_comm_allreduce_f64(cpx_comm *c, const void *const *d_send, void *const *d_recv, size_t count, int op,
+                           void *const *streams);
 
 #ifdef __cplusplus
 }

@@ -102,6 +102,18 @@ def viterbi_decode(coded_bits, trellis, tb_depth=None, decoding_type='hard'):
     return dec[:L]
 
 
+def viterbi_decode_mt(coded_bits, trellis, tb_depth=None, decoding_type='hard', threads=None):
+    """``viterbi_decode`` of a 2-D batch spread over host threads (every slice is one C call, GIL released)."""
+    import concurrent.futures as cf
+    x = _f64(coded_bits)
+    threads = threads or max(1, len(os.sched_getaffinity(0)))
+    threads = max(1, min(threads, len(x)))
+    parts = np.array_split(np.arange(len(x)), threads)
+    with cf.ThreadPoolExecutor(threads) as ex:
+        outs = list(ex.map(lambda idx: viterbi_decode(x[idx[0]:idx[-1] + 1], trellis, tb_depth, decoding_type), parts))
+    return np.concatenate(outs, axis=0)
+
+
 def map_decode(sys_symbols, non_sys_symbols, trellis, noise_variance, L_int, mode='decode'):
     """Oracle of turbo.py:163; returns [L_ext, decoded_bits]."""
     lib = load()

@@ -89,3 +89,68 @@ def test_demodulate():
         fin = np.isfinite(ref)
         assert np.array_equal(np.isfinite(soft), fin)
         assert np.max(np.abs(soft[fin] - ref[fin])) < 1e-12, nm
+
+
+# ---- round-2 fixtures: the configs at (closer to) their real sizes, all from the live reference ----------------------
+def c2x_case(tag):
+    """(llr float64 [256, 2060], reference bits uint8 [256, 1030], messages [256, 1024]) of viterbi_c2x.npz."""
+    g = golden("viterbi_c2x")
+    llr = g[tag + "__llr_q"].astype(np.float64) / float(g["llr_scale"])
+    dec = np.unpackbits(g[tag + "__dec"], axis=1)[:, :1030]
+    msg = np.unpackbits(g[tag + "__msg"], axis=1)[:, :1024]
+    return llr, dec, msg
+
+
+def test_viterbi_config2_768_reference_codewords():
+    """256 live-reference codewords at each of Eb/N0 = 1, 3, 5 dB (K = 7 soft, 1024-bit blocks): bit-exact."""
+    tr = TableTrellis("k7_133_171")
+    for tag in ("e1", "e3", "e5"):
+        llr, dec, msg = c2x_case(tag)
+        got = oracle.viterbi_decode(llr, tr, None, "soft")
+        assert got.shape == (256, 1030)
+        assert np.array_equal(got, dec), (tag, int(np.sum(got != dec)))
+    assert 3e-2 < np.mean(c2x_case("e1")[1][:, :1024] != c2x_case("e1")[2]) < 8e-2      # the 1 dB set really has errors
+
+
+def test_turbo_config3_48_reference_codewords():
+    """Config-3 shape through the live reference: N = 1024, RandInterlv(1024, 1234), 6 iterations, 1.5 dB."""
+    g = golden("turbo_c3x")
+    tr = TableTrellis("rsc_legacy_4")
+    rx = g["rx"].astype(np.float64)
+    dec = np.unpackbits(g["dec"], axis=1)[:, :1024]
+    nv, iters = float(g["nv"]), int(g["iters"])
+    for b in range(rx.shape[0]):
+        got = oracle.turbo_decode(rx[b, 0], rx[b, 1], rx[b, 2], tr, nv, iters, Perm(g["perm"]))
+        assert np.array_equal(got, dec[b]), b
+        L, _ = oracle.map_decode(rx[b, 0], rx[b, 1], tr, nv, np.zeros(1024), "compute")
+        assert np.max(np.abs(L - g["L_map1"][b])) < 1e-11, b
+
+
+def test_ldpc_config4_chain_reference_blocks():
+    """Config-4 chain (64-QAM -> soft demod -> sign flip -> BP on the (1944,1296) code, 50 iterations) at 8 and 9 dB:
+    the oracle's demodulator and decoder against the reference's on 12 blocks per point, converged or not."""
+    from commpy_amd.modulation import QAMModem
+    g = golden("ldpc_c4x")
+    p = ldpc_params("n1944")
+    const = QAMModem(64).constellation
+    iters = int(g["iters"])
+    for tag in ("e8", "e9"):
+        llr_ref = g[tag + "__llr"]
+        llr = -oracle.demodulate(const, g[tag + "__y"], "soft", float(g[tag + "__N0"]))
+        assert np.max(np.abs(llr - llr_ref)) < 1e-11
+        for alg in ("SPA", "MSA"):
+            dec, out = oracle.ldpc_bp_decode(llr_ref.copy(), p, alg, iters)
+            want_dec, want_out = g["%s__dec_%s" % (tag, alg)].T, g["%s__out_%s" % (tag, alg)].T
+            assert np.array_equal(dec, want_dec), (tag, alg)
+            sent = g[tag + "__code"].T.astype(np.int8)
+            conv = np.all(want_dec == sent, axis=0)                # blocks the reference decoded to the sent codeword
+            if alg == "MSA":
+                assert np.array_equal(out, want_out)
+            else:
+                # 2*atanh(x) near |x| -> 1 amplifies a last-ulp difference of x = P/t by 1/(1 - |x|): glibc (the oracle)
+                # and NumPy's SIMD tanh/arctanh (the reference) agree to 5e-7 where |LLR| <= 26 and drift apart above
+                # (0.04 at |LLR| = 56 on one converged 8 dB block) -- the 1e-5 bar is meaningful below 26 only
+                dev, mag = np.abs(out[:, conv] - want_out[:, conv]), np.abs(want_out[:, conv])
+                assert np.max(dev[mag <= 26.0]) < 1e-5
+                assert np.all(dev[mag > 26.0] <= 1e-2 * mag[mag > 26.0])
+        assert not np.all(np.all(g[tag + "__dec_MSA"] == g[tag + "__code"], axis=1)) or tag == "e9"   # 8 dB: a mix
