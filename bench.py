@@ -2,16 +2,20 @@
 """Headline benchmark: soft-decision Viterbi, K=7 rate-1/2 (0o133, 0o171), 1024-bit blocks,
 QPSK + AWGN at Eb/N0 = 3 dB, batch 65536 codewords per GPU (BASELINE.json configs[1]).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--gather] [--comm rccl|torch]
 
 A "step" is one pass of the HIP Viterbi decoder over the whole per-GPU batch with the float64 LLRs
 already resident in HBM.  N > 1 (launched by torch.distributed.run, one process per GPU): weak
-scaling, every rank decodes and keeps its own 65536-codeword batch -- the path shards by codeword and has no
-exchange step, so the timed region contains no collective (barrier + max over ranks only; the error counts of the
-shards are all-reduced once, after the measurement).  Rank 0 prints ONE JSON line with the contract
-fields plus `roofline` (dominant kernel, HIP-event timed on its own stream) and `cpu_baseline`
-(the C oracle -- a port of the reference's algorithm -- timed on the host cores on a bounded sample;
-the unmodified Python reference is not available on the GPU box).
+scaling, every rank decodes its own 65536-codeword batch.  The path shards by codeword and has no exchange step, so
+by default the timed region contains no collective; ``--gather`` adds the one collective north_star names -- an
+RCCL all-gather of the decoded bits (uint8, 67.5 MB per rank and step) on the decode stream -- to every step.
+Collectives (closing barrier, max over ranks, error-count all-reduce, the optional all-gather) go through the
+engine's own RCCL binding (``cpx_comm_*``, commpy_amd.parallel.RankComm); torch is NOT imported.  ``--comm torch``
+uses torch.distributed instead, and is also what the launcher plumbing falls back to -- loudly, in the JSON line --
+if the RCCL communicator cannot be formed.  Rank 0 prints ONE JSON line with the contract fields plus `roofline`
+(dominant kernel as reported by the library, HIP-event timed on its own stream) and `cpu_baseline` (the C oracle -- a
+port of the reference's algorithm -- timed on the host cores on a bounded sample; the unmodified Python reference is
+not available on the GPU box).
 """
 import argparse
 import ctypes
@@ -29,6 +33,7 @@ MSG_BITS = 1024
 EBN0_DB = 3.0
 ALG_BYTES_PER_CW = 2060 * 8 + 1030 * 1      # float64 LLRs in + uint8 bits out
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: 8.0 TB/s spec
+PMC_FILE = "r02_viterbi_c2_pmc.json"        # written by scripts/collect_pmc.sh from rocprofv3 passes over this script
 
 
 def synth_inputs(B, seed_msg, seed_noise):
@@ -98,6 +103,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=65536, help="codewords per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather", action="store_true",
+                    help="N > 1: all-gather the decoded bits of all ranks in every step (RCCL, on the decode stream)")
+    ap.add_argument("--comm", choices=("rccl", "torch"), default="rccl",
+                    help="collectives of the N > 1 run: the engine's own RCCL binding (default) or torch.distributed")
     ap.add_argument("--synth", choices=("device", "host"), default="device",
                     help="where the synthetic input is generated: on the GPU (Philox bits/noise, device encoder and "
                          "modulator; fast, no large host arrays) or on the host (NumPy MT19937, SURVEY 8d seeds)")
@@ -107,8 +116,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = "RANK" in os.environ and "WORLD_SIZE" in os.environ
-    torch = dist = None
-    if distributed:
+    torch = dist = comm = None
+    comm_note = None
+    if distributed and args.comm == "torch":
         # torch first: its bundled HIP runtime (same SONAME) is then shared by libcommpy_amd.so
         import torch
         import torch.distributed as dist
@@ -118,6 +128,17 @@ def main():
     lib = _lib.load()
     _lib.require_device()
     _lib.check(lib.cpx_set_device(local_rank))
+    if distributed and args.comm == "rccl":
+        from commpy_amd.parallel import RankComm
+        try:
+            comm = RankComm(rank, world)
+        except Exception as exc:                      # launcher plumbing only: fall back, and say so in the JSON line
+            comm_note = "RankComm failed (%s: %s); torch.distributed used instead" % (type(exc).__name__, exc)
+            print("bench.py: " + comm_note, file=sys.stderr, flush=True)
+            import torch
+            import torch.distributed as dist
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     B = args.batch
     nsym = (MSG_BITS + 6) * 2 // 2                                 # 1030 QPSK symbols per codeword
@@ -134,7 +155,8 @@ def main():
         msgs = y = None
     h_tr, h_md = tr._device_handle(), md._device_handle()
 
-    if distributed:
+    d_full = ctypes.c_void_p()                                      # --gather: [world][B][L] uint8, every rank's bits
+    if dist is not None:
         # a real (non-null) torch stream made current: the C-ABI launches on it and torch.distributed's collectives
         # (closing barrier, error-count all-reduce) are ordered after the decodes (the null stream handle would make
         # the library fall back to its own stream, unordered with respect to them)
@@ -143,22 +165,26 @@ def main():
         stream = ctypes.c_void_p(tstream.cuda_stream)
         t_y = torch.empty((B, nsym, 2), dtype=torch.float64, device="cuda")
         t_llr = torch.empty((B, LEN), dtype=torch.float64, device="cuda")
-        t_bits = torch.empty((B, L), dtype=torch.uint8, device="cuda")
+        t_full = torch.empty((world if args.gather else 1, B, L), dtype=torch.uint8, device="cuda")
+        t_bits = t_full[rank if args.gather else 0]
         d_y, d_llr, d_bits = (ctypes.c_void_p(t.data_ptr()) for t in (t_y, t_llr, t_bits))
+        d_full = ctypes.c_void_p(t_full.data_ptr())
         sync = torch.cuda.synchronize
         barrier = dist.barrier
     else:
         stream = None
-        d_y, d_llr, d_bits = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        d_y, d_llr = ctypes.c_void_p(), ctypes.c_void_p()
         _lib.check(lib.cpx_malloc(ctypes.byref(d_y), B * nsym * 16))
         _lib.check(lib.cpx_malloc(ctypes.byref(d_llr), B * LEN * 8))
-        _lib.check(lib.cpx_malloc(ctypes.byref(d_bits), B * L))
+        _lib.check(lib.cpx_malloc(ctypes.byref(d_full), (world if args.gather else 1) * B * L))
+        d_bits = ctypes.c_void_p(d_full.value + (rank * B * L if args.gather else 0))   # this rank's slot (in-place gather)
 
         def sync():
             _lib.check(lib.cpx_stream_sync(None))
 
         def barrier():
-            pass
+            if comm is not None:
+                comm.barrier()                                      # RCCL all-reduce of one word + stream sync
 
     if args.synth == "host":
         _lib.check(lib.cpx_memcpy_h2d(d_y, _lib.ptr(y), y.nbytes))
@@ -197,6 +223,11 @@ def main():
         if k is not None:
             _lib.check(lib.cpx_timer_start(timers[k], stream))
         _lib.check(lib.cpx_viterbi_decode_batch_dev(h_tr, d_llr, B, LEN, L, T, TB, 1, d_bits, stream))
+        if args.gather and world > 1:                               # the collective north_star names, on the decode stream
+            if comm is not None:
+                comm.allgather_dev(d_bits, d_full, B * L, stream)
+            else:
+                dist.all_gather_into_tensor(t_full.view(-1), t_bits.reshape(-1))
         if k is not None:
             _lib.check(lib.cpx_timer_stop(timers[k], stream))
 
@@ -208,6 +239,7 @@ def main():
     for _ in range(max(args.warmup, 1)):
         step(len(timers) - 1)
     barrier(); sync()
+    kernel_name = _lib.last_kernel()                               # what the library really launched for this workload
     if distributed:
         # untimed rehearsal of the whole timed region (same K launches, same closing barrier + synchronize): one-time
         # host-side costs of the collective path (seen sporadically as a ~70 ms stall in the first closing barrier of
@@ -231,58 +263,67 @@ def main():
         ms = ctypes.c_float()
         _lib.check(lib.cpx_timer_elapsed_ms(tmr, ctypes.byref(ms)))
         kernel_ms.append(ms.value)
-    if distributed:
+    if comm is not None:
+        elapsed = float(comm.allreduce(np.array([elapsed]), "max")[0])          # MAX over ranks
+    elif dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
     # ---- correctness of what was timed: BER vs the messages, parity vs the oracle on a sample ----
     bits = np.empty((B, L), dtype=np.uint8)
-    if distributed:
-        bits[...] = t_bits.cpu().numpy()
-    else:
-        _lib.check(lib.cpx_memcpy_d2h(_lib.ptr(bits), d_bits, bits.nbytes))
+    _lib.check(lib.cpx_memcpy_d2h(_lib.ptr(bits), d_bits, bits.nbytes))
     nerr = int(np.sum(bits[:, :MSG_BITS] != msgs))
-    if distributed and world > 1:
-        # the only collective of the job, outside the timed region: error counts of all shards (RCCL all-reduce).
-        # The decode path itself has no exchange step -- every rank decodes and keeps its own codewords.
-        terr = torch.tensor([nerr], dtype=torch.int64, device="cuda")
-        dist.all_reduce(terr, op=dist.ReduceOp.SUM)
-        nerr = int(terr.item())
+    gather_ok = None
+    if args.gather and world > 1:
+        # every rank holds every rank's bits: this rank's own slot must equal what it decoded, and the error count over the
+        # gathered array (against the all-reduced total below) shows the other slots carry the other ranks' results
+        full = np.empty((world, B, L), dtype=np.uint8)
+        _lib.check(lib.cpx_memcpy_d2h(_lib.ptr(full), d_full, full.nbytes))
+        gather_ok = bool(np.array_equal(full[rank], bits))
+    if world > 1:
+        # error counts of all shards: an RCCL all-reduce of int64 counters (links.py:252-260), outside the timed region
+        if comm is not None:
+            nerr = int(comm.allreduce(np.array([nerr], np.int64))[0])
+        else:
+            terr = torch.tensor([nerr], dtype=torch.int64, device="cuda")
+            dist.all_reduce(terr, op=dist.ReduceOp.SUM)
+            nerr = int(terr.item())
     ber = nerr / float(world * B * MSG_BITS)
     out = None
     if rank == 0:
         import oracle
-        ns = 128
-        llr_s = np.empty((max(ns, 4096), LEN))
-        if distributed:
-            llr_s[...] = t_llr[:llr_s.shape[0]].cpu().numpy()
-        else:
-            _lib.check(lib.cpx_memcpy_d2h(_lib.ptr(llr_s), d_llr, llr_s.nbytes))
-        want = oracle.viterbi_decode(llr_s[:ns], tr, None, "soft")
-        mism = int(np.sum(want != bits[:ns]))
+        # parity of what was timed: 16384 codewords (first / middle / last 5462 of the batch: every wavefront position of
+        # the first, middle and last workgroups) against the oracle, decoded on the host threads
+        ns = min(B, 5462)
+        starts = sorted({0, max(0, B // 2 - ns // 2), B - ns})
+        mism, checked = 0, 0
+        llr_s = None
+        for lo in starts:
+            blk = np.empty((ns, LEN))
+            _lib.check(lib.cpx_memcpy_d2h(_lib.ptr(blk), ctypes.c_void_p(d_llr.value + lo * LEN * 8), blk.nbytes))
+            want = oracle.viterbi_decode_mt(blk, tr, None, "soft", usable_cores())
+            mism += int(np.sum(want != bits[lo:lo + ns]))
+            checked += ns
+            if lo == 0:
+                llr_s = blk
         llr_ref = oracle.demodulate(md.constellation, y[0], "soft", N0)
         demod_err = float(np.max(np.abs(llr_ref - llr_s[0])))
         kavg = float(np.mean(kernel_ms))
         achieved = ALG_BYTES_PER_CW * B / (kavg * 1e-3) / 1e9
         value = world * B * MSG_BITS * args.steps / elapsed
-        # which kernels ran: the library takes the codeword-per-lane path (csrc/viterbi_cw.hip) for batches that give every
-        # SIMD a wavefront of 64 codewords (B >= 3/4 * CUs * 4 * 64) unless CPX_VITERBI_PATH=wave
-        cus = ctypes.c_int(0)
-        lib.cpx_device_info(None, 0, ctypes.byref(cus), None)
-        forced = os.environ.get("CPX_VITERBI_PATH", "")
-        cw_path = (not forced.startswith("w")) and (forced.startswith("c") or B >= 3 * cus.value * 4 * 64 // 4)
-        two = "2" in forced                                    # "cw2": ACS + traceback kernels instead of the fused kernel
-        kernel_name = ("viterbi_wave_kernel<6,2,true,2>" if not cw_path else
-                       "viterbi_cw_acs_kernel<6,0155,0117,soft> + viterbi_cw_tb_kernel<6>" if two else
-                       "viterbi_cw_fused_kernel<6,0155,0117,soft,28>")
-        traffic, traffic_src = None, None    # HBM bytes per launch from the committed PMC passes (same workload and kernels only)
+        # HBM traffic and VALU occupancy of this kernel from the committed rocprofv3 PMC passes (scripts/collect_pmc.sh),
+        # used only when they were taken on the same kernel and batch
+        traffic = traffic_src = valu = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_viterbi_c2_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
                 tj = json.load(f)
-            if B == 65536 and tj.get("path") == (("cw2" if two else "fused") if cw_path else "wave"):
+            same = tj.get("batch") == B and kernel_name.split("<")[0] in tj.get("kernel", "?")   # rocprofv3 prints the
+            # template arguments as numbers ("<6, 109u, 79u, 1, 28>"): the kernel's base name and the batch identify it
+            if same:
                 traffic = tj["traffic_bytes_per_launch"]
-                traffic_src = "profiles/r01_viterbi_c2_traffic.json (rocprofv3 FETCH_SIZE / WRITE_SIZE passes, KiB; see the file for the gfx950 correction)"
+                traffic_src = "profiles/%s (rocprofv3 FETCH_SIZE / WRITE_SIZE passes; gfx950 correction as in the file)" % PMC_FILE
+                valu = tj.get("valu")
         except (OSError, ValueError, KeyError):
             pass
         out = {
@@ -292,23 +333,38 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic (%s-generated: random messages -> conv_encode -> QPSK -> AWGN -> soft demod on device)" % args.synth,
             "config": {"workload": "configs[1]: K=7 (0o133,0o171) r=1/2, 1024-bit blocks, soft Viterbi over "
-                                   "AWGN+QPSK at Eb/N0=3 dB, batch=65536 codewords per GPU, tb_depth=30",
+                                   "AWGN+QPSK at Eb/N0=3 dB, batch=%d codewords per GPU, tb_depth=30" % B,
                        "batch_per_gpu": B, "block_bits": MSG_BITS, "ebn0_db": EBN0_DB,
-                       "parallelism": "codewords sharded x%d, no data-path collective" % (world if distributed else 1)},
-            "ber": ber, "oracle_mismatched_bits": mism, "oracle_sample_codewords": ns,
+                       "parallelism": "codewords sharded x%d, %s" % (
+                           world, "RCCL all-gather of the decoded bits in every step" if (args.gather and world > 1)
+                           else "no data-path collective"),
+                       "collectives": ("engine RCCL binding (cpx_comm_*)" if comm is not None else
+                                       "torch.distributed (nccl)" if dist is not None else "none (single process)")},
+            "ber": ber, "oracle_mismatched_bits": mism, "oracle_sample_codewords": checked,
             "demod_max_abs_err_vs_oracle": demod_err,
-            "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved,
+            # the kernel is bound by VALU issue, not by HBM: achieved / peak / frac are the HBM figures the
+            # contract asks for, `valu` carries the ceiling that actually binds (from the PMC passes in profiles/)
+            "roofline": {"bound": "valu", "kernel": kernel_name, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src,
                          "kernel_ms_avg": kavg,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_CW * B,
-                         "note": "serial float64 add-compare-select recursion: VALU-issue bound, not HBM bound (DESIGN 4.1)"},
+                         "valu": valu,
+                         "note": "serial float64 add-compare-select recursion: VALU-issue bound (valu.busy_frac), the HBM "
+                                 "fraction is reported because the metric asks for it"},
         }
+        if gather_ok is not None:
+            out["gather_own_slot_ok"] = gather_ok
+        if comm_note:
+            out["comm_note"] = comm_note
         if not args.no_cpu_baseline and world == 1:                # reported at N = 1 only; the other ranks would idle
             out["cpu_baseline"] = cpu_baseline(tr, llr_s)
         else:
             out["cpu_baseline"] = None
-    if distributed:
+    if comm is not None:
+        comm.barrier()
+        comm.close()
+    elif dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if out is not None:

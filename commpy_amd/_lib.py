@@ -206,3 +206,36 @@ def viterbi_last_path():
 def viterbi_set_path(mode):
     """Force a Viterbi kernel path: None/'auto', 'wave', 'cw', 'cw!', 'cw2', 'cw2!' (tests and benchmarks)."""
     check(load().cpx_viterbi_set_path(None if mode is None else mode.encode()))
+
+
+class DeviceHandles:
+    """Opaque engine handles of ONE host object (a Trellis, a Modem, an LDPC code ...), one per device.
+
+    A handle owns small tables in the HBM of the device that was current when it was created, and the engine refuses it
+    on any other device (CPX_EINVAL); so a host object that is used after ``cpx_set_device(other)`` -- the single-process
+    multi-GPU driver of commpy_amd.parallel does exactly that -- gets a second handle there instead of a fault.
+    """
+
+    def __init__(self, create, destroy_name):
+        self._create = create              # () -> c_void_p, on the current device
+        self._destroy_name = destroy_name
+        self._h = {}
+
+    def get(self):
+        dev = current_device()
+        h = self._h.get(dev)
+        if h is None:
+            require_device()
+            h = self._h[dev] = self._create()
+        return h
+
+    def drop(self):
+        hs, self._h = self._h, {}
+        for h in hs.values():
+            try:
+                getattr(load(), self._destroy_name)(h)
+            except Exception:              # interpreter shutdown
+                pass
+
+    def __del__(self):
+        self.drop()

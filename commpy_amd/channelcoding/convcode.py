@@ -59,7 +59,6 @@ class Trellis:
         self.number_inputs = 2 ** self.k
         self.next_state_table = np.zeros([self.number_states, self.number_inputs], 'int')
         self.output_table = np.zeros([self.number_states, self.number_inputs], 'int')
-        self._cpx_handle = None
 
         if isinstance(feedback, int):
             warn('Trellis  will only accept feedback as a matrix in the future. '
@@ -142,28 +141,21 @@ class Trellis:
 
     # -- device handle ---------------------------------------------------------------------------
     def _device_handle(self):
-        """Opaque cpx_trellis* carrying the tables to the GPU (created on first use)."""
-        if self._cpx_handle is None:
-            lib = _lib.load()
-            _lib.require_device()
-            nxt = _lib.as_i32(self.next_state_table)
-            out = _lib.as_i32(self.output_table)
-            h = ctypes.c_void_p()
-            _lib.check(lib.cpx_trellis_create(int(self.k), int(self.n), int(self.number_states),
-                                              int(self.number_inputs),
-                                              nxt.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
-                                              out.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
-                                              ctypes.byref(h)))
-            self._cpx_handle = h
-        return self._cpx_handle
-
-    def __del__(self):
-        h = getattr(self, '_cpx_handle', None)
-        if h is not None:
-            try:
-                _lib.load().cpx_trellis_destroy(h)
-            except Exception:  # interpreter shutdown
-                pass
+        """Opaque cpx_trellis* carrying the tables to the current GPU (created on first use, one per device)."""
+        hs = self.__dict__.get('_cpx_handles')
+        if hs is None:
+            def create():
+                nxt = _lib.as_i32(self.next_state_table)
+                out = _lib.as_i32(self.output_table)
+                h = ctypes.c_void_p()
+                _lib.check(_lib.load().cpx_trellis_create(int(self.k), int(self.n), int(self.number_states),
+                                                          int(self.number_inputs),
+                                                          nxt.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                                                          out.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                                                          ctypes.byref(h)))
+                return h
+            hs = self.__dict__['_cpx_handles'] = _lib.DeviceHandles(create, 'cpx_trellis_destroy')
+        return hs.get()
 
 
 def conv_encode(message_bits, trellis, termination='term', puncture_matrix=None):
@@ -234,8 +226,9 @@ def conv_encode_batch(message_bits, trellis, termination='term'):
     if msgs.ndim != 2:
         raise ValueError('message_bits must be [B, nbits]')
     B, nmsg = msgs.shape
-    rsc_term = trellis.code_type == 'rsc' and termination != 'cont'
-    if termination == 'cont' or rsc_term:
+    rsc = trellis.code_type == 'rsc' and termination != 'cont'
+    rsc_term = rsc and termination == 'term'                  # the tail is clocked for 'term' only (:538), whereas ANY
+    if termination == 'cont' or rsc:                          # termination but 'cont' reserves room for it (:509-512)
         inbits = msgs
     else:
         pad = total_memory + total_memory % k
@@ -258,37 +251,43 @@ def conv_encode_batch(message_bits, trellis, termination='term'):
             cur = grp.dot(1 << np.arange(grp.shape[1] - 1, -1, -1))
             symbols.append(outt[state, cur])
             state = nxt[state, cur]
-    sym = np.stack(symbols, axis=1)                                  # [B, steps]
-    bits = (sym[:, :, None] >> np.arange(n - 1, -1, -1)) & 1         # MSB-first n bits per step
-    return bits.reshape(B, -1).astype(np.int64)
+    sym = np.stack(symbols, axis=1) if symbols else np.zeros((B, 0), np.int64)   # [B, steps]
+    bits = ((sym[:, :, None] >> np.arange(n - 1, -1, -1)) & 1).reshape(B, -1)     # MSB-first n bits per step
+    nout = int((nmsg + k * total_memory) / (float(k) / n)) if rsc else bits.shape[1]
+    if nout > bits.shape[1]:                                         # e.g. termination='rsc' (turbo.py:47): zero tail
+        bits = np.concatenate([bits, np.zeros((B, nout - bits.shape[1]), bits.dtype)], axis=1)
+    return bits[:, :nout].astype(np.int64)
+
+
+def puncture_keep_mask(n_positions, punct_vec):
+    """Boolean mask of the positions ``puncturing`` keeps / ``depuncturing`` fills, for a sequence of ``n_positions``.
+
+    The reference walks the positions with a running ``shift`` that grows after every position ``idx`` with
+    ``idx % N == 0`` and looks up ``punct_vec[idx - shift * N]`` (convcode.py:766-772, :795-802).  At position ``idx``
+    the shift is the number of earlier multiples of ``N``, ``ceil(idx / N)``, so the looked-up index lies in
+    ``(-N, 0]`` and wraps like any negative Python index.  This is that rule as one index table."""
+    pv = np.asarray(punct_vec)
+    N = len(pv)
+    idx = np.arange(int(n_positions))
+    return pv[idx - -(-idx // N) * N] == 1
 
 
 def puncturing(message, punct_vec):
-    """Drop the positions whose puncture-vector entry is 0 -- convcode.py:752-774 (same index walk)."""
-    shift = 0
-    N = len(punct_vec)
-    punctured = []
-    for idx, item in enumerate(message):
-        if punct_vec[idx - shift * N] == 1:
-            punctured.append(item)
-        if idx % N == 0:
-            shift = shift + 1
-    return np.array(punctured)
+    """Drop the positions whose puncture-vector entry is 0 -- convcode.py:752-774."""
+    message = np.asarray(message)
+    return message[puncture_keep_mask(len(message), punct_vec)]
 
 
 def depuncturing(punctured, punct_vec, shouldbe):
-    """Re-insert zeros at punctured positions -- convcode.py:777-804 (same index walk)."""
-    shift = 0
-    shift2 = 0
-    N = len(punct_vec)
-    depunctured = np.zeros((shouldbe,))
-    for idx in range(shouldbe):
-        if punct_vec[idx - shift * N] == 1:
-            depunctured[idx] = float(punctured[idx - shift2])
-        else:
-            shift2 = shift2 + 1
-        if idx % N == 0:
-            shift = shift + 1
+    """Re-insert zeros at punctured positions -- convcode.py:777-804; float64 array of length ``shouldbe``.
+    ``IndexError`` when ``punctured`` is too short for the pattern, like the reference's ``punctured[idx - shift2]``."""
+    keep = puncture_keep_mask(shouldbe, punct_vec)
+    punctured = np.asarray(punctured)
+    nkeep = int(keep.sum())
+    if nkeep > len(punctured):
+        raise IndexError('index %d is out of bounds for axis 0 with size %d' % (len(punctured), len(punctured)))
+    depunctured = np.zeros((int(shouldbe),))
+    depunctured[keep] = punctured[:nkeep].astype(float)
     return depunctured
 
 

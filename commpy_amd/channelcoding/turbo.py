@@ -20,8 +20,9 @@ def turbo_encode(msg_bits, trellis1, trellis2, interleaver):
     """Parallel-concatenated rate-1/3 turbo encoder (host) -- turbo.py:14-59.
 
     Returns ``[sys_stream, non_sys_stream_1, non_sys_stream_2]`` exactly like the reference,
-    including: ``'rsc'`` passed as the *termination* argument (turbo.py:47, anything but 'cont'
-    terminates), the tailed systematic stream being interleaved, and the second parity stream
+    including: ``'rsc'`` passed as the *termination* argument (turbo.py:47: ``conv_encode`` then reserves room
+    for a tail -- anything but 'cont' does, convcode.py:509-512 -- but clocks none, which only 'term' would,
+    :538, so the reserved tail stays zero), the tailed systematic stream being interleaved, and the second parity stream
     keeping ``conv_encode``'s unpunctured length with a zero tail (quirks B3/B4) -- use
     ``non_sys_stream_2[:N]``.
     """

@@ -79,8 +79,11 @@ def conv_encode_gpu(message_bits, trellis, termination='term'):
     B, nmsg = msgs.shape
     nout = _encoded_length(nmsg, trellis, termination)
     d_msg, d_out = DeviceBuf.from_array(msgs), DeviceBuf(B * nout)
-    _lib.check(lib.cpx_conv_encode_batch_dev(trellis._device_handle(), d_msg.ptr, B, nmsg, int(termination != 'cont'),
-                                             int(trellis.code_type == 'rsc'), d_out.ptr, nout, None))
+    rsc = trellis.code_type == 'rsc'
+    # recursive codes clock a tail for 'term' only (convcode.py:538); other codes append zeros for anything but 'cont'
+    terminate = (termination == 'term') if rsc else (termination != 'cont')
+    _lib.check(lib.cpx_conv_encode_batch_dev(trellis._device_handle(), d_msg.ptr, B, nmsg, int(terminate),
+                                             int(rsc), d_out.ptr, nout, None))
     _lib.check(lib.cpx_stream_sync(None))
     return d_out.to_array((B, nout), np.uint8).astype(np.int64)
 
@@ -265,12 +268,12 @@ class DeviceWifiLink:
             self.nde = self.ncoded
             self.de_idx = None
         else:
-            pmask = np.asarray(pvec) == 1
-            keep = pmask[np.arange(self.ncoded) % len(pmask)]
+            from commpy_amd.channelcoding.convcode import puncture_keep_mask
+            keep = puncture_keep_mask(self.ncoded, pvec)
             self.keep_idx = np.flatnonzero(keep).astype(np.int32)
             self.ntx = len(self.keep_idx)
             self.nde = math.ceil(self.ntx * self.coding[0] / self.coding[1] * 2)
-            keep2 = pmask[np.arange(self.nde) % len(pmask)]
+            keep2 = puncture_keep_mask(self.nde, pvec)
             de = -np.ones(self.nde, dtype=np.int32)
             de[keep2] = np.arange(keep2.sum(), dtype=np.int32)
             if keep2.sum() > self.ntx:

@@ -10,10 +10,12 @@ MI355X-first difference: the transmissions of one SNR point are *batched*.  When
 marked batch-capable (attribute ``batched = True``; the ones built by ``commpy_amd.wifi80211`` are) a block
 of ``tx_batch`` transmissions is generated, modulated, propagated, demodulated and decoded as 2-D
 arrays -- one GPU launch per stage instead of one Python call per transmission -- and the reference's
-sequential stop rule is applied to the per-transmission error counts afterwards.  Unmarked callbacks
-are called per transmission exactly like the reference.  MIMO channels are out of scope.
+sequential stop rule is applied to the per-transmission error counts afterwards.  As soon as one callback is
+not marked, transmissions run one at a time exactly like the reference (same random stream, same stop rule,
+six-argument decoders recognised by arity).  MIMO channels are out of scope.
 """
 from fractions import Fraction
+from inspect import getfullargspec
 
 import numpy as np
 
@@ -50,24 +52,40 @@ class LinkModel:
         self.tx_batch = 64            # transmissions generated / decoded per GPU batch
 
     # -- one block of transmissions ------------------------------------------------------------
+    def _all_batched(self):
+        return _is_batched(self.modulate) and _is_batched(self.receive) and _is_batched(self.decoder)
+
+    def _block_size(self, remaining):
+        """Transmissions per block: ``tx_batch`` on the batched (GPU) path; ONE when any callback is the reference's
+        per-transmission kind, so that the sequential stop rule never runs (and discards) extra transmissions and the
+        NumPy random stream is consumed exactly like the reference's."""
+        return max(1, min(self.tx_batch if self._all_batched() else 1, remaining))
+
     def _run_block(self, n_tx, n_bits):
         """Returns (msgs [n_tx, n_bits], decoded [n_tx, >= n_bits]) for n_tx independent transmissions."""
-        batched = _is_batched(self.modulate) and _is_batched(self.receive) and _is_batched(self.decoder)
-        noise_var = None
-        if batched:
+        if self._all_batched():
             msgs = np.random.choice((0, 1), (n_tx, n_bits))
             symbs = self.modulate(msgs)
             out = self.channel.propagate(symbs)
             noise_var = self.channel.noise_std ** 2
             received = self.receive(out, self.channel.channel_gains, self.constellation, noise_var)
             return msgs, np.asarray(self.decoder(received))
+        # per transmission, the reference's protocol (links.py:229-250), including the six-argument decoders
+        # (``idd_decoder``-style, links.py:216, 246-248) that are recognised by their arity
+        full_args_decoder = len(getfullargspec(self.decoder).args) > 1
         msgs, decs = [], []
         for _ in range(n_tx):
             msg = np.random.choice((0, 1), n_bits)
             out = self.channel.propagate(self.modulate(msg))
-            received = self.receive(out, self.channel.channel_gains, self.constellation, self.channel.noise_std ** 2)
+            noise_var = self.channel.noise_std ** 2
+            received = self.receive(out, self.channel.channel_gains, self.constellation, noise_var)
+            if full_args_decoder:
+                dec = self.decoder(out, self.channel.channel_gains, self.constellation, noise_var, received,
+                                   self.channel.nb_tx * self.num_bits_symbol)
+            else:
+                dec = self.decoder(received)
             msgs.append(msg)
-            decs.append(np.asarray(self.decoder(received)))
+            decs.append(np.asarray(dec).reshape(-1))
         return np.stack(msgs), np.stack(decs)
 
     def _prepare(self, send_chunk, err_min, code_rate):
@@ -102,7 +120,9 @@ class LinkModel:
             id_tx = 0
             stopped = False
             while id_tx < tx_max and not stopped:
-                n_blk = min(self.tx_batch, tx_max - id_tx)
+                if stop_on_surpass_error and bit_err.sum() > err_min:   # tested BEFORE a transmission is made (:226)
+                    break
+                n_blk = self._block_size(tx_max - id_tx)
                 msgs, dec = self._run_block(n_blk, n_bits)
                 errs = (msgs != dec[:, :n_bits].astype(int)).reshape(n_blk, number_chunks_per_send, send_chunk).sum(2)
                 for j in range(n_blk):                      # the reference's per-transmission bookkeeping
@@ -132,7 +152,7 @@ class LinkModel:
             bit_err = 0
             while bit_send < send_max and bit_err < err_min:
                 remaining = int(np.ceil((send_max - bit_send) / send_chunk))
-                n_blk = max(1, min(self.tx_batch, remaining))
+                n_blk = self._block_size(remaining)
                 msgs, dec = self._run_block(n_blk, send_chunk)
                 errs = (msgs != dec[:, :send_chunk].astype(int)).sum(1)
                 for j in range(n_blk):                      # sequential stop rule of the reference

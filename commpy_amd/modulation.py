@@ -28,7 +28,7 @@ class Modem:
     """Custom modem -- modulation.py:39-172.  ``constellation`` must have a power-of-two length."""
 
     def __init__(self, constellation, reorder_as_gray=True):
-        self._cpx_handle = None
+        self._cpx_handles = None
         if reorder_as_gray:
             self.constellation = np.array(constellation)[_gray_rank(len(constellation))]
         else:
@@ -82,26 +82,44 @@ class Modem:
 
     # -- device handle -----------------------------------------------------------------------
     def _device_handle(self):
-        if self._cpx_handle is None:
-            lib = _lib.load()
-            _lib.require_device()
-            c = np.ascontiguousarray(self._constellation, dtype=np.complex128)
-            h = ctypes.c_void_p()
-            _lib.check(lib.cpx_modem_create(_lib.ptr(c), int(self.m), ctypes.byref(h)))
-            self._cpx_handle = h
-        return self._cpx_handle
+        """Opaque cpx_modem* of the current device (created on first use, one per device)."""
+        if self._cpx_handles is None:
+            def create():
+                c = np.ascontiguousarray(self._constellation, dtype=np.complex128)
+                h = ctypes.c_void_p()
+                _lib.check(_lib.load().cpx_modem_create(_lib.ptr(c), int(self.m), ctypes.byref(h)))
+                return h
+            self._cpx_handles = _lib.DeviceHandles(create, 'cpx_modem_destroy')
+        return self._cpx_handles.get()
 
     def _drop_handle(self):
-        h = getattr(self, '_cpx_handle', None)
-        if h is not None:
-            try:
-                _lib.load().cpx_modem_destroy(h)
-            except Exception:
-                pass
-        self._cpx_handle = None
+        hs = getattr(self, '_cpx_handles', None)
+        if hs is not None:
+            hs.drop()
+        self._cpx_handles = None
 
-    def __del__(self):
-        self._drop_handle()
+    def demodulate_viterbi_hard(self, input_symbols, trellis, tb_depth=None):
+        """``viterbi_decode(self.demodulate(y, 'hard'), trellis, tb_depth, 'hard')`` in ONE kernel
+        (modulation.py:121-123 feeding convcode.py:578-580, 661-749): the hard decisions are taken inside the
+        Viterbi kernel while it prepares the branch metrics, the int8 bits never exist in HBM.  ``input_symbols``:
+        1-D (one codeword) or ``[B, nsym]``; returns what the two calls return (int64, tail included).
+        Trellises above 64 states take the two calls (the fused kernel keeps one state per lane)."""
+        from commpy_amd.channelcoding.convcode import _viterbi_sizes, viterbi_decode
+        y = np.ascontiguousarray(input_symbols, dtype=np.complex128)
+        single = y.ndim == 1
+        y2 = np.atleast_2d(y)
+        B, nsym = y2.shape
+        length = nsym * self.num_bits_symbol
+        if trellis.number_states > 64 or length == 0:
+            bits = self.demodulate(y2.reshape(-1), 'hard').reshape(B, length)
+            return viterbi_decode(bits[0] if single else bits, trellis, tb_depth, 'hard')
+        L, T, tb = _viterbi_sizes(length, trellis, tb_depth)
+        out = np.zeros((B, L), dtype=np.uint8)
+        if B and L:
+            _lib.check(_lib.load().cpx_demod_hard_viterbi_batch(self._device_handle(), trellis._device_handle(),
+                                                                _lib.ptr(y2), B, nsym, L, T, tb, _lib.ptr(out)))
+        out = out.astype(np.int64)
+        return out[0] if single else out
 
 
 class PSKModem(Modem):

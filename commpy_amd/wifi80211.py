@@ -67,36 +67,43 @@ class Wifi80211:
         modem = self.get_modem()
         self.modem = modem
         pvec = self._get_puncture_matrix(coding[0], coding[1])
-        pmask = None if pvec is None else np.asarray(pvec) == 1
+
+        # Every closure accepts the reference's 1-D arrays (one transmission -> 1-D result, wifi80211.py:178-206) and
+        # 2-D [T, n] blocks (-> 2-D); LinkModel only batches when ALL callbacks are marked, so a user-supplied
+        # per-transmission `receiver` sees exactly what the reference would hand it.
+        @_batched
+        def modulate(bits):                                  # bits [n] or [T, n] -> symbols [nsym] or [T, nsym]
+            bits = np.asarray(bits)
+            res = cc.conv_encode_batch(np.atleast_2d(bits), trellis1, 'cont')
+            if pvec is not None:
+                res = res[:, cc.convcode.puncture_keep_mask(res.shape[1], pvec)]
+            sym = modem.modulate(res.reshape(-1)).reshape(res.shape[0], -1)
+            return sym[0] if bits.ndim == 1 else sym
 
         @_batched
-        def modulate(bits):                                  # bits [T, n] -> symbols [T, nsym]
-            bits = np.atleast_2d(bits)
-            res = cc.conv_encode_batch(bits, trellis1, 'cont')
-            if pmask is not None:                            # puncturing keeps position i iff vec[i % N] == 1
-                res = res[:, pmask[np.arange(res.shape[1]) % len(pmask)]]
-            return modem.modulate(res.reshape(-1)).reshape(res.shape[0], -1)
-
-        @_batched
-        def _receiver(y, h, constellation, noise_var):       # soft LLRs on the GPU, [T, nsym*nb]
-            y = np.atleast_2d(y)
-            return modem.demodulate(y.reshape(-1), 'soft', noise_var).reshape(y.shape[0], -1)
+        def _receiver(y, h, constellation, noise_var):       # soft LLRs on the GPU, [nsym*nb] or [T, nsym*nb]
+            y = np.asarray(y)
+            llr = modem.demodulate(y.reshape(-1), 'soft', noise_var)
+            return llr if y.ndim == 1 else llr.reshape(y.shape[0], -1)
 
         if not receiver:
             receiver = _receiver
 
         @_batched
         def decoder_soft(msg):
+            msg = np.asarray(msg)
+            single = msg.ndim == 1
             msg = np.atleast_2d(msg)
-            if pmask is not None:                            # depuncturing: zeros at the punctured positions
+            if pvec is not None:                             # depuncturing: zeros at the punctured positions
                 shouldbe = math.ceil(msg.shape[1] * coding[0] / coding[1] * 2)
-                keep = pmask[np.arange(shouldbe) % len(pmask)]
+                keep = cc.convcode.puncture_keep_mask(shouldbe, pvec)
                 if keep.sum() > msg.shape[1]:
                     raise IndexError('depuncturing: message too short for the puncturing pattern')
                 full = np.zeros((msg.shape[0], shouldbe))
                 full[:, keep] = msg[:, :keep.sum()]
                 msg = full
-            return cc.viterbi_decode(msg, trellis1, decoding_type='soft')
+            dec = cc.viterbi_decode(msg, trellis1, decoding_type='soft')
+            return dec[0] if single else dec
 
         self.model = lk.LinkModel(modulate, channel, receiver, modem.num_bits_symbol, modem.constellation, modem.Es,
                                   decoder_soft, coding[0] / coding[1])

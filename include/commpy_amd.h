@@ -218,7 +218,9 @@ int cpx_demod_hard_dev(const cpx_modem *m, const double *d_y_re_im, int64_t Ns, 
  *   cpx_random_bits_dev       message bits (links.py:229); Philox4x32-10 counter stream (seed, stream_id)
  *   cpx_conv_encode_batch_dev conv_encode(msg, trellis, termination) convcode.py:475-558 for B rows:
  *                             msg [B][nmsg] uint8 -> coded [B][nout] uint8 (nout as the reference computes
- *                             number_outbits; terminate = termination != 'cont'; rsc = code_type == 'rsc')
+ *                             number_outbits; rsc = code_type == 'rsc'; terminate = (termination == 'term') for
+ *                             recursive codes -- the only case whose tail is clocked, convcode.py:538 -- and
+ *                             (termination != 'cont') otherwise; positions past the clocked steps are zero)
  *   cpx_gather_u8_dev         out[b][j] = in[b][idx[j]]: puncturing (convcode.py:752-774) with the kept
  *                             positions as idx
  *   cpx_gather_f64_dev        out[b][j] = idx[j] >= 0 ? in[b][idx[j]] : 0: depuncturing (convcode.py:777-804)

@@ -11,7 +11,7 @@ tr = Trellis(np.array([6]), np.array([[0o133, 0o171]]))
 B, n, L, T = 65536, 2060, 1030, 1035
 rs = np.random.RandomState(0)
 def timeit(d_in, d_out, path, reps=5):
-    os.environ["CPX_VITERBI_PATH"] = path
+    _lib.viterbi_set_path(path)
     tm = ctypes.c_void_p(); lib.cpx_timer_create(ctypes.byref(tm))
     best = 1e9
     for i in range(reps + 1):

@@ -98,19 +98,20 @@ def test_device_wifi_link_matches_host_pipeline(gpu):
 
 def test_device_wifi_link_batched_sweep_noiseless_and_equal_paths(gpu):
     """The batched sweep decodes every frame of every point (very high SNR -> zero errors), and its BER does not depend
-    on which Viterbi kernels decode it (same random streams, CPX_VITERBI_PATH = wave vs default)."""
-    import os
+    on which Viterbi kernels decode it (same random streams, cpx_viterbi_set_path('wave') vs automatic)."""
     from commpy_amd.devicelink import DeviceWifiLink
     snrs = np.array([40.0, 41.0, 42.0])
     assert not DeviceWifiLink(5, 1200, generator_matrix=[[0o133, 0o171]], seed=9).ber_sweep_batched(snrs, 1200 * 20000).any()
     snrs = np.array([14.0, 15.0, 16.0])
     res = {}
+    from commpy_amd import _lib
     for path in ("wave", "auto"):
-        os.environ["CPX_VITERBI_PATH"] = path
+        _lib.viterbi_set_path(path)
         try:
             res[path] = DeviceWifiLink(5, 1200, generator_matrix=[[0o133, 0o171]], seed=9).ber_sweep_batched(snrs, 1200 * 20000)
+            assert ("wave" in _lib.viterbi_last_path()) and (("fused" in _lib.viterbi_last_path()) == (path == "auto"))
         finally:
-            os.environ.pop("CPX_VITERBI_PATH", None)
+            _lib.viterbi_set_path(None)
     assert np.array_equal(res["wave"], res["auto"]) and res["auto"][0] > 0
 
 

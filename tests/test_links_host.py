@@ -105,3 +105,134 @@ def test_linkmodel_stop_rules():
     assert bers[0] == bes[0].sum() / (counted * 100)
     # second SNR has no errors -> sweep stops, third SNR never simulated
     assert bes[1].sum() == 0 and ncs[2].sum() == 0
+
+
+def _reference_puncture_walk(message, punct_vec):
+    """The reference's index walk (convcode.py:752-774), restated: the oracle of `puncture_keep_mask`."""
+    shift, N, out = 0, len(punct_vec), []
+    for idx, item in enumerate(message):
+        if punct_vec[idx - shift * N] == 1:
+            out.append(item)
+        if idx % N == 0:
+            shift += 1
+    return np.array(out)
+
+
+def _reference_depuncture_walk(punctured, punct_vec, shouldbe):
+    shift = shift2 = 0
+    N = len(punct_vec)
+    out = np.zeros((shouldbe,))
+    for idx in range(shouldbe):
+        if punct_vec[idx - shift * N] == 1:
+            out[idx] = float(punctured[idx - shift2])
+        else:
+            shift2 += 1
+        if idx % N == 0:
+            shift += 1
+    return out
+
+
+def test_puncturing_index_table_equals_reference_walk():
+    rs = np.random.RandomState(4)
+    for pv in ([1], [1, 0], [0, 1], [1, 1, 1, 0], [1, 1, 1, 0, 0, 1], [1, 1, 1, 0, 0, 1, 1, 0, 0, 1], [0, 0, 1, 0, 1, 1, 1]):
+        for n in (0, 1, 2, len(pv) - 1, len(pv), len(pv) + 1, 61, 240):
+            if n < 0:
+                continue
+            msg = rs.randint(0, 2, n)
+            got = puncturing(msg, pv)
+            assert np.array_equal(got, _reference_puncture_walk(msg, pv)), (pv, n)
+            soft = rs.randn(len(got))
+            assert np.array_equal(depuncturing(soft, pv, n), _reference_depuncture_walk(soft, pv, n)), (pv, n)
+    with pytest.raises(IndexError):
+        depuncturing(np.zeros(3), [1, 1, 1, 0], 12)
+    with pytest.raises(IndexError):
+        _reference_depuncture_walk(np.zeros(3), [1, 1, 1, 0], 12)
+
+
+def test_conv_encode_batch_terminations_match_conv_encode():
+    """Row b of conv_encode_batch equals conv_encode for every termination string, including 'rsc' -- the value
+    turbo_encode passes positionally (turbo.py:47): room for a tail is reserved but no tail is clocked."""
+    import warnings
+    from commpy_amd.channelcoding import Trellis, conv_encode_batch
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        codes = [Trellis(np.array([2]), np.array([[1, 7]]), 5, "rsc"), Trellis(np.array([2]), np.array([[5, 7]])),
+                 Trellis(np.array([3]), np.array([[1, 0o15]]), 0o13, "rsc")]
+    msgs = np.random.RandomState(9).randint(0, 2, (5, 40))
+    for tr in codes:
+        for term in ("term", "cont", "rsc"):
+            got = conv_encode_batch(msgs, tr, term)
+            for b in range(len(msgs)):
+                want = conv_encode(msgs[b], tr, term)
+                assert got[b].shape == want.shape and np.array_equal(got[b], want), (tr.code_type, term, b)
+
+
+def test_linkmodel_per_transmission_protocol():
+    """Callbacks that are not marked batched: one transmission per block (nothing simulated and thrown away, same
+    np.random stream as the reference's loop) and six-argument decoders receive the reference's full argument list
+    (links.py:216, 246-248)."""
+    calls = {"mod": 0, "dec6": 0}
+
+    def modulate(bits):
+        calls["mod"] += 1
+        assert np.ndim(bits) == 1
+        return 2.0 * np.asarray(bits) - 1
+
+    def receive(y, h, constellation, noise_var):
+        assert np.ndim(y) == 1
+        return (np.asarray(y) > 0).astype(int)
+
+    def decoder6(y, h, constellation, noise_var, received, bits_per_send):
+        calls["dec6"] += 1
+        assert bits_per_send == 1 and len(received) == len(y) and noise_var > 0
+        return received
+
+    np.random.seed(11)
+    model = LinkModel(modulate, SISOFlatChannel(fading_param=(1, 0)), receive, 1, np.array([-1, 1]), 1.0, decoder6)
+    bers, bes, ces, ncs = model.link_performance_full_metrics(np.array([-3.0]), 40, 30, 100)
+    counted = int(np.count_nonzero(ncs[0]))
+    assert 0 < counted < 40 and calls["mod"] == counted == calls["dec6"]      # stops at once: no extra transmissions
+    # identical random stream to a literal per-transmission loop
+    np.random.seed(11)
+    ch = SISOFlatChannel(fading_param=(1, 0))
+    ch.set_SNR_dB(-3.0, 1.0, 1.0)
+    errs = []
+    for _ in range(counted):
+        msg = np.random.choice((0, 1), 100)
+        errs.append(int(np.sum(msg != (ch.propagate(2.0 * msg - 1) > 0))))
+    assert np.array_equal(bes[0, :counted], errs)
+    calls["mod"] = 0
+    np.random.seed(12)
+    model.link_performance(np.array([-3.0]), 10000, 50, 100)
+    assert calls["mod"] < 20                                                    # 50 errors need only a few chunks at -3 dB
+
+
+def test_wifi_custom_receiver_gets_1d_arrays(monkeypatch):
+    """Wifi80211.link_performance(receiver=custom) (wifi80211.py:132, a documented argument): an unmarked receiver makes
+    the link run per transmission; it is handed 1-D symbols and the decoder its 1-D output, as in the reference."""
+    import commpy_amd.channelcoding as cc
+    seen = []
+
+    def fake_viterbi(msg, trellis, tb_depth=None, decoding_type='hard'):       # host-only stand-in: shapes are the point
+        msg = np.asarray(msg)
+        L = msg.shape[-1] // 2
+        return np.zeros(msg.shape[:-1] + (L,), dtype=np.int64)
+
+    monkeypatch.setattr(cc, "viterbi_decode", fake_viterbi)
+
+    def receiver(y, h, constellation, noise_var):
+        seen.append(np.shape(y))
+        assert np.ndim(y) == 1 and len(constellation) == 4
+        out = np.empty(2 * len(y))
+        out[0::2], out[1::2] = y.real, y.imag                                    # any soft metric of the right length
+        return out
+
+    np.random.seed(2)
+    w = Wifi80211(1)                                                             # QPSK, rate 1/2: no puncturing
+    bers, bes, ces, ncs = w.link_performance(SISOFlatChannel(fading_param=(1 + 0j, 0j)), np.array([5.0]), 4, 10 ** 9, 60,
+                                             receiver=receiver, stop_on_surpass_error=False)
+    assert len(seen) == 4 and all(len(s) == 1 for s in seen)
+    assert bes.shape == (1, 4) and 0.3 < bers[0] < 0.7                           # all-zero "decoder" vs random bits
+    w3 = Wifi80211(2)                                                            # rate 3/4: the depuncturing branch
+    w3.link_performance(SISOFlatChannel(fading_param=(1 + 0j, 0j)), np.array([5.0]), 2, 10 ** 9, 60, receiver=receiver,
+                        stop_on_surpass_error=False)

@@ -1,0 +1,180 @@
+"""Round-2 additions on the GPU: fused hard-demod -> hard-Viterbi entry point, compiled LDPC designs, the engine's RCCL
+collectives (communicators of one device: the collectives really run through librccl, trivially), single-process
+DeviceGroup drivers, handle/device checks, kernel-name reporting."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from helpers import golden, ldpc_params, make_trellis
+
+pytestmark = pytest.mark.gpu
+
+
+# ------------------------------------------------------------------ fused hard demodulation + Viterbi
+def _modems():
+    from commpy_amd.modulation import Modem, PSKModem, QAMModem
+    return {"psk2": PSKModem(2), "qam4": QAMModem(4), "psk8": PSKModem(8), "qam16": QAMModem(16), "qam64": QAMModem(64),
+            "custom4": Modem([1 + 1j, -1.2 + 0.8j, 0.3 - 1j, -1 - 1.5j])}
+
+
+@pytest.mark.parametrize("tname", ["t57", "k7_133_171", "k2_default", "rsc_legacy_8", "r13_k4"])
+def test_fused_hard_demod_viterbi_equals_two_calls(gpu, tname):
+    from commpy_amd import _lib
+    from commpy_amd.channelcoding import conv_encode_batch, viterbi_decode
+    tr = make_trellis(tname)
+    rs = np.random.RandomState(len(tname))
+    for mname, md in _modems().items():
+        nb = md.num_bits_symbol
+        B, nmsg = 37, 60 * tr.k
+        coded = conv_encode_batch(rs.randint(0, 2, (B, nmsg)), tr)
+        pad = (-coded.shape[1]) % nb                                   # whole symbols
+        coded = np.concatenate([coded, np.zeros((B, pad), coded.dtype)], axis=1)
+        s = md.modulate(coded.reshape(-1)).reshape(B, -1)
+        N0 = md.Es / 10 ** 0.9
+        y = s + np.sqrt(N0 / 2) * (rs.randn(*s.shape) + 1j * rs.randn(*s.shape))
+        bits = md.demodulate(y.reshape(-1), "hard").reshape(B, -1)
+        for tb in (None, 12):
+            two = viterbi_decode(bits, tr, tb, "hard")
+            one = md.demodulate_viterbi_hard(y, tr, tb)
+            assert "demod" in _lib.last_kernel(), _lib.last_kernel()
+            assert one.dtype == np.int64 and np.array_equal(one, two), (tname, mname, tb)
+        want = oracle.viterbi_decode(oracle.demodulate(md.constellation, y[3], "hard"), tr, None, "hard")
+        assert np.array_equal(md.demodulate_viterbi_hard(y[3], tr), want)          # 1-D in -> 1-D out, vs the oracle pair
+
+
+def test_fused_hard_demod_viterbi_boundaries_and_limits(gpu):
+    """Symbols exactly on decision boundaries take the first-minimum label in both paths; 128-state trellises take the
+    two-call path inside the wrapper."""
+    from commpy_amd.channelcoding import viterbi_decode
+    from commpy_amd.modulation import QAMModem
+    md = QAMModem(16)
+    tr = make_trellis("k7_133_171")
+    rs = np.random.RandomState(1)
+    y = (rs.randint(-4, 5, (9, 64)) + 1j * rs.randint(-4, 5, (9, 64))).astype(complex)   # grid lines and midpoints
+    bits = md.demodulate(y.reshape(-1), "hard").reshape(9, -1)
+    assert np.array_equal(md.demodulate_viterbi_hard(y, tr), viterbi_decode(bits, tr, None, "hard"))
+    big = make_trellis("k8_247_371")
+    y2 = y[:, :32]
+    bits2 = md.demodulate(y2.reshape(-1), "hard").reshape(9, -1)
+    assert np.array_equal(md.demodulate_viterbi_hard(y2, big), viterbi_decode(bits2, big, None, "hard"))
+    assert md.demodulate_viterbi_hard(np.zeros((0, 8), complex), tr).shape == (0, 16)
+
+
+# ------------------------------------------------------------------ compiled LDPC designs
+def test_ldpc_handle_from_blob_decodes_like_edge_list(gpu, tmp_path, monkeypatch):
+    from commpy_amd.channelcoding import ldpc as L
+    monkeypatch.setenv("CPX_CACHE_DIR", str(tmp_path))
+    design = os.path.join(os.path.dirname(L.__file__), "designs/ldpc/ieee80211n/1944.1296.txt")
+    g = golden("ldpc_c4x")
+    llr = g["e9__llr"][:1944 * 4]
+    p1 = L.get_ldpc_code_params(design)              # cold: parses, compiles, stores
+    p2 = L.get_ldpc_code_params(design)              # warm: arrays + blob from the cache
+    p3 = ldpc_params("n1944")                        # no blob: edge list from the matrices
+    outs = [L.ldpc_bp_decode(llr.copy(), p, "MSA", 50) for p in (p1, p2, p3)]
+    for d, o in outs[1:]:
+        assert np.array_equal(d, outs[0][0]) and np.array_equal(o, outs[0][1])
+    assert np.array_equal(outs[0][0], g["e9__dec_MSA"][:4].T)
+    assert "parity_check_matrix" in p1 and "generator_matrix" in p1                 # quirk B9 kept
+
+
+def test_handles_are_per_device_and_checked(gpu):
+    """A handle used while another device is current is an error, not a fault; the host objects create one handle per
+    device on demand."""
+    from commpy_amd import _lib
+    lib = _lib.load()
+    tr = make_trellis("t57")
+    h = tr._device_handle()
+    assert tr._device_handle().value == h.value                                   # cached per device
+    if _lib.device_count() < 2:
+        return
+    _lib.check(lib.cpx_set_device(1))
+    try:
+        d_in, d_out = ctypes.c_void_p(), ctypes.c_void_p()
+        _lib.check(lib.cpx_malloc(ctypes.byref(d_in), 8 * 20))
+        _lib.check(lib.cpx_malloc(ctypes.byref(d_out), 10))
+        assert lib.cpx_viterbi_decode_batch_dev(h, d_in, 1, 20, 10, 11, 10, 0, d_out, None) == _lib.CPX_EINVAL
+        assert "device" in _lib.last_error()
+        assert tr._device_handle().value != h.value
+    finally:
+        _lib.check(lib.cpx_set_device(0))
+
+
+# ------------------------------------------------------------------ collectives and multi-GPU drivers
+def test_rank_comm_world1_collectives(gpu):
+    """cpx_comm_init_rank / allgather / allreduce through librccl with a communicator of one rank."""
+    from commpy_amd.parallel import RankComm, reduce_counters, sharded_decode
+    comm = RankComm(0, 1)
+    rows = np.arange(35, dtype=np.uint8).reshape(7, 5)
+    assert np.array_equal(comm.allgather_rows(rows, 7), rows)
+    assert np.array_equal(comm.allreduce(np.array([5, -2, 1 << 40], np.int64)), [5, -2, 1 << 40])
+    assert np.array_equal(comm.allreduce(np.array([0.5, 2.0]), "max"), [0.5, 2.0])
+    comm.barrier()
+    assert np.array_equal(reduce_counters([1, 2, 3], comm), [1, 2, 3])
+    assert np.array_equal(sharded_decode(lambda x: x * 2, [rows], comm), rows * 2)
+    comm.close()
+
+
+def test_device_group_viterbi_ldpc_and_counters(gpu):
+    """DeviceGroup over every visible GPU (one on the test box): sharded Viterbi and LDPC decodes equal the
+    single-device calls, gathered or not; counters are all-reduced through RCCL."""
+    from commpy_amd import _lib
+    from commpy_amd.channelcoding import conv_encode_batch, ldpc_bp_decode, viterbi_decode
+    from commpy_amd.parallel import DeviceGroup
+    grp = DeviceGroup()
+    assert grp.G == _lib.device_count()
+    tr = make_trellis("k7_133_171")
+    rs = np.random.RandomState(2)
+    msgs = rs.randint(0, 2, (203, 128))
+    llr = 6.0 * (2.0 * conv_encode_batch(msgs, tr) - 1) + 4.0 * rs.randn(203, 268)
+    want = viterbi_decode(llr, tr, None, "soft")
+    for gather in (True, False):
+        got = grp.viterbi_decode(llr, tr, None, "soft", gather=gather)
+        assert got.dtype == np.int64 and np.array_equal(got, want), gather
+    g = golden("ldpc_c4x")
+    p = ldpc_params("n1944")
+    x = g["e9__llr"].copy()
+    dec, out = grp.ldpc_bp_decode(x, p, "MSA", 50)
+    d1, o1 = ldpc_bp_decode(g["e9__llr"].copy(), p, "MSA", 50)
+    assert np.array_equal(dec, d1) and np.array_equal(out, o1) and np.array_equal(dec, g["e9__dec_MSA"].T)
+    tot = grp.allreduce_counters([np.array([3 + i, 10], np.int64) for i in range(grp.G)])
+    assert tot[1] == 10 * grp.G and tot[0] == sum(3 + i for i in range(grp.G))
+    ber, errs, bits = grp.wifi_ber_sweep(5, np.array([14.0, 40.0]), 600 * 400, generator_matrix=[[0o133, 0o171]])
+    assert bits[0] >= 600 * 400 and errs[1] == 0 and 0 < ber[0] < 0.5
+    grp.close()
+
+
+# ------------------------------------------------------------------ ADVICE items that need the device
+def test_conv_encode_gpu_rsc_termination_string(gpu):
+    from commpy_amd.channelcoding import conv_encode
+    from commpy_amd.devicelink import conv_encode_gpu
+    rs = np.random.RandomState(5)
+    msgs = rs.randint(0, 2, (9, 50))
+    for tname in ("rsc_legacy_4", "rsc_legacy_8", "t57", "k7_133_171"):
+        tr = make_trellis(tname)
+        for term in ("term", "cont", "rsc"):
+            got = conv_encode_gpu(msgs, tr, term)
+            for b in (0, 8):
+                want = conv_encode(msgs[b], tr, term)
+                assert got[b].shape == want.shape and np.array_equal(got[b], want), (tname, term)
+
+
+def test_wifi_custom_receiver_end_to_end(gpu):
+    """Wifi80211.link_performance(receiver=...) with a per-transmission receiver: runs, one call per
+    transmission, BER of a sensible receiver is sensible."""
+    from commpy_amd.channels import SISOFlatChannel
+    from commpy_amd.wifi80211 import Wifi80211
+    w = Wifi80211(1, generator_matrix=[[0o133, 0o171]])
+    calls = []
+
+    def receiver(y, h, constellation, noise_var):
+        calls.append(np.shape(y))
+        return w.modem.demodulate(y, "soft", noise_var)
+
+    np.random.seed(4)
+    bers, bes, ces, ncs = w.link_performance(SISOFlatChannel(fading_param=(1 + 0j, 0j)), np.array([9.0]), 6, 10 ** 9, 240,
+                                             receiver=receiver, stop_on_surpass_error=False)
+    assert len(calls) == 6 and all(len(c) == 1 for c in calls)
+    assert bers[0] < 0.05

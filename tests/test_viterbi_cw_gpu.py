@@ -1,5 +1,5 @@
 """The codeword-per-lane Viterbi path (csrc/viterbi_cw.hip) against the reference goldens, the CPU oracle and the
-state-per-lane kernels -- bit-exact for every decoding type.  CPX_VITERBI_PATH forces a path: "cw!" = codeword path or
+state-per-lane kernels -- bit-exact for every decoding type.  cpx_viterbi_set_path forces a path: "cw!" = codeword path or
 fail (the fused single kernel when tb_depth = 30, else ACS + traceback kernels), "cw2!" = always the two-kernel form,
 "wave" = state-per-lane kernels."""
 import os
@@ -14,18 +14,18 @@ pytestmark = pytest.mark.gpu
 
 
 class _path:
+    """Force a Viterbi kernel path for the duration of a ``with`` block (cpx_viterbi_set_path)."""
+
     def __init__(self, name):
         self.name = name
 
     def __enter__(self):
-        self.old = os.environ.get("CPX_VITERBI_PATH")
-        os.environ["CPX_VITERBI_PATH"] = self.name
+        from commpy_amd import _lib
+        _lib.viterbi_set_path(self.name)
 
     def __exit__(self, *a):
-        if self.old is None:
-            os.environ.pop("CPX_VITERBI_PATH", None)
-        else:
-            os.environ["CPX_VITERBI_PATH"] = self.old
+        from commpy_amd import _lib
+        _lib.viterbi_set_path(None)
 
 
 def _decode(x, tr, tb, dtype, path):
