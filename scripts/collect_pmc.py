@@ -12,7 +12,8 @@ counter, the mean duration, and derived figures:
   traffic_bytes_per_launch   FETCH_SIZE (KiB) x 1024 x fetch_scale + WRITE_SIZE (KiB) x 1024; --fetch-scale 2 applies the
                              guide's gfx950 correction for wide (16 B/lane) coalesced streaming reads, which FETCH_SIZE
                              reports at half their size
-  valu.busy_frac             SQ_ACTIVE_INST_VALU (quad-cycles, summed over waves) x 4 / (SIMDs in use x kernel cycles)
+  valu.busy_frac             SQ_ACTIVE_INST_VALU (quad-cycles, summed over waves) x 4 / (SIMDs in use x kernel cycles),
+                             kernel cycles = GRBM_GUI_ACTIVE / 8 (the counter is summed over the XCDs)
   valu.insts_per_launch      SQ_INSTS_VALU
 Raw rocprofv3 output directories are deleted; only the JSON and the stats CSV are kept (copy them to profiles/).
 """
@@ -36,6 +37,7 @@ GROUPS = [
 ]
 CLOCK_HZ = 2.4e9
 SIMDS = 1024
+N_XCD = 8
 
 
 def short(name):
@@ -97,7 +99,7 @@ def main():
     # ---- derived ----
     res = {"name": a.name, "command": " ".join(cmd), "batch": a.batch, "fetch_scale": a.fetch_scale,
            "units": "FETCH_SIZE / WRITE_SIZE in KiB per dispatch; SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* in quad-cycles "
-                    "summed over waves; GRBM_GUI_ACTIVE in cycles",
+                    "summed over waves; GRBM_GUI_ACTIVE in cycles summed over the 8 XCDs",
            "kernels": {}}
     for k, v in kern.items():
         e = dict(v)
@@ -105,7 +107,8 @@ def main():
             e["fetch_bytes_per_launch"] = v["FETCH_SIZE"] * 1024 * a.fetch_scale
             e["write_bytes_per_launch"] = v["WRITE_SIZE"] * 1024
             e["traffic_bytes_per_launch"] = e["fetch_bytes_per_launch"] + e["write_bytes_per_launch"]
-        cycles = v.get("GRBM_GUI_ACTIVE") or (v.get("duration_ns_avg", 0) * 1e-9 * CLOCK_HZ)
+        # GRBM_GUI_ACTIVE comes back summed over the 8 XCDs (32.2 M for a 1.85 ms kernel = 8 x 4.03 M cycles)
+        cycles = (v.get("GRBM_GUI_ACTIVE", 0) / N_XCD) or (v.get("duration_ns_avg", 0) * 1e-9 * CLOCK_HZ)
         if cycles and "SQ_ACTIVE_INST_VALU" in v:
             simds = min(SIMDS, v.get("SQ_WAVES", SIMDS)) or SIMDS
             e["valu"] = {"insts_per_launch": v.get("SQ_INSTS_VALU"),

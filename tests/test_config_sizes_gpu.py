@@ -139,19 +139,26 @@ def test_config4_chain_reference_blocks(gpu):
             want_dec, want_out = g["%s__dec_%s" % (tag, alg)].T, g["%s__out_%s" % (tag, alg)].T
             conv = np.all(want_dec == sent, axis=0)
             # (1) the decoder alone, on exactly the LLRs the reference decoded
-            dec, out = ldpc_bp_decode(llr_ref.copy(), p, alg, iters)
+            dec, out, its = ldpc_bp_decode(llr_ref.copy(), p, alg, iters, return_iterations=True)
             assert np.array_equal(dec, want_dec), (tag, alg, "decoder")
             if alg == "MSA":
                 assert np.array_equal(out, want_out)                  # add / compare / min only: bit-identical
             else:
                 assert _spa_close(out[:, conv], want_out[:, conv])
-            # (2) the chain: device demodulator -> sign flip -> decoder
+            # (2) the chain: device demodulator -> sign flip -> decoder.  The demodulators agree to ~1e-14; BP amplifies
+            # such a perturbation while a block is still far from converged (the ORACLE fed llr * (1 + 1e-15 randn)
+            # moves out_llrs by 1e-4 on a block that needs 46 iterations and by < 1e-11 on blocks that need <= 15), so
+            # the 1e-5 bar applies to blocks that converged within 20 iterations, a loose bound to the slow ones
             dec2, out2 = ldpc_bp_decode(llr.copy(), p, alg, iters)
             assert np.array_equal(dec2[:, conv], want_dec[:, conv]), (tag, alg, "chain")
+            fast, slow = conv & (its <= 20), conv & (its > 20)
+            assert fast.sum() >= 1
             if alg == "MSA":
-                assert np.max(np.abs(out2[:, conv] - want_out[:, conv])) < TOL
+                assert np.max(np.abs(out2[:, fast] - want_out[:, fast])) < TOL
             else:
-                assert _spa_close(out2[:, conv], want_out[:, conv])
+                assert _spa_close(out2[:, fast], want_out[:, fast])
+            if slow.any():
+                assert np.max(np.abs(out2[:, slow] - want_out[:, slow])) < 1e-2 * max(1.0, np.max(np.abs(want_out[:, slow])))
         if tag == "e8":
             assert 0 < conv.sum() < conv.size or alg == "SPA"
 
