@@ -6,39 +6,47 @@
 //   gamma = exp(-((r0-c0)^2+(r1-c1)^2)/(2*nv)), priors p0 = 1/(1+e^L), p1 = 1-p0, beta_N = 1 (unterminated),
 //   alpha_0 = delta(state 0), L = L_int + log(app1/app0) (app without prior).
 //
-// Mapping (wave64): lane = g*S + s -- G = 64/S codewords per wavefront, one trellis state per lane.
+// Mapping (wave64): lane = g*S + s -- GW <= 64/S codewords per wavefront, one trellis state per lane -- and TWO
+// wavefronts per group of GW codewords: the alpha recursion (:114-158) and the beta recursion (:78-111) of a MAP pass are
+// independent until the a-posteriori combine, so a FORWARD wave and a REVERSE wave run them concurrently from the two
+// ends of the block and cross in the middle:
+//   phase 1   F: alpha over the first half of the chunks,  R: beta over the second half; each keeps only its state
+//             vector at the chunk boundaries (one 512-byte row per chunk in an HBM scratch -- a checkpoint, not a row
+//             per step);
+//   phase 2   F continues alpha over the second half: per chunk it RECOMPUTES the chunk's beta rows from R's checkpoint
+//             (same operations, registers only), then runs alpha and the combine; R continues beta over the first half,
+//             recomputing the chunk's alpha rows from F's checkpoint.
+// (Round 1 ran beta over the whole block, streamed every beta row to HBM, then alpha: one wave per SIMD on a dependent
+//  float64 chain -- rocprofv3: VALU busy 38 %, 41 % of the wave cycles waiting, 30 GB of HBM traffic per config-3 launch.
+//  Now the chain a wave walks is half as long, two waves share a SIMD, and the HBM traffic of a pass is its inputs, its
+//  LLRs and 1/8 row per step.)
 // Time is processed in chunks of CH steps; every chunk has
-//   (1) a TIME-PARALLEL stage: the 64 lanes load the chunk's received values (coalesced segments), evaluate
-//       the four distinct branch probabilities and the prior of every (codeword, step) pair -- all the exp()
-//       work, off the serial chain -- and park them in LDS;
-//   (2) the SERIAL recursion over the chunk: alpha/beta of a state live in one VGPR pair of its lane, the
-//       neighbours' values are exchanged through a 512-byte LDS buffer (cheaper than ds_bpermute for
-//       float64, see viterbi.hip), sums over the states of a codeword are DPP butterflies (no LDS).
-// With one wavefront per SIMD (B = 16384 codewords fill the chip exactly once) the recursion is bound by the
-// LATENCY of its dependent chain, so everything that is not alpha/beta itself is moved off it:
-//   * the sum-normalisation of the reference (turbo.py:110-111, :155-158) is applied every KNORM = 4 steps
-//     instead of every step (a common positive factor per time step cancels in app1/app0 and in every later
-//     normalisation: LLRs differ from the reference's only by rounding, measured <= 1e-13; tolerance 1e-5);
-//   * for 4-state trellises the neighbour exchange is 4 quad-broadcast DPP moves + per-lane selects (depth ~25
-//     cycles) instead of an LDS round trip (~130 cycles);
-//   * the a-posteriori sums are not reduced in the loop: every lane parks its two branch products in LDS and the
-//     time-parallel epilogue of the chunk adds them, divides and takes the log;
-//   * received values of the NEXT chunk are prefetched into registers before the serial loop of the current one.
-// beta is CHECKPOINTED, not stored: the backward pass keeps beta only at chunk boundaries ([chunk][lane] rows in
-// an HBM slab, 1/16 of the per-step traffic that made the first version HBM-bound); the forward pass recomputes
-// the chunk's beta rows into LDS from the checkpoint with the same operations in the same order (bit-identical),
-// then runs alpha over the chunk.
-// Butterfly / epilogue sums differ from the reference's sequential order by O(1e-16) relative.
-// LLRs of a chunk are staged in LDS, log() evaluated time-parallel, and written back as coalesced segments.  turbo_decode runs its whole iteration loop inside ONE launch; the
-// interleaver is a gather/scatter through per-codeword L arrays in the slab.
+//   (1) a TIME-PARALLEL stage: the 64 lanes load the chunk's received values (coalesced segments, prefetched one chunk
+//       ahead), evaluate the four distinct branch probabilities and the two priors of every (codeword, step) item --
+//       all the exp() work, off the serial chain -- and park them in LDS;
+//   (2) the SERIAL recursion(s) over the chunk: alpha/beta of a state live in one VGPR pair of its lane; neighbours'
+//       values are exchanged by DPP quad permutes (4-state trellises) or through a 512-byte LDS buffer; sums over the
+//       states of a codeword are DPP butterflies (no LDS).  A full chunk is unrolled (compile-time LDS offsets);
+//   (3) phase 2 only: the per-lane branch products alpha*gamma*beta are parked in LDS and a time-parallel epilogue adds
+//       them in state order, divides, takes the log and writes the LLRs as coalesced segments.
+// The sum-normalisation of the reference (turbo.py:110-111, :155-158) is applied every KNORM = 4 steps with the hardware
+// reciprocal: a common positive factor per time step cancels in app1/app0 and in every later normalisation, so LLRs
+// differ from the reference's only by rounding (measured <= 1e-13; tolerance 1e-5).
+// Waves of a workgroup only meet at the phase boundary and between the stages of turbo_decode (__syncthreads +
+// agent-scope fences: the partner's checkpoints / LLRs are read through L2).  turbo_decode runs its whole iteration loop
+// inside ONE launch; the interleaver is a gather/scatter through per-codeword L arrays in a slab.
 #include "cpx_internal.h"
 #include "cpx_math.h"
+
+#include <cstdlib>
 
 using namespace cpx;
 
 namespace {
 
-constexpr int MAXCH = 16;      // steps per chunk (upper bound; keeps LDS <= 37 KiB per wave)
+constexpr int CH = 8;          // steps per chunk
+constexpr int KNORM = 4;       // renormalise alpha / beta every KNORM steps
+constexpr int NPAIR = 4;       // (forward, reverse) wave pairs per full-size workgroup: 8 waves = 2 per SIMD of a CU
 
 struct MapTables {
     const int32_t *next_state, *output;                       // [S][2]
@@ -63,38 +71,38 @@ __device__ __forceinline__ double group_sum(double v) {
     return v;
 }
 
-// GW = codewords actually decoded by a wavefront (power of two, <= 64/S and <= 16).  When the batch cannot fill
-// the chip with full wavefronts (B*S/64 < ~4 waves per SIMD) the host picks GW < 64/S: lanes of the unused
-// codeword slots idle, but four times as many wavefronts hide the latency of the serial recursion.
+// One wavefront of a pair.  GW = codewords decoded by the pair (power of two, <= 64/S and <= 16): when the batch
+// cannot fill the chip the host picks GW < 64/S (idle lanes, more pairs).
 template <int LGS>
 struct Ctx {
-    static constexpr int S = 1 << LGS, G = 64 >> LGS;
-    static constexpr int CH = MAXCH;                                   // steps per chunk
-    static constexpr int NI = 4;                                       // max (codeword, step) items per lane (CH*GW <= 256)
-    int lane, g, s, GW;
-    bool sr4;                                                          // 4-state shift-register trellis: static DPP exchange
+    static constexpr int S = 1 << LGS;
+    static constexpr int NI = 2;                                       // (codeword, step) items per lane: CH*GW <= 128
+    int lane, g, s, GW, P;                                             // P: doubles per step row of `tab`
+    bool fwd;                                                          // forward (alpha) wave of the pair
     int sb[2];                                                         // sr4: MSB of next_state[s][i] (which successor input i leads to)
     bool active;                                                       // lane belongs to one of the GW decoded slots
     int nxt[2], code[2];              // outgoing branches of state s: next-state lane, 2-bit code (sys, parity)
     int plane[2], pin[2], pcode[2];   // incoming branches in np.where order: predecessor lane, input, code
-    // LDS carve-up
-    double *gam;    // [CH][GW][4]
-    double *pr0;    // [CH][GW]
-    double *lin;    // [CH][GW]   L_int of the chunk
-    double *xs;     // [CH][GW*S][2] per-lane branch products a*gamma*beta of the chunk (forward pass)
-    double *bt;     // [CH][GW*S]  beta rows of the chunk (forward pass)
-    double *xch;    // [64]       exchange buffer
+    // LDS of this wave
+    double *tab;    // [CH][GW][6] (+2 pad per step): gamma[4], p0, p1 of every (step, codeword) item
+    double *xs;     // [CH][64][2]  per-lane branch products alpha*gamma*beta of the chunk (phase 2)
+    double *xch;    // [64]         exchange buffer (trellises without the DPP fast path)
 };
 
 template <int LGS>
+__host__ __device__ constexpr size_t wave_lds_doubles(int GW) { return (size_t)CH * (GW * 6 + 2) + (size_t)CH * 64 * 2 + 64; }
+
+template <int LGS>
 __device__ __forceinline__ void init_ctx(Ctx<LGS> &c, const MapTables &tb, unsigned char *smem, int GW) {
-    constexpr int S = Ctx<LGS>::S, CH = Ctx<LGS>::CH;
-    c.lane = threadIdx.x;
+    constexpr int S = Ctx<LGS>::S;
+    const int wave = threadIdx.x >> 6;
+    c.lane = threadIdx.x & 63;
+    c.fwd = (wave & 1) == 0;
     c.GW = GW;
+    c.P = GW * 6 + 2;
     c.active = (c.lane >> LGS) < GW;
     c.g = c.active ? (c.lane >> LGS) : 0;                         // idle lanes shadow slot 0 (reads only)
     c.s = c.lane & (S - 1);
-    c.sr4 = (LGS == 2) && tb.sr4;
     const int gbase = (c.lane >> LGS) << LGS, sh = tb.n - 2;      // exchanges stay inside the lane's own group
     for (int i = 0; i < 2; i++) {
         c.nxt[i] = gbase + tb.next_state[c.s * 2 + i];
@@ -104,21 +112,11 @@ __device__ __forceinline__ void init_ctx(Ctx<LGS> &c, const MapTables &tb, unsig
         c.pin[i] = tb.pred_input[c.s * 2 + i];
         c.pcode[i] = (tb.pred_code[c.s * 2 + i] >> sh) & 3;
     }
-    double *p = reinterpret_cast<double *>(smem);
-    c.gam = p; p += CH * GW * 4;
-    c.pr0 = p; p += CH * GW;
-    c.lin = p; p += CH * GW;
-    c.xs = p;  p += CH * GW * S * 2;
-    c.bt = p;  p += CH * GW * S;
+    double *p = reinterpret_cast<double *>(smem) + (size_t)wave * wave_lds_doubles<LGS>(GW);
+    c.tab = p; p += CH * c.P;
+    c.xs = p;  p += CH * 64 * 2;
     c.xch = p;
 }
-
-template <int LGS>
-size_t lds_bytes(int GW) {
-    return sizeof(double) * (size_t)(Ctx<LGS>::CH * GW * 6 + Ctx<LGS>::CH * GW * Ctx<LGS>::S * 3 + 64);
-}
-
-constexpr int KNORM = 4;       // renormalise alpha / beta every KNORM steps
 
 // value of `v` in lane (quad base + idx), idx in 0..3 per lane: 4 quad broadcasts + selects (no LDS)
 __device__ __forceinline__ double quad_fetch(double v, int idx) {
@@ -143,11 +141,10 @@ __device__ __forceinline__ void exchange2(const Ctx<LGS> &c, double v, int la, i
 }
 
 // beta of the two successors of this lane's state, ordered by INPUT (0, 1).  4-state shift-register trellises:
-// the successors of state s are (s>>1) and 2|(s>>1) -- two constant quad permutes + a per-lane select instead of
-// four quad broadcasts and a select tree.
-template <int LGS>
+// the successors of state s are (s>>1) and 2|(s>>1) -- two constant quad permutes + a per-lane select.
+template <int LGS, bool SR>
 __device__ __forceinline__ void exchange_succ(const Ctx<LGS> &c, double v, double &v0, double &v1) {
-    if (LGS == 2 && c.sr4) {
+    if (LGS == 2 && SR) {
         const double lo = dppd<0x50>(v);                          // quad_perm [0,0,1,1]: lane s <- lane s>>1
         const double hi = dppd<0xFA>(v);                          // quad_perm [2,2,3,3]: lane s <- lane 2|(s>>1)
         v0 = c.sb[0] ? hi : lo;
@@ -159,9 +156,9 @@ __device__ __forceinline__ void exchange_succ(const Ctx<LGS> &c, double v, doubl
 
 // alpha of the two predecessors of this lane's state in np.where order (increasing predecessor state).
 // 4-state shift-register trellises: predecessors of ns are 2(ns&1) and 2(ns&1)+1.
-template <int LGS>
+template <int LGS, bool SR>
 __device__ __forceinline__ void exchange_pred(const Ctx<LGS> &c, double v, double &v0, double &v1) {
-    if (LGS == 2 && c.sr4) {
+    if (LGS == 2 && SR) {
         v0 = dppd<0x88>(v);                                       // quad_perm [0,2,0,2]
         v1 = dppd<0xDD>(v);                                       // quad_perm [1,3,1,3]
     } else {
@@ -170,184 +167,237 @@ __device__ __forceinline__ void exchange_pred(const Ctx<LGS> &c, double v, doubl
 }
 
 // ---- time-parallel stage of a chunk --------------------------------------------------------------------------
-// A chunk has CH*GW (codeword, step) items, at most 4 per lane: item p = lane + 64*q -> codeword slot p / CH,
-// step p % CH (consecutive lanes -> consecutive steps of one codeword: coalesced 128-byte segments).
+// A chunk has CH*GW (codeword, step) items, at most 2 per lane: item p = lane + 64*q -> codeword slot p / CH,
+// step p % CH (consecutive lanes -> consecutive steps of one codeword: coalesced 64-byte segments).
 struct RawChunk {
-    double r0[4], r1[4], li[4];
+    double r0[2], r1[2], li[2];
+};
+
+struct PassIO {
+    const double *sys;            // [B][N]
+    const int32_t *sys_perm;      // null, or sys is read through the interleaver (sys_symbols_i = interlv(sys), turbo.py:310)
+    const double *par;            // [B][N]
+    const double *Lin;            // L_int, stride lstride per codeword
+    double *Lout;                 // L_int + log(app1/app0), stride lstride
+    int64_t lstride, cw0, B, N;
+    double nv2;
+    double *ckpt;                 // this pair's checkpoint rows [nchunks + 1][64]
 };
 
 template <int LGS>
-__device__ __forceinline__ void load_raw(const Ctx<LGS> &c, RawChunk &rc, int64_t cw0, int64_t B, int64_t N, int64_t t0,
-                                         int len, const double *sys, const int32_t *sys_perm, const double *par,
-                                         const double *Lin, int64_t lstride) {
-    constexpr int CH = Ctx<LGS>::CH;
+__device__ __forceinline__ void load_raw(const Ctx<LGS> &c, const PassIO &io, RawChunk &rc, int64_t t0, int len) {
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
+    for (int q = 0; q < 2; q++) {
         const int p = c.lane + 64 * q, gg = p / CH, tl = p % CH;
-        const int64_t cw = cw0 + gg, t = t0 + tl;                 // 0-based step index
+        const int64_t cw = io.cw0 + gg, t = t0 + tl;              // 0-based step index
         rc.r0[q] = 0.0; rc.r1[q] = 0.0; rc.li[q] = 0.0;
-        if (gg < c.GW && cw < B && tl < len) {
-            rc.r0[q] = sys[cw * N + (sys_perm ? sys_perm[t] : t)];   // sys_symbols_i = interlv(sys) (turbo.py:310)
-            rc.r1[q] = par[cw * N + t];
-            rc.li[q] = Lin[cw * lstride + t];
+        if (gg < c.GW && cw < io.B && tl < len) {
+            rc.r0[q] = io.sys[cw * io.N + (io.sys_perm ? io.sys_perm[t] : t)];
+            rc.r1[q] = io.par[cw * io.N + t];
+            rc.li[q] = io.Lin[cw * io.lstride + t];
         }
     }
 }
 
-// gam[tl][g][code] (_compute_branch_prob :62-76), pr0[tl][g] (priors[0] :239), lin[tl][g] into LDS
+// tab[tl][g] = gamma[0..3] (_compute_branch_prob :62-76), p0, p1 (priors :239-240) into LDS.  The row stride P = 6 GW + 2
+// doubles makes the eight lanes that hold consecutive steps of a codeword hit eight different 16-byte bank groups.
 template <int LGS>
 __device__ __forceinline__ void stage_chunk(const Ctx<LGS> &c, const RawChunk &rc, double nv2) {
-    constexpr int CH = Ctx<LGS>::CH;
     const int GW = c.GW;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
+    for (int q = 0; q < 2; q++) {
         const int p = c.lane + 64 * q, gg = p / CH, tl = p % CH;
         if (gg < GW) {
-            double *gm = c.gam + (tl * GW + gg) * 4;
+            double g4[4];
 #pragma unroll
             for (int code = 0; code < 4; code++) {
                 const double x = rc.r0[q] - (double)(2 * ((code >> 1) & 1) - 1);
                 const double y = rc.r1[q] - (double)(2 * (code & 1) - 1);
-                gm[code] = exp(-(x * x + y * y) / nv2);
+                g4[code] = exp(-(x * x + y * y) / nv2);
             }
-            c.pr0[tl * GW + gg] = 1.0 / (1.0 + exp(rc.li[q]));
-            c.lin[tl * GW + gg] = rc.li[q];
+            const double p0 = 1.0 / (1.0 + exp(rc.li[q]));
+            double2 *row = reinterpret_cast<double2 *>(c.tab + tl * c.P + gg * 6);
+            row[0] = make_double2(g4[0], g4[1]);
+            row[1] = make_double2(g4[2], g4[3]);
+            row[2] = make_double2(p0, 1.0 - p0);                  // priors[1] = 1 - priors[0] (:240)
         }
     }
+    asm volatile("" ::: "memory");
 }
 
-// Backward recursion over one staged chunk (:78-111): beta of reference time t_lo+tl for tl = len-1 .. 0, starting
-// from `b` = beta at the chunk's upper boundary.  Every row is streamed to `rows` ([CH][64] float64 in HBM, one
-// coalesced 512-byte store per step, off the dependent chain): rows[tl] = beta of time t_lo + tl + 1, the row the
-// forward pass needs at step tl.
+// One beta step (:106-111): b <- sum_i b[next(s,i)] * gamma(code(s,i)) * prior(i), inputs 0 then 1.
+// With X = true also parks x_i = a_own * gamma(code(s,i)) * b[next(s,i)] (the branch products of :141-143).
+template <int LGS, bool SR, bool X>
+__device__ __forceinline__ void beta_step(const Ctx<LGS> &c, int tl, double &b, double a_own) {
+    const double *it = c.tab + tl * c.P + c.g * 6;
+    const double g0 = it[c.code[0]], g1 = it[c.code[1]], p0 = it[4], p1 = it[5];
+    double bn0, bn1;
+    exchange_succ<LGS, SR>(c, b, bn0, bn1);
+    if (X) {
+        double2 xv;
+        xv.x = a_own * g0 * bn0;
+        xv.y = a_own * g1 * bn1;
+        *reinterpret_cast<double2 *>(c.xs + (tl * 64 + c.lane) * 2) = xv;   // idle lanes own a slot too
+    }
+    double nb = 0.0;
+    nb += (bn0 * g0 * p0);
+    nb += (bn1 * g1 * p1);
+    b = nb;
+    // (:110-111) every KNORM steps; any positive common factor is a valid normalisation, so the hardware
+    // reciprocal (v_rcp_f64) is used instead of a correctly rounded division
+    if ((tl & (KNORM - 1)) == 0) b = b * __builtin_amdgcn_rcp(group_sum<LGS>(b));
+}
+
+// One alpha step (:136-138, :155-158): a <- sum over the incoming branches in (predecessor state, input) order.
+// With X = true first parks x_i = a * gamma(code(s,i)) * beta_next[next(s,i)] for this lane's outgoing branches.
+template <int LGS, bool SR, bool X>
+__device__ __forceinline__ void alpha_step(const Ctx<LGS> &c, int tl, double &a, double beta_row) {
+    const double *it = c.tab + tl * c.P + c.g * 6;
+    const double gi0 = it[c.pcode[0]], gi1 = it[c.pcode[1]];
+    const double q0 = it[4 + c.pin[0]], q1 = it[4 + c.pin[1]];
+    if (X) {
+        const double go0 = it[c.code[0]], go1 = it[c.code[1]];
+        double bt0, bt1;
+        exchange_succ<LGS, SR>(c, beta_row, bt0, bt1);
+        double2 xv;
+        xv.x = a * go0 * bt0;
+        xv.y = a * go1 * bt1;
+        *reinterpret_cast<double2 *>(c.xs + (tl * 64 + c.lane) * 2) = xv;   // idle lanes own a slot too
+    }
+    double ap0, ap1;
+    exchange_pred<LGS, SR>(c, a, ap0, ap1);
+    double na = 0.0;
+    na += (ap0 * gi0 * q0);
+    na += (ap1 * gi1 * q1);
+    a = na;
+    if ((tl & (KNORM - 1)) == KNORM - 1) a = a * __builtin_amdgcn_rcp(group_sum<LGS>(a));
+}
+
+// time-parallel epilogue of a phase-2 chunk: app sums in state order, L = L_int + log(app1/app0) (:145)
 template <int LGS>
-__device__ __forceinline__ double beta_chunk(const Ctx<LGS> &c, double b, int len, double *__restrict__ rows) {
-    const int GW = c.GW;
-    if (len <= 0) return b;
-    rows[(len - 1) * 64 + c.lane] = b;                            // beta[t_lo + len]: row used by the last step of the chunk
-    // one step; a full chunk is unrolled (compile-time LDS offsets, operand loads hoisted by the scheduler, no
-    // pointer bumps or register rotation on the dependent chain), a partial last chunk runs the same body rolled
-    auto step = [&](int tl) {
-        const double *gm = c.gam + (tl * GW + c.g) * 4;
-        const double g0 = gm[c.code[0]], g1 = gm[c.code[1]], p0 = c.pr0[tl * GW + c.g];
-        const double p1 = 1.0 - p0;                               // priors[1] = 1 - priors[0] (:240)
-        double bn0, bn1;
-        exchange_succ<LGS>(c, b, bn0, bn1);
-        double nb = 0.0;
-        nb += (bn0 * g0 * p0);                                    // (:106-108), input 0 then input 1
-        nb += (bn1 * g1 * p1);
-        b = nb;
-        // (:110-111) every KNORM steps; any positive common factor is a valid normalisation, so the hardware
-        // reciprocal (v_rcp_f64) is used instead of a correctly rounded division
-        if ((tl & (KNORM - 1)) == 0) b = b * __builtin_amdgcn_rcp(group_sum<LGS>(b));
-        if (tl > 0) rows[(tl - 1) * 64 + c.lane] = b;            // beta[t_lo + tl]: row used by step tl-1
-    };
-    if (len == Ctx<LGS>::CH) {
+__device__ __forceinline__ void epilogue(const Ctx<LGS> &c, const PassIO &io, const RawChunk &rc, int64_t t_lo, int len) {
+    constexpr int S = Ctx<LGS>::S;
+    asm volatile("" ::: "memory");
 #pragma unroll
-        for (int tl = Ctx<LGS>::CH - 1; tl >= 0; --tl) step(tl);
-    } else {
-        for (int tl = len - 1; tl >= 0; --tl) step(tl);
+    for (int q = 0; q < 2; q++) {
+        const int p = c.lane + 64 * q, gg = p / CH, tl = p % CH;
+        const int64_t cw = io.cw0 + gg;
+        if (gg < c.GW && cw < io.B && tl < len) {
+            const double2 *x = reinterpret_cast<const double2 *>(c.xs + (tl * 64 + gg * S) * 2);
+            double app0 = 0.0, app1 = 0.0;
+#pragma unroll
+            for (int st = 0; st < S; st++) { const double2 v = x[st]; app0 += v.x; app1 += v.y; }
+            io.Lout[cw * io.lstride + t_lo + tl] = rc.li[q] + fast_log(app1 / app0);
+        }
     }
-    return b;
+    asm volatile("" ::: "memory");
 }
 
-// One MAP pass over the GW codewords of this wavefront.  ckpt: [nchunks][CH][64] beta rows of this wave (HBM).
-// Lout (stride lstride per codeword) receives L_int + log(app1/app0).
-template <int LGS>
-__device__ void map_pass(const Ctx<LGS> &c, int64_t cw0, int64_t B, int64_t N, double nv2, const double *sys,
-                         const int32_t *sys_perm, const double *par, const double *Lin, int64_t lstride,
-                         double *ckpt, double *Lout) {
-    constexpr int S = Ctx<LGS>::S, CH = Ctx<LGS>::CH;
-    const int GW = c.GW, W = GW * S, col = c.g * S + c.s;
-    const int nx0 = c.nxt[0] & (W - 1), nx1 = c.nxt[1] & (W - 1);   // next-state columns inside the bt rows
-    const int64_t nchunks = (N + CH - 1) / CH;
-    RawChunk cur, nxt;
-    // ---------------- backward pass: chunks from the end, beta rows streamed to HBM ----------------
-    double b = 1.0;                                               // b_state_metrics[:, N] = 1 (:225)
-    {
-        const int64_t t_lo = (nchunks - 1) * CH;
-        load_raw<LGS>(c, cur, cw0, B, N, t_lo, (int)(N - t_lo), sys, sys_perm, par, Lin, lstride);
-    }
-    for (int64_t k = nchunks - 1; k >= 0; --k) {                  // chunk k = 0-based steps [k*CH, min(N, (k+1)*CH))
-        const int64_t t_lo = k * CH;
-        const int len = (int)((N - t_lo < CH) ? (N - t_lo) : CH);
-        __syncthreads();
-        stage_chunk<LGS>(c, cur, nv2);
-        if (k > 0) load_raw<LGS>(c, nxt, cw0, B, N, t_lo - CH, CH, sys, sys_perm, par, Lin, lstride);   // prefetch
-        __syncthreads();
-        b = beta_chunk<LGS>(c, b, len, ckpt + k * CH * 64);
-        cur = nxt;
-    }
+// The two waves of a pair belong to one workgroup, i.e. one CU and one (write-through) vector L1: workgroup-scope
+// fences order their global stores and loads.  (Agent-scope fences -- __threadfence() -- write back / invalidate the
+// XCD's whole L2 on gfx950, whose L2s are not coherent with each other: measured 15.8 ms instead of 12.3 ms per
+// config-3 launch with eight of them per iteration.)
+__device__ __forceinline__ void pair_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
-    // ---------------- forward pass: the chunk's beta rows come back from HBM (prefetched one chunk ahead),
-    // then alpha + LLR (:114-158) ----------------
-    double a = (c.s == 0) ? 1.0 : 0.0;                            // f_state_metrics[0][0] = 1 (:221)
-    load_raw<LGS>(c, cur, cw0, B, N, 0, (int)((N < CH) ? N : CH), sys, sys_perm, par, Lin, lstride);
-    double brow[CH], brown[CH];
-#pragma unroll
-    for (int tl = 0; tl < CH; tl++) brow[tl] = ckpt[tl * 64 + c.lane];
-    for (int64_t k = 0; k < nchunks; ++k) {
-        const int64_t t_lo = k * CH;
-        const int len = (int)((N - t_lo < CH) ? (N - t_lo) : CH);
-        __syncthreads();
-        stage_chunk<LGS>(c, cur, nv2);
-        if (c.active) {
-#pragma unroll
-            for (int tl = 0; tl < CH; tl++) c.bt[tl * W + col] = brow[tl];   // bt[tl] = beta[t_lo + tl + 1]
-        }
-        if (k + 1 < nchunks) {
-            const int64_t t2 = t_lo + CH;
-            load_raw<LGS>(c, nxt, cw0, B, N, t2, (int)((N - t2 < CH) ? (N - t2) : CH), sys, sys_perm, par, Lin, lstride);
-#pragma unroll
-            for (int tl = 0; tl < CH; tl++) brown[tl] = ckpt[((k + 1) * CH + tl) * 64 + c.lane];
-        }
-        __syncthreads();
-        {
-            auto step = [&](int tl) {
-                const double *gm = c.gam + (tl * GW + c.g) * 4;
-                const double go0 = gm[c.code[0]], go1 = gm[c.code[1]], gi0 = gm[c.pcode[0]], gi1 = gm[c.pcode[1]];
-                const double p0 = c.pr0[tl * GW + c.g], p1 = 1.0 - p0;
-                const double bt0 = c.bt[tl * W + c.g * S + (nx0 & (S - 1))], bt1 = c.bt[tl * W + c.g * S + (nx1 & (S - 1))];
-                // app[i] += f[cs,0] * branch_prob * b[next_state, t]   (:141-143): products parked, summed in the epilogue
-                double2 xv;
-                xv.x = a * go0 * bt0;
-                xv.y = a * go1 * bt1;
-                if (c.active) *reinterpret_cast<double2 *>(c.xs + (tl * W + col) * 2) = xv;
-                // f[next,1] += f[cs,0] * branch_prob * priors[input]     (:136-138), accumulation in (cs, input) order
-                double ap0, ap1;
-                exchange_pred<LGS>(c, a, ap0, ap1);
-                double na = 0.0;
-                na += (ap0 * gi0 * (c.pin[0] ? p1 : p0));
-                na += (ap1 * gi1 * (c.pin[1] ? p1 : p0));
-                a = na;
-                if ((tl & (KNORM - 1)) == KNORM - 1) a = a * __builtin_amdgcn_rcp(group_sum<LGS>(a));   // (:155-158), every KNORM steps
-            };
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// One MAP pass over the GW codewords of this pair of wavefronts.  Collective over the workgroup (one pair_sync).
+template <int LGS, bool SR>
+__device__ void map_pass(const Ctx<LGS> &c, const PassIO &io) {
+    const int64_t N = io.N;
+    const int K = (int)((N + CH - 1) / CH), K1 = K / 2;          // F: chunks [0,K1) then [K1,K); R: [K1,K) then [0,K1)
+    auto clen = [&](int k) { const int64_t r = N - (int64_t)k * CH; return (int)(r < CH ? r : CH); };
+    double *ck = io.ckpt + c.lane;                                // row k: state vector at time k*CH
+    RawChunk cur, nxt;
+    if (c.fwd) {
+        // ---------------- phase 1: alpha over chunks 0 .. K1-1, checkpoint before every chunk ----------------
+        double a = (c.s == 0) ? 1.0 : 0.0;                        // f_state_metrics[0][0] = 1 (:221)
+        if (K1 > 0) load_raw<LGS>(c, io, cur, 0, clen(0));
+        for (int k = 0; k < K1; k++) {
+            ck[(int64_t)k * 64] = a;                              // alpha at time k*CH (read by R in phase 2)
+            stage_chunk<LGS>(c, cur, io.nv2);
+            if (k + 1 < K1) load_raw<LGS>(c, io, nxt, (int64_t)(k + 1) * CH, clen(k + 1));
+            const int len = clen(k);
             if (len == CH) {
 #pragma unroll
-                for (int tl = 0; tl < CH; tl++) step(tl);
+                for (int tl = 0; tl < CH; tl++) alpha_step<LGS, SR, false>(c, tl, a, 0.0);
             } else {
-                for (int tl = 0; tl < len; tl++) step(tl);
+                for (int tl = 0; tl < len; tl++) alpha_step<LGS, SR, false>(c, tl, a, 0.0);
             }
+            cur = nxt;
         }
-        __syncthreads();
-        // time-parallel epilogue of the chunk: app sums in state order, L = L_int + log(app1/app0) (:145)
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int p = c.lane + 64 * q, gg = p / CH, tl = p % CH;
-            const int64_t cw = cw0 + gg;
-            if (gg < GW && cw < B && tl < len) {
-                const double *x = c.xs + (tl * W + gg * S) * 2;
-                double app0 = 0.0, app1 = 0.0;
-#pragma unroll
-                for (int st = 0; st < S; st++) { app0 += x[2 * st]; app1 += x[2 * st + 1]; }
-                Lout[cw * lstride + t_lo + tl] = c.lin[tl * GW + gg] + fast_log(app1 / app0);
+        load_raw<LGS>(c, io, cur, (int64_t)K1 * CH, clen(K1));    // first chunk of phase 2 (K1 < K always)
+        pair_sync();
+        // ---------------- phase 2: chunks K1 .. K-1: beta rows from R's checkpoint, alpha + combine ----------------
+        double bup = ck[(int64_t)(K1 + 1) * 64];                  // beta at the upper boundary of chunk K1
+        for (int k = K1; k < K; k++) {
+            const int len = clen(k);
+            stage_chunk<LGS>(c, cur, io.nv2);
+            double bupn = 0.0;
+            if (k + 1 < K) {
+                load_raw<LGS>(c, io, nxt, (int64_t)(k + 1) * CH, clen(k + 1));
+                bupn = ck[(int64_t)(k + 2) * 64];
             }
-        }
-        cur = nxt;
+            double brow[CH];                                      // brow[tl] = beta at time k*CH + tl + 1
+            double b = bup;
+            if (len == CH) {
 #pragma unroll
-        for (int tl = 0; tl < CH; tl++) brow[tl] = brown[tl];
+                for (int tl = CH - 1; tl >= 0; --tl) { brow[tl] = b; beta_step<LGS, SR, false>(c, tl, b, 0.0); }
+#pragma unroll
+                for (int tl = 0; tl < CH; tl++) alpha_step<LGS, SR, true>(c, tl, a, brow[tl]);
+            } else {
+#pragma unroll
+                for (int tl = CH - 1; tl >= 0; --tl)
+                    if (tl < len) { brow[tl] = b; beta_step<LGS, SR, false>(c, tl, b, 0.0); }
+#pragma unroll
+                for (int tl = 0; tl < CH; tl++)
+                    if (tl < len) alpha_step<LGS, SR, true>(c, tl, a, brow[tl]);
+            }
+            epilogue<LGS>(c, io, cur, (int64_t)k * CH, len);
+            cur = nxt;
+            bup = bupn;
+        }
+    } else {
+        // ---------------- phase 1: beta over chunks K-1 .. K1, checkpoint before every chunk ----------------
+        double b = 1.0;                                           // b_state_metrics[:, N] = 1 (:225)
+        load_raw<LGS>(c, io, cur, (int64_t)(K - 1) * CH, clen(K - 1));
+        for (int k = K - 1; k >= K1; --k) {
+            ck[(int64_t)(k + 1) * 64] = b;                        // beta at the upper boundary of chunk k (read by F)
+            stage_chunk<LGS>(c, cur, io.nv2);
+            if (k > K1) load_raw<LGS>(c, io, nxt, (int64_t)(k - 1) * CH, CH);
+            const int len = clen(k);
+            if (len == CH) {
+#pragma unroll
+                for (int tl = CH - 1; tl >= 0; --tl) beta_step<LGS, SR, false>(c, tl, b, 0.0);
+            } else {
+                for (int tl = len - 1; tl >= 0; --tl) beta_step<LGS, SR, false>(c, tl, b, 0.0);
+            }
+            cur = nxt;
+        }
+        if (K1 > 0) load_raw<LGS>(c, io, cur, (int64_t)(K1 - 1) * CH, CH);
+        pair_sync();
+        // ---------------- phase 2: chunks K1-1 .. 0: alpha rows from F's checkpoint, beta + combine ----------------
+        double alo = K1 > 0 ? ck[(int64_t)(K1 - 1) * 64] : 0.0;   // alpha at the lower boundary of chunk K1-1
+        for (int k = K1 - 1; k >= 0; --k) {
+            stage_chunk<LGS>(c, cur, io.nv2);
+            double alon = 0.0;
+            if (k > 0) {
+                load_raw<LGS>(c, io, nxt, (int64_t)(k - 1) * CH, CH);
+                alon = ck[(int64_t)(k - 1) * 64];
+            }
+            double arow[CH];                                      // arow[tl] = alpha at time k*CH + tl (full chunks only here)
+            double a = alo;
+#pragma unroll
+            for (int tl = 0; tl < CH; tl++) { arow[tl] = a; alpha_step<LGS, SR, false>(c, tl, a, 0.0); }
+#pragma unroll
+            for (int tl = CH - 1; tl >= 0; --tl) beta_step<LGS, SR, true>(c, tl, b, arow[tl]);
+            epilogue<LGS>(c, io, cur, (int64_t)k * CH, CH);
+            cur = nxt;
+            alo = alon;
+        }
     }
-    __syncthreads();
 }
 
 struct MapParams {
@@ -355,25 +405,32 @@ struct MapParams {
     const double *sys, *par, *Lin;     // [B][N]
     double *Lout;                      // [B][N]
     uint8_t *bits;                     // [B][N]
-    double *scratch;                   // per wave: beta rows [nchunks][CH][64]
+    double *scratch;                   // per pair: checkpoint rows [nchunks + 1][64]
     int64_t B, N;
     double nv2;
     int want_bits, GW;
 };
 
-template <int LGS>
-__global__ __launch_bounds__(64) void map_decode_kernel(MapParams p) {
+template <int LGS, bool SR>
+__global__ __launch_bounds__(128 * NPAIR) void map_decode_kernel(MapParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Ctx<LGS> c;
     init_ctx<LGS>(c, p.tb, smem, p.GW);
-    const int64_t cw0 = (int64_t)blockIdx.x * p.GW;
-    const int64_t wslab = ((p.N + Ctx<LGS>::CH - 1) / Ctx<LGS>::CH) * Ctx<LGS>::CH * 64;
-    double *ckpt = p.scratch + (int64_t)blockIdx.x * wslab;
-    map_pass<LGS>(c, cw0, p.B, p.N, p.nv2, p.sys, nullptr, p.par, p.Lin, p.N, ckpt, p.Lout);
-    const int64_t cw = cw0 + c.g;
-    if (c.active && cw < p.B)
-        for (int64_t t = c.s; t < p.N; t += Ctx<LGS>::S)           // decoded_bits: L > 0 in 'decode' mode only (:148-152)
+    const int64_t pair = (int64_t)blockIdx.x * (blockDim.x >> 7) + (threadIdx.x >> 7);
+    const int64_t K = (p.N + CH - 1) / CH;
+    PassIO io;
+    io.sys = p.sys; io.sys_perm = nullptr; io.par = p.par; io.Lin = p.Lin; io.Lout = p.Lout; io.lstride = p.N;
+    io.cw0 = pair * p.GW; io.B = p.B; io.N = p.N; io.nv2 = p.nv2;
+    io.ckpt = p.scratch + pair * (K + 1) * 64;
+    map_pass<LGS, SR>(c, io);
+    pair_sync();
+    // decoded_bits: L > 0 in 'decode' mode only (:148-152); the two waves of the pair take alternate codewords
+    for (int g = (threadIdx.x >> 6) & 1; g < p.GW; g += 2) {
+        const int64_t cw = io.cw0 + g;
+        if (cw >= p.B) break;
+        for (int64_t t = c.lane; t < p.N; t += 64)
             p.bits[cw * p.N + t] = (uint8_t)((p.want_bits && p.Lout[cw * p.N + t] > 0) ? 1 : 0);
+    }
 }
 
 struct TurboParams {
@@ -381,73 +438,70 @@ struct TurboParams {
     const double *sys, *p1, *p2, *Lint;   // [B][N], Lint may be null
     const int32_t *perm;                  // [N]
     uint8_t *bits;                        // [B][N]
-    double *beta;                         // per wave: beta rows [nchunks][CH][64]
+    double *ckpt;                         // per pair: checkpoint rows [nchunks + 1][64]
     double *larr;                         // per codeword: A[N] B[N] C[N]
     int64_t B, N;
     double nv2;
     int n_iter, GW;
 };
 
-template <int LGS>
-__global__ __launch_bounds__(64) void turbo_decode_kernel(TurboParams p) {
+template <int LGS, bool SR>
+__global__ __launch_bounds__(128 * NPAIR) void turbo_decode_kernel(TurboParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Ctx<LGS> c;
     init_ctx<LGS>(c, p.tb, smem, p.GW);
-    constexpr int S = Ctx<LGS>::S;
-    const int64_t cw0 = (int64_t)blockIdx.x * p.GW, N = p.N;
-    const int64_t cw = cw0 + c.g;
-    const bool valid = c.active && cw < p.B;
-    const int64_t wslab = ((N + Ctx<LGS>::CH - 1) / Ctx<LGS>::CH) * Ctx<LGS>::CH * 64;
-    double *beta = p.beta + (int64_t)blockIdx.x * wslab;
+    const int64_t pair = (int64_t)blockIdx.x * (blockDim.x >> 7) + (threadIdx.x >> 7);
+    const int64_t N = p.N, K = (N + CH - 1) / CH, cw0 = pair * p.GW;
     // L arrays of all codewords: [B][3][N] -> per-codeword stride 3N; A at +0, B at +N, C at +2N
     double *A0 = p.larr, *B0 = p.larr + N, *C0 = p.larr + 2 * N;
     const int64_t ls = 3 * N;
-    // The element-wise stages between the MAP passes are done by the whole wave, one codeword after the other, 64
-    // consecutive elements per instruction and four independent rounds in flight.  (The first version gave every
-    // codeword to its own S lanes: N/S dependent load -> store rounds per stage, 3.9 of the 14.0 ms of config 3.)
-    const int lane = c.lane, GW = p.GW;
-    (void)cw; (void)valid; (void)S;
-    for (int g = 0; g < GW; g++) {
+    PassIO io;
+    io.sys = p.sys; io.lstride = ls; io.cw0 = cw0; io.B = p.B; io.N = N; io.nv2 = p.nv2;
+    io.ckpt = p.ckpt + pair * (K + 1) * 64;
+    // The element-wise stages between the MAP passes are done wave-wide, one codeword after the other (the two waves of
+    // the pair take alternate codewords), 64 consecutive elements per instruction and four independent rounds in flight.
+    const int lane = c.lane, GW = p.GW, w2 = (threadIdx.x >> 6) & 1;
+    for (int g = w2; g < GW; g += 2) {
         const int64_t cwg = cw0 + g;
         if (cwg >= p.B) break;
         double *A = A0 + cwg * ls;
 #pragma unroll 4
         for (int64_t t = lane; t < N; t += 64) A[t] = p.Lint ? p.Lint[cwg * N + t] : 0.0;      // L_int_1 (:305-308)
     }
-    __syncthreads();
-    for (int it = 0; it < p.n_iter; it++) {
-        // [L_ext_1, _] = map_decode(sys, non_sys_1, trellis, nv, L_int_1, 'compute')   (:315)
-        map_pass<LGS>(c, cw0, p.B, N, p.nv2, p.sys, nullptr, p.p1, A0, ls, beta, B0);
-        __syncthreads();
-        // L_ext_1 -= L_int_1 ; L_int_2 = interlv(L_ext_1)                               (:318-319), one pass: same subtraction
-        for (int g = 0; g < GW; g++) {
+    pair_sync();
+    // 2 n_iter half-iterations through ONE map_pass call site (two inlined copies of the unrolled pass spill registers):
+    //   even h: [L_ext_1, _] = map_decode(sys, non_sys_1, trellis, nv, L_int_1, 'compute')          (:315)
+    //           L_ext_1 -= L_int_1 ; L_int_2 = interlv(L_ext_1)                                     (:318-319)
+    //   odd h:  [L_2, bits] = map_decode(sys_i, non_sys_2, trellis, nv, L_int_2, mode)              (:326)
+    //           L_ext_2 = L_2 - L_int_2 ; L_int_1 = deinterlv(L_ext_2)                              (:328-329)
+    for (int h = 0; h < 2 * p.n_iter; h++) {
+        const bool second = h & 1;
+        io.sys_perm = second ? p.perm : nullptr;
+        io.par = second ? p.p2 : p.p1;
+        io.Lin = second ? C0 : A0;
+        io.Lout = B0;
+        map_pass<LGS, SR>(c, io);
+        pair_sync();
+        for (int g = w2; g < GW; g += 2) {
             const int64_t cwg = cw0 + g;
             if (cwg >= p.B) break;
-            const double *A = A0 + cwg * ls, *Bb = B0 + cwg * ls;
-            double *C = C0 + cwg * ls;
+            double *A = A0 + cwg * ls, *C = C0 + cwg * ls;
+            const double *Bb = B0 + cwg * ls;
+            if (!second) {
 #pragma unroll 4
-            for (int64_t t = lane; t < N; t += 64) {
-                const int32_t q = p.perm[t];
-                C[t] = Bb[q] - A[q];
+                for (int64_t t = lane; t < N; t += 64) {      // same subtraction, fused with the interleaver gather
+                    const int32_t q = p.perm[t];
+                    C[t] = Bb[q] - A[q];
+                }
+            } else {
+#pragma unroll 4
+                for (int64_t t = lane; t < N; t += 64) A[p.perm[t]] = Bb[t] - C[t];
             }
         }
-        __syncthreads();
-        // [L_2, bits] = map_decode(sys_i, non_sys_2, trellis, nv, L_int_2, mode)          (:326)
-        map_pass<LGS>(c, cw0, p.B, N, p.nv2, p.sys, p.perm, p.p2, C0, ls, beta, B0);
-        __syncthreads();
-        // L_ext_2 = L_2 - L_int_2 ; L_int_1 = deinterlv(L_ext_2)                          (:328-329)
-        for (int g = 0; g < GW; g++) {
-            const int64_t cwg = cw0 + g;
-            if (cwg >= p.B) break;
-            const double *Bb = B0 + cwg * ls, *C = C0 + cwg * ls;
-            double *A = A0 + cwg * ls;
-#pragma unroll 4
-            for (int64_t t = lane; t < N; t += 64) A[p.perm[t]] = Bb[t] - C[t];
-        }
-        __syncthreads();
+        pair_sync();
     }
     // decoded_bits = deinterlv(decoded_bits of the last MAP2)                              (:331)
-    for (int g = 0; g < GW; g++) {
+    for (int g = w2; g < GW; g += 2) {
         const int64_t cwg = cw0 + g;
         if (cwg >= p.B) break;
         const double *Bb = B0 + cwg * ls;
@@ -457,16 +511,22 @@ __global__ __launch_bounds__(64) void turbo_decode_kernel(TurboParams p) {
     }
 }
 
-// codewords per wavefront: full wavefronts as soon as the batch gives every SIMD of the chip one of them; for
-// smaller batches fewer codewords per wavefront (idle lanes) spread the work over more SIMDs.  (Measured on
-// MI355X, B = 16384 x N = 1024: GW = 16 -> 1.07 ms per MAP pass, GW = 4 -> 1.78 ms: the pass is bound by
-// instruction issue, not by latency, so idle lanes do not pay once the chip is full.)
+// codewords per pair of wavefronts: full wavefronts as soon as the batch gives every SIMD of the chip its two waves; for
+// smaller batches fewer codewords per pair (idle lanes) spread the work over more SIMDs.
 int pick_gw(int S, int64_t B) {
     int G = 64 / S;
-    if (G > 16) G = 16;                                            // CH*GW <= 256 items per chunk
+    if (G > 16) G = 16;                                            // CH*GW <= 128 items per chunk
     int gw = G;
     while (gw > 1 && (B + gw - 1) / gw < 1024) gw >>= 1;
     return gw;
+}
+
+// pairs per workgroup: four (eight waves, one workgroup per CU at full size) when there are enough pairs to give every
+// CU such a workgroup, else one pair per workgroup
+int pick_npair(int64_t npairs) {
+    static const int forced = [] { const char *e = getenv("CPX_BCJR_NPAIR"); return e ? atoi(e) : 0; }();   // experiments
+    if (forced == 1 || forced == 2 || forced == NPAIR) return forced;
+    return npairs >= (int64_t)NPAIR * device_cus() ? NPAIR : 1;
 }
 
 int fill_tables(const cpx_trellis *t, MapTables &tb) {
@@ -504,19 +564,27 @@ int cpx_map_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const do
     if (B == 0 || N == 0) return CPX_OK;
     hipStream_t st = pick_stream(stream);
     const int GW = pick_gw(t->S, B);
-    const int64_t nblocks = (B + GW - 1) / GW;
+    const int64_t npairs = (B + GW - 1) / GW;
+    const int np = pick_npair(npairs);
+    const int64_t nblocks = (npairs + np - 1) / np, K = (N + CH - 1) / CH;
     p.GW = GW;
     p.sys = d_sys; p.par = d_par; p.Lin = d_L_int; p.Lout = d_L_ext; p.bits = d_bits;
     p.B = B; p.N = N; p.nv2 = 2 * noise_variance; p.want_bits = want_bits;
-    if ((rc = workspace(st, 0, sizeof(double) * (size_t)(nblocks * ((N + MAXCH - 1) / MAXCH) * MAXCH * 64), (void **)&p.scratch))) return rc;
-    dim3 grid((unsigned)nblocks), block(64);
+    CPX_REQUIRE(nblocks < (1ll << 31), CPX_ELIMIT, "map_decode: batch too large");
+    if ((rc = workspace(st, 0, sizeof(double) * (size_t)(nblocks * np * (K + 1) * 64), (void **)&p.scratch))) return rc;
+    dim3 grid((unsigned)nblocks), block(128 * np);
     switch (p.tb.lgS) {
-#define CASE(LG) case LG: hipLaunchKernelGGL(map_decode_kernel<LG>, grid, block, lds_bytes<LG>(GW), st, p); break;
-        CASE(1) CASE(2) CASE(3) CASE(4)
+#define CASE(LG) case LG: hipLaunchKernelGGL((map_decode_kernel<LG, false>), grid, block, sizeof(double) * 2 * np * wave_lds_doubles<LG>(GW), st, p); break;
+        case 2:                                                   // 4 states: the shift-register fast path where it applies
+            if (p.tb.sr4) hipLaunchKernelGGL((map_decode_kernel<2, true>), grid, block, sizeof(double) * 2 * np * wave_lds_doubles<2>(GW), st, p);
+            else hipLaunchKernelGGL((map_decode_kernel<2, false>), grid, block, sizeof(double) * 2 * np * wave_lds_doubles<2>(GW), st, p);
+            break;
+        CASE(1) CASE(3) CASE(4)
 #undef CASE
         default: set_error("map_decode: unsupported state count"); return CPX_ELIMIT;
     }
     CPX_HIP(hipGetLastError());
+    note_kernel("map_decode_kernel<%d,%s> (%d wave pairs per workgroup, %d codewords per pair)", p.tb.lgS, (p.tb.lgS == 2 && p.tb.sr4) ? "true" : "false", np, GW);
     return CPX_OK;
 }
 
@@ -530,20 +598,28 @@ int cpx_turbo_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const 
     if (B == 0 || N == 0) return CPX_OK;
     hipStream_t st = pick_stream(stream);
     const int GW = pick_gw(t->S, B);
-    const int64_t nblocks = (B + GW - 1) / GW;
+    const int64_t npairs = (B + GW - 1) / GW;
+    const int np = pick_npair(npairs);
+    const int64_t nblocks = (npairs + np - 1) / np, K = (N + CH - 1) / CH;
     p.GW = GW;
     p.sys = d_sys; p.p1 = d_p1; p.p2 = d_p2; p.Lint = d_L_int_or_null; p.perm = d_perm; p.bits = d_bits;
     p.B = B; p.N = N; p.nv2 = 2 * noise_variance; p.n_iter = n_iter;
-    if ((rc = workspace(st, 0, sizeof(double) * (size_t)(nblocks * ((N + MAXCH - 1) / MAXCH) * MAXCH * 64), (void **)&p.beta))) return rc;
+    CPX_REQUIRE(nblocks < (1ll << 31), CPX_ELIMIT, "turbo_decode: batch too large");
+    if ((rc = workspace(st, 0, sizeof(double) * (size_t)(nblocks * np * (K + 1) * 64), (void **)&p.ckpt))) return rc;
     if ((rc = workspace(st, 1, sizeof(double) * (size_t)(B * 3 * N), (void **)&p.larr))) return rc;
-    dim3 grid((unsigned)nblocks), block(64);
+    dim3 grid((unsigned)nblocks), block(128 * np);
     switch (p.tb.lgS) {
-#define CASE(LG) case LG: hipLaunchKernelGGL(turbo_decode_kernel<LG>, grid, block, lds_bytes<LG>(GW), st, p); break;
-        CASE(1) CASE(2) CASE(3) CASE(4)
+#define CASE(LG) case LG: hipLaunchKernelGGL((turbo_decode_kernel<LG, false>), grid, block, sizeof(double) * 2 * np * wave_lds_doubles<LG>(GW), st, p); break;
+        case 2:
+            if (p.tb.sr4) hipLaunchKernelGGL((turbo_decode_kernel<2, true>), grid, block, sizeof(double) * 2 * np * wave_lds_doubles<2>(GW), st, p);
+            else hipLaunchKernelGGL((turbo_decode_kernel<2, false>), grid, block, sizeof(double) * 2 * np * wave_lds_doubles<2>(GW), st, p);
+            break;
+        CASE(1) CASE(3) CASE(4)
 #undef CASE
         default: set_error("turbo_decode: unsupported state count"); return CPX_ELIMIT;
     }
     CPX_HIP(hipGetLastError());
+    note_kernel("turbo_decode_kernel<%d,%s> (%d wave pairs per workgroup, %d codewords per pair)", p.tb.lgS, (p.tb.lgS == 2 && p.tb.sr4) ? "true" : "false", np, GW);
     return CPX_OK;
 }
 
