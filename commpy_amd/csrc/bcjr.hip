@@ -83,14 +83,19 @@ struct Ctx {
     bool active;                                                       // lane belongs to one of the GW decoded slots
     int nxt[2], code[2];              // outgoing branches of state s: next-state lane, 2-bit code (sys, parity)
     int plane[2], pin[2], pcode[2];   // incoming branches in np.where order: predecessor lane, input, code
+    // 4-state shift-register trellises: the successors of s are lo = s>>1 and hi = 2|(s>>1) whatever the input; ilo is
+    // the input that leads to lo.  Everything a step needs is then a STATIC per-lane offset -- no selects on the chain.
+    int ilo, lane_lo, lane_hi;
+    int o_glo, o_ghi;                 // offsets of gamma(code of the branch to lo / hi) inside an item of `tab`
     // LDS of this wave
-    double *tab;    // [CH][GW][6] (+2 pad per step): gamma[4], p0, p1 of every (step, codeword) item
+    double *tab;    // [CH][GW][6] (+2 pad per step): gamma[4], prior weights q0, q1 of every (step, codeword) item
     double *xs;     // [CH][64][2]  per-lane branch products alpha*gamma*beta of the chunk (phase 2)
+    double *rw;     // [CH][64]     beta rows of the chunk recomputed by the forward wave (phase 2)
     double *xch;    // [64]         exchange buffer (trellises without the DPP fast path)
 };
 
 template <int LGS>
-__host__ __device__ constexpr size_t wave_lds_doubles(int GW) { return (size_t)CH * (GW * 6 + 2) + (size_t)CH * 64 * 2 + 64; }
+__host__ __device__ constexpr size_t wave_lds_doubles(int GW) { return (size_t)CH * (GW * 6 + 2) + (size_t)CH * 64 * 3 + 64; }
 
 template <int LGS>
 __device__ __forceinline__ void init_ctx(Ctx<LGS> &c, const MapTables &tb, unsigned char *smem, int GW) {
@@ -112,9 +117,15 @@ __device__ __forceinline__ void init_ctx(Ctx<LGS> &c, const MapTables &tb, unsig
         c.pin[i] = tb.pred_input[c.s * 2 + i];
         c.pcode[i] = (tb.pred_code[c.s * 2 + i] >> sh) & 3;
     }
+    c.ilo = c.sb[0] ? 1 : 0;
+    c.o_glo = c.sb[0] ? c.code[1] : c.code[0];
+    c.o_ghi = c.sb[0] ? c.code[0] : c.code[1];
+    c.lane_lo = gbase + (c.s >> 1);
+    c.lane_hi = gbase + ((c.s >> 1) | (S >> 1));
     double *p = reinterpret_cast<double *>(smem) + (size_t)wave * wave_lds_doubles<LGS>(GW);
     c.tab = p; p += CH * c.P;
     c.xs = p;  p += CH * 64 * 2;
+    c.rw = p;  p += CH * 64;
     c.xch = p;
 }
 
@@ -140,20 +151,6 @@ __device__ __forceinline__ void exchange2(const Ctx<LGS> &c, double v, int la, i
     }
 }
 
-// beta of the two successors of this lane's state, ordered by INPUT (0, 1).  4-state shift-register trellises:
-// the successors of state s are (s>>1) and 2|(s>>1) -- two constant quad permutes + a per-lane select.
-template <int LGS, bool SR>
-__device__ __forceinline__ void exchange_succ(const Ctx<LGS> &c, double v, double &v0, double &v1) {
-    if (LGS == 2 && SR) {
-        const double lo = dppd<0x50>(v);                          // quad_perm [0,0,1,1]: lane s <- lane s>>1
-        const double hi = dppd<0xFA>(v);                          // quad_perm [2,2,3,3]: lane s <- lane 2|(s>>1)
-        v0 = c.sb[0] ? hi : lo;
-        v1 = c.sb[1] ? hi : lo;
-    } else {
-        exchange2<LGS>(c, v, c.nxt[0], c.nxt[1], v0, v1);
-    }
-}
-
 // alpha of the two predecessors of this lane's state in np.where order (increasing predecessor state).
 // 4-state shift-register trellises: predecessors of ns are 2(ns&1) and 2(ns&1)+1.
 template <int LGS, bool SR>
@@ -174,11 +171,14 @@ struct RawChunk {
 };
 
 struct PassIO {
-    const double *sys;            // [B][N]
-    const int32_t *sys_perm;      // null, or sys is read through the interleaver (sys_symbols_i = interlv(sys), turbo.py:310)
+    const double *sys;            // systematic values, stride sstride per codeword
     const double *par;            // [B][N]
+    uint8_t *bits;                // map_decode: hard decisions [B][N] (L > 0 in 'decode' mode), or null
+    int want_bits;
+    int64_t sstride;
     const double *Lin;            // L_int, stride lstride per codeword
-    double *Lout;                 // L_int + log(app1/app0), stride lstride
+    double *Lout;                 // L_int + log(app1/app0) -- or, with `ext`, log(app1/app0) alone --, stride lstride
+    bool ext;                     // turbo: write L - L_int, the quantity the next half-iteration interleaves (:318, :328)
     int64_t lstride, cw0, B, N;
     double nv2;
     double *ckpt;                 // this pair's checkpoint rows [nchunks + 1][64]
@@ -192,85 +192,169 @@ __device__ __forceinline__ void load_raw(const Ctx<LGS> &c, const PassIO &io, Ra
         const int64_t cw = io.cw0 + gg, t = t0 + tl;              // 0-based step index
         rc.r0[q] = 0.0; rc.r1[q] = 0.0; rc.li[q] = 0.0;
         if (gg < c.GW && cw < io.B && tl < len) {
-            rc.r0[q] = io.sys[cw * io.N + (io.sys_perm ? io.sys_perm[t] : t)];
+            rc.r0[q] = io.sys[cw * io.sstride + t];
             rc.r1[q] = io.par[cw * io.N + t];
             rc.li[q] = io.Lin[cw * io.lstride + t];
         }
     }
 }
 
-// tab[tl][g] = gamma[0..3] (_compute_branch_prob :62-76), p0, p1 (priors :239-240) into LDS.  The row stride P = 6 GW + 2
-// doubles makes the eight lanes that hold consecutive steps of a codeword hit eight different 16-byte bank groups.
+// tab[tl][g] = gamma'[0..3], q0, q1 into LDS -- the branch probabilities (_compute_branch_prob :62-76) and the priors
+// (:239-240) of every item, each up to a factor that is COMMON to the step and therefore cancels in the normalised
+// recursions and in app1/app0:
+//   gamma[c] = exp(-((r0-c0)^2 + (r1-c1)^2)/nv2) = E * (c0 matches sign(r0) ? 1 : Qa) * (c1 matches sign(r1) ? 1 : Qb),
+//     E = exp(-((|r0|-1)^2 + (|r1|-1)^2)/nv2) (dropped), Qa = exp(-4|r0|/nv2), Qb = exp(-4|r1|/nv2): two exps instead
+//     of four, every factor <= 1;
+//   (p0, p1) = (1, e^L)/(1+e^L): q = (1, e^L) for L < 0, (e^-L, 1) otherwise -- one exp of a non-positive argument, no
+//     division; same limits as the reference (p0 -> 0 / p1 -> 0 when e^L overflows / underflows).
+// The row stride P = 6 GW + 2 doubles makes the eight lanes that hold consecutive steps of a codeword hit eight
+// different 16-byte bank groups.
 template <int LGS>
 __device__ __forceinline__ void stage_chunk(const Ctx<LGS> &c, const RawChunk &rc, double nv2) {
     const int GW = c.GW;
+    const double k4 = -4.0 / nv2;
 #pragma unroll
     for (int q = 0; q < 2; q++) {
         const int p = c.lane + 64 * q, gg = p / CH, tl = p % CH;
         if (gg < GW) {
-            double g4[4];
-#pragma unroll
-            for (int code = 0; code < 4; code++) {
-                const double x = rc.r0[q] - (double)(2 * ((code >> 1) & 1) - 1);
-                const double y = rc.r1[q] - (double)(2 * (code & 1) - 1);
-                g4[code] = exp(-(x * x + y * y) / nv2);
-            }
-            const double p0 = 1.0 / (1.0 + exp(rc.li[q]));
+            const double r0 = rc.r0[q], r1 = rc.r1[q], li = rc.li[q];
+            const double qa = exp(k4 * fabs(r0)), qb = exp(k4 * fabs(r1)), e = exp(-fabs(li));
+            const bool n0 = r0 < 0.0, n1 = r1 < 0.0, pos = li >= 0.0;
+            const double a0 = n0 ? 1.0 : qa, a1 = n0 ? qa : 1.0;  // systematic bit 0 (c0 = -1) / 1 (c0 = +1)
+            const double b0 = n1 ? 1.0 : qb, b1 = n1 ? qb : 1.0;  // parity bit
             double2 *row = reinterpret_cast<double2 *>(c.tab + tl * c.P + gg * 6);
-            row[0] = make_double2(g4[0], g4[1]);
-            row[1] = make_double2(g4[2], g4[3]);
-            row[2] = make_double2(p0, 1.0 - p0);                  // priors[1] = 1 - priors[0] (:240)
+            row[0] = make_double2(a0 * b0, a0 * b1);              // code = 2*sys_bit + parity_bit
+            row[1] = make_double2(a1 * b0, a1 * b1);
+            row[2] = make_double2(pos ? e : 1.0, pos ? 1.0 : e);
         }
     }
     asm volatile("" ::: "memory");
 }
 
-// One beta step (:106-111): b <- sum_i b[next(s,i)] * gamma(code(s,i)) * prior(i), inputs 0 then 1.
-// With X = true also parks x_i = a_own * gamma(code(s,i)) * b[next(s,i)] (the branch products of :141-143).
-template <int LGS, bool SR, bool X>
-__device__ __forceinline__ void beta_step(const Ctx<LGS> &c, int tl, double &b, double a_own) {
+// ---- serial recursions over one staged chunk -----------------------------------------------------------------------
+// The operands of a step that come from LDS (branch probabilities and prior weights of this lane's two branches) do not
+// depend on the recursion, so a full chunk first issues ALL its LDS reads and forms the branch weights w = gamma * prior
+// off the chain; the chain itself is then, per step, one cross-lane exchange, a multiply and a fused multiply-add on
+// registers.  (Reading them step by step put an LDS round trip -- s_waitcnt lgkmcnt(0) -- on every step: rocprofv3 showed
+// 55 % of the wave cycles waiting at 45 % VALU utilisation.)  The sum-normalisation of (:110-111, :155-158) is applied every
+// KNORM steps with the hardware reciprocal: any positive common factor is a valid normalisation.
+
+// branch weights of this lane for the beta recursion at step tl: "lo"/"hi" are the branches into successor s>>1 /
+// 2|(s>>1) on the shift-register fast path, the branches of input 0 / 1 otherwise
+template <int LGS, bool SR>
+__device__ __forceinline__ void beta_w(const Ctx<LGS> &c, int tl, double &g_lo, double &g_hi, double &w_lo, double &w_hi) {
     const double *it = c.tab + tl * c.P + c.g * 6;
-    const double g0 = it[c.code[0]], g1 = it[c.code[1]], p0 = it[4], p1 = it[5];
-    double bn0, bn1;
-    exchange_succ<LGS, SR>(c, b, bn0, bn1);
-    if (X) {
-        double2 xv;
-        xv.x = a_own * g0 * bn0;
-        xv.y = a_own * g1 * bn1;
-        *reinterpret_cast<double2 *>(c.xs + (tl * 64 + c.lane) * 2) = xv;   // idle lanes own a slot too
+    if (LGS == 2 && SR) {
+        g_lo = it[c.o_glo]; g_hi = it[c.o_ghi];
+        w_lo = g_lo * it[4 + c.ilo]; w_hi = g_hi * it[5 - c.ilo];
+    } else {
+        g_lo = it[c.code[0]]; g_hi = it[c.code[1]];
+        w_lo = g_lo * it[4]; w_hi = g_hi * it[5];
     }
-    double nb = 0.0;
-    nb += (bn0 * g0 * p0);
-    nb += (bn1 * g1 * p1);
-    b = nb;
-    // (:110-111) every KNORM steps; any positive common factor is a valid normalisation, so the hardware
-    // reciprocal (v_rcp_f64) is used instead of a correctly rounded division
+}
+
+// weights of the two incoming branches of this lane's state, in np.where order (:136-138)
+template <int LGS>
+__device__ __forceinline__ void alpha_w(const Ctx<LGS> &c, int tl, double &w0, double &w1) {
+    const double *it = c.tab + tl * c.P + c.g * 6;
+    w0 = it[c.pcode[0]] * it[4 + c.pin[0]];
+    w1 = it[c.pcode[1]] * it[4 + c.pin[1]];
+}
+
+// beta of this lane's two successors (see beta_w for the order)
+template <int LGS, bool SR>
+__device__ __forceinline__ void beta_nbrs(const Ctx<LGS> &c, double b, double &lo, double &hi) {
+    if (LGS == 2 && SR) {
+        lo = dppd<0x50>(b);                                       // quad_perm [0,0,1,1]: lane s <- lane s>>1
+        hi = dppd<0xFA>(b);                                       // quad_perm [2,2,3,3]: lane s <- lane 2|(s>>1)
+    } else {
+        exchange2<LGS>(c, b, c.nxt[0], c.nxt[1], lo, hi);
+    }
+}
+
+// One beta step (:106-108): b <- sum_i b[next(s,i)] * gamma(code(s,i)) * prior(i).  ROWS: the row before the update
+// (beta of the step's upper time) goes to c.rw; X: the branch products x_i = a_own * gamma_i * b[next(s,i)] of
+// (:141-143) are parked at slot i of c.xs.
+template <int LGS, bool SR, bool ROWS, bool X>
+__device__ __forceinline__ void beta_step(const Ctx<LGS> &c, int tl, double &b, double a_own, double g_lo, double g_hi,
+                                          double w_lo, double w_hi) {
+    if (ROWS) c.rw[tl * 64 + c.lane] = b;
+    double lo, hi;
+    beta_nbrs<LGS, SR>(c, b, lo, hi);
+    if (X) {
+        double *xo = c.xs + (tl * 64 + c.lane) * 2;               // idle lanes own a slot too
+        const int s_lo = (LGS == 2 && SR) ? c.ilo : 0;
+        xo[s_lo] = (a_own * g_lo) * lo;
+        xo[1 - s_lo] = (a_own * g_hi) * hi;
+    }
+    b = __builtin_fma(hi, w_hi, lo * w_lo);
     if ((tl & (KNORM - 1)) == 0) b = b * __builtin_amdgcn_rcp(group_sum<LGS>(b));
 }
 
-// One alpha step (:136-138, :155-158): a <- sum over the incoming branches in (predecessor state, input) order.
-// With X = true first parks x_i = a * gamma(code(s,i)) * beta_next[next(s,i)] for this lane's outgoing branches.
-template <int LGS, bool SR, bool X>
-__device__ __forceinline__ void alpha_step(const Ctx<LGS> &c, int tl, double &a, double beta_row) {
-    const double *it = c.tab + tl * c.P + c.g * 6;
-    const double gi0 = it[c.pcode[0]], gi1 = it[c.pcode[1]];
-    const double q0 = it[4 + c.pin[0]], q1 = it[4 + c.pin[1]];
-    if (X) {
-        const double go0 = it[c.code[0]], go1 = it[c.code[1]];
-        double bt0, bt1;
-        exchange_succ<LGS, SR>(c, beta_row, bt0, bt1);
-        double2 xv;
-        xv.x = a * go0 * bt0;
-        xv.y = a * go1 * bt1;
-        *reinterpret_cast<double2 *>(c.xs + (tl * 64 + c.lane) * 2) = xv;   // idle lanes own a slot too
-    }
+template <int LGS, bool SR>
+__device__ __forceinline__ void alpha_step(const Ctx<LGS> &c, int tl, double &a, double w0, double w1) {
     double ap0, ap1;
     exchange_pred<LGS, SR>(c, a, ap0, ap1);
-    double na = 0.0;
-    na += (ap0 * gi0 * q0);
-    na += (ap1 * gi1 * q1);
-    a = na;
+    a = __builtin_fma(ap1, w1, ap0 * w0);
     if ((tl & (KNORM - 1)) == KNORM - 1) a = a * __builtin_amdgcn_rcp(group_sum<LGS>(a));
+}
+
+// beta over the `len` staged steps, downwards; arow[tl] = alpha of this lane's state at step tl (X only)
+template <int LGS, bool SR, bool ROWS, bool X>
+__device__ __forceinline__ void beta_chunk(const Ctx<LGS> &c, double &b, int len, const double (&arow)[CH]) {
+    if (len == CH) {
+        double gl[CH], gh[CH], wl[CH], wh[CH];
+#pragma unroll
+        for (int tl = 0; tl < CH; tl++) beta_w<LGS, SR>(c, tl, gl[tl], gh[tl], wl[tl], wh[tl]);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int tl = CH - 1; tl >= 0; --tl) beta_step<LGS, SR, ROWS, X>(c, tl, b, arow[tl], gl[tl], gh[tl], wl[tl], wh[tl]);
+    } else {                                                      // the last, partial chunk of a block: rolled
+#pragma unroll 1
+        for (int tl = len - 1; tl >= 0; --tl) {
+            double gl, gh, wl, wh;
+            beta_w<LGS, SR>(c, tl, gl, gh, wl, wh);
+            beta_step<LGS, SR, ROWS, false>(c, tl, b, 0.0, gl, gh, wl, wh);
+        }
+    }
+    asm volatile("" ::: "memory");
+}
+
+// alpha over the `len` staged steps, upwards; KEEP: arow[tl] = alpha before step tl
+template <int LGS, bool SR, bool KEEP>
+__device__ __forceinline__ void alpha_chunk(const Ctx<LGS> &c, double &a, int len, double (&arow)[CH]) {
+    if (len == CH) {
+        double w0[CH], w1[CH];
+#pragma unroll
+        for (int tl = 0; tl < CH; tl++) alpha_w<LGS>(c, tl, w0[tl], w1[tl]);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int tl = 0; tl < CH; tl++) {
+            if (KEEP) arow[tl] = a;
+            alpha_step<LGS, SR>(c, tl, a, w0[tl], w1[tl]);
+        }
+    } else {
+#pragma unroll 1
+        for (int tl = 0; tl < len; tl++) {
+            double w0, w1;
+            alpha_w<LGS>(c, tl, w0, w1);
+            alpha_step<LGS, SR>(c, tl, a, w0, w1);
+        }
+    }
+}
+
+// forward wave, phase 2: x_i = alpha * gamma(code(s,i)) * beta[next(s,i)] for the whole chunk, beta from the rows in c.rw
+template <int LGS, bool SR>
+__device__ __forceinline__ void park_products(const Ctx<LGS> &c, int tl, double a) {
+    const double *it = c.tab + tl * c.P + c.g * 6, *br = c.rw + tl * 64;
+    double *xo = c.xs + (tl * 64 + c.lane) * 2;
+    if (LGS == 2 && SR) {
+        xo[c.ilo] = (a * it[c.o_glo]) * br[c.lane_lo];
+        xo[1 - c.ilo] = (a * it[c.o_ghi]) * br[c.lane_hi];
+    } else {
+        xo[0] = (a * it[c.code[0]]) * br[c.nxt[0]];
+        xo[1] = (a * it[c.code[1]]) * br[c.nxt[1]];
+    }
 }
 
 // time-parallel epilogue of a phase-2 chunk: app sums in state order, L = L_int + log(app1/app0) (:145)
@@ -287,7 +371,10 @@ __device__ __forceinline__ void epilogue(const Ctx<LGS> &c, const PassIO &io, co
             double app0 = 0.0, app1 = 0.0;
 #pragma unroll
             for (int st = 0; st < S; st++) { const double2 v = x[st]; app0 += v.x; app1 += v.y; }
-            io.Lout[cw * io.lstride + t_lo + tl] = rc.li[q] + fast_log(app1 / app0);
+            const double lr = fast_log(app1 / app0);
+            const double L = io.ext ? lr : rc.li[q] + lr;
+            io.Lout[cw * io.lstride + t_lo + tl] = L;
+            if (io.bits) io.bits[cw * io.N + t_lo + tl] = (uint8_t)((io.want_bits && L > 0) ? 1 : 0);   // (:148-152)
         }
     }
     asm volatile("" ::: "memory");
@@ -311,6 +398,9 @@ __device__ void map_pass(const Ctx<LGS> &c, const PassIO &io) {
     auto clen = [&](int k) { const int64_t r = N - (int64_t)k * CH; return (int)(r < CH ? r : CH); };
     double *ck = io.ckpt + c.lane;                                // row k: state vector at time k*CH
     RawChunk cur, nxt;
+    double arow[CH];                                              // alpha of this lane's state at the chunk's steps
+#pragma unroll
+    for (int tl = 0; tl < CH; tl++) arow[tl] = 0.0;
     if (c.fwd) {
         // ---------------- phase 1: alpha over chunks 0 .. K1-1, checkpoint before every chunk ----------------
         double a = (c.s == 0) ? 1.0 : 0.0;                        // f_state_metrics[0][0] = 1 (:221)
@@ -319,18 +409,12 @@ __device__ void map_pass(const Ctx<LGS> &c, const PassIO &io) {
             ck[(int64_t)k * 64] = a;                              // alpha at time k*CH (read by R in phase 2)
             stage_chunk<LGS>(c, cur, io.nv2);
             if (k + 1 < K1) load_raw<LGS>(c, io, nxt, (int64_t)(k + 1) * CH, clen(k + 1));
-            const int len = clen(k);
-            if (len == CH) {
-#pragma unroll
-                for (int tl = 0; tl < CH; tl++) alpha_step<LGS, SR, false>(c, tl, a, 0.0);
-            } else {
-                for (int tl = 0; tl < len; tl++) alpha_step<LGS, SR, false>(c, tl, a, 0.0);
-            }
+            alpha_chunk<LGS, SR, false>(c, a, CH, arow);          // chunks below K1 are full
             cur = nxt;
         }
         load_raw<LGS>(c, io, cur, (int64_t)K1 * CH, clen(K1));    // first chunk of phase 2 (K1 < K always)
         pair_sync();
-        // ---------------- phase 2: chunks K1 .. K-1: beta rows from R's checkpoint, alpha + combine ----------------
+        // ---------------- phase 2: chunks K1 .. K-1: beta rows from R's checkpoint, alpha, combine ----------------
         double bup = ck[(int64_t)(K1 + 1) * 64];                  // beta at the upper boundary of chunk K1
         for (int k = K1; k < K; k++) {
             const int len = clen(k);
@@ -340,20 +424,20 @@ __device__ void map_pass(const Ctx<LGS> &c, const PassIO &io) {
                 load_raw<LGS>(c, io, nxt, (int64_t)(k + 1) * CH, clen(k + 1));
                 bupn = ck[(int64_t)(k + 2) * 64];
             }
-            double brow[CH];                                      // brow[tl] = beta at time k*CH + tl + 1
-            double b = bup;
+            double b = bup;                                       // row tl of c.rw = beta at time k*CH + tl + 1
+            beta_chunk<LGS, SR, true, false>(c, b, len, arow);
             if (len == CH) {
+                alpha_chunk<LGS, SR, true>(c, a, CH, arow);
 #pragma unroll
-                for (int tl = CH - 1; tl >= 0; --tl) { brow[tl] = b; beta_step<LGS, SR, false>(c, tl, b, 0.0); }
-#pragma unroll
-                for (int tl = 0; tl < CH; tl++) alpha_step<LGS, SR, true>(c, tl, a, brow[tl]);
+                for (int tl = 0; tl < CH; tl++) park_products<LGS, SR>(c, tl, arow[tl]);
             } else {
-#pragma unroll
-                for (int tl = CH - 1; tl >= 0; --tl)
-                    if (tl < len) { brow[tl] = b; beta_step<LGS, SR, false>(c, tl, b, 0.0); }
-#pragma unroll
-                for (int tl = 0; tl < CH; tl++)
-                    if (tl < len) alpha_step<LGS, SR, true>(c, tl, a, brow[tl]);
+#pragma unroll 1
+                for (int tl = 0; tl < len; tl++) {                // partial last chunk: step by step
+                    park_products<LGS, SR>(c, tl, a);
+                    double w0, w1;
+                    alpha_w<LGS>(c, tl, w0, w1);
+                    alpha_step<LGS, SR>(c, tl, a, w0, w1);
+                }
             }
             epilogue<LGS>(c, io, cur, (int64_t)k * CH, len);
             cur = nxt;
@@ -367,18 +451,12 @@ __device__ void map_pass(const Ctx<LGS> &c, const PassIO &io) {
             ck[(int64_t)(k + 1) * 64] = b;                        // beta at the upper boundary of chunk k (read by F)
             stage_chunk<LGS>(c, cur, io.nv2);
             if (k > K1) load_raw<LGS>(c, io, nxt, (int64_t)(k - 1) * CH, CH);
-            const int len = clen(k);
-            if (len == CH) {
-#pragma unroll
-                for (int tl = CH - 1; tl >= 0; --tl) beta_step<LGS, SR, false>(c, tl, b, 0.0);
-            } else {
-                for (int tl = len - 1; tl >= 0; --tl) beta_step<LGS, SR, false>(c, tl, b, 0.0);
-            }
+            beta_chunk<LGS, SR, false, false>(c, b, clen(k), arow);
             cur = nxt;
         }
         if (K1 > 0) load_raw<LGS>(c, io, cur, (int64_t)(K1 - 1) * CH, CH);
         pair_sync();
-        // ---------------- phase 2: chunks K1-1 .. 0: alpha rows from F's checkpoint, beta + combine ----------------
+        // ---------------- phase 2: chunks K1-1 .. 0 (all full): alpha rows from F's checkpoint, beta + combine ----------------
         double alo = K1 > 0 ? ck[(int64_t)(K1 - 1) * 64] : 0.0;   // alpha at the lower boundary of chunk K1-1
         for (int k = K1 - 1; k >= 0; --k) {
             stage_chunk<LGS>(c, cur, io.nv2);
@@ -387,12 +465,9 @@ __device__ void map_pass(const Ctx<LGS> &c, const PassIO &io) {
                 load_raw<LGS>(c, io, nxt, (int64_t)(k - 1) * CH, CH);
                 alon = ck[(int64_t)(k - 1) * 64];
             }
-            double arow[CH];                                      // arow[tl] = alpha at time k*CH + tl (full chunks only here)
             double a = alo;
-#pragma unroll
-            for (int tl = 0; tl < CH; tl++) { arow[tl] = a; alpha_step<LGS, SR, false>(c, tl, a, 0.0); }
-#pragma unroll
-            for (int tl = CH - 1; tl >= 0; --tl) beta_step<LGS, SR, true>(c, tl, b, arow[tl]);
+            alpha_chunk<LGS, SR, true>(c, a, CH, arow);           // arow[tl] = alpha at time k*CH + tl
+            beta_chunk<LGS, SR, false, true>(c, b, CH, arow);
             epilogue<LGS>(c, io, cur, (int64_t)k * CH, CH);
             cur = nxt;
             alo = alon;
@@ -419,18 +494,11 @@ __global__ __launch_bounds__(128 * NPAIR) void map_decode_kernel(MapParams p) {
     const int64_t pair = (int64_t)blockIdx.x * (blockDim.x >> 7) + (threadIdx.x >> 7);
     const int64_t K = (p.N + CH - 1) / CH;
     PassIO io;
-    io.sys = p.sys; io.sys_perm = nullptr; io.par = p.par; io.Lin = p.Lin; io.Lout = p.Lout; io.lstride = p.N;
+    io.sys = p.sys; io.sstride = p.N; io.par = p.par; io.Lin = p.Lin; io.Lout = p.Lout; io.lstride = p.N; io.ext = false;
+    io.bits = p.bits; io.want_bits = p.want_bits;
     io.cw0 = pair * p.GW; io.B = p.B; io.N = p.N; io.nv2 = p.nv2;
     io.ckpt = p.scratch + pair * (K + 1) * 64;
-    map_pass<LGS, SR>(c, io);
-    pair_sync();
-    // decoded_bits: L > 0 in 'decode' mode only (:148-152); the two waves of the pair take alternate codewords
-    for (int g = (threadIdx.x >> 6) & 1; g < p.GW; g += 2) {
-        const int64_t cw = io.cw0 + g;
-        if (cw >= p.B) break;
-        for (int64_t t = c.lane; t < p.N; t += 64)
-            p.bits[cw * p.N + t] = (uint8_t)((p.want_bits && p.Lout[cw * p.N + t] > 0) ? 1 : 0);
-    }
+    map_pass<LGS, SR>(c, io);                                     // L_ext and the hard decisions leave in the pass's epilogue
 }
 
 struct TurboParams {
@@ -439,7 +507,7 @@ struct TurboParams {
     const int32_t *perm;                  // [N]
     uint8_t *bits;                        // [B][N]
     double *ckpt;                         // per pair: checkpoint rows [nchunks + 1][64]
-    double *larr;                         // per codeword: A[N] B[N] C[N]
+    double *larr;                         // per codeword: A[N] B[N] C[N] Si[N]
     int64_t B, N;
     double nv2;
     int n_iter, GW;
@@ -452,62 +520,99 @@ __global__ __launch_bounds__(128 * NPAIR) void turbo_decode_kernel(TurboParams p
     init_ctx<LGS>(c, p.tb, smem, p.GW);
     const int64_t pair = (int64_t)blockIdx.x * (blockDim.x >> 7) + (threadIdx.x >> 7);
     const int64_t N = p.N, K = (N + CH - 1) / CH, cw0 = pair * p.GW;
-    // L arrays of all codewords: [B][3][N] -> per-codeword stride 3N; A at +0, B at +N, C at +2N
-    double *A0 = p.larr, *B0 = p.larr + N, *C0 = p.larr + 2 * N;
-    const int64_t ls = 3 * N;
+    // per-codeword arrays in one slab [B][4][N]: A (L_int_1), B (a pass's output), C (L_int_2), Si (interlv(sys), :310)
+    double *A0 = p.larr, *B0 = p.larr + N, *C0 = p.larr + 2 * N, *S0 = p.larr + 3 * N;
+    const int64_t ls = 4 * N;
     PassIO io;
-    io.sys = p.sys; io.lstride = ls; io.cw0 = cw0; io.B = p.B; io.N = N; io.nv2 = p.nv2;
+    io.lstride = ls; io.cw0 = cw0; io.B = p.B; io.N = N; io.nv2 = p.nv2; io.bits = nullptr; io.want_bits = 0;
     io.ckpt = p.ckpt + pair * (K + 1) * 64;
-    // The element-wise stages between the MAP passes are done wave-wide, one codeword after the other (the two waves of
-    // the pair take alternate codewords), 64 consecutive elements per instruction and four independent rounds in flight.
+    // Between the MAP passes only the interleaver is left to do: a pass writes E = L - L_int directly (`ext`), so
+    //   even h: L_int_2 = interlv(E_1)      C[t] = B[perm[t]]         (:318-319)
+    //   odd h:  L_int_1 = deinterlv(E_2)    A[perm[t]] = B[t]         (:328-329)
+    // A codeword's array (8 KB for N = 1024) is permuted THROUGH LDS -- coalesced read, LDS scatter / gather, coalesced
+    // write -- one codeword per wave at a time, the two waves of the pair taking alternate codewords.  (Round 1 gathered
+    // from HBM: every 8-byte element fetched a 64-byte line, 2 x 8-fold read amplification per stage, 1.5 of 8.4 ms.)
     const int lane = c.lane, GW = p.GW, w2 = (threadIdx.x >> 6) & 1;
+    double *buf = c.tab;                                           // the wave's whole LDS region, free between passes
+    const bool in_lds = N <= (int64_t)wave_lds_doubles<LGS>(GW);
     for (int g = w2; g < GW; g += 2) {
         const int64_t cwg = cw0 + g;
         if (cwg >= p.B) break;
-        double *A = A0 + cwg * ls;
+        double *A = A0 + cwg * ls, *Si = S0 + cwg * ls;
+        const double *sy = p.sys + cwg * N;
 #pragma unroll 4
         for (int64_t t = lane; t < N; t += 64) A[t] = p.Lint ? p.Lint[cwg * N + t] : 0.0;      // L_int_1 (:305-308)
+        // sys_symbols_i = interlv(sys) (:310), once: coalesced read -> LDS -> gather -> coalesced write.  (Reading sys[perm[t]]
+        // in every second MAP pass fetched a 64-byte line per 8-byte value: 8 of the 17 GB a launch read.)
+        if (in_lds) {
+            asm volatile("" ::: "memory");
+#pragma unroll 4
+            for (int64_t t = lane; t < N; t += 64) buf[t] = sy[t];
+            asm volatile("" ::: "memory");
+#pragma unroll 4
+            for (int64_t t = lane; t < N; t += 64) Si[t] = buf[p.perm[t]];
+            asm volatile("" ::: "memory");
+        } else {
+#pragma unroll 4
+            for (int64_t t = lane; t < N; t += 64) Si[t] = sy[p.perm[t]];
+        }
     }
     pair_sync();
+    io.ext = true;
     // 2 n_iter half-iterations through ONE map_pass call site (two inlined copies of the unrolled pass spill registers):
     //   even h: [L_ext_1, _] = map_decode(sys, non_sys_1, trellis, nv, L_int_1, 'compute')          (:315)
-    //           L_ext_1 -= L_int_1 ; L_int_2 = interlv(L_ext_1)                                     (:318-319)
     //   odd h:  [L_2, bits] = map_decode(sys_i, non_sys_2, trellis, nv, L_int_2, mode)              (:326)
-    //           L_ext_2 = L_2 - L_int_2 ; L_int_1 = deinterlv(L_ext_2)                              (:328-329)
     for (int h = 0; h < 2 * p.n_iter; h++) {
         const bool second = h & 1;
-        io.sys_perm = second ? p.perm : nullptr;
+        io.sys = second ? S0 : p.sys;
+        io.sstride = second ? ls : N;
         io.par = second ? p.p2 : p.p1;
         io.Lin = second ? C0 : A0;
         io.Lout = B0;
         map_pass<LGS, SR>(c, io);
         pair_sync();
+        if (h == 2 * p.n_iter - 1) break;                          // the last E_2 only feeds the decisions below
         for (int g = w2; g < GW; g += 2) {
             const int64_t cwg = cw0 + g;
             if (cwg >= p.B) break;
-            double *A = A0 + cwg * ls, *C = C0 + cwg * ls;
-            const double *Bb = B0 + cwg * ls;
-            if (!second) {
+            const double *src = B0 + cwg * ls;
+            double *dst = (second ? A0 : C0) + cwg * ls;
+            if (in_lds) {
+                asm volatile("" ::: "memory");
+                if (!second) {
 #pragma unroll 4
-                for (int64_t t = lane; t < N; t += 64) {      // same subtraction, fused with the interleaver gather
-                    const int32_t q = p.perm[t];
-                    C[t] = Bb[q] - A[q];
+                    for (int64_t t = lane; t < N; t += 64) buf[t] = src[t];
+                } else {
+#pragma unroll 4
+                    for (int64_t t = lane; t < N; t += 64) buf[p.perm[t]] = src[t];
                 }
+                asm volatile("" ::: "memory");                    // LDS operations of one wave execute in order
+                if (!second) {
+#pragma unroll 4
+                    for (int64_t t = lane; t < N; t += 64) dst[t] = buf[p.perm[t]];
+                } else {
+#pragma unroll 4
+                    for (int64_t t = lane; t < N; t += 64) dst[t] = buf[t];
+                }
+                asm volatile("" ::: "memory");
+            } else if (!second) {
+#pragma unroll 4
+                for (int64_t t = lane; t < N; t += 64) dst[t] = src[p.perm[t]];
             } else {
 #pragma unroll 4
-                for (int64_t t = lane; t < N; t += 64) A[p.perm[t]] = Bb[t] - C[t];
+                for (int64_t t = lane; t < N; t += 64) dst[p.perm[t]] = src[t];
             }
         }
         pair_sync();
     }
-    // decoded_bits = deinterlv(decoded_bits of the last MAP2)                              (:331)
+    // decoded_bits = deinterlv(L_2 > 0), L_2 = L_int_2 + log(app1/app0) of the last MAP2          (:148-152, :331)
     for (int g = w2; g < GW; g += 2) {
         const int64_t cwg = cw0 + g;
         if (cwg >= p.B) break;
-        const double *Bb = B0 + cwg * ls;
+        const double *Bb = B0 + cwg * ls, *C = C0 + cwg * ls;
 #pragma unroll 4
         for (int64_t t = lane; t < N; t += 64)
-            p.bits[cwg * N + p.perm[t]] = (uint8_t)((p.n_iter > 0 && Bb[t] > 0) ? 1 : 0);
+            p.bits[cwg * N + p.perm[t]] = (uint8_t)((p.n_iter > 0 && C[t] + Bb[t] > 0) ? 1 : 0);
     }
 }
 
@@ -606,7 +711,7 @@ int cpx_turbo_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const 
     p.B = B; p.N = N; p.nv2 = 2 * noise_variance; p.n_iter = n_iter;
     CPX_REQUIRE(nblocks < (1ll << 31), CPX_ELIMIT, "turbo_decode: batch too large");
     if ((rc = workspace(st, 0, sizeof(double) * (size_t)(nblocks * np * (K + 1) * 64), (void **)&p.ckpt))) return rc;
-    if ((rc = workspace(st, 1, sizeof(double) * (size_t)(B * 3 * N), (void **)&p.larr))) return rc;
+    if ((rc = workspace(st, 1, sizeof(double) * (size_t)(B * 4 * N), (void **)&p.larr))) return rc;
     dim3 grid((unsigned)nblocks), block(128 * np);
     switch (p.tb.lgS) {
 #define CASE(LG) case LG: hipLaunchKernelGGL((turbo_decode_kernel<LG, false>), grid, block, sizeof(double) * 2 * np * wave_lds_doubles<LG>(GW), st, p); break;
