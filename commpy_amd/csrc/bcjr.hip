@@ -13,9 +13,10 @@
 //   phase 1   F: alpha over the first half of the chunks,  R: beta over the second half; each keeps only its state
 //             vector at the chunk boundaries (one 512-byte row per chunk in an HBM scratch -- a checkpoint, not a row
 //             per step);
-//   phase 2   F continues alpha over the second half: per chunk it RECOMPUTES the chunk's beta rows from R's checkpoint
-//             (same operations, registers only), then runs alpha and the combine; R continues beta over the first half,
-//             recomputing the chunk's alpha rows from F's checkpoint.
+//   phase 2   F continues alpha over the second half and R continues beta over the first half.  Per chunk a wave runs
+//             alpha over the chunk (values kept in registers), then beta over it together with the a-posteriori
+//             products; one of the two is the wave's own chain, the other is RECOMPUTED from the partner's checkpoint
+//             (same operations) and dropped.
 // (Round 1 ran beta over the whole block, streamed every beta row to HBM, then alpha: one wave per SIMD on a dependent
 //  float64 chain -- rocprofv3: VALU busy 38 %, 41 % of the wave cycles waiting, 30 GB of HBM traffic per config-3 launch.
 //  Now the chain a wave walks is half as long, two waves share a SIMD, and the HBM traffic of a pass is its inputs, its
@@ -85,12 +86,12 @@ struct Ctx {
     int plane[2], pin[2], pcode[2];   // incoming branches in np.where order: predecessor lane, input, code
     // 4-state shift-register trellises: the successors of s are lo = s>>1 and hi = 2|(s>>1) whatever the input; ilo is
     // the input that leads to lo.  Everything a step needs is then a STATIC per-lane offset -- no selects on the chain.
-    int ilo, lane_lo, lane_hi;
+    int ilo;
     int o_glo, o_ghi;                 // offsets of gamma(code of the branch to lo / hi) inside an item of `tab`
     // LDS of this wave
     double *tab;    // [CH][GW][6] (+2 pad per step): gamma[4], prior weights q0, q1 of every (step, codeword) item
     double *xs;     // [CH][64][2]  per-lane branch products alpha*gamma*beta of the chunk (phase 2)
-    double *rw;     // [CH][64]     beta rows of the chunk recomputed by the forward wave (phase 2)
+    double *rw;     // [CH][64]     alpha rows of a partial (last) chunk: the rolled code path keeps them here
     double *xch;    // [64]         exchange buffer (trellises without the DPP fast path)
 };
 
@@ -120,8 +121,6 @@ __device__ __forceinline__ void init_ctx(Ctx<LGS> &c, const MapTables &tb, unsig
     c.ilo = c.sb[0] ? 1 : 0;
     c.o_glo = c.sb[0] ? c.code[1] : c.code[0];
     c.o_ghi = c.sb[0] ? c.code[0] : c.code[1];
-    c.lane_lo = gbase + (c.s >> 1);
-    c.lane_hi = gbase + ((c.s >> 1) | (S >> 1));
     double *p = reinterpret_cast<double *>(smem) + (size_t)wave * wave_lds_doubles<LGS>(GW);
     c.tab = p; p += CH * c.P;
     c.xs = p;  p += CH * 64 * 2;
@@ -272,13 +271,12 @@ __device__ __forceinline__ void beta_nbrs(const Ctx<LGS> &c, double b, double &l
     }
 }
 
-// One beta step (:106-108): b <- sum_i b[next(s,i)] * gamma(code(s,i)) * prior(i).  ROWS: the row before the update
-// (beta of the step's upper time) goes to c.rw; X: the branch products x_i = a_own * gamma_i * b[next(s,i)] of
-// (:141-143) are parked at slot i of c.xs.
-template <int LGS, bool SR, bool ROWS, bool X>
+// One beta step (:106-108): b <- sum_i b[next(s,i)] * gamma(code(s,i)) * prior(i).  X: the branch products
+// x_i = a_own * gamma_i * b[next(s,i)] of (:141-143) are parked at slot i of c.xs (a_own = alpha of this lane's state
+// at the step, b = beta of the step's upper time before the update).
+template <int LGS, bool SR, bool X>
 __device__ __forceinline__ void beta_step(const Ctx<LGS> &c, int tl, double &b, double a_own, double g_lo, double g_hi,
                                           double w_lo, double w_hi) {
-    if (ROWS) c.rw[tl * 64 + c.lane] = b;
     double lo, hi;
     beta_nbrs<LGS, SR>(c, b, lo, hi);
     if (X) {
@@ -299,8 +297,9 @@ __device__ __forceinline__ void alpha_step(const Ctx<LGS> &c, int tl, double &a,
     if ((tl & (KNORM - 1)) == KNORM - 1) a = a * __builtin_amdgcn_rcp(group_sum<LGS>(a));
 }
 
-// beta over the `len` staged steps, downwards; arow[tl] = alpha of this lane's state at step tl (X only)
-template <int LGS, bool SR, bool ROWS, bool X>
+// beta over the `len` staged steps, downwards.  X: also parks the branch products; arow[tl] = alpha of this lane's state
+// at step tl (full chunks: registers; the partial last chunk of a block runs rolled and keeps them in c.rw)
+template <int LGS, bool SR, bool X>
 __device__ __forceinline__ void beta_chunk(const Ctx<LGS> &c, double &b, int len, const double (&arow)[CH]) {
     if (len == CH) {
         double gl[CH], gh[CH], wl[CH], wh[CH];
@@ -308,19 +307,19 @@ __device__ __forceinline__ void beta_chunk(const Ctx<LGS> &c, double &b, int len
         for (int tl = 0; tl < CH; tl++) beta_w<LGS, SR>(c, tl, gl[tl], gh[tl], wl[tl], wh[tl]);
         asm volatile("" ::: "memory");
 #pragma unroll
-        for (int tl = CH - 1; tl >= 0; --tl) beta_step<LGS, SR, ROWS, X>(c, tl, b, arow[tl], gl[tl], gh[tl], wl[tl], wh[tl]);
-    } else {                                                      // the last, partial chunk of a block: rolled
+        for (int tl = CH - 1; tl >= 0; --tl) beta_step<LGS, SR, X>(c, tl, b, arow[tl], gl[tl], gh[tl], wl[tl], wh[tl]);
+    } else {
 #pragma unroll 1
         for (int tl = len - 1; tl >= 0; --tl) {
             double gl, gh, wl, wh;
             beta_w<LGS, SR>(c, tl, gl, gh, wl, wh);
-            beta_step<LGS, SR, ROWS, false>(c, tl, b, 0.0, gl, gh, wl, wh);
+            beta_step<LGS, SR, X>(c, tl, b, X ? c.rw[tl * 64 + c.lane] : 0.0, gl, gh, wl, wh);
         }
     }
     asm volatile("" ::: "memory");
 }
 
-// alpha over the `len` staged steps, upwards; KEEP: arow[tl] = alpha before step tl
+// alpha over the `len` staged steps, upwards; KEEP: arow[tl] (c.rw for a partial chunk) = alpha before step tl
 template <int LGS, bool SR, bool KEEP>
 __device__ __forceinline__ void alpha_chunk(const Ctx<LGS> &c, double &a, int len, double (&arow)[CH]) {
     if (len == CH) {
@@ -338,22 +337,10 @@ __device__ __forceinline__ void alpha_chunk(const Ctx<LGS> &c, double &a, int le
         for (int tl = 0; tl < len; tl++) {
             double w0, w1;
             alpha_w<LGS>(c, tl, w0, w1);
+            if (KEEP) c.rw[tl * 64 + c.lane] = a;
             alpha_step<LGS, SR>(c, tl, a, w0, w1);
         }
-    }
-}
-
-// forward wave, phase 2: x_i = alpha * gamma(code(s,i)) * beta[next(s,i)] for the whole chunk, beta from the rows in c.rw
-template <int LGS, bool SR>
-__device__ __forceinline__ void park_products(const Ctx<LGS> &c, int tl, double a) {
-    const double *it = c.tab + tl * c.P + c.g * 6, *br = c.rw + tl * 64;
-    double *xo = c.xs + (tl * 64 + c.lane) * 2;
-    if (LGS == 2 && SR) {
-        xo[c.ilo] = (a * it[c.o_glo]) * br[c.lane_lo];
-        xo[1 - c.ilo] = (a * it[c.o_ghi]) * br[c.lane_hi];
-    } else {
-        xo[0] = (a * it[c.code[0]]) * br[c.nxt[0]];
-        xo[1] = (a * it[c.code[1]]) * br[c.nxt[1]];
+        asm volatile("" ::: "memory");
     }
 }
 
@@ -401,6 +388,12 @@ __device__ void map_pass(const Ctx<LGS> &c, const PassIO &io) {
     double arow[CH];                                              // alpha of this lane's state at the chunk's steps
 #pragma unroll
     for (int tl = 0; tl < CH; tl++) arow[tl] = 0.0;
+    // Phase 2 of either wave, one chunk: alpha over the chunk (kept per step), then beta over it with the branch products,
+    // then the epilogue.  One of the two recursions continues the wave's own chain, the other starts from the partner's
+    // checkpoint and is discarded afterwards.  The checkpoint is loaded at the TOP of the iteration, before the prefetch
+    // of the next chunk is issued: loads return in order, so the chain then only waits for that one load (with the
+    // checkpoint prefetched an iteration earlier the compiler had to put a full vmcnt(0) in front of the chain, i.e.
+    // the chain waited for the HBM round trip of the prefetch issued just before it: +1000 cycles per chunk).
     if (c.fwd) {
         // ---------------- phase 1: alpha over chunks 0 .. K1-1, checkpoint before every chunk ----------------
         double a = (c.s == 0) ? 1.0 : 0.0;                        // f_state_metrics[0][0] = 1 (:221)
@@ -414,34 +407,16 @@ __device__ void map_pass(const Ctx<LGS> &c, const PassIO &io) {
         }
         load_raw<LGS>(c, io, cur, (int64_t)K1 * CH, clen(K1));    // first chunk of phase 2 (K1 < K always)
         pair_sync();
-        // ---------------- phase 2: chunks K1 .. K-1: beta rows from R's checkpoint, alpha, combine ----------------
-        double bup = ck[(int64_t)(K1 + 1) * 64];                  // beta at the upper boundary of chunk K1
+        // ---------------- phase 2: chunks K1 .. K-1: own alpha, beta from R's checkpoint, combine ----------------
         for (int k = K1; k < K; k++) {
             const int len = clen(k);
+            double b = ck[(int64_t)(k + 1) * 64];                 // beta at the upper boundary of chunk k
             stage_chunk<LGS>(c, cur, io.nv2);
-            double bupn = 0.0;
-            if (k + 1 < K) {
-                load_raw<LGS>(c, io, nxt, (int64_t)(k + 1) * CH, clen(k + 1));
-                bupn = ck[(int64_t)(k + 2) * 64];
-            }
-            double b = bup;                                       // row tl of c.rw = beta at time k*CH + tl + 1
-            beta_chunk<LGS, SR, true, false>(c, b, len, arow);
-            if (len == CH) {
-                alpha_chunk<LGS, SR, true>(c, a, CH, arow);
-#pragma unroll
-                for (int tl = 0; tl < CH; tl++) park_products<LGS, SR>(c, tl, arow[tl]);
-            } else {
-#pragma unroll 1
-                for (int tl = 0; tl < len; tl++) {                // partial last chunk: step by step
-                    park_products<LGS, SR>(c, tl, a);
-                    double w0, w1;
-                    alpha_w<LGS>(c, tl, w0, w1);
-                    alpha_step<LGS, SR>(c, tl, a, w0, w1);
-                }
-            }
+            if (k + 1 < K) load_raw<LGS>(c, io, nxt, (int64_t)(k + 1) * CH, clen(k + 1));
+            alpha_chunk<LGS, SR, true>(c, a, len, arow);
+            beta_chunk<LGS, SR, true>(c, b, len, arow);
             epilogue<LGS>(c, io, cur, (int64_t)k * CH, len);
             cur = nxt;
-            bup = bupn;
         }
     } else {
         // ---------------- phase 1: beta over chunks K-1 .. K1, checkpoint before every chunk ----------------
@@ -451,26 +426,20 @@ __device__ void map_pass(const Ctx<LGS> &c, const PassIO &io) {
             ck[(int64_t)(k + 1) * 64] = b;                        // beta at the upper boundary of chunk k (read by F)
             stage_chunk<LGS>(c, cur, io.nv2);
             if (k > K1) load_raw<LGS>(c, io, nxt, (int64_t)(k - 1) * CH, CH);
-            beta_chunk<LGS, SR, false, false>(c, b, clen(k), arow);
+            beta_chunk<LGS, SR, false>(c, b, clen(k), arow);
             cur = nxt;
         }
         if (K1 > 0) load_raw<LGS>(c, io, cur, (int64_t)(K1 - 1) * CH, CH);
         pair_sync();
-        // ---------------- phase 2: chunks K1-1 .. 0 (all full): alpha rows from F's checkpoint, beta + combine ----------------
-        double alo = K1 > 0 ? ck[(int64_t)(K1 - 1) * 64] : 0.0;   // alpha at the lower boundary of chunk K1-1
+        // ---------------- phase 2: chunks K1-1 .. 0 (all full): alpha from F's checkpoint, own beta, combine ----------------
         for (int k = K1 - 1; k >= 0; --k) {
+            double a = ck[(int64_t)k * 64];                       // alpha at the lower boundary of chunk k
             stage_chunk<LGS>(c, cur, io.nv2);
-            double alon = 0.0;
-            if (k > 0) {
-                load_raw<LGS>(c, io, nxt, (int64_t)(k - 1) * CH, CH);
-                alon = ck[(int64_t)(k - 1) * 64];
-            }
-            double a = alo;
+            if (k > 0) load_raw<LGS>(c, io, nxt, (int64_t)(k - 1) * CH, CH);
             alpha_chunk<LGS, SR, true>(c, a, CH, arow);           // arow[tl] = alpha at time k*CH + tl
-            beta_chunk<LGS, SR, false, true>(c, b, CH, arow);
+            beta_chunk<LGS, SR, true>(c, b, CH, arow);
             epilogue<LGS>(c, io, cur, (int64_t)k * CH, CH);
             cur = nxt;
-            alo = alon;
         }
     }
 }
