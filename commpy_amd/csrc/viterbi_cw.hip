@@ -354,13 +354,27 @@ __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_fused_kernel(CwPara
     // i.e. output step tc0 + li - 1 - H
     auto flush = [&](int tc0, int n) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                         // the tile rows are complete (same wave wrote them)
-        for (int c = 0; c < 64; c++) {
-            const int64_t cwc = grp * 64 + c;
-            if (cwc >= p.B) break;
-            for (int li = lane; li < n; li += 64) {
-                const int so = tc0 + li - 1 - H;
-                if (so >= 1 && so <= T - H && so - 1 < p.L) p.bits[cwc * p.L + so - 1] = obuf[c * FR_OBPAD + li];
-            }
+        const int64_t cwb = grp * 64;
+        const int ncw = (int)((p.B - cwb < 64) ? (p.B - cwb) : 64);
+        // eight codewords per round: their LDS reads are all in flight before the first store waits for one (one codeword
+        // per round put an LDS round trip in front of every store: ~19 k cycles per 96 steps, 5 % of the kernel)
+        for (int c0 = 0; c0 < 64; c0 += 8) {
+            unsigned char v[8][2];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int li = lane + 64 * h;
+                    v[u][h] = (li < n) ? obuf[(c0 + u) * FR_OBPAD + li] : (unsigned char)0;
+                }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int li = lane + 64 * h, so = tc0 + li - 1 - H;
+                    if (c0 + u < ncw && li < n && so >= 1 && so <= T - H && so - 1 < p.L)
+                        p.bits[(cwb + c0 + u) * p.L + so - 1] = v[u][h];
+                }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                         // tile read before the next chunk overwrites it
     };
@@ -370,12 +384,18 @@ __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_fused_kernel(CwPara
         const int ngroups = left < FR_GROUPS ? left : FR_GROUPS;
         for (int g = 0; g < ngroups; g++) {
             const int t = tc0 + g * LGS;
+            // prefetch of the NEXT group, all of it at the top of this one: a whole group (~4700 instructions) lies between
+            // a load and the vmcnt(0) the compiler puts at the loop head.  (Reloading cur[R] inside step R saved 12
+            // registers but left the youngest load only one step of lead: rocprofv3 showed 14.5 % of the wave cycles
+            // parked in s_waitcnt.)
+            double2 nxt[LGS];
+#pragma unroll
+            for (int u = 0; u < LGS; u++) nxt[u] = load(t + LGS + u);
             auto one = [&](auto rtag) {
                 constexpr int R = decltype(rtag)::value;
                 const int tt = t + R;
                 const bool have = tt <= tmax;
                 const double r0 = have ? cur[R].x : pad, r1 = have ? cur[R].y : pad;
-                cur[R] = load(tt + LGS);                                          // prefetch: needed one group later
                 unsigned long long word;
                 int bst;
                 cw_step<LGS, G0, G1, TYPE, R>(pm, r0, r1, word, bst, walk);      // + hops 0 .. 3/4 H of the walk of step tt - 1
@@ -400,6 +420,8 @@ __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_fused_kernel(CwPara
             if constexpr (LGS >= 4) one(std::integral_constant<int, 3 % LGS>{});
             if constexpr (LGS >= 5) one(std::integral_constant<int, 4 % LGS>{});
             if constexpr (LGS >= 6) one(std::integral_constant<int, 5 % LGS>{});
+#pragma unroll
+            for (int u = 0; u < LGS; u++) cur[u] = nxt[u];
         }
         int n = ngroups * LGS;
         if (tc0 + CHUNK > T) {                                                     // last chunk: finish the pending walk (of its last step)
