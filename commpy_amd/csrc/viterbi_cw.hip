@@ -643,6 +643,10 @@ bool viterbi_codeword_path(const cpx_trellis *t, const double *d_coded, int64_t 
     // (133,171) -> (155,117).
     CPX_TRY(6, 0155u, 0117u)      // K = 7 (133,171), commpy default format: 802.11 / BASELINE configs 2 and 5
     CPX_TRY(6, 0117u, 0155u)      // K = 7 (171,133)
+    // Wifi80211 as shipped: its generators are written in DECIMAL, (133, 171), and dec2bitarray wraps them to (5, 43)
+    // (wifi80211.py:49, utilities.py:81-85) -- 0000101 / 0101011, bit-reversed 0120 / 0152.  The reference's
+    // own link simulation (BASELINE config 5 with default arguments) decodes this 64-state code.
+    CPX_TRY(6, 0120u, 0152u)
     // (K = 3 (5,7) and K = 5 (23,35) instantiate and pass the same tests -- CPX_TRY(2, 05u, 07u), CPX_TRY(4, 031u, 027u) --
     //  but are not built: with 4 or 16 states the wave kernels already pack 16 / 4 codewords into a wavefront and the
     //  one-wave-per-SIMD structure of this path loses -- BASELINE config 1, 2^20 codewords: 0.77 ms here, 0.56 ms there.)

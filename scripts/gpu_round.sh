@@ -30,6 +30,7 @@ if [[ $SEC == *l* ]]; then
   timeout 600 python benchmarks/bench_link.py --mcs 5 2>&1 | tail -1 | tee $OUT/bench_link.jsonl | cut -c1-300
   timeout 600 python benchmarks/bench_link.py --mcs 5 --generators decimal --bits 2e7 2>&1 | tail -1 | tee -a $OUT/bench_link.jsonl | cut -c1-300
   timeout 600 python benchmarks/bench_host_api.py 2>&1 | tail -2 | tee $OUT/bench_host_api.json | cut -c1-300
+  timeout 900 python benchmarks/bench_multigpu.py 2>&1 | grep "^{" | tee $OUT/bench_multigpu.jsonl | cut -c1-330
 fi
 if [[ $SEC == *v* ]]; then
   timeout 1500 python scripts/collect_pmc.py --out $OUT --name viterbi_c2 --match viterbi --batch 65536 -- \
