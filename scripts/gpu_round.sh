@@ -11,7 +11,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd $R
 if [[ $SEC == *t* ]]; then
-  timeout 1500 python -m pytest tests -m gpu -q --durations=8 2>&1 | tail -40 | tee $OUT/pytest_gpu.txt
+  timeout 1500 python -m pytest tests -m gpu -q --durations=8 2>&1 | tail -120 | tee $OUT/pytest_gpu.txt
 fi
 if [[ $SEC == *s* ]]; then
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee $OUT/smoke.txt
@@ -28,7 +28,7 @@ if [[ $SEC == *k* ]]; then
 fi
 if [[ $SEC == *l* ]]; then
   timeout 600 python benchmarks/bench_link.py --mcs 5 2>&1 | tail -1 | tee $OUT/bench_link.jsonl | cut -c1-300
-  timeout 600 python benchmarks/bench_link.py --mcs 5 --generators decimal --bits 2e7 2>&1 | tail -1 | tee -a $OUT/bench_link.jsonl | cut -c1-300
+  timeout 600 python benchmarks/bench_link.py --mcs 5 --generators decimal 2>&1 | tail -1 | tee -a $OUT/bench_link.jsonl | cut -c1-300
   timeout 600 python benchmarks/bench_host_api.py 2>&1 | tail -2 | tee $OUT/bench_host_api.json | cut -c1-300
   timeout 900 python benchmarks/bench_multigpu.py 2>&1 | grep "^{" | tee $OUT/bench_multigpu.jsonl | cut -c1-330
 fi
