@@ -786,7 +786,12 @@ int cpx_viterbi_decode_batch_i64(const cpx_trellis *t, const double *coded, int6
     if ((rc = dout.alloc(nout))) return rc;
     hipStream_t st = lib_stream();
     // (cutting the batch into chunks on two streams to overlap upload and decode was measured: 44.7 ms against
-    // 39.2 ms for B = 65536 -- smaller pageable uploads lose more than the 3 ms of decode they hide)
+    // 39.2 ms for B = 65536 -- smaller pageable uploads lose more than the 3 ms of decode they hide.  Round 2 also
+    // measured the other pipeline: 16 host threads copying 128 MB chunks into two pinned staging blocks, DMA of chunk
+    // c-1 and decode of chunk c-2 in flight meanwhile, widening of finished chunks between copies: 42.6 ms against
+    // 40.3 ms.  The runtime's own pageable path already moves the 1.08 GB at ~49 GB/s, i.e. near the PCIe Gen5 rate,
+    // without a staging copy; an extra pass over host memory costs more than the 3 + 1 ms of decode and download it
+    // can hide.)
     CPX_HIP(hipMemcpyAsync(din.p, coded, sizeof(double) * (size_t)(B * len), hipMemcpyHostToDevice, st));
     rc = cpx_viterbi_decode_batch_dev(t, din.as<double>(), B, len, L, n_steps, tb_depth, decoding_type,
                                       dout.as<uint8_t>(), st);

@@ -50,7 +50,7 @@ def test_config2_full_batch_vs_oracle_16k(gpu):
     llr = (4.0 / N0) * ((2.0 * coded - 1.0) + np.sqrt(N0 / 2) * rs.standard_normal(coded.shape, ).astype(np.float32))
     llr = np.ascontiguousarray(llr, dtype=np.float64)
     got = viterbi_decode(llr, tr, None, "soft")
-    assert _lib.viterbi_last_path() == "fused"
+    assert _lib.viterbi_last_path() == "fused", _lib.last_kernel()
     n = 5462
     for lo in (0, B // 2 - n // 2, B - n):
         want = oracle.viterbi_decode_mt(llr[lo:lo + n], tr, None, "soft")
