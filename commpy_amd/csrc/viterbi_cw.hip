@@ -283,11 +283,14 @@ constexpr size_t fused_wave_lds() {
 // step: the LDS reads of a batch are issued one phase before their hops, so their latency hides behind the
 // add-compare-select arithmetic (left to itself the compiler emits the walk as 14 read -> wait -> 2-hop rounds at the end
 // of the step: +0.5 ms).  sched_barrier pins the batches where they are put.
-template <int LGS, int H>
+// RT: the number of hops is a run-time value hr <= H (traceback depths below the default): hops h >= hr leave the state alone
+// (one v_cndmask each, +4 % per step); their LDS reads still go to valid, older ring slots.
+template <int LGS, int H, bool RT = false>
 struct WalkHook {
     static constexpr int NB = 4, PER = (H + NB - 1) / NB;
     const unsigned long long *pw;           // ring pointer of the walked step t': word of step t' - h at pw[(FR_RING - h) * 64]
     mutable unsigned st;                    // state of the walk
+    int hr;                                 // hops to execute (RT only)
     mutable unsigned long long buf[PER];
     template <int B> __device__ __forceinline__ void issue() const {
 #pragma unroll
@@ -297,7 +300,10 @@ struct WalkHook {
     template <int B> __device__ __forceinline__ void hops() const {
 #pragma unroll
         for (int i = 0; i < PER; i++)
-            if (B * PER + i < H) st = tb_hop<LGS>(buf[i], st);
+            if (B * PER + i < H) {
+                const unsigned nx = tb_hop<LGS>(buf[i], st);
+                st = (!RT || B * PER + i < hr) ? nx : st;
+            }
     }
     template <int P> __device__ __forceinline__ void at() const {
         __builtin_amdgcn_sched_barrier(0);
@@ -316,10 +322,11 @@ struct WalkHook {
     }
 };
 
-template <int LGS, unsigned G0, unsigned G1, int TYPE, int H>
+template <int LGS, unsigned G0, unsigned G1, int TYPE, int HT, bool RT = false>
 __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_fused_kernel(CwParams p) {
     constexpr int S = 1 << LGS, FR_GROUPS = FR_CHUNK / LGS, CHUNK = FR_GROUPS * LGS;
-    static_assert(H >= 0 && H + 1 <= FR_RING && CHUNK + 1 <= FR_OBPAD, "ring / tile too small");
+    static_assert(HT >= 0 && HT + 1 <= FR_RING && CHUNK + 1 <= FR_OBPAD, "ring / tile too small");
+    const int H = RT ? p.tb - 2 : HT;                                              // hops of a walk = tb_depth - 2
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t grp = (int64_t)blockIdx.x * ACS_WAVES + wv;
@@ -346,9 +353,10 @@ __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_fused_kernel(CwPara
 #pragma unroll
     for (int u = 0; u < LGS; u++) cur[u] = load(1 + u);
     int best_T = 0;                                                               // first-argmin state of step T
-    WalkHook<LGS, H> walk;                                                             // walk of the previous step (step 0: a dummy)
+    WalkHook<LGS, HT, RT> walk;                                                        // walk of the previous step (step 0: a dummy)
     walk.pw = mycol;
     walk.st = 0;
+    walk.hr = H;
 
     // writes the decoded bits staged in tile entries 0 .. n-1: entry li holds the result of the walk of step tc0 + li - 1,
     // i.e. output step tc0 + li - 1 - H
@@ -534,12 +542,13 @@ void launch(const CwParams &p, size_t tb_lds, hipStream_t st) {
     hipLaunchKernelGGL((viterbi_cw_tb_kernel<LGS>), dim3(groups), dim3(TB_THREADS), tb_lds, st, p);
 }
 
-// fused kernel: instantiated for the reference's default traceback depth, tb_depth = 5 * total_memory (convcode.py:701)
+// fused kernel: the walk is compiled for the reference's default traceback depth, tb_depth = 5 * total_memory
+// (convcode.py:701); every smaller depth runs it with a run-time hop count
 template <int LGS> constexpr int fused_tb() { return 5 * LGS; }
 
-template <int LGS, unsigned G0, unsigned G1, int TYPE>
+template <int LGS, unsigned G0, unsigned G1, int TYPE, bool RT>
 int launch_fused_typed(const CwParams &p, hipStream_t st) {
-    auto *fn = viterbi_cw_fused_kernel<LGS, G0, G1, TYPE, fused_tb<LGS>() - 2>;
+    auto *fn = viterbi_cw_fused_kernel<LGS, G0, G1, TYPE, fused_tb<LGS>() - 2, RT>;
     const size_t lds = ACS_WAVES * fused_wave_lds<LGS>();
     static bool raised[64] = {};                                 // > 64 KiB of dynamic LDS is opt-in, once per kernel and device
     static std::mutex raised_mu;                                 // host threads may launch concurrently (ctypes drops the GIL)
@@ -558,11 +567,13 @@ int launch_fused_typed(const CwParams &p, hipStream_t st) {
     return 1;
 }
 
+// the default depth runs the compile-time walk; smaller depths the same kernel with a run-time hop count
 template <int LGS, unsigned G0, unsigned G1>
 int launch_fused(const CwParams &p, hipStream_t st) {
-    if (p.type == CPX_VIT_HARD) return launch_fused_typed<LGS, G0, G1, CPX_VIT_HARD>(p, st);
-    if (p.type == CPX_VIT_SOFT) return launch_fused_typed<LGS, G0, G1, CPX_VIT_SOFT>(p, st);
-    return launch_fused_typed<LGS, G0, G1, CPX_VIT_UNQUANTIZED>(p, st);
+    const bool rt = p.tb != fused_tb<LGS>();
+    if (p.type == CPX_VIT_HARD) return rt ? launch_fused_typed<LGS, G0, G1, CPX_VIT_HARD, true>(p, st) : launch_fused_typed<LGS, G0, G1, CPX_VIT_HARD, false>(p, st);
+    if (p.type == CPX_VIT_SOFT) return rt ? launch_fused_typed<LGS, G0, G1, CPX_VIT_SOFT, true>(p, st) : launch_fused_typed<LGS, G0, G1, CPX_VIT_SOFT, false>(p, st);
+    return rt ? launch_fused_typed<LGS, G0, G1, CPX_VIT_UNQUANTIZED, true>(p, st) : launch_fused_typed<LGS, G0, G1, CPX_VIT_UNQUANTIZED, false>(p, st);
 }
 
 }  // namespace
@@ -622,9 +633,10 @@ bool viterbi_codeword_path(const cpx_trellis *t, const double *d_coded, int64_t 
     p.type = type; p.tb = tb;
 #define CPX_TRY(LG, GA, GB)                                                                                         \
     if (tables_match<LG, GA, GB>(t)) {                                                                              \
-        if (tb == fused_tb<LG>() && !two_kernels && launch_fused<LG, GA, GB>(p, st)) {                                    \
+        if (tb >= 2 && tb <= fused_tb<LG>() && !two_kernels && launch_fused<LG, GA, GB>(p, st)) {                       \
             if (hipGetLastError() != hipSuccess) { set_error("viterbi (fused codeword path): launch failed"); *rc = CPX_EHIP; } \
-            note_kernel("viterbi_cw_fused_kernel<%d,0%o,0%o,%s,%d>", LG, GA, GB, type_name(type), tb - 2);             \
+            note_kernel("viterbi_cw_fused_kernel<%d,0%o,0%o,%s,%d%s>", LG, GA, GB, type_name(type), fused_tb<LG>() - 2,       \
+                        tb == fused_tb<LG>() ? "" : ",runtime hops");                                                  \
             return true;                                                                                            \
         }                                                                                                           \
         void *w0 = nullptr, *w1 = nullptr;                                                                          \

@@ -99,9 +99,9 @@ int cpx_trellis_destroy(cpx_trellis *t);
  * Decision rule: the bit(s) of step s come from the survivor of the
  * first-minimum state at step min(s+tb_depth-2, n_steps), ties -> lowest index.
  * Kernel selection is internal and does not change a single output bit: batches of >= 3/4 * (SIMDs of the device) * 64
- * codewords of the K = 7 (133,171) code run one codeword per lane (csrc/viterbi_cw.hip: a single fused kernel when
- * tb_depth is the default 5*m = 30, an add-compare-select + a traceback kernel with a 9 B per codeword-step device
- * workspace otherwise, tb_depth <= 48); everything else runs one trellis state per lane (csrc/viterbi.hip).
+ * codewords of the K = 7 codes (133,171), (171,133) and (5,43) run one codeword per lane (csrc/viterbi_cw.hip: a single
+ * fused kernel for tb_depth <= 5*m = 30, an add-compare-select + a traceback kernel with a 9 B per codeword-step device
+ * workspace for 31 <= tb_depth <= 48); everything else runs one trellis state per lane (csrc/viterbi.hip).
  * cpx_viterbi_set_path (or the environment variable CPX_VITERBI_PATH = wave | cw | cw! | cw2 | cw2! at load time)
  * overrides the choice (tests, benchmarks); cpx_last_kernel reports which kernel ran.
  */
