@@ -2,7 +2,8 @@
 # One gpurun call: GPU tests, smoke, bench, rocprofv3 kernel stats + PMC passes.  Results -> gpurun_out/<tag>/
 # usage: bash scripts/gpu_round.sh [tag] [sections]
 #   sections: t(ests) s(moke) b(ench.py) d(ist: torchrun N=1 over the engine's RCCL binding) k(ernel benches)
-#             l(ink + host-api benches) v(iterbi PMC passes) u(turbo/map PMC passes) x(ldpc PMC passes)
+#             l(ink + host-api + multi-GPU benches) v(iterbi PMC passes) u(turbo/map PMC passes) m(demod PMC passes)
+#             x(ldpc PMC passes)
 TAG=${1:-r02}
 SEC=${2:-tsbdklvu}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -39,6 +40,10 @@ fi
 if [[ $SEC == *u* ]]; then
   timeout 1500 python scripts/collect_pmc.py --out $OUT --name turbo_c3 --match _decode_kernel --fetch-scale 1 -- \
       python $R/benchmarks/bench_kernels.py --which turbo,map 2>&1 | tail -60
+fi
+if [[ $SEC == *m* ]]; then
+  timeout 1500 python scripts/collect_pmc.py --out $OUT --name demod --match demod_ --fetch-scale 2 -- \
+      python $R/benchmarks/bench_kernels.py --which demod 2>&1 | tail -60
 fi
 if [[ $SEC == *x* ]]; then
   timeout 1500 python scripts/collect_pmc.py --out $OUT --name ldpc_c4 --match ldpc_ --fetch-scale 1 -- \
