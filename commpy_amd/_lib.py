@@ -10,7 +10,8 @@ from ctypes import (POINTER, c_char_p, c_double, c_float, c_int, c_int8, c_int32
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libcommpy_amd.so")
+# CPX_LIB_PATH: load another build of the engine (kernel experiments); the default is the in-tree library
+LIB_PATH = os.environ.get("CPX_LIB_PATH") or os.path.join(_HERE, "csrc", "libcommpy_amd.so")
 
 CPX_OK, CPX_EINVAL, CPX_EHIP, CPX_ENOMEM, CPX_ENODEV, CPX_ELIMIT = 0, -1, -2, -3, -4, -5
 
