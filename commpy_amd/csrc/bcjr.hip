@@ -174,7 +174,7 @@ struct PassIO {
     const double *par;            // [B][N]
     uint8_t *bits;                // map_decode: hard decisions [B][N] (L > 0 in 'decode' mode), or null
     int want_bits;
-    int64_t sstride;
+    int64_t sstride, pstride;     // per-codeword strides of sys / par
     const double *Lin;            // L_int, stride lstride per codeword
     double *Lout;                 // L_int + log(app1/app0) -- or, with `ext`, log(app1/app0) alone --, stride lstride
     bool ext;                     // turbo: write L - L_int, the quantity the next half-iteration interleaves (:318, :328)
@@ -192,7 +192,7 @@ __device__ __forceinline__ void load_raw(const Ctx<LGS> &c, const PassIO &io, Ra
         rc.r0[q] = 0.0; rc.r1[q] = 0.0; rc.li[q] = 0.0;
         if (gg < c.GW && cw < io.B && tl < len) {
             rc.r0[q] = io.sys[cw * io.sstride + t];
-            rc.r1[q] = io.par[cw * io.N + t];
+            rc.r1[q] = io.par[cw * io.pstride + t];
             rc.li[q] = io.Lin[cw * io.lstride + t];
         }
     }
@@ -208,7 +208,12 @@ __device__ __forceinline__ void load_raw(const Ctx<LGS> &c, const PassIO &io, Ra
 //     division; same limits as the reference (p0 -> 0 / p1 -> 0 when e^L overflows / underflows).
 // The row stride P = 6 GW + 2 doubles makes the eight lanes that hold consecutive steps of a codeword hit eight
 // different 16-byte bank groups.
-template <int LGS>
+// PRE (turbo_decode): the channel factors do not change between the passes of a decode, so they are evaluated ONCE per
+// launch (signed_q below) and a pass reads copysign(Qa, r0), copysign(Qb, r1) where it would read r0, r1: one exp per item
+// and pass -- the prior -- instead of three.
+__device__ __forceinline__ double signed_q(double r, double k4) { return __builtin_copysign(exp(k4 * fabs(r)), r); }
+
+template <int LGS, bool PRE>
 __device__ __forceinline__ void stage_chunk(const Ctx<LGS> &c, const RawChunk &rc, double nv2) {
     const int GW = c.GW;
     const double k4 = -4.0 / nv2;
@@ -217,8 +222,9 @@ __device__ __forceinline__ void stage_chunk(const Ctx<LGS> &c, const RawChunk &r
         const int p = c.lane + 64 * q, gg = p / CH, tl = p % CH;
         if (gg < GW) {
             const double r0 = rc.r0[q], r1 = rc.r1[q], li = rc.li[q];
-            const double qa = exp(k4 * fabs(r0)), qb = exp(k4 * fabs(r1)), e = exp(-fabs(li));
-            const bool n0 = r0 < 0.0, n1 = r1 < 0.0, pos = li >= 0.0;
+            const double qa = PRE ? fabs(r0) : exp(k4 * fabs(r0)), qb = PRE ? fabs(r1) : exp(k4 * fabs(r1)), e = exp(-fabs(li));
+            // sign of the received value; the sign BIT, so that an underflowed factor stored as -0.0 keeps its sign
+            const bool n0 = PRE ? __double2hiint(r0) < 0 : r0 < 0.0, n1 = PRE ? __double2hiint(r1) < 0 : r1 < 0.0, pos = li >= 0.0;
             const double a0 = n0 ? 1.0 : qa, a1 = n0 ? qa : 1.0;  // systematic bit 0 (c0 = -1) / 1 (c0 = +1)
             const double b0 = n1 ? 1.0 : qb, b1 = n1 ? qb : 1.0;  // parity bit
             double2 *row = reinterpret_cast<double2 *>(c.tab + tl * c.P + gg * 6);
@@ -378,7 +384,7 @@ __device__ __forceinline__ void pair_sync() {
 }
 
 // One MAP pass over the GW codewords of this pair of wavefronts.  Collective over the workgroup (one pair_sync).
-template <int LGS, bool SR>
+template <int LGS, bool SR, bool PRE>
 __device__ void map_pass(const Ctx<LGS> &c, const PassIO &io) {
     const int64_t N = io.N;
     const int K = (int)((N + CH - 1) / CH), K1 = K / 2;          // F: chunks [0,K1) then [K1,K); R: [K1,K) then [0,K1)
@@ -400,7 +406,7 @@ __device__ void map_pass(const Ctx<LGS> &c, const PassIO &io) {
         if (K1 > 0) load_raw<LGS>(c, io, cur, 0, clen(0));
         for (int k = 0; k < K1; k++) {
             ck[(int64_t)k * 64] = a;                              // alpha at time k*CH (read by R in phase 2)
-            stage_chunk<LGS>(c, cur, io.nv2);
+            stage_chunk<LGS, PRE>(c, cur, io.nv2);
             if (k + 1 < K1) load_raw<LGS>(c, io, nxt, (int64_t)(k + 1) * CH, clen(k + 1));
             alpha_chunk<LGS, SR, false>(c, a, CH, arow);          // chunks below K1 are full
             cur = nxt;
@@ -411,7 +417,7 @@ __device__ void map_pass(const Ctx<LGS> &c, const PassIO &io) {
         for (int k = K1; k < K; k++) {
             const int len = clen(k);
             double b = ck[(int64_t)(k + 1) * 64];                 // beta at the upper boundary of chunk k
-            stage_chunk<LGS>(c, cur, io.nv2);
+            stage_chunk<LGS, PRE>(c, cur, io.nv2);
             if (k + 1 < K) load_raw<LGS>(c, io, nxt, (int64_t)(k + 1) * CH, clen(k + 1));
             alpha_chunk<LGS, SR, true>(c, a, len, arow);
             beta_chunk<LGS, SR, true>(c, b, len, arow);
@@ -424,7 +430,7 @@ __device__ void map_pass(const Ctx<LGS> &c, const PassIO &io) {
         load_raw<LGS>(c, io, cur, (int64_t)(K - 1) * CH, clen(K - 1));
         for (int k = K - 1; k >= K1; --k) {
             ck[(int64_t)(k + 1) * 64] = b;                        // beta at the upper boundary of chunk k (read by F)
-            stage_chunk<LGS>(c, cur, io.nv2);
+            stage_chunk<LGS, PRE>(c, cur, io.nv2);
             if (k > K1) load_raw<LGS>(c, io, nxt, (int64_t)(k - 1) * CH, CH);
             beta_chunk<LGS, SR, false>(c, b, clen(k), arow);
             cur = nxt;
@@ -434,7 +440,7 @@ __device__ void map_pass(const Ctx<LGS> &c, const PassIO &io) {
         // ---------------- phase 2: chunks K1-1 .. 0 (all full): alpha from F's checkpoint, own beta, combine ----------------
         for (int k = K1 - 1; k >= 0; --k) {
             double a = ck[(int64_t)k * 64];                       // alpha at the lower boundary of chunk k
-            stage_chunk<LGS>(c, cur, io.nv2);
+            stage_chunk<LGS, PRE>(c, cur, io.nv2);
             if (k > 0) load_raw<LGS>(c, io, nxt, (int64_t)(k - 1) * CH, CH);
             alpha_chunk<LGS, SR, true>(c, a, CH, arow);           // arow[tl] = alpha at time k*CH + tl
             beta_chunk<LGS, SR, true>(c, b, CH, arow);
@@ -463,11 +469,11 @@ __global__ __launch_bounds__(128 * NPAIR) void map_decode_kernel(MapParams p) {
     const int64_t pair = (int64_t)blockIdx.x * (blockDim.x >> 7) + (threadIdx.x >> 7);
     const int64_t K = (p.N + CH - 1) / CH;
     PassIO io;
-    io.sys = p.sys; io.sstride = p.N; io.par = p.par; io.Lin = p.Lin; io.Lout = p.Lout; io.lstride = p.N; io.ext = false;
+    io.sys = p.sys; io.sstride = p.N; io.pstride = p.N; io.par = p.par; io.Lin = p.Lin; io.Lout = p.Lout; io.lstride = p.N; io.ext = false;
     io.bits = p.bits; io.want_bits = p.want_bits;
     io.cw0 = pair * p.GW; io.B = p.B; io.N = p.N; io.nv2 = p.nv2;
     io.ckpt = p.scratch + pair * (K + 1) * 64;
-    map_pass<LGS, SR>(c, io);                                     // L_ext and the hard decisions leave in the pass's epilogue
+    map_pass<LGS, SR, false>(c, io);                              // L_ext and the hard decisions leave in the pass's epilogue
 }
 
 struct TurboParams {
@@ -476,7 +482,7 @@ struct TurboParams {
     const int32_t *perm;                  // [N]
     uint8_t *bits;                        // [B][N]
     double *ckpt;                         // per pair: checkpoint rows [nchunks + 1][64]
-    double *larr;                         // per codeword: A[N] B[N] C[N] Si[N]
+    double *larr;                         // per codeword: A, B, C, Qs, Qsi, Qp1, Qp2 [N] each
     int64_t B, N;
     double nv2;
     int n_iter, GW;
@@ -489,11 +495,15 @@ __global__ __launch_bounds__(128 * NPAIR) void turbo_decode_kernel(TurboParams p
     init_ctx<LGS>(c, p.tb, smem, p.GW);
     const int64_t pair = (int64_t)blockIdx.x * (blockDim.x >> 7) + (threadIdx.x >> 7);
     const int64_t N = p.N, K = (N + CH - 1) / CH, cw0 = pair * p.GW;
-    // per-codeword arrays in one slab [B][4][N]: A (L_int_1), B (a pass's output), C (L_int_2), Si (interlv(sys), :310)
-    double *A0 = p.larr, *B0 = p.larr + N, *C0 = p.larr + 2 * N, *S0 = p.larr + 3 * N;
-    const int64_t ls = 4 * N;
+    // per-codeword arrays in one slab [B][7][N]: A (L_int_1), B (a pass's output), C (L_int_2) and the signed channel
+    // factors (signed_q) of sys, interlv(sys) (:310), non_sys_1 and non_sys_2
+    double *A0 = p.larr, *B0 = p.larr + N, *C0 = p.larr + 2 * N;
+    double *QS = p.larr + 3 * N, *QSI = p.larr + 4 * N, *QP1 = p.larr + 5 * N, *QP2 = p.larr + 6 * N;
+    const int64_t ls = 7 * N;
+    const double k4 = -4.0 / p.nv2;
     PassIO io;
-    io.lstride = ls; io.cw0 = cw0; io.B = p.B; io.N = N; io.nv2 = p.nv2; io.bits = nullptr; io.want_bits = 0;
+    io.lstride = ls; io.sstride = ls; io.pstride = ls; io.cw0 = cw0; io.B = p.B; io.N = N; io.nv2 = p.nv2; io.bits = nullptr;
+    io.want_bits = 0;
     io.ckpt = p.ckpt + pair * (K + 1) * 64;
     // Between the MAP passes only the interleaver is left to do: a pass writes E = L - L_int directly (`ext`), so
     //   even h: L_int_2 = interlv(E_1)      C[t] = B[perm[t]]         (:318-319)
@@ -507,23 +517,27 @@ __global__ __launch_bounds__(128 * NPAIR) void turbo_decode_kernel(TurboParams p
     for (int g = w2; g < GW; g += 2) {
         const int64_t cwg = cw0 + g;
         if (cwg >= p.B) break;
-        double *A = A0 + cwg * ls, *Si = S0 + cwg * ls;
-        const double *sy = p.sys + cwg * N;
-#pragma unroll 4
-        for (int64_t t = lane; t < N; t += 64) A[t] = p.Lint ? p.Lint[cwg * N + t] : 0.0;      // L_int_1 (:305-308)
-        // sys_symbols_i = interlv(sys) (:310), once: coalesced read -> LDS -> gather -> coalesced write.  (Reading sys[perm[t]]
-        // in every second MAP pass fetched a 64-byte line per 8-byte value: 8 of the 17 GB a launch read.)
+        double *A = A0 + cwg * ls, *qs = QS + cwg * ls, *qsi = QSI + cwg * ls, *qp1 = QP1 + cwg * ls, *qp2 = QP2 + cwg * ls;
+        const double *sy = p.sys + cwg * N, *y1 = p.p1 + cwg * N, *y2 = p.p2 + cwg * N;
+#pragma unroll 2
+        for (int64_t t = lane; t < N; t += 64) {
+            A[t] = p.Lint ? p.Lint[cwg * N + t] : 0.0;             // L_int_1 (:305-308)
+            qp1[t] = signed_q(y1[t], k4);
+            qp2[t] = signed_q(y2[t], k4);
+            const double v = signed_q(sy[t], k4);
+            qs[t] = v;
+            if (in_lds) buf[t] = v;
+        }
+        // sys_symbols_i = interlv(sys) (:310), once: through LDS -- coalesced read, LDS gather, coalesced write.  (Reading
+        // sys[perm[t]] in every second MAP pass fetched a 64-byte line per 8-byte value: 8 of the 17 GB a launch read.)
+        asm volatile("" ::: "memory");
         if (in_lds) {
-            asm volatile("" ::: "memory");
 #pragma unroll 4
-            for (int64_t t = lane; t < N; t += 64) buf[t] = sy[t];
-            asm volatile("" ::: "memory");
-#pragma unroll 4
-            for (int64_t t = lane; t < N; t += 64) Si[t] = buf[p.perm[t]];
+            for (int64_t t = lane; t < N; t += 64) qsi[t] = buf[p.perm[t]];
             asm volatile("" ::: "memory");
         } else {
-#pragma unroll 4
-            for (int64_t t = lane; t < N; t += 64) Si[t] = sy[p.perm[t]];
+#pragma unroll 2
+            for (int64_t t = lane; t < N; t += 64) qsi[t] = signed_q(sy[p.perm[t]], k4);
         }
     }
     pair_sync();
@@ -533,12 +547,11 @@ __global__ __launch_bounds__(128 * NPAIR) void turbo_decode_kernel(TurboParams p
     //   odd h:  [L_2, bits] = map_decode(sys_i, non_sys_2, trellis, nv, L_int_2, mode)              (:326)
     for (int h = 0; h < 2 * p.n_iter; h++) {
         const bool second = h & 1;
-        io.sys = second ? S0 : p.sys;
-        io.sstride = second ? ls : N;
-        io.par = second ? p.p2 : p.p1;
+        io.sys = second ? QSI : QS;
+        io.par = second ? QP2 : QP1;
         io.Lin = second ? C0 : A0;
         io.Lout = B0;
-        map_pass<LGS, SR>(c, io);
+        map_pass<LGS, SR, true>(c, io);
         pair_sync();
         if (h == 2 * p.n_iter - 1) break;                          // the last E_2 only feeds the decisions below
         for (int g = w2; g < GW; g += 2) {
@@ -680,7 +693,7 @@ int cpx_turbo_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const 
     p.B = B; p.N = N; p.nv2 = 2 * noise_variance; p.n_iter = n_iter;
     CPX_REQUIRE(nblocks < (1ll << 31), CPX_ELIMIT, "turbo_decode: batch too large");
     if ((rc = workspace(st, 0, sizeof(double) * (size_t)(nblocks * np * (K + 1) * 64), (void **)&p.ckpt))) return rc;
-    if ((rc = workspace(st, 1, sizeof(double) * (size_t)(B * 4 * N), (void **)&p.larr))) return rc;
+    if ((rc = workspace(st, 1, sizeof(double) * (size_t)(B * 7 * N), (void **)&p.larr))) return rc;
     dim3 grid((unsigned)nblocks), block(128 * np);
     switch (p.tb.lgS) {
 #define CASE(LG) case LG: hipLaunchKernelGGL((turbo_decode_kernel<LG, false>), grid, block, sizeof(double) * 2 * np * wave_lds_doubles<LG>(GW), st, p); break;
