@@ -56,6 +56,7 @@ SYMBOLS = {
     "cpx_viterbi_decode_batch_i64": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int,
                                      c_void_p]),
     "cpx_viterbi_set_path": (c_int, [c_char_p]),
+    "cpx_ldpc_set_path": (c_int, [c_char_p]),
     "cpx_demod_hard_viterbi_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int,
                                              c_void_p]),
     "cpx_demod_hard_viterbi_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int,
@@ -207,6 +208,11 @@ def viterbi_last_path():
 def viterbi_set_path(mode):
     """Force a Viterbi kernel path: None/'auto', 'wave', 'cw', 'cw!', 'cw2', 'cw2!' (tests and benchmarks)."""
     check(load().cpx_viterbi_set_path(None if mode is None else mode.encode()))
+
+
+def ldpc_set_path(mode):
+    """Force an LDPC decoder path: None/'auto', 'tiled' (HBM-resident tiles), 'resident' (LDS-resident, strict)."""
+    check(load().cpx_ldpc_set_path(None if mode is None else mode.encode()))
 
 
 class DeviceHandles:

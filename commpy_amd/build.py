@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(CSRC, "libcommpy_amd.so")
-SOURCES = ["runtime.hip", "viterbi.hip", "viterbi_cw.hip", "bcjr.hip", "ldpc.hip", "demod.hip", "linksim.hip", "encoders.hip",
+SOURCES = ["runtime.hip", "viterbi.hip", "viterbi_cw.hip", "bcjr.hip", "ldpc.hip", "ldpc_resident.hip", "demod.hip", "linksim.hip", "encoders.hip",
            "comm.hip"]
 
 
@@ -25,7 +25,7 @@ def _hipcc():
     return "hipcc"
 
 
-HEADERS = [os.path.join(CSRC, h) for h in ("cpx_internal.h", "cpx_math.h", "demod_dev.h")] + [os.path.join(INCLUDE, "commpy_amd.h")]
+HEADERS = [os.path.join(CSRC, h) for h in ("cpx_internal.h", "cpx_math.h", "demod_dev.h", "ldpc_dev.h")] + [os.path.join(INCLUDE, "commpy_amd.h")]
 OBJDIR = os.path.join(CSRC, "build")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-result",
          "-I", INCLUDE, "-I", CSRC]

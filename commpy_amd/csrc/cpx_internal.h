@@ -52,6 +52,10 @@ int workspace(hipStream_t stream, int slot, size_t bytes, void **out);
 bool viterbi_codeword_path(const ::cpx_trellis *t, const double *d_coded, int64_t B, int64_t len, int64_t L, int64_t T,
                            int tb, int type, uint8_t *d_bits, hipStream_t st, int *rc);
 
+// LDS-resident LDPC path (ldpc_resident.hip): true when it handled the call (*rc = status)
+bool ldpc_resident_path(const ::cpx_ldpc *c, double *d_llr, int64_t B, int alg, int n_iters, int8_t *d_dec, double *d_out,
+                        int32_t *d_iters, hipStream_t st, int *rc);
+
 int viterbi_path_flags();   // bit 0 wave only, bit 1 codeword path forced, bit 2 strict, bit 3 two-kernel form
 
 inline hipStream_t pick_stream(void *s) { return s ? reinterpret_cast<hipStream_t>(s) : lib_stream(); }

@@ -39,6 +39,7 @@
 // is decided and applied on the device (control block in HBM, no host synchronisation).
 #include "cpx_internal.h"
 #include "cpx_math.h"
+#include "ldpc_dev.h"
 
 #include <algorithm>
 
@@ -57,11 +58,6 @@ struct Bufs {
     int32_t *dst;
     Ctl *ctl;
 };
-
-__device__ __forceinline__ double clip_nan(double v, double lo, double hi) {
-    // np.clip propagates NaN
-    return (v != v) ? v : fmin(fmax(v, lo), hi);
-}
 
 // view of the control block for compute passes: a pending move is already in effect for them
 __device__ __forceinline__ void effective(const Ctl *c, int &n_slots, int &buf) {
@@ -115,28 +111,6 @@ __global__ __launch_bounds__(LB) void ldpc_init_kernel(double *__restrict__ llr,
     const int xcd = blockIdx.x & 7, jstride = gridDim.x >> 3;                                        \
     for (int idx = blockIdx.x >> 3;; idx += jstride)
 
-__device__ __forceinline__ double min_f64(double a, double b) {     // one v_min_f64 (fmin adds two canonicalising v_max)
-    double r;
-    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ double ntload(const double *p) { return __builtin_nontemporal_load(p); }
-__device__ __forceinline__ void ntstore(double v, double *p) { __builtin_nontemporal_store(v, p); }
-
-// tanh(v/2) and 2*atanh(x) for the sum-product pass.  ocml's tanh/atanh are correctly rounded to < 1 ulp through
-// double-double arithmetic (~300 VALU instructions per edge for the pair, which bounded the check pass); these
-// evaluate the same functions through one exp / one log with an ABSOLUTE error of a few 1e-16:
-//   tanh(v/2) = sign(v) (1 - e) / (1 + e),  e = exp(-|v|)        (cancellation in 1 - e only costs relative accuracy
-//                                                                  of results that are themselves ~|v|/2 << 1)
-//   2 atanh(x) = log((1 + x) / (1 - x))                            (1 - x is exact for x > 1/2; x = +-1 gives +-inf)
-// The decoder's sensitivity to the last ulp of these functions is the same either way ("LDPC-SPA note").
-__device__ __forceinline__ double tanh_half(double v) {
-    const double e = exp(-fabs(v));
-    const double t = (1.0 - e) / (1.0 + e);
-    return __builtin_copysign(t, v);                              // NaN propagates through exp
-}
-__device__ __forceinline__ double atanh_twice(double x) { return fast_log((1.0 + x) / (1.0 - x)); }
-
 // ---- sum-product (:209-227): R keeps one float64 per edge --------------------------------------------------
 template <int DEG>
 __device__ __forceinline__ void cn_spa_row(double *__restrict__ Rrow, const double *__restrict__ Qt,
@@ -180,31 +154,7 @@ __device__ __forceinline__ void cn_spa_row(double *__restrict__ Rrow, const doub
 #undef CPX_SPA_OUT
 }
 
-// ---- min-sum (:229-238): the messages of a row are (+-) one of TWO magnitudes, so the row is kept as a record
-//   rec[0] = min1 = smallest |v->c message| of the row, rec[1] = min2 = second smallest (ties: a later equal
-//   value), rec[2] = meta: bits 0..7 position of min1, bit 8 parity of the negatives, bits 32..63 negative mask.
-// Edge j receives  (-1)^(negatives among the others) * (j == imin ? min2 : min1)  -- exactly
-// sign(other).prod() * abs(other).min(): a zero among the others makes the minimum zero by itself.
-struct MsaRec { double m1, m2; unsigned neg; int imin, par; };
-
-__device__ __forceinline__ MsaRec msa_load(const double *__restrict__ rec) {
-    MsaRec r;
-    r.m1 = ntload(&rec[0]);
-    r.m2 = ntload(&rec[64]);
-    const double meta = ntload(&rec[128]);
-    const int lo = __double2loint(meta);
-    r.neg = (unsigned)__double2hiint(meta);
-    r.imin = lo & 0xff;
-    r.par = (lo >> 8) & 1;
-    return r;
-}
-// the message edge j of the row received, negated or not (flip = 1 returns -R)
-__device__ __forceinline__ double msa_edge(const MsaRec &r, int j, int flip) {
-    const double mn = (j == r.imin) ? r.m2 : r.m1;
-    const unsigned ng = ((r.neg >> j) ^ (unsigned)r.par ^ (unsigned)flip) & 1u;
-    return __hiloint2double(__double2hiint(mn) | (int)(ng << 31), __double2loint(mn));
-}
-
+// ---- min-sum (:229-238): a row is kept as a record (MsaRec, ldpc_dev.h) -------------------------------------
 template <int DEG>
 __device__ __forceinline__ void cn_msa_row(const MsaRec &o, double *__restrict__ rec, const double *__restrict__ Qt,
                                            const int32_t *__restrict__ ev, int deg, int k, int32_t *st) {
@@ -834,6 +784,10 @@ int cpx_ldpc_bp_decode_batch_dev(const cpx_ldpc *c, double *d_llr, int64_t B, in
     CPX_REQUIRE(d_llr && d_dec && d_out, CPX_EINVAL, "ldpc: null device pointer");
     CPX_REQUIRE(B <= (1ll << 30), CPX_ELIMIT, "ldpc: batch too large");
     hipStream_t st = pick_stream(stream);
+    {   // the whole decoder state of a block in LDS, one persistent launch (ldpc_resident.hip) -- unless it does not fit
+        int rcr = CPX_OK;
+        if (ldpc_resident_path(c, d_llr, B, alg, n_iters, d_dec, d_out, d_iters, st, &rcr)) return rcr;
+    }
     const int64_t E = c->n_edges, nv = c->n_v;
     const int64_t n_tiles = (B + 63) / 64, S = n_tiles * 64;
     const int64_t RR = alg == CPX_LDPC_MSA ? 3 * (int64_t)c->n_c : E;      // rows of R per tile (records / edges)
@@ -893,6 +847,7 @@ int cpx_ldpc_bp_decode_batch_dev(const cpx_ldpc *c, double *d_llr, int64_t B, in
     }
     hipLaunchKernelGGL(ldpc_final_kernel, dim3(g_vn), dim3(LB), 0, st, bf, (int)nv, B, d_out, d_dec);
     CPX_HIP(hipGetLastError());
+    note_kernel("ldpc_cn_%s_kernel + ldpc_vn_%s_kernel (tiled)", alg == CPX_LDPC_MSA ? "msa" : "spa", alg == CPX_LDPC_MSA ? "msa" : "spa");
     return CPX_OK;
 }
 

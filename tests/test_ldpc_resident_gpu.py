@@ -1,0 +1,108 @@
+"""LDS-resident LDPC path (csrc/ldpc_resident.hip) against the tiled HBM path (csrc/ldpc.hip) and the oracle.
+
+Both paths replace ldpc_bp_decode (/root/reference/commpy/channelcoding/ldpc.py:144-254) with the same float64
+operations per edge in the same order, so dec_word, out_llrs and the executed iterations must be IDENTICAL for both
+algorithms -- whatever slot of whatever workgroup a block lands in.  The other LDPC tests of the suite run through the
+default (resident) path and compare with the oracle; here the two paths are forced and compared with each other on
+batches that exercise slot replacement (more blocks than slots, blocks that converge at very different iterations,
+blocks that never converge), plus special values.
+"""
+import numpy as np
+import pytest
+
+import oracle
+from helpers import ldpc_params
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def paths():
+    from commpy_amd import _lib
+    yield _lib
+    _lib.ldpc_set_path(None)
+
+
+def _decode(_lib, path, llr, p, alg, iters):
+    from commpy_amd.channelcoding import ldpc_bp_decode
+    _lib.ldpc_set_path(path)
+    x = llr.copy()
+    dec, out, its = ldpc_bp_decode(x, p, alg, iters, return_iterations=True)
+    return dec, out, its, x, _lib.last_kernel()
+
+
+def _staggered(rs, B, n, rate, ebn0s):
+    ebn0 = rs.choice(ebn0s, size=B)
+    sig = 1 / np.sqrt(10 ** (ebn0 / 10.0) * rate * 2)
+    return (2.0 * (1.0 + sig[:, None] * rs.randn(B, n)) / sig[:, None] ** 2).reshape(-1)
+
+
+@pytest.mark.parametrize("alg,iters", [("MSA", 50), ("SPA", 14), ("MSA", 1), ("SPA", 2)])
+def test_resident_equals_tiled_1944(gpu, paths, alg, iters):
+    p = ldpc_params("n1944")
+    rs = np.random.RandomState(5)
+    B = 2100                                                        # > 256 CUs x 4 slots: every workgroup refills slots
+    llr = _staggered(rs, B, 1944, 2.0 / 3, [0.5, 2.0, 2.6, 3.2, 4.5, 30.0])
+    d1, o1, i1, x1, k1 = _decode(paths, "tiled", llr, p, alg, iters)
+    d2, o2, i2, x2, k2 = _decode(paths, "resident", llr, p, alg, iters)
+    assert "tiled" in k1 and "ldpc_resident_kernel" in k2 and alg in k2, (k1, k2)
+    assert len(set(i1.tolist())) >= min(iters, 5)
+    assert np.array_equal(i1, i2)
+    assert np.array_equal(d1, d2)
+    assert np.array_equal(o1, o2)                                   # bit-identical, both algorithms
+    assert np.array_equal(x1, x2)
+
+
+@pytest.mark.parametrize("name,n", [("gallager96", 96), ("wimax1440", 1440)])
+def test_resident_other_codes_vs_oracle_and_tiled(gpu, paths, name, n):
+    """Smaller codes take more slots per workgroup (G = 16 / 4)."""
+    p = ldpc_params(name)
+    rs = np.random.RandomState(11)
+    B = 777
+    llr = _staggered(rs, B, n, 0.5, [1.0, 2.5, 4.0, 30.0])
+    for alg, iters in (("MSA", 20), ("SPA", 8)):
+        d1, o1, i1, _, _ = _decode(paths, "tiled", llr, p, alg, iters)
+        d2, o2, i2, _, k2 = _decode(paths, "resident", llr, p, alg, iters)
+        assert "ldpc_resident_kernel" in k2
+        assert np.array_equal(i1, i2) and np.array_equal(d1, d2) and np.array_equal(o1, o2), (name, alg)
+        sel = slice(0, 64 * n)
+        do, oo, io = oracle.ldpc_bp_decode(llr[sel].copy(), p, alg, iters, True)
+        assert np.array_equal(i2[:64], io) and np.array_equal(d2[:, :64], do), (name, alg)
+        if alg == "MSA":
+            assert np.array_equal(o2[:, :64], oo)
+
+
+@pytest.mark.parametrize("B", [1, 3, 5, 64, 65])
+def test_resident_small_batches_and_special_values(gpu, paths, B):
+    """Fewer blocks than slots; +-inf, NaN, zeros, values beyond the +-500 clip (in-place clip, ldpc.py:186)."""
+    p = ldpc_params("n1944")
+    rs = np.random.RandomState(100 + B)
+    llr = _staggered(rs, B, 1944, 2.0 / 3, [2.0, 3.5, 30.0])
+    llr[rs.randint(llr.size, size=40)] = 0.0
+    llr[rs.randint(llr.size, size=10)] = -0.0
+    llr[rs.randint(llr.size, size=10)] = 1e4
+    llr[rs.randint(llr.size, size=10)] = -np.inf
+    if B >= 3:
+        llr[1944 * 2 + 7] = np.nan
+    for alg, iters in (("MSA", 9), ("SPA", 5)):
+        d1, o1, i1, x1, _ = _decode(paths, "tiled", llr, p, alg, iters)
+        d2, o2, i2, x2, _ = _decode(paths, "resident", llr, p, alg, iters)
+        assert np.array_equal(i1, i2), alg
+        assert np.array_equal(o1, o2, equal_nan=True), alg
+        ok = ~np.isnan(o1)                                         # the sign bit of a NaN is nobody's contract (np.signbit of it, :248)
+        assert np.array_equal(d1[ok], d2[ok]), alg
+        assert np.array_equal(x1, x2, equal_nan=True) and np.nanmax(np.abs(x2)) <= 500.0
+
+
+def test_resident_strict_mode_and_zero_iterations(gpu, paths):
+    from commpy_amd.channelcoding import ldpc_bp_decode
+    p = ldpc_params("gallager96")
+    llr = np.random.RandomState(3).randn(96 * 4) * 3
+    paths.ldpc_set_path("resident")
+    with pytest.raises(Exception):
+        ldpc_bp_decode(llr.copy(), p, "MSA", 0)                     # n_iters == 0 is the tiled path's job; strict mode says so
+    paths.ldpc_set_path(None)
+    dec, out = ldpc_bp_decode(llr.copy(), p, "MSA", 0)
+    assert np.array_equal(out.reshape(-1, order="F"), llr)          # out_llrs = llr (ldpc.py:194)
+    with pytest.raises(Exception):
+        paths.ldpc_set_path("bogus")
