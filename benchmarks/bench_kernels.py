@@ -140,20 +140,21 @@ def bench_ldpc(lib, scale):
             its = dev.get(d_it, (B,), np.int32)
             dec = dev.get(d_dec, (n, B), np.int8)
             # SURVEY 8d figure: the reference formulation moves (4E + 2n) float64 per executed iteration per block.
-            # The engine's own compulsory traffic is smaller (ldpc.hip header): (3E + 3n) for SPA, (9 n_c + 3n)
-            # for min-sum records, plus one speculative check pass per block that converges.
+            # The LDS-resident engine (csrc/ldpc_resident.hip) keeps messages and a-posteriori LLRs in LDS: per block it
+            # reads llr once per executed iteration (8n, L2 hits after the first), writes the staging row (8n) and the
+            # transpose kernel moves 8n in, 9n out.  Its bound is VALU issue + LDS bandwidth (PMC: profiles/), so the HBM
+            # fraction below is reported for completeness, not as the kernel's roofline.
             alg_bytes = int(its.sum()) * (4 * E + 2 * n) * 8 + B * n * 17
-            n_c = n - 1296
-            per_it = (9 * n_c + 3 * n) * 8 if alg else (3 * E + 3 * n) * 8
-            eng_bytes = int(its.sum()) * per_it + B * n * 25
-            # roofline on the bytes the ENGINE moves (the SURVEY figure describes the reference
-            # formulation, which the min-sum kernel does not move -- quoted against it the pass would exceed HBM peak)
+            eng_bytes = int(its.sum()) * 8 * n + B * n * 33
+            kname = _lib.last_kernel()
             emit("ldpc_bp_%s" % name, "(1944,1296) Eb/N0=%.1f dB, <=50 its, B=%d, mean executed its %.2f" % (
-                ebn0, B, its.mean()), B * 1296, "info-bits", v.value, eng_bytes, "hbm" if alg else "f64-transcendental",
-                 {"frame_error_rate": float(np.mean(dec.any(axis=0))), "mean_iterations": float(its.mean()),
+                ebn0, B, its.mean()), B * 1296, "info-bits", v.value, eng_bytes, "valu+lds" if "resident" in kname else "hbm",
+                 {"kernel_name": kname,
+                  "frame_error_rate": float(np.mean(dec.any(axis=0))), "mean_iterations": float(its.mean()),
                   "max_iterations": int(its.max()),
-                  "bytes_model": "engine: executed iterations x (9 n_c + 3 n) x 8 B (min-sum records) or (3 E + 3 n) x 8 B "
-                                 "(sum-product) + 25 n B per block for input / output",
+                  "block_iterations_per_s": float(its.sum()) / (v.value * 1e-3),
+                  "bytes_model": "engine (LDS-resident path): executed iterations x 8 n B (channel LLR re-read) + 33 n B per "
+                                 "block (input, staging, transposed outputs)",
                   "survey_8d_formulation_bytes_per_launch": alg_bytes})
         dev.free()
 
@@ -191,12 +192,15 @@ def bench_config4(lib, scale):
             its = dev.get(d_it, (B,), np.int32)
             dec = dev.get(d_dec, (n, B), np.int8)
             sent = dev.get(d_bits, (B, n), np.int8)
-            per_it = (9 * (n - 1296) + 3 * n) * 8 if alg else (3 * 7128 + 3 * n) * 8       # engine bytes per iteration
-            alg_bytes = B * nsym * 64 + int(its.sum()) * per_it + B * n * 25
+            # bytes the chain moves through HBM: symbols + noise + LLRs + sign flip (64 B per symbol and its 6 LLRs, twice),
+            # the decoder's channel-LLR re-read per executed iteration (8 n) and its staging / transposed outputs (33 n)
+            alg_bytes = B * nsym * (16 * 3 + 48 * 3) + int(its.sum()) * 8 * n + B * n * 33
+            kname = _lib.last_kernel()
             emit("config4_pipeline_%s" % name, "encode + 64-QAM + AWGN + demod + LDPC (1944,1296) %s, Eb/N0=%.0f dB, B=%d, "
                  "mean its %.2f" % (name, ebn0, B, its.mean()), B * 1296, "info-bits", ms, alg_bytes,
-                 "hbm" if alg else "f64-transcendental",
-                 {"frame_error_rate": float(np.mean((dec.T != sent).any(axis=1))),
+                 "valu+lds" if "resident" in kname else "hbm",
+                 {"decoder_kernel": kname,
+                  "frame_error_rate": float(np.mean((dec.T != sent).any(axis=1))),
                   "bit_error_rate": float(np.mean(dec.T[:, :1296] != sent[:, :1296])),
                   "mean_iterations": float(its.mean())})
     dev.free()

@@ -749,6 +749,10 @@ int cpx_ldpc_create_from_blob(const void *blob, size_t nbytes, cpx_ldpc **out) {
             return CPX_EHIP;
         }
     }
+    if ((rc = ldpc_resident_tables(c, v.row_ptr, v.row_pad, v.col_ptr, v.col_pad_edge))) {
+        cpx_ldpc_destroy(c);
+        return rc;
+    }
     *out = c;
     return CPX_OK;
 }
@@ -769,6 +773,7 @@ int cpx_ldpc_destroy(cpx_ldpc *c) {
     if (!c) return CPX_OK;
     (void)hipFree(c->d_edge_var); (void)hipFree(c->d_row_ptr); (void)hipFree(c->d_col_ptr); (void)hipFree(c->d_col_edge); (void)hipFree(c->d_col_cj);
     (void)hipFree(c->d_row_pad); (void)hipFree(c->d_col_pad_edge); (void)hipFree(c->d_col_pad_cj);
+    ldpc_resident_free(c);
     delete c;
     return CPX_OK;
 }

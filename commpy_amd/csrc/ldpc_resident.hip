@@ -1,22 +1,26 @@
 // LDPC belief propagation with the whole decoder state of a block resident in LDS (gfx950: 160 KB per CU).
-// Same contract and same per-edge float64 operations as ldpc.hip, which documents the formulation
+// Same contract and the same float64 operations per edge, in the same order, as ldpc.hip -- which documents the formulation
 //   ldpc_bp_decode  (/root/reference/commpy/channelcoding/ldpc.py:144-254)
 // and stays the path for codes whose state does not fit (and for n_iters == 0).
 //
 // Why.  The tiled path keeps R/Q/L of 64 blocks per wavefront in HBM and runs one launch per pass: an iteration gathers
 // 2 E rows per tile through L2 (latency-bound: 0.4 + 0.6 ms per iteration at B = 32 768), frozen blocks hold lanes until a
 // move pass compacts the working set, and a decode is 4 launches x n_iters.  Here ONE persistent launch does everything:
-//   * a workgroup owns G = 2^LG block slots; per slot the a-posteriori LLRs Q[n_v] and the check->variable state
-//     (min-sum: a 24-byte record per check; sum-product: one float64 per edge) live in LDS for the block's whole life.
-//     (1944,1296): 31 KB per block for min-sum -> G = 4; 71 KB for sum-product -> G = 2.
-//   * thread = (node, slot).  The check pass walks the checks, the variable pass the variables; both gather from LDS
-//     (~100 cycles, hidden by the 14-16 waves of the workgroup) instead of L2.  Only the channel LLR of the variable
-//     pass (`+ llr`, :245) is re-read from HBM/L2: 8 B per variable and iteration.
-//   * every slot has its own iteration counter.  After a check pass a slot whose syndrome is zero (:203-206) -- or that
-//     has used n_iters iterations -- is retired to a block-major staging buffer and REFILLED with the next block of a
-//     global queue: continuous batching replaces the scan / move / compaction kernels, and nobody waits for the slowest
-//     block of a tile.  A zero-initialised state makes the first iteration of a fresh slot exact without a special case:
-//     the first variable->check message is R * -1 + 1.0 * Q = -0.0 + Q = Q bit for bit (:199 vs :244-245).
+//   * a workgroup decodes ONE block at a time: the a-posteriori LLRs Q[n_v] and one check->variable message R[e] per edge
+//     live in LDS for the block's whole life ((1944,1296): 72.6 KB, two workgroups per compute unit);
+//   * thread = node.  The check pass walks the checks, the variable pass the variables; both gather from LDS (~100 cycles)
+//     instead of L2, through tables of pre-scaled LDS byte offsets (no address arithmetic in the loops).  Only the channel
+//     LLR of the variable pass (`+ llr`, :245) is re-read from HBM/L2: 8 B per variable and iteration;
+//   * rows and columns are padded to a multiple of four entries that point at two dummy slots -- Q = +inf, R = +0.0 --
+//     which are neutral for every accumulation of the passes (min, sign parity, syndrome parity, column sum), so the inner
+//     loops carry no per-edge predicate;
+//   * when its block's syndrome is zero (:203-206), or after n_iters iterations, the workgroup retires the block to a
+//     block-major staging buffer and takes the next one from a global queue: continuous batching replaces the scan / move /
+//     compaction kernels, and nobody waits for the slowest block of a tile.  A zero-initialised R makes the first
+//     iteration exact without a special case: the first variable->check message is R * -1 + 1.0 * Q = -0.0 + Q = Q
+//     bit for bit (:199 vs :244-245);
+//   * min-sum stores the messages themselves (the tiled path stores a 3-word record per check and regenerates them: same
+//     values, fewer bytes, more instructions -- here instructions are what is scarce: the kernels run at ~88 % VALU busy);
 //   * a final transpose kernel turns the staging buffer [B][n_v] into the reference layout [n_v][B] (:251-253) and
 //     writes dec_word.
 // HBM traffic per block: llr read once per executed iteration (L2 hits after the first), staging written once.
@@ -33,7 +37,6 @@ using namespace cpx;
 
 namespace {
 
-constexpr int MAXG = 16;
 constexpr size_t LDS_BYTES = 160 * 1024;
 
 struct ResParams {
@@ -41,221 +44,166 @@ struct ResParams {
     double *stage;           // [B][n_v] a-posteriori LLRs of retired blocks
     int32_t *iters;          // [B] executed iterations, may be null
     int *queue;              // next block to hand out
-    const int32_t *row_ptr, *row_pad, *col_ptr, *col_pad;   // col_pad: (check << 5 | position) min-sum, edge id sum-product
+    const int2 *row_hdr;     // [n_c] (LDS byte offset of the row's first R entry, degree)
+    const int32_t *row_q;    // [n_c][cpad] LDS byte offset of Q[variable of the j-th edge]; padding -> the +inf slot
+    const int32_t *col_r;    // [n_v][vpad] LDS byte offset of R[q-th edge of the variable], increasing check; padding -> the 0.0 slot
+    const int32_t *vgrp;     // [ceil(n_v / 64)] chunks of four column entries the 64 variables of a wavefront need
     int64_t B, E;
-    int n_v, nvp, n_c, cpad, vpad, max_iter;
-    int dbg;
+    int n_v, n_c, cpad, vpad, max_iter, min_cdeg;
+    int roff, ctl_off;       // LDS byte offsets of R and of the control words
 };
 
-struct SlotTab { int blk[MAXG], k[MAXG], flag[MAXG], oblk[MAXG], ok[MAXG]; };
+__device__ __forceinline__ double ldsd(const char *base, int off) { return *reinterpret_cast<const double *>(base + off); }
+__device__ __forceinline__ void stsd(char *base, int off, double v) { *reinterpret_cast<double *>(base + off) = v; }
 
-// ---- min-sum check pass of one (check, slot): syndrome bit + new record (:203-206, :229-238, :244-245) ----------
-template <int G>
-__device__ __forceinline__ void check_msa(const ResParams &p, const double *__restrict__ Q, double2 *__restrict__ M,
-                                          uint2 *__restrict__ T, int c, int cw, int *flag) {
-    const int cq = (p.dbg & 1) ? (c & 63) : c;
-    const int deg = p.row_ptr[cq + 1] - p.row_ptr[cq];
-    const int32_t *__restrict__ ev = p.row_pad + (int64_t)((p.dbg & 1) ? (c & 63) : c) * p.cpad;
-    const double2 om = M[c * G + cw];
-    const uint2 ot = T[c * G + cw];
-    const MsaRec o{om.x, om.y, ot.y, (int)(ot.x & 0xffu), (int)((ot.x >> 8) & 1u)};
+// ---- min-sum check node (:229-238 after :244-245): m_j = Q[v_j] - R_j;  R_j <- prod_{i != j} sign(m_i) * min_{i != j} |m_i| ----
+// CQ > 0: rows of at most 4 CQ entries, fully unrolled.  The messages are written from (min1, min2, argmin, signs), exactly
+// sign(other).prod() * abs(other).min(): a zero among the others makes the minimum zero by itself.
+template <int CQ>
+__device__ __forceinline__ void check_msa(const ResParams &p, char *lds, int c, int *flag) {
+    const int2 hdr = p.row_hdr[c];
+    const int4 *__restrict__ qv = reinterpret_cast<const int4 *>(p.row_q + (int64_t)c * p.cpad);
+    const int rb = hdr.x, deg = hdr.y;
     int sx = 0, imin = 0;
     unsigned neg = 0;
     double m1 = __builtin_huge_val(), m2 = __builtin_huge_val();
-    for (int j0 = 0; __builtin_amdgcn_ballot_w64(j0 < deg) != 0; j0 += 4) {      // rows are padded to a multiple of 4
-        const int4 e = *reinterpret_cast<const int4 *>(ev + j0);
-        const double q[4] = {Q[e.x * G + cw], Q[e.y * G + cw], Q[e.z * G + cw], Q[e.w * G + cw]};
+    constexpr int NQ = CQ > 0 ? CQ : 1;
+#define CPX_MSA_IN(j, qoff)                                                                            \
+    {                                                                                                  \
+        const double q = ldsd(lds, (qoff));                                                            \
+        sx ^= __double2hiint(q);                                 /* dec_word = out_llrs < 0 (:193, :248) */ \
+        const double m = ldsd(lds, rb + 8 * (j)) * -1.0 + q;     /* data * -1 + 1.0 * (msg_sum + llr) (:244-245); first pass -0.0 + q (:199) */ \
+        const double a = fabs(m);                                                                      \
+        const bool c1 = a < m1;                                                                        \
+        m2 = min_f64(m2, c1 ? m1 : a);                                                                 \
+        m1 = min_f64(m1, a);                                                                           \
+        imin = c1 ? (j) : imin;                                                                        \
+        neg |= (m < 0.0) ? (1u << (j)) : 0u;                                                           \
+    }
+    if (CQ > 0) {
+        int4 a[NQ];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int j = j0 + u;
-            if (j < deg) {
-                sx ^= __double2hiint(q[u]);                      // dec_word = out_llrs < 0 (:193, :248)
-                const double m = msa_edge(o, j, 1) + q[u];       // data * -1 + 1.0 * (msg_sum + llr) (:244-245); first pass: -0.0 + q (:199)
-                const double a = fabs(m);
-                const bool c1 = a < m1;
-                m2 = min_f64(m2, c1 ? m1 : a);
-                m1 = min_f64(m1, a);
-                imin = c1 ? j : imin;
-                neg |= (m < 0.0) ? (1u << j) : 0u;
-            }
+        for (int t = 0; t < NQ; t++) a[t] = qv[t];
+#pragma unroll
+        for (int t = 0; t < NQ; t++) {
+            CPX_MSA_IN(4 * t + 0, a[t].x) CPX_MSA_IN(4 * t + 1, a[t].y) CPX_MSA_IN(4 * t + 2, a[t].z) CPX_MSA_IN(4 * t + 3, a[t].w)
+        }
+    } else {
+        const int nq = p.cpad >> 2;
+        for (int t = 0; t < nq; t++) {
+            const int4 a = qv[t];
+            CPX_MSA_IN(4 * t + 0, a.x) CPX_MSA_IN(4 * t + 1, a.y) CPX_MSA_IN(4 * t + 2, a.z) CPX_MSA_IN(4 * t + 3, a.w)
         }
     }
+#undef CPX_MSA_IN
     if (sx < 0) *flag = 1;                                       // odd row: this iteration is executed (:205)
-    M[c * G + cw] = double2{m1, m2};
-    T[c * G + cw] = uint2{(unsigned)imin | ((unsigned)(__popc(neg) & 1) << 8), neg};
-}
-
-// ---- min-sum variable pass of one (variable, slot): column sum in increasing check order + llr (:243-247) ----------
-template <int G>
-__device__ __forceinline__ void var_msa(const ResParams &p, double *__restrict__ Q, const double2 *__restrict__ M,
-                                        const uint2 *__restrict__ T, int v, int cw, const double *__restrict__ lrow) {
-    const int vq = (p.dbg & 1) ? (v & 63) : v;
-    const int deg = p.col_ptr[vq + 1] - p.col_ptr[vq];
-    const int32_t *__restrict__ refs = p.col_pad + (int64_t)((p.dbg & 1) ? (v & 63) : v) * p.vpad;
-    const double l = (p.dbg & 2) ? 1.0 : lrow[v];
-    double msum = 0.0;
-    for (int q0 = 0; __builtin_amdgcn_ballot_w64(q0 < deg) != 0; q0 += 4) {
-        const int4 r4 = *reinterpret_cast<const int4 *>(refs + q0);
-        const int ref[4] = {r4.x, r4.y, r4.z, r4.w};
-        double2 mm[4];
-        uint2 tt[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            mm[u] = M[(ref[u] >> 5) * G + cw];
-            tt[u] = T[(ref[u] >> 5) * G + cw];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if (q0 + u < deg) {
-                const int j = ref[u] & 31;
-                const double mn = (j == (int)(tt[u].x & 0xffu)) ? mm[u].y : mm[u].x;
-                const unsigned ng = ((tt[u].y >> j) ^ (tt[u].x >> 8)) & 1u;
-                msum += __hiloint2double(__double2hiint(mn) | (int)(ng << 31), __double2loint(mn));
-            }
-        }
+    const unsigned negp = (__popc(neg) & 1) ? ~neg : neg;        // bit j: sign of the product of the OTHER messages
+#define CPX_MSA_OUT(j)                                                                                 \
+    {                                                                                                  \
+        const double mn = ((j) == imin) ? m2 : m1;                                                     \
+        const int hi = __double2hiint(mn) | (int)(((negp >> (j)) & 1u) << 31);                         \
+        if ((j) < p.min_cdeg || (j) < deg) stsd(lds, rb + 8 * (j), __hiloint2double(hi, __double2loint(mn))); \
     }
-    Q[v * G + cw] = msum + l;                                    // msg_sum + llr (:245, :247)
+    if (CQ > 0) {
+#pragma unroll
+        for (int j = 0; j < 4 * NQ; j++) CPX_MSA_OUT(j)
+    } else {
+        for (int j = 0; j < deg; j++) CPX_MSA_OUT(j)
+    }
+#undef CPX_MSA_OUT
 }
 
-// ---- sum-product check pass (:209-227); the tanh values of the row are parked in the row's own R entries ----------
-template <int G>
-__device__ __forceinline__ void check_spa(const ResParams &p, const double *__restrict__ Q, double *__restrict__ R, int c,
-                                          int cw, int *flag) {
-    const int e0 = p.row_ptr[c], deg = p.row_ptr[c + 1] - e0;
-    const int32_t *__restrict__ ev = p.row_pad + (int64_t)((p.dbg & 1) ? (c & 63) : c) * p.cpad;
-    double *__restrict__ Rr = R + (int64_t)e0 * G + cw;
+// ---- sum-product check node (:209-227); the tanh values of the row are parked in the row's own R entries ----------
+__device__ __forceinline__ void check_spa(const ResParams &p, char *lds, int c, int *flag) {
+    const int2 hdr = p.row_hdr[c];
+    const int4 *__restrict__ qv = reinterpret_cast<const int4 *>(p.row_q + (int64_t)c * p.cpad);
+    const int rb = hdr.x, deg = hdr.y;
     int sx = 0;
     double prod = 1.0;
     for (int j0 = 0; __builtin_amdgcn_ballot_w64(j0 < deg) != 0; j0 += 4) {
-        const int4 e = *reinterpret_cast<const int4 *>(ev + j0);
-        const double q[4] = {Q[e.x * G + cw], Q[e.y * G + cw], Q[e.z * G + cw], Q[e.w * G + cw]};
+        const int4 a = qv[j0 >> 2];
+        const double q[4] = {ldsd(lds, a.x), ldsd(lds, a.y), ldsd(lds, a.z), ldsd(lds, a.w)};
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int j = j0 + u;
             if (j < deg) {
                 sx ^= __double2hiint(q[u]);                      // dec_word = out_llrs < 0 (:193, :248)
-                double m = Rr[j * G] * -1.0;                     // data *= -1 (:244); first pass: 0 * -1 = -0.0
+                double m = ldsd(lds, rb + 8 * j) * -1.0;         // data *= -1 (:244); first pass: 0 * -1 = -0.0
                 m += 1.0 * q[u];                                 // data += H.multiply(msg_sum + llr).data (:245); first pass (:199)
                 m = tanh_half(m);                                // data *= .5; tanh (:210-211)
                 prod *= m;                                       // row product (reference: exp2(sum(log2)) :217-219)
-                Rr[j * G] = m;
+                stsd(lds, rb + 8 * j, m);
             }
         }
     }
     if (sx < 0) *flag = 1;
     for (int j = 0; __builtin_amdgcn_ballot_w64(j < deg) != 0; j++) {
         if (j < deg) {
-            double x = (1.0 / Rr[j * G]) * prod;                 // data = 1/data; multiply(msg_products) (:222-223)
+            double x = (1.0 / ldsd(lds, rb + 8 * j)) * prod;     // data = 1/data; multiply(msg_products) (:222-223)
             x = clip_nan(x, -1.0, 1.0);                          // (:224)
             x = atanh_twice(x);                                  // (:225-226)
-            Rr[j * G] = clip_nan(x, -500.0, 500.0);              // (:227)
+            stsd(lds, rb + 8 * j, clip_nan(x, -500.0, 500.0));   // (:227)
         }
     }
 }
 
-template <int G>
-__device__ __forceinline__ void var_spa(const ResParams &p, double *__restrict__ Q, const double *__restrict__ R, int v,
-                                        int cw, const double *__restrict__ lrow) {
-    const int vq = (p.dbg & 1) ? (v & 63) : v;
-    const int deg = p.col_ptr[vq + 1] - p.col_ptr[vq];
-    const int32_t *__restrict__ refs = p.col_pad + (int64_t)((p.dbg & 1) ? (v & 63) : v) * p.vpad;
-    const double l = (p.dbg & 2) ? 1.0 : lrow[v];
+// ---- variable node, both algorithms: column sum in increasing check order + llr (:243-247) ----------
+__device__ __forceinline__ void var_node(const ResParams &p, char *lds, int v, const double *__restrict__ lrow) {
+    const int trips = p.vgrp[__builtin_amdgcn_readfirstlane(v) >> 6];      // the lanes of a wavefront hold 64 consecutive variables
+    const int4 *__restrict__ rf = reinterpret_cast<const int4 *>(p.col_r + (int64_t)v * p.vpad);
+    const double l = lrow[v];
     double msum = 0.0;
-    for (int q0 = 0; __builtin_amdgcn_ballot_w64(q0 < deg) != 0; q0 += 4) {
-        const int4 r4 = *reinterpret_cast<const int4 *>(refs + q0);
-        const double r[4] = {R[(int64_t)r4.x * G + cw], R[(int64_t)r4.y * G + cw], R[(int64_t)r4.z * G + cw],
-                             R[(int64_t)r4.w * G + cw]};
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-            if (q0 + u < deg) msum += r[u];                      // message_matrix.sum(0) in increasing check order (:243)
+    for (int t = 0; t < trips; t++) {
+        const int4 a = rf[t];
+        const double r0 = ldsd(lds, a.x), r1 = ldsd(lds, a.y), r2 = ldsd(lds, a.z), r3 = ldsd(lds, a.w);
+        msum += r0; msum += r1; msum += r2; msum += r3;          // message_matrix.sum(0); padding adds +0.0 to a sum that is never -0.0
     }
-    Q[v * G + cw] = msum + l;
+    stsd(lds, 8 * v, msum + l);                                  // msg_sum + llr (:245, :247)
 }
 
-template <int ALG, int LG>
-__global__ __launch_bounds__(1024) void ldpc_resident_kernel(ResParams p) {
-    extern __shared__ __align__(16) double lds[];
-    constexpr int G = 1 << LG;
-    double *__restrict__ Q = lds;                                             // [nvp][G]
-    double *__restrict__ R = Q + (int64_t)p.nvp * G;                          // sum-product: [E][G]
-    double2 *__restrict__ M = reinterpret_cast<double2 *>(R);                 // min-sum: (min1, min2) [n_c][G]
-    uint2 *__restrict__ T = reinterpret_cast<uint2 *>(M + (int64_t)p.n_c * G);   // min-sum: (imin | parity << 8, negatives)
-    SlotTab *sl = ALG == CPX_LDPC_MSA ? reinterpret_cast<SlotTab *>(T + (int64_t)p.n_c * G)
-                                      : reinterpret_cast<SlotTab *>(R + p.E * G);
-    const int tid = threadIdx.x, cw = tid & (G - 1), sub = tid >> LG, npar = blockDim.x >> LG;
-    if (tid < G) { sl->blk[tid] = -1; sl->k[tid] = 0; sl->flag[tid] = 0; }
-    bool drained = false;                                                     // of the slot's own thread (tid < G)
+template <int ALG, int CQ>
+__global__ __launch_bounds__(1024, 6) void ldpc_resident_kernel(ResParams p) {
+    extern __shared__ __align__(16) char lds[];
+    int *ctl = reinterpret_cast<int *>(lds + p.ctl_off);         // [0], [1]: "unsatisfied" flag of even / odd iterations; [2]: block
+    const int tid = threadIdx.x, nt = blockDim.x;
+    if (tid == 0) {
+        stsd(lds, 8 * p.n_v, __builtin_huge_val());              // dummy Q (row padding)
+        stsd(lds, p.roff + 8 * (int)p.E, 0.0);                   // dummy R (column padding)
+    }
     for (;;) {
-        // ---- slots: an empty slot, or one that has used all its iterations, takes the next block of the queue ----
-        if (tid < G) {
-            const int b = sl->blk[tid], k = sl->k[tid];
-            sl->oblk[tid] = b;
-            sl->ok[tid] = k;
-            if (b < 0 || k >= p.max_iter) {
-                int nb = -1;
-                if (!drained) {
-                    const int t = atomicAdd(p.queue, 1);
-                    if (t < p.B) nb = t; else drained = true;
-                }
-                sl->blk[tid] = nb;
-                sl->k[tid] = 0;
-            }
+        if (tid == 0) {
+            const int t = atomicAdd(p.queue, 1);
+            ctl[2] = t < p.B ? t : -1;
         }
         __syncthreads();
-        const int b_old = sl->oblk[cw], b = sl->blk[cw];
-        if (b_old != b) {                                                     // block indices are unique: replaced
-            if (b_old >= 0) {                                                 // out of iterations: retire as it is
-                double *__restrict__ out = p.stage + (int64_t)b_old * p.n_v;
-                for (int v = sub; v < p.n_v; v += npar) out[v] = Q[v * G + cw];
-                if (sub == 0 && p.iters) p.iters[b_old] = sl->ok[cw];
-            }
-            if (b >= 0) {
-                double *__restrict__ in = p.llr + (int64_t)b * p.n_v;
-                for (int v = sub; v < p.n_v; v += npar) {
-                    const double raw = in[v];
-                    const double x = clip_nan(raw, -500.0, 500.0);
-                    if (x != raw) in[v] = x;                                  // in-place clip (:186); untouched values are not rewritten
-                    Q[v * G + cw] = x;                                        // out_llrs = llr (:194)
-                }
-                if (ALG == CPX_LDPC_MSA) {
-                    for (int c = sub; c < p.n_c; c += npar) { M[c * G + cw] = double2{0.0, 0.0}; T[c * G + cw] = uint2{0u, 0u}; }
-                } else {
-                    for (int64_t e = sub; e < p.E; e += npar) R[e * G + cw] = 0.0;
-                }
-            }
+        const int b = ctl[2];
+        if (b < 0) break;
+        if (tid == 0) { ctl[0] = 0; ctl[1] = 0; }
+        double *__restrict__ in = p.llr + (int64_t)b * p.n_v;
+        for (int v = tid; v < p.n_v; v += nt) {
+            const double raw = in[v];
+            const double x = clip_nan(raw, -500.0, 500.0);
+            if (x != raw) in[v] = x;                             // in-place clip (:186); untouched values are not rewritten
+            stsd(lds, 8 * v, x);                                 // out_llrs = llr (:194)
         }
-        int any = 0, rep = 0;
-#pragma unroll
-        for (int g = 0; g < G; g++) { any |= sl->blk[g] >= 0; rep |= sl->blk[g] != sl->oblk[g]; }
-        if (!any) break;
-        if (rep) __syncthreads();
-        // ---- check pass ----
-        if (b >= 0) {
-            for (int c = sub; c < p.n_c; c += npar) {
-                if (ALG == CPX_LDPC_MSA) check_msa<G>(p, Q, M, T, c, cw, &sl->flag[cw]);
-                else check_spa<G>(p, Q, R, c, cw, &sl->flag[cw]);
-            }
-        }
+        for (int e = tid; e < (int)p.E; e += nt) stsd(lds, p.roff + 8 * e, 0.0);
         __syncthreads();
-        // ---- verdict: an unsatisfied slot runs the variable pass, a satisfied one is retired with the Q it has (:205-206) ----
-        if (b >= 0) {
-            if (sl->flag[cw]) {
-                const double *__restrict__ lrow = p.llr + (int64_t)b * p.n_v;
-                for (int v = sub; v < p.n_v; v += npar) {
-                    if (ALG == CPX_LDPC_MSA) var_msa<G>(p, Q, M, T, v, cw, lrow);
-                    else var_spa<G>(p, Q, R, v, cw, lrow);
-                }
-            } else {
-                double *__restrict__ out = p.stage + (int64_t)b * p.n_v;
-                for (int v = sub; v < p.n_v; v += npar) out[v] = Q[v * G + cw];
-                if (sub == 0 && p.iters) p.iters[b] = sl->k[cw];
+        int k = 0;
+        for (; k < p.max_iter; k++) {
+            int *flag = &ctl[k & 1];
+            for (int c = tid; c < p.n_c; c += nt) {
+                if (ALG == CPX_LDPC_MSA) check_msa<CQ>(p, lds, c, flag);
+                else check_spa(p, lds, c, flag);
             }
+            __syncthreads();
+            if (!*flag) break;                                   // zero syndrome: the block keeps the Q it has (:205-206)
+            if (tid == 0) ctl[(k + 1) & 1] = 0;
+            for (int v = tid; v < p.n_v; v += nt) var_node(p, lds, v, in);
+            __syncthreads();
         }
-        __syncthreads();
-        if (tid < G && sl->blk[tid] >= 0) {
-            if (sl->flag[tid]) { sl->k[tid] += 1; sl->flag[tid] = 0; }
-            else sl->blk[tid] = -1;
-        }
+        double *__restrict__ out = p.stage + (int64_t)b * p.n_v;
+        for (int v = tid; v < p.n_v; v += nt) out[v] = ldsd(lds, 8 * v);     // the same thread reloads these entries for the next block
+        if (tid == 0 && p.iters) p.iters[b] = k;
     }
 }
 
@@ -283,25 +231,6 @@ __global__ __launch_bounds__(256) void ldpc_unstage_kernel(const double *__restr
     }
 }
 
-size_t state_doubles(const cpx_ldpc *c, int alg, int G) {
-    const size_t nvp = (size_t)(c->n_v + 1) & ~(size_t)1;
-    return alg == CPX_LDPC_MSA ? (nvp + 3 * (size_t)c->n_c) * G : (nvp + (size_t)c->n_edges) * G;
-}
-
-// workgroup size: the multiple of 64 in [512, 1024] that wastes the fewest thread slots in the last round of the
-// two passes (thread = (node, slot); a pass is ceil(nodes / (threads / G)) rounds)
-int pick_threads(const cpx_ldpc *c, int G) {
-    const double wc = 40.0 + 14.0 * (double)c->n_edges / c->n_c, wv = 25.0 + 12.0 * (double)c->n_edges / c->n_v;
-    int best = 1024;
-    double best_cost = 1e300;
-    for (int n = 1024; n >= 512; n -= 64) {
-        const int npar = n / G;
-        const double cost = (double)n * (((c->n_c + npar - 1) / npar) * wc + ((c->n_v + npar - 1) / npar) * wv);
-        if (cost < best_cost * 0.97) { best_cost = cost; best = n; }         // larger workgroups win near-ties
-    }
-    return best;
-}
-
 std::atomic<int> g_ldpc_path{-1};                                 // 0 auto, 1 tiled, 2 resident (strict)
 int parse_ldpc_path(const char *m) {
     if (!m || !m[0] || strcmp(m, "auto") == 0) return 0;
@@ -322,7 +251,7 @@ int ldpc_path() {
     return v;
 }
 
-template <int ALG, int LG>
+template <int ALG, int CQ>
 int launch_resident(const ResParams &p, int grid, int threads, size_t lds, hipStream_t st) {
     static bool raised[64] = {};                                  // > 64 KiB of dynamic LDS is opt-in, once per kernel and device
     static std::mutex raised_mu;
@@ -331,18 +260,57 @@ int launch_resident(const ResParams &p, int grid, int threads, size_t lds, hipSt
     {
         std::lock_guard<std::mutex> lk(raised_mu);
         if (dev >= 0 && dev < 64 && !raised[dev]) {
-            CPX_HIP(hipFuncSetAttribute((const void *)ldpc_resident_kernel<ALG, LG>, hipFuncAttributeMaxDynamicSharedMemorySize,
+            CPX_HIP(hipFuncSetAttribute((const void *)ldpc_resident_kernel<ALG, CQ>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)LDS_BYTES));
             raised[dev] = true;
         }
     }
-    hipLaunchKernelGGL((ldpc_resident_kernel<ALG, LG>), dim3((unsigned)grid), dim3((unsigned)threads), lds, st, p);
+    hipLaunchKernelGGL((ldpc_resident_kernel<ALG, CQ>), dim3((unsigned)grid), dim3((unsigned)threads), lds, st, p);
     return CPX_OK;
 }
+
+int res_roff(int n_v) { return ((n_v + 2) & ~1) * 8; }            // Q[n_v] + the dummy slot, R 16-byte aligned
+size_t res_lds_bytes(const cpx_ldpc *c) { return (size_t)res_roff(c->n_v) + 8 * ((size_t)c->n_edges + 1 + c->cpad) + 64; }
 
 }  // namespace
 
 namespace cpx {
+
+// Offset tables of the resident path, built once per handle from the blob's tables (host pointers).
+int ldpc_resident_tables(cpx_ldpc *c, const int32_t *row_ptr, const int32_t *row_pad, const int32_t *col_ptr,
+                         const int32_t *col_pad_edge) {
+    if (res_lds_bytes(c) > LDS_BYTES) return CPX_OK;              // does not fit: the handle only serves the tiled path
+    const int n_v = c->n_v, n_c = c->n_c, cpad = c->cpad, vpad = c->vpad;
+    const int roff = res_roff(n_v);
+    std::vector<int32_t> hdr(2 * (size_t)n_c), rq((size_t)n_c * cpad + 16, 8 * n_v),
+        cr((size_t)n_v * vpad + 16, roff + 8 * (int)c->n_edges), vg((size_t)(n_v + 63) / 64, 0);
+    int min_cdeg = 1 << 30;
+    for (int k = 0; k < n_c; k++) {
+        const int d = row_ptr[k + 1] - row_ptr[k];
+        min_cdeg = std::min(min_cdeg, d);
+        hdr[2 * (size_t)k] = roff + 8 * row_ptr[k];
+        hdr[2 * (size_t)k + 1] = d;
+        for (int j = 0; j < d; j++) rq[(size_t)k * cpad + j] = 8 * row_pad[(size_t)k * cpad + j];
+    }
+    for (int v = 0; v < n_v; v++) {
+        const int d = col_ptr[v + 1] - col_ptr[v];
+        vg[v >> 6] = std::max(vg[v >> 6], (d + 3) / 4);
+        for (int q = 0; q < d; q++) cr[(size_t)v * vpad + q] = roff + 8 * col_pad_edge[(size_t)v * vpad + q];
+    }
+    c->res_min_cdeg = min_cdeg;
+    struct Up { int32_t **dst; std::vector<int32_t> *src; } ups[] = {{&c->d_res_row_hdr, &hdr}, {&c->d_res_row_q, &rq},
+                                                                     {&c->d_res_col_r, &cr}, {&c->d_res_vgrp, &vg}};
+    for (auto &u : ups) {
+        hipError_t e1 = hipMalloc((void **)u.dst, sizeof(int32_t) * u.src->size());
+        hipError_t e2 = e1 == hipSuccess ? hipMemcpy(*u.dst, u.src->data(), sizeof(int32_t) * u.src->size(), hipMemcpyHostToDevice) : e1;
+        if (e2 != hipSuccess) { set_error("cpx_ldpc_create: device upload failed: %s", hipGetErrorString(e2)); return CPX_EHIP; }
+    }
+    return CPX_OK;
+}
+
+void ldpc_resident_free(cpx_ldpc *c) {
+    (void)hipFree(c->d_res_row_hdr); (void)hipFree(c->d_res_row_q); (void)hipFree(c->d_res_col_r); (void)hipFree(c->d_res_vgrp);
+}
 
 bool ldpc_resident_path(const cpx_ldpc *c, double *d_llr, int64_t B, int alg, int n_iters, int8_t *d_dec, double *d_out,
                         int32_t *d_iters, hipStream_t st, int *rc) {
@@ -355,47 +323,43 @@ bool ldpc_resident_path(const cpx_ldpc *c, double *d_llr, int64_t B, int alg, in
     if (mode == 1) return false;
     if (n_iters < 1) return reject("n_iters == 0");
     if (B >= (1ll << 30)) return reject("batch too large");
-    int LG = -1;
-    for (int lg = 4; lg >= 0; lg--)
-        if (8 * state_doubles(c, alg, 1 << lg) + sizeof(SlotTab) + 64 <= LDS_BYTES) { LG = lg; break; }
-    if (const char *e = getenv("CPX_LDPC_G")) {                   // experiment knob: slots per workgroup (log2)
-        const int lg = atoi(e);
-        if (lg >= 0 && lg <= LG) LG = lg;
-    }
-    if (LG < 0) return reject("decoder state of one block exceeds the LDS of a compute unit");
-    const int G = 1 << LG;
-    int threads = pick_threads(c, G);
+    if (!c->d_res_row_q) return reject("decoder state of one block exceeds the LDS of a compute unit");
+    const size_t lds = res_lds_bytes(c);
+    // workgroup size: the check pass in one round (two for > 1024 checks) -- (1944,1296): 704 threads, the variable pass
+    // takes three rounds; measured 2.51 ms at 704, 2.75 at 512, 3.38 at 1024 (scripts/micro/ldpc_knobs.py)
+    const int rounds = (c->n_c + 1023) / 1024;
+    int threads = std::min(1024, std::max(64, ((c->n_c + rounds - 1) / rounds + 63) / 64 * 64));
     if (const char *e = getenv("CPX_LDPC_THREADS")) {             // experiment knob
         const int t = atoi(e);
         if (t >= 64 && t <= 1024 && t % 64 == 0) threads = t;
     }
-    const size_t lds = 8 * state_doubles(c, alg, G) + sizeof(SlotTab) + 64;
     char *slab = nullptr;
     const size_t sz_stage = (sizeof(double) * (size_t)(B * c->n_v) + 255) & ~(size_t)255;
     if ((*rc = workspace(st, 0, sz_stage + 256, (void **)&slab))) return true;
     ResParams p;
     p.llr = d_llr; p.stage = (double *)slab; p.iters = d_iters; p.queue = (int *)(slab + sz_stage);
-    p.row_ptr = c->d_row_ptr; p.row_pad = c->d_row_pad; p.col_ptr = c->d_col_ptr;
-    p.col_pad = alg == CPX_LDPC_MSA ? c->d_col_pad_cj : c->d_col_pad_edge;
-    p.B = B; p.E = c->n_edges; p.n_v = c->n_v; p.nvp = (c->n_v + 1) & ~1; p.n_c = c->n_c; p.cpad = c->cpad; p.vpad = c->vpad;
-    p.max_iter = n_iters;
-    p.dbg = getenv("CPX_LDPC_DBG") ? atoi(getenv("CPX_LDPC_DBG")) : 0;
+    p.row_hdr = reinterpret_cast<const int2 *>(c->d_res_row_hdr); p.row_q = c->d_res_row_q; p.col_r = c->d_res_col_r; p.vgrp = c->d_res_vgrp;
+    p.B = B; p.E = c->n_edges; p.n_v = c->n_v; p.n_c = c->n_c; p.cpad = c->cpad; p.vpad = c->vpad;
+    p.max_iter = n_iters; p.min_cdeg = c->res_min_cdeg;
+    p.roff = res_roff(c->n_v); p.ctl_off = (int)(lds - 64);
     if (hipMemsetAsync(p.queue, 0, sizeof(int), st) != hipSuccess) { set_error("ldpc: hipMemsetAsync failed"); *rc = CPX_EHIP; return true; }
-    // one workgroup per compute unit (its LDS holds one set of slots), no more than there are slot sets to fill
-    const int per_cu = std::max<int>(1, (int)(LDS_BYTES / lds));
-    const int grid = (int)std::min<int64_t>((int64_t)device_cus() * std::min(per_cu, std::max(1, 2048 / threads)), (B + G - 1) / G);
-    int lrc = CPX_OK;
-#define CPX_RES(A, L) case (A) * 8 + (L): lrc = launch_resident<A, L>(p, grid, threads, lds, st); break;
-    switch (alg * 8 + LG) {
-        CPX_RES(CPX_LDPC_SPA, 0) CPX_RES(CPX_LDPC_SPA, 1) CPX_RES(CPX_LDPC_SPA, 2) CPX_RES(CPX_LDPC_SPA, 3) CPX_RES(CPX_LDPC_SPA, 4)
-        CPX_RES(CPX_LDPC_MSA, 0) CPX_RES(CPX_LDPC_MSA, 1) CPX_RES(CPX_LDPC_MSA, 2) CPX_RES(CPX_LDPC_MSA, 3) CPX_RES(CPX_LDPC_MSA, 4)
-    }
-#undef CPX_RES
+    // persistent grid: as many workgroups as fit a compute unit (LDS, 2048 threads, 16 workgroups), no more than blocks
+    const int per_cu = std::max(1, std::min({(int)(LDS_BYTES / lds), 2048 / threads, 16}));
+    const int grid = (int)std::min<int64_t>((int64_t)device_cus() * per_cu, B);
+    const int cq = c->cpad / 4;
+    int lrc;
+    if (alg == CPX_LDPC_SPA) lrc = launch_resident<CPX_LDPC_SPA, 0>(p, grid, threads, lds, st);
+    else if (cq == 1) lrc = launch_resident<CPX_LDPC_MSA, 1>(p, grid, threads, lds, st);
+    else if (cq == 2) lrc = launch_resident<CPX_LDPC_MSA, 2>(p, grid, threads, lds, st);
+    else if (cq == 3) lrc = launch_resident<CPX_LDPC_MSA, 3>(p, grid, threads, lds, st);
+    else if (cq == 4) lrc = launch_resident<CPX_LDPC_MSA, 4>(p, grid, threads, lds, st);
+    else lrc = launch_resident<CPX_LDPC_MSA, 0>(p, grid, threads, lds, st);
     if (lrc) { *rc = lrc; return true; }
     hipLaunchKernelGGL(ldpc_unstage_kernel, dim3((unsigned)((B + 63) / 64), (unsigned)((c->n_v + 63) / 64)), dim3(256), 0, st,
                        p.stage, B, c->n_v, d_out, d_dec);
     if (hipGetLastError() != hipSuccess) { set_error("ldpc (resident path): launch failed"); *rc = CPX_EHIP; }
-    note_kernel("ldpc_resident_kernel<%s,G=%d,threads=%d>", alg == CPX_LDPC_MSA ? "MSA" : "SPA", G, threads);
+    note_kernel("ldpc_resident_kernel<%s,%d> threads=%d workgroups/CU=%d", alg == CPX_LDPC_MSA ? "MSA" : "SPA",
+                alg == CPX_LDPC_MSA && cq <= 4 ? cq : 0, threads, per_cu);
     return true;
 }
 

@@ -1,6 +1,5 @@
 #!/usr/bin/env python3
-"""Experiment: LDS-resident LDPC kernel, workgroup size and slots per workgroup (CPX_LDPC_THREADS / CPX_LDPC_G are read
-per call by csrc/ldpc_resident.hip).  (1944,1296), B = 32768, <= 50 iterations, Eb/N0 = 3 dB and 2.2 dB."""
+"""Experiment: LDS-resident LDPC kernel, workgroup size (CPX_LDPC_THREADS is read per call by csrc/ldpc_resident.hip).  (1944,1296), B = 32768, <= 50 iterations, Eb/N0 = 3 dB and 2.2 dB."""
 import ctypes
 import os
 import sys
@@ -30,7 +29,7 @@ def main():
         tm = ctypes.c_void_p()
         lib.cpx_timer_create(ctypes.byref(tm))
         for alg, name in ((1, "MSA"), (0, "SPA")):
-            for knobs in sys.argv[1:] or ["", "T=1024", "T=896", "T=768", "T=640", "T=512", "G=1", "G=1,T=512", "G=0,T=512"]:
+            for knobs in sys.argv[1:] or ["", "T=1024", "T=768", "T=704", "T=512", "T=384", "T=256"]:
                 os.environ.pop("CPX_LDPC_THREADS", None)
                 os.environ.pop("CPX_LDPC_G", None)
                 for kv in filter(None, knobs.split(",")):
