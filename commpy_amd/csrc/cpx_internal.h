@@ -54,7 +54,7 @@ bool viterbi_codeword_path(const ::cpx_trellis *t, const double *d_coded, int64_
 
 // LDS-resident LDPC path (ldpc_resident.hip): true when it handled the call (*rc = status)
 int ldpc_resident_tables(::cpx_ldpc *c, const int32_t *row_ptr, const int32_t *row_pad, const int32_t *col_ptr,
-                         const int32_t *col_pad_edge);
+                         const int32_t *col_pad_cj);
 void ldpc_resident_free(::cpx_ldpc *c);
 bool ldpc_resident_path(const ::cpx_ldpc *c, double *d_llr, int64_t B, int alg, int n_iters, int8_t *d_dec, double *d_out,
                         int32_t *d_iters, hipStream_t st, int *rc);
@@ -114,11 +114,10 @@ struct cpx_ldpc {
     int32_t *d_col_pad_cj = nullptr;    // [n_v][vpad] (check << 5) | position
     // LDS-resident path (ldpc_resident.hip): tables of pre-scaled LDS byte offsets, null when the state of one block
     // does not fit the LDS of a compute unit
-    int32_t *d_res_row_hdr = nullptr;   // [n_c][2] (offset of the row's first R entry, degree)
+    int32_t *d_res_row_deg = nullptr;   // [n_c] check degree
     int32_t *d_res_row_q = nullptr;     // [n_c][cpad] offset of Q[variable]; padding -> a +inf slot
-    int32_t *d_res_col_r = nullptr;     // [n_v][vpad] offset of R[edge], increasing check; padding -> a +0.0 slot
+    int32_t *d_res_col_r = nullptr;     // [n_v][vpad] offset of R[check][position], increasing check; padding -> a +0.0 slot
     int32_t *d_res_vgrp = nullptr;      // [ceil(n_v/64)] chunks of four entries per group of 64 variables
-    int res_min_cdeg = 0;
 };
 
 struct cpx_modem {

@@ -749,7 +749,7 @@ int cpx_ldpc_create_from_blob(const void *blob, size_t nbytes, cpx_ldpc **out) {
             return CPX_EHIP;
         }
     }
-    if ((rc = ldpc_resident_tables(c, v.row_ptr, v.row_pad, v.col_ptr, v.col_pad_edge))) {
+    if ((rc = ldpc_resident_tables(c, v.row_ptr, v.row_pad, v.col_ptr, v.col_pad_cj))) {
         cpx_ldpc_destroy(c);
         return rc;
     }

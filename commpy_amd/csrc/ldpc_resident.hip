@@ -6,14 +6,16 @@
 // Why.  The tiled path keeps R/Q/L of 64 blocks per wavefront in HBM and runs one launch per pass: an iteration gathers
 // 2 E rows per tile through L2 (latency-bound: 0.4 + 0.6 ms per iteration at B = 32 768), frozen blocks hold lanes until a
 // move pass compacts the working set, and a decode is 4 launches x n_iters.  Here ONE persistent launch does everything:
-//   * a workgroup decodes ONE block at a time: the a-posteriori LLRs Q[n_v] and one check->variable message R[e] per edge
-//     live in LDS for the block's whole life ((1944,1296): 72.6 KB, two workgroups per compute unit);
+//   * a workgroup decodes ONE block at a time: the a-posteriori LLRs Q[n_v] and one check->variable message per edge,
+//     R[check][position] with a fixed odd row stride (the largest check degree: 11 for (1944,1296)), live in LDS for the
+//     block's whole life (72.6 KB, two workgroups per compute unit).  An even stride, e.g. the 12 doubles of the padded
+//     tables, puts every 8th lane of a wavefront on the same LDS banks: measured 3.1 instead of 2.5 ms;
 //   * thread = node.  The check pass walks the checks, the variable pass the variables; both gather from LDS (~100 cycles)
 //     instead of L2, through tables of pre-scaled LDS byte offsets (no address arithmetic in the loops).  Only the channel
 //     LLR of the variable pass (`+ llr`, :245) is re-read from HBM/L2: 8 B per variable and iteration;
 //   * rows and columns are padded to a multiple of four entries that point at two dummy slots -- Q = +inf, R = +0.0 --
-//     which are neutral for every accumulation of the passes (min, sign parity, syndrome parity, column sum), so the inner
-//     loops carry no per-edge predicate;
+//     which are neutral for every accumulation of the passes (min, sign parity, syndrome parity, column sum), and a padded
+//     row entry has its own (never gathered) R slot: the min-sum loops carry no per-edge predicate at all;
 //   * when its block's syndrome is zero (:203-206), or after n_iters iterations, the workgroup retires the block to a
 //     block-major staging buffer and takes the next one from a global queue: continuous batching replaces the scan / move /
 //     compaction kernels, and nobody waits for the slowest block of a tile.  A zero-initialised R makes the first
@@ -44,39 +46,46 @@ struct ResParams {
     double *stage;           // [B][n_v] a-posteriori LLRs of retired blocks
     int32_t *iters;          // [B] executed iterations, may be null
     int *queue;              // next block to hand out
-    const int2 *row_hdr;     // [n_c] (LDS byte offset of the row's first R entry, degree)
+    const int32_t *row_deg;  // [n_c] check degree
     const int32_t *row_q;    // [n_c][cpad] LDS byte offset of Q[variable of the j-th edge]; padding -> the +inf slot
     const int32_t *col_r;    // [n_v][vpad] LDS byte offset of R[q-th edge of the variable], increasing check; padding -> the 0.0 slot
     const int32_t *vgrp;     // [ceil(n_v / 64)] chunks of four column entries the 64 variables of a wavefront need
-    int64_t B, E;
-    int n_v, n_c, cpad, vpad, max_iter, min_cdeg;
+    int64_t B;
+    int n_r;                 // R slots = n_c * rstride (+ 1 dummy + slack for the padded reads of the last row)
+    int rstride;             // doubles per row of R: max check degree, made odd (an even stride of 8-byte words is an LDS bank conflict)
+    int n_v, n_c, cpad, vpad, max_iter;
     int roff, ctl_off;       // LDS byte offsets of R and of the control words
 };
 
-__device__ __forceinline__ double ldsd(const char *base, int off) { return *reinterpret_cast<const double *>(base + off); }
-__device__ __forceinline__ void stsd(char *base, int off, double v) { *reinterpret_cast<double *>(base + off) = v; }
+// LDS accesses by absolute byte address: the kernel declares no static LDS, so its dynamic segment starts at address 0
+// (checked at kernel entry) and the offset tables hold ready-made addresses -- no base add in front of every ds_read.
+typedef __attribute__((address_space(3))) double lds_f64;
+__device__ __forceinline__ double ldsd(int off) { return *reinterpret_cast<lds_f64 *>((unsigned)off); }
+__device__ __forceinline__ void stsd(int off, double v) { *reinterpret_cast<lds_f64 *>((unsigned)off) = v; }
+__device__ __forceinline__ void min_in_place(double &acc, double v) {   // one v_min_f64, no copy (fmin adds two canonicalising v_max)
+    asm("v_min_f64 %0, %0, %1" : "+v"(acc) : "v"(v));
+}
 
 // ---- min-sum check node (:229-238 after :244-245): m_j = Q[v_j] - R_j;  R_j <- prod_{i != j} sign(m_i) * min_{i != j} |m_i| ----
 // CQ > 0: rows of at most 4 CQ entries, fully unrolled.  The messages are written from (min1, min2, argmin, signs), exactly
 // sign(other).prod() * abs(other).min(): a zero among the others makes the minimum zero by itself.
 template <int CQ>
-__device__ __forceinline__ void check_msa(const ResParams &p, char *lds, int c, int *flag) {
-    const int2 hdr = p.row_hdr[c];
+__device__ __forceinline__ void check_msa(const ResParams &p, int c, int *flag) {
     const int4 *__restrict__ qv = reinterpret_cast<const int4 *>(p.row_q + (int64_t)c * p.cpad);
-    const int rb = hdr.x, deg = hdr.y;
+    const int rb = p.roff + 8 * c * p.rstride;
     int sx = 0, imin = 0;
     unsigned neg = 0;
     double m1 = __builtin_huge_val(), m2 = __builtin_huge_val();
     constexpr int NQ = CQ > 0 ? CQ : 1;
 #define CPX_MSA_IN(j, qoff)                                                                            \
     {                                                                                                  \
-        const double q = ldsd(lds, (qoff));                                                            \
+        const double q = ldsd(qoff);                                                                   \
         sx ^= __double2hiint(q);                                 /* dec_word = out_llrs < 0 (:193, :248) */ \
-        const double m = ldsd(lds, rb + 8 * (j)) * -1.0 + q;     /* data * -1 + 1.0 * (msg_sum + llr) (:244-245); first pass -0.0 + q (:199) */ \
+        const double m = ldsd(rb + 8 * (j)) * -1.0 + q;          /* data * -1 + 1.0 * (msg_sum + llr) (:244-245); first pass -0.0 + q (:199) */ \
         const double a = fabs(m);                                                                      \
         const bool c1 = a < m1;                                                                        \
-        m2 = min_f64(m2, c1 ? m1 : a);                                                                 \
-        m1 = min_f64(m1, a);                                                                           \
+        min_in_place(m2, c1 ? m1 : a);                                                                 \
+        min_in_place(m1, a);                                                                           \
         imin = c1 ? (j) : imin;                                                                        \
         neg |= (m < 0.0) ? (1u << (j)) : 0u;                                                           \
     }
@@ -97,78 +106,80 @@ __device__ __forceinline__ void check_msa(const ResParams &p, char *lds, int c, 
     }
 #undef CPX_MSA_IN
     if (sx < 0) *flag = 1;                                       // odd row: this iteration is executed (:205)
+    // every entry of the row (padding included: its slot is never gathered) gets +-min1, then the argmin's own entry +-min2
     const unsigned negp = (__popc(neg) & 1) ? ~neg : neg;        // bit j: sign of the product of the OTHER messages
-#define CPX_MSA_OUT(j)                                                                                 \
-    {                                                                                                  \
-        const double mn = ((j) == imin) ? m2 : m1;                                                     \
-        const int hi = __double2hiint(mn) | (int)(((negp >> (j)) & 1u) << 31);                         \
-        if ((j) < p.min_cdeg || (j) < deg) stsd(lds, rb + 8 * (j), __hiloint2double(hi, __double2loint(mn))); \
-    }
+    const int h1 = __double2hiint(m1), l1 = __double2loint(m1);
+#define CPX_MSA_OUT(j) stsd(rb + 8 * (j), __hiloint2double(h1 | (int)(((negp >> (j)) & 1u) << 31), l1));
     if (CQ > 0) {
 #pragma unroll
-        for (int j = 0; j < 4 * NQ; j++) CPX_MSA_OUT(j)
+        for (int j = 0; j < 4 * NQ - 4; j++) CPX_MSA_OUT(j)      // rstride > 4 (NQ - 1): these positions always belong to the row
+#pragma unroll
+        for (int j = 4 * NQ - 4; j < 4 * NQ; j++)
+            if (j < p.rstride) CPX_MSA_OUT(j)                    // wave-uniform: positions past the stride are the next row's
     } else {
-        for (int j = 0; j < deg; j++) CPX_MSA_OUT(j)
+        for (int j = 0; j < p.rstride; j++) CPX_MSA_OUT(j)
     }
 #undef CPX_MSA_OUT
+    stsd(rb + 8 * imin, __hiloint2double(__double2hiint(m2) | (int)(((negp >> imin) & 1u) << 31), __double2loint(m2)));
 }
 
 // ---- sum-product check node (:209-227); the tanh values of the row are parked in the row's own R entries ----------
-__device__ __forceinline__ void check_spa(const ResParams &p, char *lds, int c, int *flag) {
-    const int2 hdr = p.row_hdr[c];
+__device__ __forceinline__ void check_spa(const ResParams &p, int c, int *flag) {
+    const int deg = p.row_deg[c];
     const int4 *__restrict__ qv = reinterpret_cast<const int4 *>(p.row_q + (int64_t)c * p.cpad);
-    const int rb = hdr.x, deg = hdr.y;
+    const int rb = p.roff + 8 * c * p.rstride;
     int sx = 0;
     double prod = 1.0;
     for (int j0 = 0; __builtin_amdgcn_ballot_w64(j0 < deg) != 0; j0 += 4) {
         const int4 a = qv[j0 >> 2];
-        const double q[4] = {ldsd(lds, a.x), ldsd(lds, a.y), ldsd(lds, a.z), ldsd(lds, a.w)};
+        const double q[4] = {ldsd(a.x), ldsd(a.y), ldsd(a.z), ldsd(a.w)};
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int j = j0 + u;
             if (j < deg) {
                 sx ^= __double2hiint(q[u]);                      // dec_word = out_llrs < 0 (:193, :248)
-                double m = ldsd(lds, rb + 8 * j) * -1.0;         // data *= -1 (:244); first pass: 0 * -1 = -0.0
+                double m = ldsd(rb + 8 * j) * -1.0;              // data *= -1 (:244); first pass: 0 * -1 = -0.0
                 m += 1.0 * q[u];                                 // data += H.multiply(msg_sum + llr).data (:245); first pass (:199)
                 m = tanh_half(m);                                // data *= .5; tanh (:210-211)
                 prod *= m;                                       // row product (reference: exp2(sum(log2)) :217-219)
-                stsd(lds, rb + 8 * j, m);
+                stsd(rb + 8 * j, m);
             }
         }
     }
     if (sx < 0) *flag = 1;
     for (int j = 0; __builtin_amdgcn_ballot_w64(j < deg) != 0; j++) {
         if (j < deg) {
-            double x = (1.0 / ldsd(lds, rb + 8 * j)) * prod;     // data = 1/data; multiply(msg_products) (:222-223)
+            double x = (1.0 / ldsd(rb + 8 * j)) * prod;          // data = 1/data; multiply(msg_products) (:222-223)
             x = clip_nan(x, -1.0, 1.0);                          // (:224)
             x = atanh_twice(x);                                  // (:225-226)
-            stsd(lds, rb + 8 * j, clip_nan(x, -500.0, 500.0));   // (:227)
+            stsd(rb + 8 * j, clip_nan(x, -500.0, 500.0));        // (:227)
         }
     }
 }
 
 // ---- variable node, both algorithms: column sum in increasing check order + llr (:243-247) ----------
-__device__ __forceinline__ void var_node(const ResParams &p, char *lds, int v, const double *__restrict__ lrow) {
+__device__ __forceinline__ void var_node(const ResParams &p, int v, const double *__restrict__ lrow) {
     const int trips = p.vgrp[__builtin_amdgcn_readfirstlane(v) >> 6];      // the lanes of a wavefront hold 64 consecutive variables
     const int4 *__restrict__ rf = reinterpret_cast<const int4 *>(p.col_r + (int64_t)v * p.vpad);
     const double l = lrow[v];
     double msum = 0.0;
     for (int t = 0; t < trips; t++) {
         const int4 a = rf[t];
-        const double r0 = ldsd(lds, a.x), r1 = ldsd(lds, a.y), r2 = ldsd(lds, a.z), r3 = ldsd(lds, a.w);
+        const double r0 = ldsd(a.x), r1 = ldsd(a.y), r2 = ldsd(a.z), r3 = ldsd(a.w);
         msum += r0; msum += r1; msum += r2; msum += r3;          // message_matrix.sum(0); padding adds +0.0 to a sum that is never -0.0
     }
-    stsd(lds, 8 * v, msum + l);                                  // msg_sum + llr (:245, :247)
+    stsd(8 * v, msum + l);                                       // msg_sum + llr (:245, :247)
 }
 
 template <int ALG, int CQ>
 __global__ __launch_bounds__(1024, 6) void ldpc_resident_kernel(ResParams p) {
     extern __shared__ __align__(16) char lds[];
+    if ((unsigned)(uintptr_t)lds != 0u) __builtin_trap();        // the tables hold absolute LDS addresses (see ldsd)
     int *ctl = reinterpret_cast<int *>(lds + p.ctl_off);         // [0], [1]: "unsatisfied" flag of even / odd iterations; [2]: block
     const int tid = threadIdx.x, nt = blockDim.x;
     if (tid == 0) {
-        stsd(lds, 8 * p.n_v, __builtin_huge_val());              // dummy Q (row padding)
-        stsd(lds, p.roff + 8 * (int)p.E, 0.0);                   // dummy R (column padding)
+        stsd(8 * p.n_v, __builtin_huge_val());                   // dummy Q (row padding)
+        stsd(p.roff + 8 * p.n_r, 0.0);                           // dummy R (column padding)
     }
     for (;;) {
         if (tid == 0) {
@@ -184,25 +195,25 @@ __global__ __launch_bounds__(1024, 6) void ldpc_resident_kernel(ResParams p) {
             const double raw = in[v];
             const double x = clip_nan(raw, -500.0, 500.0);
             if (x != raw) in[v] = x;                             // in-place clip (:186); untouched values are not rewritten
-            stsd(lds, 8 * v, x);                                 // out_llrs = llr (:194)
+            stsd(8 * v, x);                                      // out_llrs = llr (:194)
         }
-        for (int e = tid; e < (int)p.E; e += nt) stsd(lds, p.roff + 8 * e, 0.0);
+        for (int e = tid; e < p.n_r; e += nt) stsd(p.roff + 8 * e, 0.0);
         __syncthreads();
         int k = 0;
         for (; k < p.max_iter; k++) {
             int *flag = &ctl[k & 1];
             for (int c = tid; c < p.n_c; c += nt) {
-                if (ALG == CPX_LDPC_MSA) check_msa<CQ>(p, lds, c, flag);
-                else check_spa(p, lds, c, flag);
+                if (ALG == CPX_LDPC_MSA) check_msa<CQ>(p, c, flag);
+                else check_spa(p, c, flag);
             }
             __syncthreads();
             if (!*flag) break;                                   // zero syndrome: the block keeps the Q it has (:205-206)
             if (tid == 0) ctl[(k + 1) & 1] = 0;
-            for (int v = tid; v < p.n_v; v += nt) var_node(p, lds, v, in);
+            for (int v = tid; v < p.n_v; v += nt) var_node(p, v, in);
             __syncthreads();
         }
         double *__restrict__ out = p.stage + (int64_t)b * p.n_v;
-        for (int v = tid; v < p.n_v; v += nt) out[v] = ldsd(lds, 8 * v);     // the same thread reloads these entries for the next block
+        for (int v = tid; v < p.n_v; v += nt) out[v] = ldsd(8 * v);          // the same thread reloads these entries for the next block
         if (tid == 0 && p.iters) p.iters[b] = k;
     }
 }
@@ -270,7 +281,8 @@ int launch_resident(const ResParams &p, int grid, int threads, size_t lds, hipSt
 }
 
 int res_roff(int n_v) { return ((n_v + 2) & ~1) * 8; }            // Q[n_v] + the dummy slot, R 16-byte aligned
-size_t res_lds_bytes(const cpx_ldpc *c) { return (size_t)res_roff(c->n_v) + 8 * ((size_t)c->n_edges + 1 + c->cpad) + 64; }
+int res_rstride(const cpx_ldpc *c) { return c->max_cdeg | 1; }
+size_t res_lds_bytes(const cpx_ldpc *c) { return (size_t)res_roff(c->n_v) + 8 * ((size_t)c->n_c * res_rstride(c) + 1 + 4) + 64; }
 
 }  // namespace
 
@@ -278,27 +290,26 @@ namespace cpx {
 
 // Offset tables of the resident path, built once per handle from the blob's tables (host pointers).
 int ldpc_resident_tables(cpx_ldpc *c, const int32_t *row_ptr, const int32_t *row_pad, const int32_t *col_ptr,
-                         const int32_t *col_pad_edge) {
+                         const int32_t *col_pad_cj) {
     if (res_lds_bytes(c) > LDS_BYTES) return CPX_OK;              // does not fit: the handle only serves the tiled path
     const int n_v = c->n_v, n_c = c->n_c, cpad = c->cpad, vpad = c->vpad;
-    const int roff = res_roff(n_v);
-    std::vector<int32_t> hdr(2 * (size_t)n_c), rq((size_t)n_c * cpad + 16, 8 * n_v),
-        cr((size_t)n_v * vpad + 16, roff + 8 * (int)c->n_edges), vg((size_t)(n_v + 63) / 64, 0);
-    int min_cdeg = 1 << 30;
+    const int roff = res_roff(n_v), rs = res_rstride(c);
+    std::vector<int32_t> dg((size_t)n_c), rq((size_t)n_c * cpad + 16, 8 * n_v),
+        cr((size_t)n_v * vpad + 16, roff + 8 * n_c * rs), vg((size_t)(n_v + 63) / 64, 0);
     for (int k = 0; k < n_c; k++) {
         const int d = row_ptr[k + 1] - row_ptr[k];
-        min_cdeg = std::min(min_cdeg, d);
-        hdr[2 * (size_t)k] = roff + 8 * row_ptr[k];
-        hdr[2 * (size_t)k + 1] = d;
+        dg[k] = d;
         for (int j = 0; j < d; j++) rq[(size_t)k * cpad + j] = 8 * row_pad[(size_t)k * cpad + j];
     }
     for (int v = 0; v < n_v; v++) {
         const int d = col_ptr[v + 1] - col_ptr[v];
         vg[v >> 6] = std::max(vg[v >> 6], (d + 3) / 4);
-        for (int q = 0; q < d; q++) cr[(size_t)v * vpad + q] = roff + 8 * col_pad_edge[(size_t)v * vpad + q];
+        for (int q = 0; q < d; q++) {
+            const int cj = col_pad_cj[(size_t)v * vpad + q];      // (check << 5) | position of the edge in its row
+            cr[(size_t)v * vpad + q] = roff + 8 * ((cj >> 5) * rs + (cj & 31));
+        }
     }
-    c->res_min_cdeg = min_cdeg;
-    struct Up { int32_t **dst; std::vector<int32_t> *src; } ups[] = {{&c->d_res_row_hdr, &hdr}, {&c->d_res_row_q, &rq},
+    struct Up { int32_t **dst; std::vector<int32_t> *src; } ups[] = {{&c->d_res_row_deg, &dg}, {&c->d_res_row_q, &rq},
                                                                      {&c->d_res_col_r, &cr}, {&c->d_res_vgrp, &vg}};
     for (auto &u : ups) {
         hipError_t e1 = hipMalloc((void **)u.dst, sizeof(int32_t) * u.src->size());
@@ -309,7 +320,7 @@ int ldpc_resident_tables(cpx_ldpc *c, const int32_t *row_ptr, const int32_t *row
 }
 
 void ldpc_resident_free(cpx_ldpc *c) {
-    (void)hipFree(c->d_res_row_hdr); (void)hipFree(c->d_res_row_q); (void)hipFree(c->d_res_col_r); (void)hipFree(c->d_res_vgrp);
+    (void)hipFree(c->d_res_row_deg); (void)hipFree(c->d_res_row_q); (void)hipFree(c->d_res_col_r); (void)hipFree(c->d_res_vgrp);
 }
 
 bool ldpc_resident_path(const cpx_ldpc *c, double *d_llr, int64_t B, int alg, int n_iters, int8_t *d_dec, double *d_out,
@@ -338,9 +349,9 @@ bool ldpc_resident_path(const cpx_ldpc *c, double *d_llr, int64_t B, int alg, in
     if ((*rc = workspace(st, 0, sz_stage + 256, (void **)&slab))) return true;
     ResParams p;
     p.llr = d_llr; p.stage = (double *)slab; p.iters = d_iters; p.queue = (int *)(slab + sz_stage);
-    p.row_hdr = reinterpret_cast<const int2 *>(c->d_res_row_hdr); p.row_q = c->d_res_row_q; p.col_r = c->d_res_col_r; p.vgrp = c->d_res_vgrp;
-    p.B = B; p.E = c->n_edges; p.n_v = c->n_v; p.n_c = c->n_c; p.cpad = c->cpad; p.vpad = c->vpad;
-    p.max_iter = n_iters; p.min_cdeg = c->res_min_cdeg;
+    p.row_deg = c->d_res_row_deg; p.row_q = c->d_res_row_q; p.col_r = c->d_res_col_r; p.vgrp = c->d_res_vgrp;
+    p.B = B; p.rstride = res_rstride(c); p.n_r = c->n_c * p.rstride; p.n_v = c->n_v; p.n_c = c->n_c; p.cpad = c->cpad; p.vpad = c->vpad;
+    p.max_iter = n_iters;
     p.roff = res_roff(c->n_v); p.ctl_off = (int)(lds - 64);
     if (hipMemsetAsync(p.queue, 0, sizeof(int), st) != hipSuccess) { set_error("ldpc: hipMemsetAsync failed"); *rc = CPX_EHIP; return true; }
     // persistent grid: as many workgroups as fit a compute unit (LDS, 2048 threads, 16 workgroups), no more than blocks
