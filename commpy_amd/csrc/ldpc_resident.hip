@@ -167,6 +167,9 @@ __device__ __forceinline__ void var_node(const ResParams &p, int v, const double
         const int4 a = rf[t];
         const double r0 = ldsd(a.x), r1 = ldsd(a.y), r2 = ldsd(a.z), r3 = ldsd(a.w);
         msum += r0; msum += r1; msum += r2; msum += r3;          // message_matrix.sum(0); padding adds +0.0 to a sum that is never -0.0
+        // (skipping the entries nobody in the wavefront has -- wave-uniform branches around the reads, same for the 12th row
+        //  position in check_msa -- saves 10 % of the LDS traffic and measured 3.55 instead of 2.30 ms: the branches fence the
+        //  scheduler and every read waits alone)
     }
     stsd(8 * v, msum + l);                                       // msg_sum + llr (:245, :247)
 }

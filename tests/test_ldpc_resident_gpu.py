@@ -106,3 +106,27 @@ def test_resident_strict_mode_and_zero_iterations(gpu, paths):
     assert np.array_equal(out.reshape(-1, order="F"), llr)          # out_llrs = llr (ldpc.py:194)
     with pytest.raises(Exception):
         paths.ldpc_set_path("bogus")
+
+
+def test_auto_falls_back_to_tiled_for_codes_beyond_lds(gpu, paths):
+    """A Tanner graph whose per-block state (Q + one message per edge) exceeds the 160 KB of a compute unit: 'auto' takes the
+    tiled HBM path, 'resident' refuses, results against the oracle."""
+    from test_random_codes_gpu import _random_ldpc
+    from commpy_amd.channelcoding import ldpc_bp_decode
+    rs = np.random.RandomState(8)
+    n_v, n_c = 9000, 4500
+    p = _random_ldpc(rs, n_v, n_c, rs.randint(3, 6, size=n_c))      # ~18 000 edges + 9 000 LLRs > 160 KB
+    B = 5
+    llr = (2.0 + 1.3 * rs.randn(B * n_v)) * 1.5
+    for alg, iters in (("MSA", 6), ("SPA", 4)):
+        dec, out, its = ldpc_bp_decode(llr.copy(), dict(p), alg, iters, return_iterations=True)
+        assert "tiled" in paths.last_kernel()
+        do, oo, io = oracle.ldpc_bp_decode(llr.copy(), dict(p), alg, iters, True)
+        assert np.array_equal(its, io) and np.array_equal(dec, do), alg
+        if alg == "MSA":
+            assert np.array_equal(out, oo)
+        else:
+            assert np.all(np.abs(out - oo) <= 1e-5 + 1e-6 * np.abs(oo))
+    paths.ldpc_set_path("resident")
+    with pytest.raises(Exception):
+        ldpc_bp_decode(llr.copy(), dict(p), "MSA", 3)
