@@ -110,6 +110,9 @@ def main():
     ap.add_argument("--synth", choices=("device", "host"), default="device",
                     help="where the synthetic input is generated: on the GPU (Philox bits/noise, device encoder and "
                          "modulator; fast, no large host arrays) or on the host (NumPy MT19937, SURVEY 8d seeds)")
+    ap.add_argument("--precision", choices=("fp64-parity", "fp32-fast"), default="fp64-parity",
+                    help="fp32-fast: the float32 variant of the fused kernel (cpx_set_precision) -- NOT the parity mode and not the "
+                         "headline: the line then carries dtype f32 and the measured mismatch count against the float64 oracle")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -128,6 +131,7 @@ def main():
     lib = _lib.load()
     _lib.require_device()
     _lib.check(lib.cpx_set_device(local_rank))
+    _lib.set_precision(args.precision)
     if distributed and args.comm == "rccl":
         from commpy_amd.parallel import RankComm
         try:
@@ -318,7 +322,8 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
                 tj = json.load(f)
-            same = tj.get("batch") == B and kernel_name.split("<")[0] in tj.get("kernel", "?")   # rocprofv3 prints the
+            same = (tj.get("batch") == B and kernel_name.split("<")[0] in tj.get("kernel", "?") and
+                    args.precision == "fp64-parity")                     # (the counters were taken in parity mode)   rocprofv3 prints the
             # template arguments as numbers ("<6, 109u, 79u, 1, 28>"): the kernel's base name and the batch identify it
             if same:
                 traffic = tj["traffic_bytes_per_launch"]
@@ -330,7 +335,8 @@ def main():
             "metric": "decoded info-bits/s at fixed Eb/N0 (Viterbi K=7 r=1/2, 1024b); BER match",
             "value": value, "unit": "info-bits/s", "n_gpus": world if distributed else 1, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64" if args.precision == "fp64-parity" else "f32 (fp32-fast mode: not bit-exact, see oracle_mismatched_bits)",
             "data": "synthetic (%s-generated: random messages -> conv_encode -> QPSK -> AWGN -> soft demod on device)" % args.synth,
             "config": {"workload": "configs[1]: K=7 (0o133,0o171) r=1/2, 1024-bit blocks, soft Viterbi over "
                                    "AWGN+QPSK at Eb/N0=3 dB, batch=%d codewords per GPU, tb_depth=30" % B,

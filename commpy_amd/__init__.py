@@ -14,4 +14,14 @@ __version__ = "0.1.0"
 
 from commpy_amd import utilities  # noqa: F401
 
-__all__ = ["channelcoding", "modulation", "utilities", "parallel"]
+
+
+def set_precision(mode):
+    """Precision mode of the engine: 'fp64-parity' (default: float64 in the reference's operation order, the mode every parity
+    claim is made in) or 'fp32-fast' (float32 variants where a kernel has one -- today the large-batch Viterbi kernel; not
+    bit-exact).  Also settable through the environment variable CPX_PRECISION before the first call."""
+    from commpy_amd import _lib
+    _lib.set_precision(mode)
+
+
+__all__ = ["channelcoding", "modulation", "utilities", "parallel", "set_precision"]

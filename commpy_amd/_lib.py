@@ -28,6 +28,8 @@ SYMBOLS = {
     "cpx_set_device": (c_int, [c_int]),
     "cpx_get_device": (c_int, [POINTER(c_int)]),
     "cpx_last_kernel": (c_int, [c_char_p, c_int]),
+    "cpx_set_precision": (c_int, [c_char_p]),
+    "cpx_get_precision": (c_int, []),
     "cpx_device_info": (c_int, [c_char_p, c_int, POINTER(c_int), POINTER(c_int64)]),
     "cpx_malloc": (c_int, [POINTER(c_void_p), c_size_t]),
     "cpx_free": (c_int, [c_void_p]),
@@ -188,6 +190,15 @@ def last_kernel():
     buf = ctypes.create_string_buffer(200)
     check(load().cpx_last_kernel(buf, 200))
     return buf.value.decode()
+
+
+def set_precision(mode):
+    """'fp64-parity' (default; None resets to it) or 'fp32-fast' (float32 variants where they exist; not bit-exact)."""
+    check(load().cpx_set_precision(None if mode is None else mode.encode()))
+
+
+def get_precision():
+    return "fp32-fast" if load().cpx_get_precision() else "fp64-parity"
 
 
 def viterbi_last_path():

@@ -59,6 +59,9 @@ void ldpc_resident_free(::cpx_ldpc *c);
 bool ldpc_resident_path(const ::cpx_ldpc *c, double *d_llr, int64_t B, int alg, int n_iters, int8_t *d_dec, double *d_out,
                         int32_t *d_iters, hipStream_t st, int *rc);
 
+// precision mode (cpx_set_precision / CPX_PRECISION): false = fp64-parity (default), true = fp32-fast
+bool precision_fast();
+
 int viterbi_path_flags();   // bit 0 wave only, bit 1 codeword path forced, bit 2 strict, bit 3 two-kernel form
 
 inline hipStream_t pick_stream(void *s) { return s ? reinterpret_cast<hipStream_t>(s) : lib_stream(); }

@@ -2,6 +2,8 @@
 // HIP-event timers.  No compute here.
 #include "cpx_internal.h"
 
+#include <atomic>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -96,6 +98,8 @@ int ensure_device() {
 
 using namespace cpx;
 
+static std::atomic<int> g_precision{-1};   // -1: not read from CPX_PRECISION yet, 0 fp64-parity, 1 fp32-fast
+
 extern "C" {
 
 const char *cpx_last_error(void) { return g_err; }
@@ -132,9 +136,32 @@ int cpx_last_kernel(char *name, int cap) {
     return CPX_OK;
 }
 
+int cpx_set_precision(const char *mode) {
+    int v = -1;
+    if (!mode || !mode[0] || strcmp(mode, "fp64-parity") == 0 || strcmp(mode, "fp64") == 0) v = 0;
+    else if (strcmp(mode, "fp32-fast") == 0 || strcmp(mode, "fp32") == 0) v = 1;
+    CPX_REQUIRE(v >= 0, CPX_EINVAL, "cpx_set_precision: unknown mode '%s' (fp64-parity | fp32-fast)", mode);
+    g_precision.store(v, std::memory_order_relaxed);
+    return CPX_OK;
+}
+
+int cpx_get_precision(void) { return cpx::precision_fast() ? 1 : 0; }
+
 }  // extern "C"
 
 namespace cpx {
+bool precision_fast() {
+    int v = g_precision.load(std::memory_order_relaxed);
+    if (v < 0) {
+        static std::once_flag once;
+        std::call_once(once, [] {
+            const char *e = getenv("CPX_PRECISION");
+            g_precision.store(e && (strcmp(e, "fp32-fast") == 0 || strcmp(e, "fp32") == 0) ? 1 : 0, std::memory_order_relaxed);
+        });
+        v = g_precision.load(std::memory_order_relaxed);
+    }
+    return v == 1;
+}
 int device_cus() {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 256;

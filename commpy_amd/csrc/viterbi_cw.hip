@@ -199,6 +199,105 @@ __device__ __forceinline__ void cw_step(double (&pm)[1 << LGS], double r0, doubl
     best = bst;
 }
 
+// ---- float32 path metrics: the "fp32-fast" mode (cpx_set_precision) -- NOT the parity mode ------------------
+// 'soft' and 'unquantized' metrics in float32: the soft branch metric is the stable form max(r,0) + log(1 + e^-|r|) of the
+// reference's log(e^r + 1) through the hardware exp2/log2, and near-ties between path metrics may resolve differently
+// (measured mismatch rate: DESIGN.md 4.1).  'hard' metrics of 0/1 inputs are Hamming distances <= 2 T, exact in float32
+// for T < 2^22: identical bits.
+// Same structure as cw_step: in-place butterflies, decision words, first-argmin state; the minimum tree uses v_min3_f32.
+__device__ __forceinline__ float acs_min_f32(unsigned &acc, float x, float y) {
+    float r;
+    asm("v_cmp_lt_f32 vcc, %3, %2\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc\n\tv_min_f32 %0, %2, %3"
+        : "=&v"(r), "+v"(acc) : "v"(x), "v"(y) : "vcc");
+    return r;
+}
+__device__ __forceinline__ float vmin3_f32(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ void bit_metrics_f32(int type, double r, float &m0, float &m1) {
+    if (type == CPX_VIT_HARD) {
+        const long long ri = (long long)r;
+        m0 = (float)(ri ^ 0ll);
+        m1 = (float)(ri ^ 1ll);
+    } else if (type == CPX_VIT_SOFT) {
+        const float x = (float)r;
+        const float sp = fmaxf(x, 0.0f) + __logf(1.0f + __expf(-fabsf(x)));
+        m0 = sp;
+        m1 = sp - x;
+    } else {
+        const float x = (float)r, d0 = x + 1.0f, d1 = x - 1.0f;
+        m0 = d0 * d0;
+        m1 = d1 * d1;
+    }
+}
+
+template <int LGS, unsigned G0, unsigned G1, int TYPE, int R, class Hook = NoHook>
+__device__ __forceinline__ void cw_step(float (&pm)[1 << LGS], double r0, double r1, unsigned long long &word, int &best,
+                                        const Hook &hook = Hook()) {
+    using C = SrCode<LGS, G0, G1>;
+    constexpr int S = 1 << LGS, H = S / 2;
+    if (TYPE == CPX_VIT_SOFT) {                                    // coded_bits.clip(-500, 500) (:719)
+        r0 = fmin(fmax(r0, -500.0), 500.0);
+        r1 = fmin(fmax(r1, -500.0), 500.0);
+    }
+    float m00, m01, m10, m11;
+    bit_metrics_f32(TYPE, r0, m00, m01);
+    bit_metrics_f32(TYPE, r1, m10, m11);
+    float bmv[4];
+    bmv[0] = (0.0f + m00) + m10; bmv[1] = (0.0f + m00) + m11;
+    bmv[2] = (0.0f + m01) + m10; bmv[3] = (0.0f + m01) + m11;
+    unsigned da = 0, db = 0;
+    hook.template at<0>();
+#pragma unroll
+    for (int j = 0; j < H; j++) {
+        if (j == H / 2) hook.template at<1>();
+        const int x = rotl<LGS>(2 * j, R), y = rotl<LGS>(2 * j + 1, R);
+        const float a = pm[x], b = pm[y];
+        const float a0 = a + bmv[C::code(j, 0)], a1 = b + bmv[C::code(j, 1)];
+        const float b0 = a + bmv[C::code(j + H, 0)], b1 = b + bmv[C::code(j + H, 1)];
+        pm[x] = acs_min_f32(da, a0, a1);
+        pm[y] = acs_min_f32(db, b0, b1);
+    }
+    hook.template at<2>();
+    float mn;
+    if constexpr (S >= 8 && S % 8 == 0) {
+        float m0 = pm[0], m1 = pm[1], m2 = pm[2], m3 = pm[3];
+#pragma unroll
+        for (int s = 4; s + 8 <= S; s += 8) {
+            m0 = vmin3_f32(m0, pm[s], pm[s + 1]); m1 = vmin3_f32(m1, pm[s + 2], pm[s + 3]);
+            m2 = vmin3_f32(m2, pm[s + 4], pm[s + 5]); m3 = vmin3_f32(m3, pm[s + 6], pm[s + 7]);
+        }
+        m0 = vmin3_f32(m0, pm[S - 4], pm[S - 3]);
+        m1 = vmin3_f32(m1, pm[S - 2], pm[S - 1]);
+        mn = fminf(vmin3_f32(m0, m1, m2), m3);
+    } else {
+        mn = pm[0];
+#pragma unroll
+        for (int s = 1; s < S; s++) mn = fminf(mn, pm[s]);
+    }
+    hook.template at<3>();
+    int bst = 0;
+    if constexpr (S % 4 == 0) {
+#pragma unroll
+        for (int s = S - 4; s >= 0; s -= 4) {
+            unsigned long long k0, k1, k2, k3;
+            asm("v_cmp_eq_f32 %1, %5, %9\n\tv_cmp_eq_f32 %2, %6, %9\n\tv_cmp_eq_f32 %3, %7, %9\n\tv_cmp_eq_f32 %4, %8, %9\n\t"
+                "v_cndmask_b32 %0, %0, %10, %1\n\tv_cndmask_b32 %0, %0, %11, %2\n\tv_cndmask_b32 %0, %0, %12, %3\n\t"
+                "v_cndmask_b32 %0, %0, %13, %4"
+                : "+v"(bst), "=&s"(k0), "=&s"(k1), "=&s"(k2), "=&s"(k3)
+                : "v"(pm[rotl<LGS>(s + 3, R + 1)]), "v"(pm[rotl<LGS>(s + 2, R + 1)]), "v"(pm[rotl<LGS>(s + 1, R + 1)]),
+                  "v"(pm[rotl<LGS>(s, R + 1)]), "v"(mn), "n"(s + 3), "n"(s + 2), "n"(s + 1), "n"(s));
+        }
+    } else {
+#pragma unroll
+        for (int s = S - 1; s >= 0; s--) bst = (pm[rotl<LGS>(s, R + 1)] == mn) ? s : bst;
+    }
+    word = ((unsigned long long)da << (64 - H)) | ((unsigned long long)db << (64 - S));
+    best = bst;
+}
+
 // Workgroups of four wavefronts (one group of 64 codewords each): the four waves of a workgroup land on the four SIMDs
 // of one CU, so 256 workgroups put exactly one wave on every SIMD of the chip.  (With single-wave workgroups the
 // dispatcher packed two waves per SIMD on half of the CUs for B = 65536: 2.98 ms instead of 1.75 ms.)
@@ -322,7 +421,7 @@ struct WalkHook {
     }
 };
 
-template <int LGS, unsigned G0, unsigned G1, int TYPE, int HT, bool RT = false>
+template <int LGS, unsigned G0, unsigned G1, int TYPE, int HT, bool RT = false, class F = double>
 __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_fused_kernel(CwParams p) {
     constexpr int S = 1 << LGS, FR_GROUPS = FR_CHUNK / LGS, CHUNK = FR_GROUPS * LGS;
     static_assert(HT >= 0 && HT + 1 <= FR_RING && CHUNK + 1 <= FR_OBPAD, "ring / tile too small");
@@ -339,9 +438,9 @@ __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_fused_kernel(CwPara
     unsigned long long *mycol = ring + lane;                                       // slot s of this lane's codeword: mycol[s * 64]
     unsigned char *myrow = obuf + lane * FR_OBPAD;
 
-    double pm[S];
+    F pm[S];
 #pragma unroll
-    for (int s = 0; s < S; s++) pm[s] = (s == 0) ? 0.0 : __builtin_huge_val();   // path_metrics[:,0] = inf, [0][0] = 0 (:705-706)
+    for (int s = 0; s < S; s++) pm[s] = (s == 0) ? (F)0.0 : (F)__builtin_huge_val();   // path_metrics[:,0] = inf, [0][0] = 0 (:705-706)
 
     const double pad = (TYPE == CPX_VIT_UNQUANTIZED) ? -1.0 : 0.0;                // t > L//k -> padding (:722-734)
     const int T = (int)p.T, tmax = (int)((p.Lk < p.T) ? p.Lk : p.T);              // 32-bit step indices, see the ACS kernel
@@ -546,9 +645,9 @@ void launch(const CwParams &p, size_t tb_lds, hipStream_t st) {
 // (convcode.py:701); every smaller depth runs it with a run-time hop count
 template <int LGS> constexpr int fused_tb() { return 5 * LGS; }
 
-template <int LGS, unsigned G0, unsigned G1, int TYPE, bool RT>
+template <int LGS, unsigned G0, unsigned G1, int TYPE, bool RT, class F>
 int launch_fused_typed(const CwParams &p, hipStream_t st) {
-    auto *fn = viterbi_cw_fused_kernel<LGS, G0, G1, TYPE, fused_tb<LGS>() - 2, RT>;
+    auto *fn = viterbi_cw_fused_kernel<LGS, G0, G1, TYPE, fused_tb<LGS>() - 2, RT, F>;
     const size_t lds = ACS_WAVES * fused_wave_lds<LGS>();
     static bool raised[64] = {};                                 // > 64 KiB of dynamic LDS is opt-in, once per kernel and device
     static std::mutex raised_mu;                                 // host threads may launch concurrently (ctypes drops the GIL)
@@ -568,12 +667,12 @@ int launch_fused_typed(const CwParams &p, hipStream_t st) {
 }
 
 // the default depth runs the compile-time walk; smaller depths the same kernel with a run-time hop count
-template <int LGS, unsigned G0, unsigned G1>
+template <int LGS, unsigned G0, unsigned G1, class F>
 int launch_fused(const CwParams &p, hipStream_t st) {
     const bool rt = p.tb != fused_tb<LGS>();
-    if (p.type == CPX_VIT_HARD) return rt ? launch_fused_typed<LGS, G0, G1, CPX_VIT_HARD, true>(p, st) : launch_fused_typed<LGS, G0, G1, CPX_VIT_HARD, false>(p, st);
-    if (p.type == CPX_VIT_SOFT) return rt ? launch_fused_typed<LGS, G0, G1, CPX_VIT_SOFT, true>(p, st) : launch_fused_typed<LGS, G0, G1, CPX_VIT_SOFT, false>(p, st);
-    return rt ? launch_fused_typed<LGS, G0, G1, CPX_VIT_UNQUANTIZED, true>(p, st) : launch_fused_typed<LGS, G0, G1, CPX_VIT_UNQUANTIZED, false>(p, st);
+    if (p.type == CPX_VIT_HARD) return rt ? launch_fused_typed<LGS, G0, G1, CPX_VIT_HARD, true, F>(p, st) : launch_fused_typed<LGS, G0, G1, CPX_VIT_HARD, false, F>(p, st);
+    if (p.type == CPX_VIT_SOFT) return rt ? launch_fused_typed<LGS, G0, G1, CPX_VIT_SOFT, true, F>(p, st) : launch_fused_typed<LGS, G0, G1, CPX_VIT_SOFT, false, F>(p, st);
+    return rt ? launch_fused_typed<LGS, G0, G1, CPX_VIT_UNQUANTIZED, true, F>(p, st) : launch_fused_typed<LGS, G0, G1, CPX_VIT_UNQUANTIZED, false, F>(p, st);
 }
 
 }  // namespace
@@ -631,12 +730,16 @@ bool viterbi_codeword_path(const cpx_trellis *t, const double *d_coded, int64_t 
     CwParams p;
     p.coded = d_coded; p.bits = d_bits; p.B = B; p.len = len; p.L = L; p.T = T; p.Lk = L;   // k = 1
     p.type = type; p.tb = tb;
+    // float32 path metrics when the caller selected "fp32-fast" (cpx_set_precision) -- fused kernel only.  ('hard' metrics
+    // of 0/1 inputs are Hamming distances <= 2 T, exact in float32: there the fast mode returns identical bits.)
+    const bool f32 = precision_fast() && T < (1ll << 22);
 #define CPX_TRY(LG, GA, GB)                                                                                         \
     if (tables_match<LG, GA, GB>(t)) {                                                                              \
-        if (tb >= 2 && tb <= fused_tb<LG>() && !two_kernels && launch_fused<LG, GA, GB>(p, st)) {                       \
+        if (tb >= 2 && tb <= fused_tb<LG>() && !two_kernels &&                                                      \
+            (f32 ? launch_fused<LG, GA, GB, float>(p, st) : launch_fused<LG, GA, GB, double>(p, st))) {                 \
             if (hipGetLastError() != hipSuccess) { set_error("viterbi (fused codeword path): launch failed"); *rc = CPX_EHIP; } \
-            note_kernel("viterbi_cw_fused_kernel<%d,0%o,0%o,%s,%d%s>", LG, GA, GB, type_name(type), fused_tb<LG>() - 2,       \
-                        tb == fused_tb<LG>() ? "" : ",runtime hops");                                                  \
+            note_kernel("viterbi_cw_fused_kernel<%d,0%o,0%o,%s,%d%s%s>", LG, GA, GB, type_name(type), fused_tb<LG>() - 2,     \
+                        tb == fused_tb<LG>() ? "" : ",runtime hops", f32 ? ",f32" : "");                               \
             return true;                                                                                            \
         }                                                                                                           \
         void *w0 = nullptr, *w1 = nullptr;                                                                          \

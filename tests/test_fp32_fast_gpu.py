@@ -1,0 +1,89 @@
+"""The "fp32-fast" precision mode (cpx_set_precision): float32 path metrics in the fused codeword-per-lane Viterbi
+kernel.  It is NOT the parity mode -- the contract here is a measured, bounded mismatch rate against the float64 kernels
+(convcode.py:661-749 semantics) and an unchanged bit error rate; 'hard' decoding of 0/1 inputs stays bit-identical (its
+metrics are small integers).  Everything else must be untouched by the switch."""
+import numpy as np
+import pytest
+
+import oracle
+from helpers import make_trellis
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def lib():
+    from commpy_amd import _lib
+    yield _lib
+    _lib.set_precision(None)
+    _lib.viterbi_set_path(None)
+
+
+def _config2_batch(B, ebn0_db, seed):
+    from commpy_amd.channelcoding import conv_encode_batch
+    tr = make_trellis("k7_133_171")
+    rs = np.random.RandomState(seed)
+    msgs = rs.randint(0, 2, (B, 1024)).astype(np.uint8)
+    coded = conv_encode_batch(msgs, tr)
+    N0 = 2.0 / (0.5 * 2 * 10 ** (ebn0_db / 10.0))
+    y = (2.0 * coded - 1.0) + np.sqrt(N0 / 2) * rs.standard_normal(coded.shape).astype(np.float32)
+    return tr, msgs, coded, np.ascontiguousarray((4.0 / N0) * y, dtype=np.float64), y
+
+
+def test_soft_fast_mode_mismatch_rate_and_ber(gpu, lib):
+    import commpy_amd
+    from commpy_amd.channelcoding import viterbi_decode
+    tr, msgs, _, llr, _ = _config2_batch(65536, 3.0, 10)
+    ref = viterbi_decode(llr, tr, None, "soft")
+    assert lib.viterbi_last_path() == "fused" and "f32" not in lib.last_kernel()
+    commpy_amd.set_precision("fp32-fast")
+    assert lib.get_precision() == "fp32-fast"
+    fast = viterbi_decode(llr, tr, None, "soft")
+    assert "viterbi_cw_fused_kernel" in lib.last_kernel() and ",f32" in lib.last_kernel(), lib.last_kernel()
+    commpy_amd.set_precision("fp64-parity")
+    again = viterbi_decode(llr, tr, None, "soft")
+    assert np.array_equal(again, ref) and "f32" not in lib.last_kernel()          # the switch really switches back
+    mism = float(np.mean(fast != ref))
+    ber_ref, ber_fast = np.mean(ref[:, :1024] != msgs), np.mean(fast[:, :1024] != msgs)
+    print("fp32-fast soft, config-2 batch at 3 dB: mismatching bits vs fp64 %.3e, BER fp64 %.4e, BER fp32 %.4e" % (
+        mism, ber_ref, ber_fast))
+    assert mism < 2e-5, mism                                                      # measured ~1e-6
+    assert abs(ber_fast - ber_ref) < 0.02 * ber_ref + 1e-6
+
+
+@pytest.mark.parametrize("dtype", ["hard", "unquantized"])
+def test_hard_is_identical_and_unquantized_close(gpu, lib, dtype):
+    from commpy_amd.channelcoding import viterbi_decode
+    tr, msgs, coded, llr, y = _config2_batch(49152, 4.0, 11)
+    x = (y > 0).astype(np.float64) if dtype == "hard" else np.ascontiguousarray(y, dtype=np.float64)
+    ref = viterbi_decode(x, tr, None, dtype)
+    assert lib.viterbi_last_path() == "fused"
+    lib.set_precision("fp32-fast")
+    fast = viterbi_decode(x, tr, None, dtype)
+    assert ",f32" in lib.last_kernel()
+    if dtype == "hard":
+        assert np.array_equal(fast, ref)                                           # integer metrics: exact in float32
+        want = oracle.viterbi_decode_mt(x[:512], tr, None, "hard")
+        assert np.array_equal(fast[:512], want)
+    else:
+        assert np.mean(fast != ref) < 2e-5
+
+
+def test_fast_mode_leaves_every_other_kernel_alone(gpu, lib):
+    """Small batches (state-per-lane kernels), other traceback depths beyond the fused kernel, LDPC, demod: same results."""
+    from commpy_amd.channelcoding import ldpc_bp_decode, viterbi_decode
+    from helpers import ldpc_params
+    tr = make_trellis("k7_133_171")
+    rs = np.random.RandomState(2)
+    x = rs.randn(40, 2 * 200) * 2
+    p = ldpc_params("gallager96")
+    l = rs.randn(96 * 7) * 3
+    a = viterbi_decode(x, tr, None, "soft")
+    d0, o0 = ldpc_bp_decode(l.copy(), p, "SPA", 5)
+    lib.set_precision("fp32-fast")
+    b = viterbi_decode(x, tr, None, "soft")
+    d1, o1 = ldpc_bp_decode(l.copy(), p, "SPA", 5)
+    assert "f32" not in lib.last_kernel()
+    assert np.array_equal(a, b) and np.array_equal(d0, d1) and np.array_equal(o0, o1)
+    with pytest.raises(Exception):
+        lib.set_precision("fp16")
