@@ -169,31 +169,43 @@ struct RawChunk {
     double r0[2], r1[2], li[2];
 };
 
+// The arrays of a pass, seen from the pair of wavefronts that runs it: every pointer is wave-uniform and already points at
+// the pair's first codeword; a lane adds a 32-bit BYTE offset (codeword-in-pair * stride + step).  With 64-bit per-lane
+// addresses the pass kept ten address pairs in VGPRs and turbo_decode_kernel spilled them: every reload is a scratch load
+// that retires through the same in-order counter as the prefetches, i.e. it waits for the HBM round trip issued just before
+// it (the "exposed memory time" of the round-2 ablations).
 struct PassIO {
     const double *sys;            // systematic values, stride sstride per codeword
-    const double *par;            // [B][N]
-    uint8_t *bits;                // map_decode: hard decisions [B][N] (L > 0 in 'decode' mode), or null
+    const double *par;            // parity values, stride pstride
+    uint8_t *bits;                // map_decode: hard decisions [.][N] (L > 0 in 'decode' mode), or null
     int want_bits;
-    int64_t sstride, pstride;     // per-codeword strides of sys / par
+    int sstride, pstride;         // per-codeword strides (elements); 16 codewords x stride x 8 B < 4 GiB (checked on the host)
     const double *Lin;            // L_int, stride lstride per codeword
     double *Lout;                 // L_int + log(app1/app0) -- or, with `ext`, log(app1/app0) alone --, stride lstride
     bool ext;                     // turbo: write L - L_int, the quantity the next half-iteration interleaves (:318, :328)
-    int64_t lstride, cw0, B, N;
+    int lstride, ncw, N;          // ncw: codewords of the batch this pair really has (<= GW, may be <= 0)
     double nv2;
     double *ckpt;                 // this pair's checkpoint rows [nchunks + 1][64]
 };
 
+__device__ __forceinline__ double ld_off(const double *base, unsigned elem) {
+    return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + (elem * 8u));
+}
+__device__ __forceinline__ void st_off(double *base, unsigned elem, double v) {
+    *reinterpret_cast<double *>(reinterpret_cast<char *>(base) + (elem * 8u)) = v;
+}
+
 template <int LGS>
-__device__ __forceinline__ void load_raw(const Ctx<LGS> &c, const PassIO &io, RawChunk &rc, int64_t t0, int len) {
+__device__ __forceinline__ void load_raw(const Ctx<LGS> &c, const PassIO &io, RawChunk &rc, int t0, int len) {
 #pragma unroll
     for (int q = 0; q < 2; q++) {
         const int p = c.lane + 64 * q, gg = p / CH, tl = p % CH;
-        const int64_t cw = io.cw0 + gg, t = t0 + tl;              // 0-based step index
+        const unsigned t = (unsigned)(t0 + tl);                   // 0-based step index
         rc.r0[q] = 0.0; rc.r1[q] = 0.0; rc.li[q] = 0.0;
-        if (gg < c.GW && cw < io.B && tl < len) {
-            rc.r0[q] = io.sys[cw * io.sstride + t];
-            rc.r1[q] = io.par[cw * io.pstride + t];
-            rc.li[q] = io.Lin[cw * io.lstride + t];
+        if (gg < io.ncw && tl < len) {
+            rc.r0[q] = ld_off(io.sys, (unsigned)(gg * io.sstride) + t);
+            rc.r1[q] = ld_off(io.par, (unsigned)(gg * io.pstride) + t);
+            rc.li[q] = ld_off(io.Lin, (unsigned)(gg * io.lstride) + t);
         }
     }
 }
@@ -352,22 +364,22 @@ __device__ __forceinline__ void alpha_chunk(const Ctx<LGS> &c, double &a, int le
 
 // time-parallel epilogue of a phase-2 chunk: app sums in state order, L = L_int + log(app1/app0) (:145)
 template <int LGS>
-__device__ __forceinline__ void epilogue(const Ctx<LGS> &c, const PassIO &io, const double (&li)[2], int64_t t_lo, int len) {
+__device__ __forceinline__ void epilogue(const Ctx<LGS> &c, const PassIO &io, const double (&li)[2], int t_lo, int len) {
     constexpr int S = Ctx<LGS>::S;
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int q = 0; q < 2; q++) {
         const int p = c.lane + 64 * q, gg = p / CH, tl = p % CH;
-        const int64_t cw = io.cw0 + gg;
-        if (gg < c.GW && cw < io.B && tl < len) {
+        if (gg < io.ncw && tl < len) {
             const double2 *x = reinterpret_cast<const double2 *>(c.xs + (tl * 64 + gg * S) * 2);
             double app0 = 0.0, app1 = 0.0;
 #pragma unroll
             for (int st = 0; st < S; st++) { const double2 v = x[st]; app0 += v.x; app1 += v.y; }
             const double lr = fast_log(app1 / app0);
             const double L = io.ext ? lr : li[q] + lr;
-            io.Lout[cw * io.lstride + t_lo + tl] = L;
-            if (io.bits) io.bits[cw * io.N + t_lo + tl] = (uint8_t)((io.want_bits && L > 0) ? 1 : 0);   // (:148-152)
+            const unsigned t = (unsigned)(t_lo + tl);
+            st_off(io.Lout, (unsigned)(gg * io.lstride) + t, L);
+            if (io.bits) io.bits[(unsigned)(gg * io.N) + t] = (uint8_t)((io.want_bits && L > 0) ? 1 : 0);   // (:148-152)
         }
     }
     asm volatile("" ::: "memory");
@@ -386,10 +398,12 @@ __device__ __forceinline__ void pair_sync() {
 // One MAP pass over the GW codewords of this pair of wavefronts.  Collective over the workgroup (one pair_sync).
 template <int LGS, bool SR, bool PRE>
 __device__ void map_pass(const Ctx<LGS> &c, const PassIO &io) {
-    const int64_t N = io.N;
-    const int K = (int)((N + CH - 1) / CH), K1 = K / 2;          // F: chunks [0,K1) then [K1,K); R: [K1,K) then [0,K1)
-    auto clen = [&](int k) { const int64_t r = N - (int64_t)k * CH; return (int)(r < CH ? r : CH); };
-    double *ck = io.ckpt + c.lane;                                // row k: state vector at time k*CH
+    const int N = io.N;
+    const int K = (N + CH - 1) / CH, K1 = K / 2;                  // F: chunks [0,K1) then [K1,K); R: [K1,K) then [0,K1)
+    auto clen = [&](int k) { const int r = N - k * CH; return r < CH ? r : CH; };
+    // checkpoint row k (state vector at time k*CH), this lane's entry
+    auto ck_ld = [&](int k) { return ld_off(io.ckpt, (unsigned)(k * 64 + c.lane)); };
+    auto ck_st = [&](int k, double v) { st_off(io.ckpt, (unsigned)(k * 64 + c.lane), v); };
     RawChunk cur, nxt;
     double arow[CH];                                              // alpha of this lane's state at the chunk's steps
 #pragma unroll
@@ -405,13 +419,13 @@ __device__ void map_pass(const Ctx<LGS> &c, const PassIO &io) {
         double a = (c.s == 0) ? 1.0 : 0.0;                        // f_state_metrics[0][0] = 1 (:221)
         if (K1 > 0) load_raw<LGS>(c, io, cur, 0, clen(0));
         for (int k = 0; k < K1; k++) {
-            ck[(int64_t)k * 64] = a;                              // alpha at time k*CH (read by R in phase 2)
+            ck_st(k, a);                                          // alpha at time k*CH (read by R in phase 2)
             stage_chunk<LGS, PRE>(c, cur, io.nv2);
-            if (k + 1 < K1) load_raw<LGS>(c, io, nxt, (int64_t)(k + 1) * CH, clen(k + 1));
+            if (k + 1 < K1) load_raw<LGS>(c, io, nxt, (k + 1) * CH, clen(k + 1));
             alpha_chunk<LGS, SR, false>(c, a, CH, arow);          // chunks below K1 are full
             cur = nxt;
         }
-        load_raw<LGS>(c, io, cur, (int64_t)K1 * CH, clen(K1));    // first chunk of phase 2 (K1 < K always)
+        load_raw<LGS>(c, io, cur, K1 * CH, clen(K1));             // first chunk of phase 2 (K1 < K always)
         pair_sync();
         // ---------------- phase 2: chunks K1 .. K-1: own alpha, beta from R's checkpoint, combine ----------------
         // The epilogue of a chunk runs at the top of the NEXT iteration, after that iteration's checkpoint load has been
@@ -419,47 +433,47 @@ __device__ void map_pass(const Ctx<LGS> &c, const PassIO &io) {
         // checkpoint load the chain waited for their write acknowledgements as well (ablation: the stores cost 0.7 of the
         // 5.3 ms of a config-3 launch, the loads 1.0).
         double li_prev[2] = {0.0, 0.0};
-        int64_t t_prev = 0;
+        int t_prev = 0;
         int len_prev = 0;                                         // first iteration: nothing to write
         for (int k = K1; k < K; k++) {
             const int len = clen(k);
-            double b = ck[(int64_t)(k + 1) * 64];                 // beta at the upper boundary of chunk k
+            double b = ck_ld(k + 1);                              // beta at the upper boundary of chunk k
             epilogue<LGS>(c, io, li_prev, t_prev, len_prev);
             stage_chunk<LGS, PRE>(c, cur, io.nv2);
-            if (k + 1 < K) load_raw<LGS>(c, io, nxt, (int64_t)(k + 1) * CH, clen(k + 1));
+            if (k + 1 < K) load_raw<LGS>(c, io, nxt, (k + 1) * CH, clen(k + 1));
             alpha_chunk<LGS, SR, true>(c, a, len, arow);
             beta_chunk<LGS, SR, true>(c, b, len, arow);
             li_prev[0] = cur.li[0]; li_prev[1] = cur.li[1];
-            t_prev = (int64_t)k * CH; len_prev = len;
+            t_prev = k * CH; len_prev = len;
             cur = nxt;
         }
         epilogue<LGS>(c, io, li_prev, t_prev, len_prev);
     } else {
         // ---------------- phase 1: beta over chunks K-1 .. K1, checkpoint before every chunk ----------------
         double b = 1.0;                                           // b_state_metrics[:, N] = 1 (:225)
-        load_raw<LGS>(c, io, cur, (int64_t)(K - 1) * CH, clen(K - 1));
+        load_raw<LGS>(c, io, cur, (K - 1) * CH, clen(K - 1));
         for (int k = K - 1; k >= K1; --k) {
-            ck[(int64_t)(k + 1) * 64] = b;                        // beta at the upper boundary of chunk k (read by F)
+            ck_st(k + 1, b);                                      // beta at the upper boundary of chunk k (read by F)
             stage_chunk<LGS, PRE>(c, cur, io.nv2);
-            if (k > K1) load_raw<LGS>(c, io, nxt, (int64_t)(k - 1) * CH, CH);
+            if (k > K1) load_raw<LGS>(c, io, nxt, (k - 1) * CH, CH);
             beta_chunk<LGS, SR, false>(c, b, clen(k), arow);
             cur = nxt;
         }
-        if (K1 > 0) load_raw<LGS>(c, io, cur, (int64_t)(K1 - 1) * CH, CH);
+        if (K1 > 0) load_raw<LGS>(c, io, cur, (K1 - 1) * CH, CH);
         pair_sync();
         // ---------------- phase 2: chunks K1-1 .. 0 (all full): alpha from F's checkpoint, own beta, combine ----------------
         double li_prev[2] = {0.0, 0.0};
-        int64_t t_prev = 0;
+        int t_prev = 0;
         int len_prev = 0;
         for (int k = K1 - 1; k >= 0; --k) {
-            double a = ck[(int64_t)k * 64];                       // alpha at the lower boundary of chunk k
+            double a = ck_ld(k);                                  // alpha at the lower boundary of chunk k
             epilogue<LGS>(c, io, li_prev, t_prev, len_prev);      // of the previous chunk (see the forward wave)
             stage_chunk<LGS, PRE>(c, cur, io.nv2);
-            if (k > 0) load_raw<LGS>(c, io, nxt, (int64_t)(k - 1) * CH, CH);
+            if (k > 0) load_raw<LGS>(c, io, nxt, (k - 1) * CH, CH);
             alpha_chunk<LGS, SR, true>(c, a, CH, arow);           // arow[tl] = alpha at time k*CH + tl
             beta_chunk<LGS, SR, true>(c, b, CH, arow);
             li_prev[0] = cur.li[0]; li_prev[1] = cur.li[1];
-            t_prev = (int64_t)k * CH; len_prev = CH;
+            t_prev = k * CH; len_prev = CH;
             cur = nxt;
         }
         epilogue<LGS>(c, io, li_prev, t_prev, len_prev);
@@ -482,12 +496,17 @@ __global__ __launch_bounds__(128 * NPAIR) void map_decode_kernel(MapParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Ctx<LGS> c;
     init_ctx<LGS>(c, p.tb, smem, p.GW);
-    const int64_t pair = (int64_t)blockIdx.x * (blockDim.x >> 7) + (threadIdx.x >> 7);
+    // wave-uniform by construction; readfirstlane tells the compiler, so that everything derived from it (the pair's base
+    // pointers, codeword counts) lives in SGPRs and the loads take the `saddr + 32-bit voffset` form
+    const int64_t pair = (int64_t)blockIdx.x * (blockDim.x >> 7) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 7));
     const int64_t K = (p.N + CH - 1) / CH;
+    const int64_t cw0 = pair * p.GW, o0 = cw0 * p.N;
+    const int64_t left = p.B - cw0;
     PassIO io;
-    io.sys = p.sys; io.sstride = p.N; io.pstride = p.N; io.par = p.par; io.Lin = p.Lin; io.Lout = p.Lout; io.lstride = p.N; io.ext = false;
-    io.bits = p.bits; io.want_bits = p.want_bits;
-    io.cw0 = pair * p.GW; io.B = p.B; io.N = p.N; io.nv2 = p.nv2;
+    io.N = (int)p.N; io.sstride = io.pstride = io.lstride = io.N; io.ext = false;
+    io.sys = p.sys + o0; io.par = p.par + o0; io.Lin = p.Lin + o0; io.Lout = p.Lout + o0;
+    io.bits = p.bits ? p.bits + o0 : nullptr; io.want_bits = p.want_bits;
+    io.ncw = (int)(left < p.GW ? left : p.GW); io.nv2 = p.nv2;
     io.ckpt = p.scratch + pair * (K + 1) * 64;
     map_pass<LGS, SR, false>(c, io);                              // L_ext and the hard decisions leave in the pass's epilogue
 }
@@ -509,7 +528,9 @@ __global__ __launch_bounds__(128 * NPAIR) void turbo_decode_kernel(TurboParams p
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Ctx<LGS> c;
     init_ctx<LGS>(c, p.tb, smem, p.GW);
-    const int64_t pair = (int64_t)blockIdx.x * (blockDim.x >> 7) + (threadIdx.x >> 7);
+    // wave-uniform by construction; readfirstlane tells the compiler, so that everything derived from it (the pair's base
+    // pointers, codeword counts) lives in SGPRs and the loads take the `saddr + 32-bit voffset` form
+    const int64_t pair = (int64_t)blockIdx.x * (blockDim.x >> 7) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 7));
     const int64_t N = p.N, K = (N + CH - 1) / CH, cw0 = pair * p.GW;
     // per-codeword arrays in one slab [B][7][N]: A (L_int_1), B (a pass's output), C (L_int_2) and the signed channel
     // factors (signed_q) of sys, interlv(sys) (:310), non_sys_1 and non_sys_2
@@ -517,8 +538,10 @@ __global__ __launch_bounds__(128 * NPAIR) void turbo_decode_kernel(TurboParams p
     double *QS = p.larr + 3 * N, *QSI = p.larr + 4 * N, *QP1 = p.larr + 5 * N, *QP2 = p.larr + 6 * N;
     const int64_t ls = 7 * N;
     const double k4 = -4.0 / p.nv2;
+    const int64_t left = p.B - cw0, o0 = cw0 * ls;               // the pair's codewords start at element o0 of every slab array
     PassIO io;
-    io.lstride = ls; io.sstride = ls; io.pstride = ls; io.cw0 = cw0; io.B = p.B; io.N = N; io.nv2 = p.nv2; io.bits = nullptr;
+    io.lstride = io.sstride = io.pstride = (int)ls; io.N = (int)N; io.nv2 = p.nv2; io.bits = nullptr;
+    io.ncw = (int)(left < p.GW ? left : p.GW);
     io.want_bits = 0;
     io.ckpt = p.ckpt + pair * (K + 1) * 64;
     // Between the MAP passes only the interleaver is left to do: a pass writes E = L - L_int directly (`ext`), so
@@ -563,10 +586,10 @@ __global__ __launch_bounds__(128 * NPAIR) void turbo_decode_kernel(TurboParams p
     //   odd h:  [L_2, bits] = map_decode(sys_i, non_sys_2, trellis, nv, L_int_2, mode)              (:326)
     for (int h = 0; h < 2 * p.n_iter; h++) {
         const bool second = h & 1;
-        io.sys = second ? QSI : QS;
-        io.par = second ? QP2 : QP1;
-        io.Lin = second ? C0 : A0;
-        io.Lout = B0;
+        io.sys = (second ? QSI : QS) + o0;
+        io.par = (second ? QP2 : QP1) + o0;
+        io.Lin = (second ? C0 : A0) + o0;
+        io.Lout = B0 + o0;
         map_pass<LGS, SR, true>(c, io);
         pair_sync();
         if (h == 2 * p.n_iter - 1) break;                          // the last E_2 only feeds the decisions below
@@ -664,6 +687,7 @@ int cpx_map_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const do
     int rc = fill_tables(t, p.tb);
     if (rc) return rc;
     CPX_REQUIRE(B >= 0 && N >= 0, CPX_EINVAL, "map_decode: negative size");
+    CPX_REQUIRE(N < (1ll << 24), CPX_ELIMIT, "map_decode: blocks of 2^24 steps or more are not supported (32-bit lane offsets)");
     if (B == 0 || N == 0) return CPX_OK;
     hipStream_t st = pick_stream(stream);
     const int GW = pick_gw(t->S, B);
@@ -698,6 +722,7 @@ int cpx_turbo_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const 
     int rc = fill_tables(t, p.tb);
     if (rc) return rc;
     CPX_REQUIRE(B >= 0 && N >= 0 && n_iter >= 0, CPX_EINVAL, "turbo_decode: negative size");
+    CPX_REQUIRE(N < (1ll << 22), CPX_ELIMIT, "turbo_decode: blocks of 2^22 steps or more are not supported (32-bit lane offsets)");
     if (B == 0 || N == 0) return CPX_OK;
     hipStream_t st = pick_stream(stream);
     const int GW = pick_gw(t->S, B);
