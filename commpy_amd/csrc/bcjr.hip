@@ -47,6 +47,8 @@ namespace {
 
 constexpr int CH = 8;          // steps per chunk
 constexpr int KNORM = 4;       // renormalise alpha / beta every KNORM steps
+constexpr int XS_ROW = 64 * 2 + 4;   // doubles per step row of the parked branch products: 128 + 4 pad (the time-parallel
+                                    // epilogue reads one step per lane: a 1024-byte row stride puts its eight steps on the same banks)
 constexpr int NPAIR = 4;       // (forward, reverse) wave pairs per full-size workgroup: 8 waves = 2 per SIMD of a CU
 
 struct MapTables {
@@ -96,7 +98,7 @@ struct Ctx {
 };
 
 template <int LGS>
-__host__ __device__ constexpr size_t wave_lds_doubles(int GW) { return (size_t)CH * (GW * 6 + 2) + (size_t)CH * 64 * 3 + 64; }
+__host__ __device__ constexpr size_t wave_lds_doubles(int GW) { return (size_t)CH * (GW * 6 + 2) + (size_t)CH * (XS_ROW + 64) + 64; }
 
 template <int LGS>
 __device__ __forceinline__ void init_ctx(Ctx<LGS> &c, const MapTables &tb, unsigned char *smem, int GW) {
@@ -123,7 +125,7 @@ __device__ __forceinline__ void init_ctx(Ctx<LGS> &c, const MapTables &tb, unsig
     c.o_ghi = c.sb[0] ? c.code[0] : c.code[1];
     double *p = reinterpret_cast<double *>(smem) + (size_t)wave * wave_lds_doubles<LGS>(GW);
     c.tab = p; p += CH * c.P;
-    c.xs = p;  p += CH * 64 * 2;
+    c.xs = p;  p += CH * XS_ROW;
     c.rw = p;  p += CH * 64;
     c.xch = p;
 }
@@ -219,7 +221,9 @@ __device__ __forceinline__ void load_raw(const Ctx<LGS> &c, const PassIO &io, Ra
 //   (p0, p1) = (1, e^L)/(1+e^L): q = (1, e^L) for L < 0, (e^-L, 1) otherwise -- one exp of a non-positive argument, no
 //     division; same limits as the reference (p0 -> 0 / p1 -> 0 when e^L overflows / underflows).
 // The row stride P = 6 GW + 2 doubles makes the eight lanes that hold consecutive steps of a codeword hit eight
-// different 16-byte bank groups.
+// different 16-byte bank groups.  (An entry-major row [6][GW], which makes the recursions' reads conflict-free, was measured:
+// six 8-byte staging stores per item instead of three 16-byte ones and the extra address arithmetic cost more than the
+// conflicts -- MAP pass 0.329 instead of 0.320 ms, config 3 5.37 instead of 5.14 ms.)
 // PRE (turbo_decode): the channel factors do not change between the passes of a decode, so they are evaluated ONCE per
 // launch (signed_q below) and a pass reads copysign(Qa, r0), copysign(Qb, r1) where it would read r0, r1: one exp per item
 // and pass -- the prior -- instead of three.
@@ -298,7 +302,7 @@ __device__ __forceinline__ void beta_step(const Ctx<LGS> &c, int tl, double &b, 
     double lo, hi;
     beta_nbrs<LGS, SR>(c, b, lo, hi);
     if (X) {
-        double *xo = c.xs + (tl * 64 + c.lane) * 2;               // idle lanes own a slot too
+        double *xo = c.xs + tl * XS_ROW + c.lane * 2;             // idle lanes own a slot too
         const int s_lo = (LGS == 2 && SR) ? c.ilo : 0;
         xo[s_lo] = (a_own * g_lo) * lo;
         xo[1 - s_lo] = (a_own * g_hi) * hi;
@@ -371,7 +375,7 @@ __device__ __forceinline__ void epilogue(const Ctx<LGS> &c, const PassIO &io, co
     for (int q = 0; q < 2; q++) {
         const int p = c.lane + 64 * q, gg = p / CH, tl = p % CH;
         if (gg < io.ncw && tl < len) {
-            const double2 *x = reinterpret_cast<const double2 *>(c.xs + (tl * 64 + gg * S) * 2);
+            const double2 *x = reinterpret_cast<const double2 *>(c.xs + tl * XS_ROW + gg * S * 2);
             double app0 = 0.0, app1 = 0.0;
 #pragma unroll
             for (int st = 0; st < S; st++) { const double2 v = x[st]; app0 += v.x; app1 += v.y; }
