@@ -100,10 +100,10 @@ def bench_demod(lib, scale):
         d_b = dev.empty(ns * md.num_bits_symbol)
         h = md._device_handle()
         ms, _ = timeit(lib, lambda: _lib.check(lib.cpx_demod_soft_dev(h, d_y, ns, float(N0), d_l, None)))
-        emit("demod_soft_kernel<%d>" % md.num_bits_symbol, "%d-QAM soft LLR, %d symbols" % (m, ns), ns, "symbols", ms,
-             ns * (16 + 8 * md.num_bits_symbol), "hbm")
+        emit(_lib.last_kernel(), "%d-QAM soft LLR, %d symbols" % (m, ns), ns, "symbols", ms,
+             ns * (16 + 8 * md.num_bits_symbol), "valu")
         ms, _ = timeit(lib, lambda: _lib.check(lib.cpx_demod_hard_dev(h, d_y, ns, d_b, None)))
-        emit("demod_hard_kernel", "%d-QAM hard decision, %d symbols" % (m, ns), ns, "symbols", ms,
+        emit(_lib.last_kernel(), "%d-QAM hard decision, %d symbols" % (m, ns), ns, "symbols", ms,
              ns * (16 + md.num_bits_symbol), "hbm")
         dev.free()
 
@@ -185,16 +185,16 @@ def bench_config4(lib, scale):
                 enc.encode_dev(d_msg, B, d_bits)
                 _lib.check(lib.cpx_modulate_dev(h_md, d_bits, B * nsym, d_sym, None))
                 _lib.check(lib.cpx_awgn_dev(d_sym, B * nsym, sc, sc, 31, 1, d_y, None))
-                _lib.check(lib.cpx_demod_soft_dev(h_md, d_y, B * nsym, float(N0), d_llr, None))
-                _lib.check(lib.cpx_scale_f64_dev(d_llr, B * n, -1.0, d_neg, None))
+                # the sign flip of quirk B6 (demodulate returns log P1/P0, the decoder takes log P0/P1) rides in the demodulator
+                _lib.check(lib.cpx_demod_soft_scaled_dev(h_md, d_y, B * nsym, float(N0), -1.0, d_neg, None))
                 _lib.check(lib.cpx_ldpc_bp_decode_batch_dev(code, d_neg, B, alg, 50, d_dec, d_out, d_it, None))
             ms, _ = timeit(lib, run, steps=3, warmup=1)
             its = dev.get(d_it, (B,), np.int32)
             dec = dev.get(d_dec, (n, B), np.int8)
             sent = dev.get(d_bits, (B, n), np.int8)
-            # bytes the chain moves through HBM: symbols + noise + LLRs + sign flip (64 B per symbol and its 6 LLRs, twice),
+            # bytes the chain moves through HBM: symbols written / read / written with noise (16 B each), 6 LLRs per symbol (48 B),
             # the decoder's channel-LLR re-read per executed iteration (8 n) and its staging / transposed outputs (33 n)
-            alg_bytes = B * nsym * (16 * 3 + 48 * 3) + int(its.sum()) * 8 * n + B * n * 33
+            alg_bytes = B * nsym * (16 * 3 + 48) + int(its.sum()) * 8 * n + B * n * 33
             kname = _lib.last_kernel()
             emit("config4_pipeline_%s" % name, "encode + 64-QAM + AWGN + demod + LDPC (1944,1296) %s, Eb/N0=%.0f dB, B=%d, "
                  "mean its %.2f" % (name, ebn0, B, its.mean()), B * 1296, "info-bits", ms, alg_bytes,

@@ -55,7 +55,8 @@ def config4(grp, B_total, ebn0=9.0):
         ck(lib.cpx_ldpc_encode_batch_dev(enc.h, bufs["msg"].ptr, B, bufs["bits"].ptr, st))
         ck(lib.cpx_modulate_dev(md._device_handle(), bufs["bits"].ptr, B * nsym, bufs["sym"].ptr, st))
         ck(lib.cpx_awgn_dev(bufs["sym"].ptr, B * nsym, sc, sc, 31 + i, 1, bufs["y"].ptr, st))
-        ck(lib.cpx_demod_soft_dev(md._device_handle(), bufs["y"].ptr, B * nsym, float(N0), bufs["llr"].ptr, st))
+        # demodulate returns log P1/P0, the decoder takes log P0/P1 (test_ldpc.py:53-54): the flip rides in the demodulator
+        ck(lib.cpx_demod_soft_scaled_dev(md._device_handle(), bufs["y"].ptr, B * nsym, float(N0), -1.0, bufs["llr"].ptr, st))
         ck(lib.cpx_stream_sync(st))
         return bufs
 
@@ -66,7 +67,7 @@ def config4(grp, B_total, ebn0=9.0):
                 B = counts[i]
                 b = bufs[i]
                 mine = ctypes.c_void_p(b["dec"].ptr.value + i * rows * n)
-                _lib.check(lib.cpx_scale_f64_dev(b["llr"].ptr, B * n, -1.0, b["neg"].ptr, st))   # the decoder clips in place
+                _lib.check(lib.cpx_memcpy_d2d_async(b["neg"].ptr, b["llr"].ptr, B * n * 8, st))    # the decoder clips in place
                 _lib.check(lib.cpx_ldpc_bp_decode_batch_dev(_device_code(p), b["neg"].ptr, B, alg, 50, mine, b["out"].ptr,
                                                             b["it"].ptr, st))
                 return mine

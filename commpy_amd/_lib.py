@@ -84,6 +84,7 @@ SYMBOLS = {
     "cpx_modem_destroy": (c_int, [c_void_p]),
     "cpx_demod_soft": (c_int, [c_void_p, c_void_p, c_int64, c_double, c_void_p]),
     "cpx_demod_soft_dev": (c_int, [c_void_p, c_void_p, c_int64, c_double, c_void_p, c_void_p]),
+    "cpx_demod_soft_scaled_dev": (c_int, [c_void_p, c_void_p, c_int64, c_double, c_double, c_void_p, c_void_p]),
     "cpx_demod_hard": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "cpx_demod_hard_dev": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "cpx_random_bits_dev": (c_int, [c_void_p, c_int64, c_uint64, c_uint64, c_void_p]),

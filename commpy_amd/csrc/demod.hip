@@ -32,10 +32,12 @@ namespace {
 constexpr int DEMOD_BLOCK = 256;
 constexpr int MAX_M = 256;
 
+// `scale` multiplies every LLR on its way out (1.0: exact identity; -1.0: the sign flip between Modem.demodulate -- log P1/P0 --
+// and ldpc_bp_decode -- log P0/P1 --, test_ldpc.py:53-54, without a second pass over the LLRs).
 template <int NB>
 __global__ __launch_bounds__(DEMOD_BLOCK) void demod_soft_kernel(const double2 *__restrict__ y, int64_t Ns,
                                                                  const double2 *__restrict__ cst, int M,
-                                                                 double noise_var, double *__restrict__ llr) {
+                                                                 double noise_var, double scale, double *__restrict__ llr) {
     __shared__ double2 c_s[MAX_M];
     for (int m = threadIdx.x; m < M; m += DEMOD_BLOCK) c_s[m] = cst[m];
     __syncthreads();
@@ -54,14 +56,18 @@ __global__ __launch_bounds__(DEMOD_BLOCK) void demod_soft_kernel(const double2 *
             }
         }
 #pragma unroll
-        for (int b = 0; b < NB; b++) llr[i * NB + NB - 1 - b] = fast_log(num[b] / den[b]);   // (:137)
+        for (int b = 0; b < NB; b++) llr[i * NB + NB - 1 - b] = fast_log(num[b] / den[b]) * scale;   // (:137)
     }
 }
 
-template <int NH>
+// RCP: the exponent -d^2 / noise_var is formed as d^2 * (-1 / noise_var) -- one multiplication instead of a 12-instruction
+// division per exponential (16 of them per 64-QAM symbol, a sixth of the kernel); the two agree to an ulp of the exponent,
+// i.e. ~1e-14 on an LLR (the bar is 1e-5).  The host selects it when 1 / noise_var is a normal number.
+template <int NH, bool RCP>
 __global__ __launch_bounds__(DEMOD_BLOCK) void demod_soft_sep_kernel(const double2 *__restrict__ y, int64_t Ns,
                                                                      const double *__restrict__ axes, double noise_var,
-                                                                     double *__restrict__ llr) {
+                                                                     double scale, double *__restrict__ llr) {
+    const double ninv = -1.0 / noise_var;
     constexpr int R = 1 << NH, NB = 2 * NH;
     __shared__ double ax_s[2 * R];
     for (int m = threadIdx.x; m < 2 * R; m += DEMOD_BLOCK) ax_s[m] = axes[m];
@@ -72,8 +78,8 @@ __global__ __launch_bounds__(DEMOD_BLOCK) void demod_soft_sep_kernel(const doubl
 #pragma unroll
         for (int a = 0; a < R; a++) {
             const double dx = cur.x - ax_s[a], dy = cur.y - ax_s[R + a];
-            ex[a] = exp((-(dx * dx)) / noise_var);
-            ey[a] = exp((-(dy * dy)) / noise_var);
+            ex[a] = exp(RCP ? (dx * dx) * ninv : (-(dx * dx)) / noise_var);
+            ey[a] = exp(RCP ? (dy * dy) * ninv : (-(dy * dy)) / noise_var);
             sx += ex[a];
             sy += ey[a];
         }
@@ -89,7 +95,7 @@ __global__ __launch_bounds__(DEMOD_BLOCK) void demod_soft_sep_kernel(const doubl
             out[b] = fast_log((ny * sx) / (qy * sx));         // label bit b    = bit b of the imag-axis index b
         }
 #pragma unroll
-        for (int b = 0; b < NB; b++) llr[i * NB + NB - 1 - b] = out[b];   // (:137)
+        for (int b = 0; b < NB; b++) llr[i * NB + NB - 1 - b] = out[b] * scale;   // (:137)
     }
 }
 
@@ -180,6 +186,11 @@ int cpx_modem_destroy(cpx_modem *m) {
 }
 
 int cpx_demod_soft_dev(const cpx_modem *m, const double *d_y, int64_t Ns, double noise_var, double *d_llr, void *stream) {
+    return cpx_demod_soft_scaled_dev(m, d_y, Ns, noise_var, 1.0, d_llr, stream);
+}
+
+int cpx_demod_soft_scaled_dev(const cpx_modem *m, const double *d_y, int64_t Ns, double noise_var, double scale, double *d_llr,
+                              void *stream) {
     CPX_REQUIRE(m, CPX_EINVAL, "demod: null modem");
     if (int rcd = check_handle_device(m->device, "demod")) return rcd;
     CPX_REQUIRE(Ns >= 0, CPX_EINVAL, "demod: negative size");
@@ -188,22 +199,28 @@ int cpx_demod_soft_dev(const cpx_modem *m, const double *d_y, int64_t Ns, double
     const double2 *y = reinterpret_cast<const double2 *>(d_y);
     const double2 *c = reinterpret_cast<const double2 *>(m->d_const);
     dim3 grid(grid_for(Ns)), block(DEMOD_BLOCK);
+    const bool rcp = noise_var > 1e-290 && noise_var < 1e290;     // 1 / noise_var is a normal number
     if (m->separable) {
         switch (m->nbits / 2) {
-#define CASE(NH) case NH: hipLaunchKernelGGL(demod_soft_sep_kernel<NH>, grid, block, 0, st, y, Ns, m->d_axes, noise_var, d_llr); break;
+#define CASE(NH) case NH:                                                                                                \
+        if (rcp) hipLaunchKernelGGL((demod_soft_sep_kernel<NH, true>), grid, block, 0, st, y, Ns, m->d_axes, noise_var, scale, d_llr);   \
+        else hipLaunchKernelGGL((demod_soft_sep_kernel<NH, false>), grid, block, 0, st, y, Ns, m->d_axes, noise_var, scale, d_llr);   \
+        break;
             CASE(1) CASE(2) CASE(3) CASE(4)
 #undef CASE
             default: set_error("demod: unsupported bits per symbol %d", m->nbits); return CPX_ELIMIT;
         }
     } else {
         switch (m->nbits) {
-#define CASE(NB) case NB: hipLaunchKernelGGL(demod_soft_kernel<NB>, grid, block, 0, st, y, Ns, c, m->M, noise_var, d_llr); break;
+#define CASE(NB) case NB: hipLaunchKernelGGL(demod_soft_kernel<NB>, grid, block, 0, st, y, Ns, c, m->M, noise_var, scale, d_llr); break;
             CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
 #undef CASE
             default: set_error("demod: unsupported bits per symbol %d", m->nbits); return CPX_ELIMIT;
         }
     }
     CPX_HIP(hipGetLastError());
+    if (m->separable) note_kernel("demod_soft_sep_kernel<%d,%s>", m->nbits / 2, rcp ? "rcp" : "div");
+    else note_kernel("demod_soft_kernel<%d>", m->nbits);
     return CPX_OK;
 }
 
@@ -227,6 +244,8 @@ int cpx_demod_hard_dev(const cpx_modem *m, const double *d_y, int64_t Ns, int8_t
         hipLaunchKernelGGL(demod_hard_kernel, grid, block, 0, st, y, Ns, c, m->M, m->nbits, d_bits);
     }
     CPX_HIP(hipGetLastError());
+    if (m->separable) note_kernel("demod_hard_sep_kernel<%d>", m->nbits / 2);
+    else note_kernel("demod_hard_kernel");
     return CPX_OK;
 }
 

@@ -221,6 +221,10 @@ int cpx_modem_destroy(cpx_modem *m);
 int cpx_demod_soft(const cpx_modem *m, const double *y_re_im, int64_t Ns, double noise_var, double *llr);
 int cpx_demod_soft_dev(const cpx_modem *m, const double *d_y_re_im, int64_t Ns, double noise_var,
                        double *d_llr, void *stream);
+/* the same with every LLR multiplied by `scale` on its way out: scale = -1 is the sign flip between Modem.demodulate (log P1/P0)
+ * and ldpc_bp_decode (log P0/P1), test_ldpc.py:53-54, without a second pass over the LLRs; scale = 1 is cpx_demod_soft_dev */
+int cpx_demod_soft_scaled_dev(const cpx_modem *m, const double *d_y_re_im, int64_t Ns, double noise_var, double scale,
+                              double *d_llr, void *stream);
 int cpx_demod_hard(const cpx_modem *m, const double *y_re_im, int64_t Ns, int8_t *bits);
 int cpx_demod_hard_dev(const cpx_modem *m, const double *d_y_re_im, int64_t Ns, int8_t *d_bits,
                        void *stream);

@@ -178,3 +178,36 @@ def test_wifi_custom_receiver_end_to_end(gpu):
                                              receiver=receiver, stop_on_surpass_error=False)
     assert len(calls) == 6 and all(len(c) == 1 for c in calls)
     assert bers[0] < 0.05
+
+
+def test_demod_soft_scaled_is_the_sign_flip_fused(gpu):
+    """cpx_demod_soft_scaled_dev(scale = -1) == -cpx_demod_soft_dev bit for bit (the config-4 chain's sign flip, test_ldpc.py:53-54,
+    without the extra pass); scale = 1 is the plain entry point; subnormal / zero noise_var keeps the division form."""
+    import ctypes
+    from commpy_amd import _lib
+    from commpy_amd.devicelink import DeviceBuf
+    from commpy_amd.modulation import PSKModem, QAMModem
+    lib = _lib.load()
+    rs = np.random.RandomState(4)
+    for md in (QAMModem(64), QAMModem(4), PSKModem(8)):
+        ns, nb = 5000, md.num_bits_symbol
+        y = md.constellation[rs.randint(0, md.m, ns)] + 0.3 * (rs.randn(ns) + 1j * rs.randn(ns))
+        for nv in (0.37, 1e-310, 0.0):
+            d_y = DeviceBuf(y.nbytes)
+            _lib.check(lib.cpx_memcpy_h2d(d_y.ptr, _lib.ptr(y), y.nbytes))
+            outs = []
+            for scale in (None, -1.0, 1.0):
+                d_l = DeviceBuf(ns * nb * 8)
+                if scale is None:
+                    _lib.check(lib.cpx_demod_soft_dev(md._device_handle(), d_y.ptr, ns, nv, d_l.ptr, None))
+                else:
+                    _lib.check(lib.cpx_demod_soft_scaled_dev(md._device_handle(), d_y.ptr, ns, nv, scale, d_l.ptr, None))
+                o = np.empty(ns * nb)
+                _lib.check(lib.cpx_memcpy_d2h(_lib.ptr(o), d_l.ptr, o.nbytes))
+                outs.append(o)
+            with np.errstate(invalid="ignore"):
+                assert np.array_equal(outs[1], -outs[0], equal_nan=True)
+                assert np.array_equal(outs[2], outs[0], equal_nan=True)
+            if nv == 0.37:
+                ref = oracle.demodulate(md.constellation, y, "soft", nv)
+                assert np.max(np.abs(outs[0] - ref)) < 1e-9
