@@ -34,13 +34,14 @@ constexpr int MAX_M = 256;
 
 // `scale` multiplies every LLR on its way out (1.0: exact identity; -1.0: the sign flip between Modem.demodulate -- log P1/P0 --
 // and ldpc_bp_decode -- log P0/P1 --, test_ldpc.py:53-54, without a second pass over the LLRs).
-template <int NB>
+template <int NB, bool RCP>
 __global__ __launch_bounds__(DEMOD_BLOCK) void demod_soft_kernel(const double2 *__restrict__ y, int64_t Ns,
                                                                  const double2 *__restrict__ cst, int M,
                                                                  double noise_var, double scale, double *__restrict__ llr) {
     __shared__ double2 c_s[MAX_M];
     for (int m = threadIdx.x; m < M; m += DEMOD_BLOCK) c_s[m] = cst[m];
     __syncthreads();
+    const double ninv = -1.0 / noise_var;                             // RCP: see demod_soft_sep_kernel
     for (int64_t i = (int64_t)blockIdx.x * DEMOD_BLOCK + threadIdx.x; i < Ns; i += (int64_t)gridDim.x * DEMOD_BLOCK) {
         const double2 cur = y[i];
         double num[NB], den[NB];
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(DEMOD_BLOCK) void demod_soft_kernel(const double2 *
         for (int m = 0; m < M; m++) {
             const double2 c = c_s[m];
             const double a = hypot(cur.x - c.x, cur.y - c.y);       // abs(current_symbol - symbol)
-            const double e = exp((-(a * a)) / noise_var);             // exp((-abs(..)**2)/noise_var) (:134,136)
+            const double e = exp(RCP ? (a * a) * ninv : (-(a * a)) / noise_var);   // exp((-abs(..)**2)/noise_var) (:134,136)
 #pragma unroll
             for (int b = 0; b < NB; b++) {
                 if ((m >> b) & 1) num[b] += e; else den[b] += e;
@@ -212,7 +213,10 @@ int cpx_demod_soft_scaled_dev(const cpx_modem *m, const double *d_y, int64_t Ns,
         }
     } else {
         switch (m->nbits) {
-#define CASE(NB) case NB: hipLaunchKernelGGL(demod_soft_kernel<NB>, grid, block, 0, st, y, Ns, c, m->M, noise_var, scale, d_llr); break;
+#define CASE(NB) case NB:                                                                                                \
+        if (rcp) hipLaunchKernelGGL((demod_soft_kernel<NB, true>), grid, block, 0, st, y, Ns, c, m->M, noise_var, scale, d_llr);   \
+        else hipLaunchKernelGGL((demod_soft_kernel<NB, false>), grid, block, 0, st, y, Ns, c, m->M, noise_var, scale, d_llr);   \
+        break;
             CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
 #undef CASE
             default: set_error("demod: unsupported bits per symbol %d", m->nbits); return CPX_ELIMIT;
@@ -220,7 +224,7 @@ int cpx_demod_soft_scaled_dev(const cpx_modem *m, const double *d_y, int64_t Ns,
     }
     CPX_HIP(hipGetLastError());
     if (m->separable) note_kernel("demod_soft_sep_kernel<%d,%s>", m->nbits / 2, rcp ? "rcp" : "div");
-    else note_kernel("demod_soft_kernel<%d>", m->nbits);
+    else note_kernel("demod_soft_kernel<%d,%s>", m->nbits, rcp ? "rcp" : "div");
     return CPX_OK;
 }
 

@@ -621,11 +621,13 @@ static int viterbi_dispatch(const cpx_trellis *t, const double *d_coded, const D
     if (n_steps <= 0) return CPX_OK;
     note_kernel("");
     if (!dm) {   // large batches of the standard rate-1/2 codes: one codeword per lane (viterbi_cw.hip).  That path runs in rounds
-        // of one wavefront of 64 codewords per SIMD; a last round that would fill less than 3/4 of the chip is cheaper on
-        // the wave kernels below (83 k codewords: 4.5 ms as two rounds, 3.2 ms as one round + wave kernels)
+        // of one wavefront of 64 codewords per SIMD, each as long as a full one; a last round that would fill less than 45 % of
+        // the chip is cheaper on the wave kernels below, whose time is proportional to the batch (config 2: 54 us per 1000
+        // codewords against 1.55 ms per round, break-even at 0.44 of a round -- scripts/micro/split_probe.py: 30 000
+        // codewords 1.63 ms on the wave kernels, 1.53 ms as a round; 99 536: 3.59 ms as round + wave kernels, 3.01 as two rounds)
         const int64_t round = (int64_t)device_cus() * 4 * 64;
         int64_t Bcw = B;
-        if (!(viterbi_path_flags() & 2) && B > round && 4 * (B % round) < 3 * round) Bcw = B / round * round;
+        if (!(viterbi_path_flags() & 2) && B > round && 20 * (B % round) < 9 * round) Bcw = B / round * round;
         int rc_cw = CPX_OK;
         if (viterbi_codeword_path(t, d_coded, Bcw, len, L, n_steps, tb_depth, decoding_type, d_bits, st, &rc_cw)) {
             if (rc_cw != CPX_OK || Bcw == B) return rc_cw;

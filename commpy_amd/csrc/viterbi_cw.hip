@@ -719,8 +719,9 @@ bool viterbi_codeword_path(const cpx_trellis *t, const double *d_coded, int64_t 
         *rc = CPX_ELIMIT;
         return true;
     };
-    // one wavefront of 64 codewords per SIMD needs 65536 codewords on 256 CUs; below ~3/4 of that the wave kernels win
-    if (!forced && B < 3 * (int64_t)device_cus() * 4 * 64 / 4) return false;
+    // one wavefront of 64 codewords per SIMD needs 65536 codewords on 256 CUs; below 45 % of that the wave kernels win
+    // (their time is proportional to the batch, a round of this path costs the same however full it is: break-even 0.44)
+    if (!forced && 20 * B < 9 * (int64_t)device_cus() * 4 * 64) return false;
     if (t->I != 2 || t->k != 1 || t->n != 2 || T < 1) return reject("needs a rate-1/2, k = 1 trellis");
     if ((len & 1) || ((uintptr_t)d_coded & 15)) return reject("rows must be 16-byte aligned");
     const size_t tb_lds = (size_t)(64 + tb - 2) * (TB_STRIDE * 8 + 64);

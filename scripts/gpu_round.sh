@@ -19,6 +19,7 @@ if [[ $SEC == *s* ]]; then
 fi
 if [[ $SEC == *b* ]]; then
   timeout 900 python bench.py --gpus 1 --steps 20 --warmup 3 2>&1 | tail -3 | tee $OUT/bench_n1.json
+  timeout 600 python bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline --precision fp32-fast 2>&1 | tail -1 | tee $OUT/bench_fp32_fast.json | cut -c1-400
 fi
 if [[ $SEC == *d* ]]; then
   timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 \
@@ -48,6 +49,8 @@ fi
 if [[ $SEC == *x* ]]; then
   timeout 1500 python scripts/collect_pmc.py --out $OUT --name ldpc_c4 --match ldpc_ --fetch-scale 1 -- \
       python $R/benchmarks/bench_kernels.py --which ldpc 2>&1 | tail -80
+  timeout 900 python scripts/collect_pmc.py --out $OUT --name ldpc_resident_fixed20 --match ldpc_resident --fetch-scale 1 -- \
+      python $R/scripts/micro/ldpc_fixed_iters.py 2>&1 | tail -5
 fi
 rm -f $OUT/*.log
 ls -la $OUT

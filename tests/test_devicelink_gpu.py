@@ -70,7 +70,7 @@ def test_device_wifi_link_overlays_reference(gpu, gname, mcs):
     snrs, ref = g[key + "__snrs"], g[key + "__ber"]
     link = DeviceWifiLink(mcs, 600, generator_matrix=[[0o133, 0o171]] if gname == "octal" else None, seed=11 + mcs)
     ref_bits = int(g[key + "__tx"]) * 600
-    # per-point calls, and the whole sweep through one Viterbi call (the large-batch kernel when 49152+ frames)
+    # per-point calls, and the whole sweep through one Viterbi call (the large-batch kernel from 29 492 frames)
     for bers in (link.ber_sweep(snrs, 600 * 2048), link.ber_sweep_batched(snrs, 600 * 8192)):
         for s, b, r in zip(snrs, bers, ref):
             ref_errors = r * ref_bits
