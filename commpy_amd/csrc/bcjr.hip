@@ -687,6 +687,7 @@ extern "C" {
 int cpx_map_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const double *d_par, const double *d_L_int,
                              int64_t B, int64_t N, double noise_variance, int want_bits, double *d_L_ext,
                              uint8_t *d_bits, void *stream) {
+    CPX_TRACE("cpx_map_decode_batch_dev");
     MapParams p;
     int rc = fill_tables(t, p.tb);
     if (rc) return rc;
@@ -722,6 +723,7 @@ int cpx_map_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const do
 int cpx_turbo_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const double *d_p1, const double *d_p2,
                                const double *d_L_int_or_null, const int32_t *d_perm, int64_t B, int64_t N,
                                double noise_variance, int n_iter, uint8_t *d_bits, void *stream) {
+    CPX_TRACE("cpx_turbo_decode_batch_dev");
     TurboParams p;
     int rc = fill_tables(t, p.tb);
     if (rc) return rc;
@@ -757,6 +759,7 @@ int cpx_turbo_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const 
 
 int cpx_map_decode_batch(const cpx_trellis *t, const double *sys, const double *par, const double *L_int, int64_t B,
                          int64_t N, double noise_variance, int want_bits, double *L_ext, uint8_t *bits) {
+    CPX_TRACE("cpx_map_decode_batch");
     CPX_REQUIRE(t && ((sys && par && L_int && L_ext && bits) || B * N == 0), CPX_EINVAL, "map_decode: null pointer");
     int rc = ensure_device();
     if (rc) return rc;
@@ -782,6 +785,7 @@ int cpx_map_decode_batch(const cpx_trellis *t, const double *sys, const double *
 int cpx_turbo_decode_batch(const cpx_trellis *t, const double *sys, const double *p1, const double *p2,
                            const double *L_int_or_null, const int32_t *perm, int64_t B, int64_t N,
                            double noise_variance, int n_iter, uint8_t *bits) {
+    CPX_TRACE("cpx_turbo_decode_batch");
     CPX_REQUIRE(t && ((sys && p1 && p2 && perm && bits) || B * N == 0), CPX_EINVAL, "turbo_decode: null pointer");
     int rc = ensure_device();
     if (rc) return rc;

@@ -59,6 +59,19 @@ void ldpc_resident_free(::cpx_ldpc *c);
 bool ldpc_resident_path(const ::cpx_ldpc *c, double *d_llr, int64_t B, int alg, int n_iters, int8_t *d_dec, double *d_out,
                         int32_t *d_iters, hipStream_t st, int *rc);
 
+// roctx range for the lifetime of the object when CPX_TRACE=1 (runtime.hip); a no-op otherwise
+struct TraceRange {
+    explicit TraceRange(const char *name);
+    ~TraceRange();
+    TraceRange(const TraceRange &) = delete;
+    TraceRange &operator=(const TraceRange &) = delete;
+    bool on;
+};
+bool trace_enabled();
+#define CPX_TRACE_CAT2(a, b) a##b
+#define CPX_TRACE_CAT(a, b) CPX_TRACE_CAT2(a, b)
+#define CPX_TRACE(name) cpx::TraceRange CPX_TRACE_CAT(cpx_trace_, __LINE__)(name)
+
 // precision mode (cpx_set_precision / CPX_PRECISION): false = fp64-parity (default), true = fp32-fast
 bool precision_fast();
 

@@ -192,6 +192,7 @@ int cpx_demod_soft_dev(const cpx_modem *m, const double *d_y, int64_t Ns, double
 
 int cpx_demod_soft_scaled_dev(const cpx_modem *m, const double *d_y, int64_t Ns, double noise_var, double scale, double *d_llr,
                               void *stream) {
+    CPX_TRACE("cpx_demod_soft_scaled_dev");
     CPX_REQUIRE(m, CPX_EINVAL, "demod: null modem");
     if (int rcd = check_handle_device(m->device, "demod")) return rcd;
     CPX_REQUIRE(Ns >= 0, CPX_EINVAL, "demod: negative size");
@@ -229,6 +230,7 @@ int cpx_demod_soft_scaled_dev(const cpx_modem *m, const double *d_y, int64_t Ns,
 }
 
 int cpx_demod_hard_dev(const cpx_modem *m, const double *d_y, int64_t Ns, int8_t *d_bits, void *stream) {
+    CPX_TRACE("cpx_demod_hard_dev");
     CPX_REQUIRE(m, CPX_EINVAL, "demod: null modem");
     if (int rcd = check_handle_device(m->device, "demod")) return rcd;
     CPX_REQUIRE(Ns >= 0, CPX_EINVAL, "demod: negative size");
@@ -254,6 +256,7 @@ int cpx_demod_hard_dev(const cpx_modem *m, const double *d_y, int64_t Ns, int8_t
 }
 
 int cpx_demod_soft(const cpx_modem *m, const double *y_re_im, int64_t Ns, double noise_var, double *llr) {
+    CPX_TRACE("cpx_demod_soft");
     CPX_REQUIRE(m && (y_re_im || Ns == 0) && (llr || Ns == 0), CPX_EINVAL, "demod: null pointer");
     int rc = ensure_device();
     if (rc) return rc;
@@ -271,6 +274,7 @@ int cpx_demod_soft(const cpx_modem *m, const double *y_re_im, int64_t Ns, double
 }
 
 int cpx_demod_hard(const cpx_modem *m, const double *y_re_im, int64_t Ns, int8_t *bits) {
+    CPX_TRACE("cpx_demod_hard");
     CPX_REQUIRE(m && (y_re_im || Ns == 0) && (bits || Ns == 0), CPX_EINVAL, "demod: null pointer");
     int rc = ensure_device();
     if (rc) return rc;

@@ -296,6 +296,7 @@ extern "C" {
 int cpx_turbo_encode_batch_dev(const cpx_trellis *t1, const cpx_trellis *t2, const uint8_t *d_msg, int64_t B, int64_t N,
                                const int32_t *d_perm, uint8_t *d_sys, uint8_t *d_p1, uint8_t *d_p2, int64_t np2,
                                int mode, void *stream) {
+    CPX_TRACE("cpx_turbo_encode_batch_dev");
     CPX_REQUIRE(t1 && t2, CPX_EINVAL, "turbo_encode: null trellis");
     if (int rcd = check_handle_device(t1->device, "turbo_encode")) return rcd;
     if (int rcd = check_handle_device(t2->device, "turbo_encode")) return rcd;
@@ -370,6 +371,7 @@ int cpx_ldpc_encoder_destroy(cpx_ldpc_encoder *e) {
 }
 
 int cpx_ldpc_encode_batch_dev(const cpx_ldpc_encoder *e, const uint8_t *d_msg, int64_t B, uint8_t *d_code, void *stream) {
+    CPX_TRACE("cpx_ldpc_encode_batch_dev");
     CPX_REQUIRE(e, CPX_EINVAL, "ldpc_encode: null encoder");
     if (int rcd = check_handle_device(e->device, "ldpc_encode")) return rcd;
     CPX_REQUIRE(B >= 0, CPX_EINVAL, "ldpc_encode: negative batch");

@@ -780,6 +780,7 @@ int cpx_ldpc_destroy(cpx_ldpc *c) {
 
 int cpx_ldpc_bp_decode_batch_dev(const cpx_ldpc *c, double *d_llr, int64_t B, int alg, int n_iters, int8_t *d_dec,
                                  double *d_out, int32_t *d_iters, void *stream) {
+    CPX_TRACE("cpx_ldpc_bp_decode_batch_dev");
     CPX_REQUIRE(c, CPX_EINVAL, "ldpc: null code");
     if (int rcd = check_handle_device(c->device, "ldpc")) return rcd;
     CPX_REQUIRE(alg == CPX_LDPC_SPA || alg == CPX_LDPC_MSA, CPX_EINVAL,
@@ -858,6 +859,7 @@ int cpx_ldpc_bp_decode_batch_dev(const cpx_ldpc *c, double *d_llr, int64_t B, in
 
 int cpx_ldpc_bp_decode_batch(const cpx_ldpc *c, double *llr, int64_t B, int alg, int n_iters, int8_t *dec_word,
                              double *out_llrs, int32_t *iters_done) {
+    CPX_TRACE("cpx_ldpc_bp_decode_batch");
     CPX_REQUIRE(c && (llr || B == 0), CPX_EINVAL, "ldpc: null pointer");
     int rc = ensure_device();
     if (rc) return rc;

@@ -247,6 +247,7 @@ int cpx_random_bits_dev(uint8_t *d_bits, int64_t n, uint64_t seed, uint64_t stre
 
 int cpx_conv_encode_batch_dev(const cpx_trellis *t, const uint8_t *d_msg, int64_t B, int64_t nmsg, int terminate, int rsc,
                               uint8_t *d_coded, int64_t nout, void *stream) {
+    CPX_TRACE("cpx_conv_encode_batch_dev");
     CPX_REQUIRE(t, CPX_EINVAL, "conv_encode: null trellis");
     if (int rcd = check_handle_device(t->device, "conv_encode")) return rcd;
     CPX_REQUIRE(B >= 0 && nmsg >= 0 && nout >= 0, CPX_EINVAL, "conv_encode: negative size");

@@ -3,6 +3,7 @@
 #include "cpx_internal.h"
 
 #include <atomic>
+#include <dlfcn.h>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -150,6 +151,33 @@ int cpx_get_precision(void) { return cpx::precision_fast() ? 1 : 0; }
 }  // extern "C"
 
 namespace cpx {
+// roctx ranges: when CPX_TRACE=1, every decoder entry point -- and the upload / kernels / download phases of the
+// host-buffer entry points -- is bracketed by roctxRangePush / roctxRangePop, resolved at run time from the profiler's roctx
+// library (rocprofv3 --marker-trace shows them next to the kernels); off by default: no dlopen, no calls.
+namespace {
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        const char *e = getenv("CPX_TRACE");
+        if (!e || e[0] != '1') return;
+        for (const char *name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+            if (void *h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
+                push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+                pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+                if (push && pop) return;
+                push = nullptr; pop = nullptr;
+            }
+        }
+    }
+};
+const Roctx &roctx() { static const Roctx r; return r; }
+}  // namespace
+
+TraceRange::TraceRange(const char *name) : on(roctx().push != nullptr) { if (on) roctx().push(name); }
+TraceRange::~TraceRange() { if (on) roctx().pop(); }
+bool trace_enabled() { return roctx().push != nullptr; }
+
 bool precision_fast() {
     int v = g_precision.load(std::memory_order_relaxed);
     if (v < 0) {

@@ -712,11 +712,13 @@ static int viterbi_dispatch(const cpx_trellis *t, const double *d_coded, const D
 
 int cpx_viterbi_decode_batch_dev(const cpx_trellis *t, const double *d_coded, int64_t B, int64_t len, int64_t L,
                                  int64_t n_steps, int tb_depth, int decoding_type, uint8_t *d_bits, void *stream) {
+    CPX_TRACE("cpx_viterbi_decode_batch_dev");
     return viterbi_dispatch(t, d_coded, nullptr, B, len, L, n_steps, tb_depth, decoding_type, d_bits, stream);
 }
 
 int cpx_demod_hard_viterbi_batch_dev(const cpx_modem *m, const cpx_trellis *t, const double *d_y_re_im, int64_t B,
                                      int64_t nsym, int64_t L, int64_t n_steps, int tb_depth, uint8_t *d_bits, void *stream) {
+    CPX_TRACE("cpx_demod_hard_viterbi_batch_dev");
     CPX_REQUIRE(m && t, CPX_EINVAL, "demod_hard_viterbi: null handle");
     if (int rcd = check_handle_device(m->device, "demod_hard_viterbi")) return rcd;
     CPX_REQUIRE(B >= 0 && nsym >= 0, CPX_EINVAL, "demod_hard_viterbi: negative size");
@@ -728,6 +730,7 @@ int cpx_demod_hard_viterbi_batch_dev(const cpx_modem *m, const cpx_trellis *t, c
 
 int cpx_demod_hard_viterbi_batch(const cpx_modem *m, const cpx_trellis *t, const double *y_re_im, int64_t B, int64_t nsym,
                                  int64_t L, int64_t n_steps, int tb_depth, uint8_t *bits) {
+    CPX_TRACE("cpx_demod_hard_viterbi_batch");
     CPX_REQUIRE(m && t && (y_re_im || B * nsym == 0) && (bits || B * L == 0), CPX_EINVAL, "demod_hard_viterbi: null pointer");
     int rc = ensure_device();
     if (rc) return rc;
@@ -746,6 +749,7 @@ int cpx_demod_hard_viterbi_batch(const cpx_modem *m, const cpx_trellis *t, const
 
 int cpx_viterbi_decode_batch(const cpx_trellis *t, const double *coded, int64_t B, int64_t len, int64_t L,
                              int64_t n_steps, int tb_depth, int decoding_type, uint8_t *bits) {
+    CPX_TRACE("cpx_viterbi_decode_batch");
     CPX_REQUIRE(t && (coded || B * len == 0) && (bits || B * L == 0), CPX_EINVAL, "viterbi: null pointer");
     int rc = ensure_device();
     if (rc) return rc;
@@ -765,6 +769,7 @@ int cpx_viterbi_decode_batch(const cpx_trellis *t, const double *coded, int64_t 
 
 int cpx_viterbi_decode_batch_i64(const cpx_trellis *t, const double *coded, int64_t B, int64_t len, int64_t L,
                                  int64_t n_steps, int tb_depth, int decoding_type, int64_t *bits64) {
+    CPX_TRACE("cpx_viterbi_decode_batch_i64");
     CPX_REQUIRE(t && (coded || B * len == 0) && (bits64 || B * L == 0), CPX_EINVAL, "viterbi: null pointer");
     int rc = ensure_device();
     if (rc) return rc;
@@ -794,12 +799,20 @@ int cpx_viterbi_decode_batch_i64(const cpx_trellis *t, const double *coded, int6
     // 40.3 ms.  The runtime's own pageable path already moves the 1.08 GB at ~49 GB/s, i.e. near the PCIe Gen5 rate,
     // without a staging copy; an extra pass over host memory costs more than the 3 + 1 ms of decode and download it
     // can hide.)
-    CPX_HIP(hipMemcpyAsync(din.p, coded, sizeof(double) * (size_t)(B * len), hipMemcpyHostToDevice, st));
+    {
+        CPX_TRACE("H2D coded");
+        CPX_HIP(hipMemcpyAsync(din.p, coded, sizeof(double) * (size_t)(B * len), hipMemcpyHostToDevice, st));
+        if (trace_enabled()) CPX_HIP(hipStreamSynchronize(st));   // ranges time the phases only if they do not overlap
+    }
     rc = cpx_viterbi_decode_batch_dev(t, din.as<double>(), B, len, L, n_steps, tb_depth, decoding_type,
                                       dout.as<uint8_t>(), st);
     if (rc) return rc;
-    CPX_HIP(hipMemcpyAsync(stage, dout.p, nout, hipMemcpyDeviceToHost, st));
-    CPX_HIP(hipStreamSynchronize(st));
+    {
+        CPX_TRACE("D2H bits");
+        CPX_HIP(hipMemcpyAsync(stage, dout.p, nout, hipMemcpyDeviceToHost, st));
+        CPX_HIP(hipStreamSynchronize(st));
+    }
+    CPX_TRACE("widen to int64 (host threads)");
     unsigned nt = std::thread::hardware_concurrency();
     if (nt > 16) nt = 16;
     if (nt < 1 || nout < (1u << 20)) nt = 1;

@@ -3,7 +3,7 @@
 # usage: bash scripts/gpu_round.sh [tag] [sections]
 #   sections: t(ests) s(moke) b(ench.py) d(ist: torchrun N=1 over the engine's RCCL binding) k(ernel benches)
 #             l(ink + host-api + multi-GPU benches) v(iterbi PMC passes) u(turbo/map PMC passes) m(demod PMC passes)
-#             x(ldpc PMC passes)
+#             x(ldpc PMC passes) r(octx marker trace of the host-API benchmark, CPX_TRACE=1)
 TAG=${1:-r02}
 SEC=${2:-tsbdklvu}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -51,6 +51,14 @@ if [[ $SEC == *x* ]]; then
       python $R/benchmarks/bench_kernels.py --which ldpc 2>&1 | tail -80
   timeout 900 python scripts/collect_pmc.py --out $OUT --name ldpc_resident_fixed20 --match ldpc_resident --fetch-scale 1 -- \
       python $R/scripts/micro/ldpc_fixed_iters.py 2>&1 | tail -5
+fi
+if [[ $SEC == *r* ]]; then
+  # roctx ranges of the entry points (CPX_TRACE=1) next to the kernels: rocprofv3 marker trace of the host-API benchmark
+  rm -rf /tmp/cpx_marker
+  (cd /tmp && CPX_TRACE=1 timeout 600 rocprofv3 --marker-trace --kernel-trace --output-format csv -d /tmp/cpx_marker -- \
+      python $R/benchmarks/bench_host_api.py --reps 1 > $OUT/roctx_marker.log 2>&1)
+  f=$(find /tmp/cpx_marker -name "*marker_api_trace.csv" | head -1)
+  if [ -n "$f" ]; then head -40 "$f" > $OUT/roctx_marker_trace_head.csv; wc -l "$f" | tee -a $OUT/roctx_marker_trace_head.csv; fi
 fi
 rm -f $OUT/*.log
 ls -la $OUT

@@ -211,3 +211,21 @@ def test_demod_soft_scaled_is_the_sign_flip_fused(gpu):
             if nv == 0.37:
                 ref = oracle.demodulate(md.constellation, y, "soft", nv)
                 assert np.max(np.abs(outs[0] - ref)) < 1e-9
+
+
+def test_trace_mode_runs(gpu):
+    """CPX_TRACE=1: the roctx ranges around the entry points are resolved at run time (dlopen) and must not change results."""
+    import subprocess
+    import sys
+    code = ("import numpy as np, sys; sys.path.insert(0, %r); sys.path.insert(0, %r);"
+            "from helpers import make_trellis; from commpy_amd.channelcoding import viterbi_decode;"
+            "tr = make_trellis('t57'); x = np.random.RandomState(1).randint(0, 2, (5, 40)).astype(float);"
+            "print(viterbi_decode(x, tr, None, 'hard').sum())") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                   os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for trace in ("0", "1"):
+        env = dict(os.environ, CPX_TRACE=trace)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1]
