@@ -24,13 +24,17 @@ def main():
     rs = np.random.RandomState(0)
     llr = rs.randn(a.B, 2060) * 4.0
     viterbi_decode(llr[:64], tr, None, "soft")            # load library, create handles
-    best = 1e9
+    best, times = 1e9, []
+    out = None
     for _ in range(a.reps):
+        del out                                            # unmapping the previous 537 MB result is not part of a call
         t0 = time.perf_counter()
         out = viterbi_decode(llr, tr, None, "soft")
-        best = min(best, time.perf_counter() - t0)
+        times.append(time.perf_counter() - t0)
+        best = min(best, times[-1])
     print(json.dumps({"kernel": "viterbi_decode host API (PCIe inclusive)", "workload": "K=7 soft, 1024-bit, B=%d" % a.B,
                       "value": a.B * 1024 / best, "unit": "info-bits/s", "ms": best * 1e3,
+                      "ms_all_repetitions": [round(t * 1e3, 2) for t in times],
                       "host_bytes_in": int(llr.nbytes), "host_bytes_out": int(out.nbytes),
                       "effective_GBps": (llr.nbytes + out.nbytes) / best / 1e9}))
 
