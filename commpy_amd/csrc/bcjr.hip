@@ -688,6 +688,7 @@ int cpx_map_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const do
                              int64_t B, int64_t N, double noise_variance, int want_bits, double *d_L_ext,
                              uint8_t *d_bits, void *stream) {
     CPX_TRACE("cpx_map_decode_batch_dev");
+    cpx::IssueGuard issue_guard;
     MapParams p;
     int rc = fill_tables(t, p.tb);
     if (rc) return rc;
@@ -724,6 +725,7 @@ int cpx_turbo_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const 
                                const double *d_L_int_or_null, const int32_t *d_perm, int64_t B, int64_t N,
                                double noise_variance, int n_iter, uint8_t *d_bits, void *stream) {
     CPX_TRACE("cpx_turbo_decode_batch_dev");
+    cpx::IssueGuard issue_guard;
     TurboParams p;
     int rc = fill_tables(t, p.tb);
     if (rc) return rc;

@@ -59,6 +59,15 @@ void ldpc_resident_free(::cpx_ldpc *c);
 bool ldpc_resident_path(const ::cpx_ldpc *c, double *d_llr, int64_t B, int alg, int n_iters, int8_t *d_dec, double *d_out,
                         int32_t *d_iters, hipStream_t st, int *rc);
 
+// per-device issue lock for entry points that take scratch-arena memory (runtime.hip)
+struct IssueGuard {
+    IssueGuard();
+    ~IssueGuard();
+    IssueGuard(const IssueGuard &) = delete;
+    IssueGuard &operator=(const IssueGuard &) = delete;
+    int dev;
+};
+
 // roctx range for the lifetime of the object when CPX_TRACE=1 (runtime.hip); a no-op otherwise
 struct TraceRange {
     explicit TraceRange(const char *name);

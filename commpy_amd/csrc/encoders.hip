@@ -372,6 +372,7 @@ int cpx_ldpc_encoder_destroy(cpx_ldpc_encoder *e) {
 
 int cpx_ldpc_encode_batch_dev(const cpx_ldpc_encoder *e, const uint8_t *d_msg, int64_t B, uint8_t *d_code, void *stream) {
     CPX_TRACE("cpx_ldpc_encode_batch_dev");
+    cpx::IssueGuard issue_guard;
     CPX_REQUIRE(e, CPX_EINVAL, "ldpc_encode: null encoder");
     if (int rcd = check_handle_device(e->device, "ldpc_encode")) return rcd;
     CPX_REQUIRE(B >= 0, CPX_EINVAL, "ldpc_encode: negative batch");

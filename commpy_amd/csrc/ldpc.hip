@@ -781,6 +781,7 @@ int cpx_ldpc_destroy(cpx_ldpc *c) {
 int cpx_ldpc_bp_decode_batch_dev(const cpx_ldpc *c, double *d_llr, int64_t B, int alg, int n_iters, int8_t *d_dec,
                                  double *d_out, int32_t *d_iters, void *stream) {
     CPX_TRACE("cpx_ldpc_bp_decode_batch_dev");
+    cpx::IssueGuard issue_guard;
     CPX_REQUIRE(c, CPX_EINVAL, "ldpc: null code");
     if (int rcd = check_handle_device(c->device, "ldpc")) return rcd;
     CPX_REQUIRE(alg == CPX_LDPC_SPA || alg == CPX_LDPC_MSA, CPX_EINVAL,

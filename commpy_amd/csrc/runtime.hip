@@ -174,6 +174,18 @@ struct Roctx {
 const Roctx &roctx() { static const Roctx r; return r; }
 }  // namespace
 
+// Host threads may call into the library concurrently (ctypes drops the GIL).  Kernels of one stream serialise, but the
+// scratch arena is shared per (device, stream, slot): between `workspace()` handing out a block and the launches that use it,
+// another thread growing the same slot would free it (the grow path synchronises the stream first -- which only protects work
+// that has already been issued).  Every entry point that takes arena memory therefore holds the device's issue lock from
+// before `workspace()` until its launches are queued; it is recursive (host-buffer entry points call the device ones).
+namespace { std::recursive_mutex g_issue_mu[64]; }
+IssueGuard::IssueGuard() : dev(0) {
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    g_issue_mu[dev].lock();
+}
+IssueGuard::~IssueGuard() { g_issue_mu[dev].unlock(); }
+
 TraceRange::TraceRange(const char *name) : on(roctx().push != nullptr) { if (on) roctx().push(name); }
 TraceRange::~TraceRange() { if (on) roctx().pop(); }
 bool trace_enabled() { return roctx().push != nullptr; }

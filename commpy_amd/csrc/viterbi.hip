@@ -713,12 +713,14 @@ static int viterbi_dispatch(const cpx_trellis *t, const double *d_coded, const D
 int cpx_viterbi_decode_batch_dev(const cpx_trellis *t, const double *d_coded, int64_t B, int64_t len, int64_t L,
                                  int64_t n_steps, int tb_depth, int decoding_type, uint8_t *d_bits, void *stream) {
     CPX_TRACE("cpx_viterbi_decode_batch_dev");
+    cpx::IssueGuard issue_guard;
     return viterbi_dispatch(t, d_coded, nullptr, B, len, L, n_steps, tb_depth, decoding_type, d_bits, stream);
 }
 
 int cpx_demod_hard_viterbi_batch_dev(const cpx_modem *m, const cpx_trellis *t, const double *d_y_re_im, int64_t B,
                                      int64_t nsym, int64_t L, int64_t n_steps, int tb_depth, uint8_t *d_bits, void *stream) {
     CPX_TRACE("cpx_demod_hard_viterbi_batch_dev");
+    cpx::IssueGuard issue_guard;
     CPX_REQUIRE(m && t, CPX_EINVAL, "demod_hard_viterbi: null handle");
     if (int rcd = check_handle_device(m->device, "demod_hard_viterbi")) return rcd;
     CPX_REQUIRE(B >= 0 && nsym >= 0, CPX_EINVAL, "demod_hard_viterbi: negative size");

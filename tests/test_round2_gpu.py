@@ -229,3 +229,53 @@ def test_trace_mode_runs(gpu):
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(r.stdout.strip().splitlines()[-1])
     assert outs[0] == outs[1]
+
+
+def test_concurrent_host_threads_share_the_arena_safely(gpu):
+    """ctypes releases the GIL, so two Python threads really are inside the library at once.  Both decode on the library's
+    default stream with batch sizes that keep growing the shared scratch arena (LDPC staging / Viterbi two-kernel workspace /
+    turbo slab): every result must equal the one computed alone (per-device issue lock, csrc/runtime.hip)."""
+    import threading
+    from commpy_amd import _lib
+    from commpy_amd.channelcoding import RandInterlv, ldpc_bp_decode, turbo_decode, viterbi_decode
+    rs = np.random.RandomState(12)
+    p = ldpc_params("wimax1440")
+    tr = make_trellis("k7_133_171")
+    tr4 = make_trellis("rsc_legacy_4")
+    il = RandInterlv(64, 7)
+    sizes = [3, 40, 9, 130, 17, 260, 5, 400]
+    ldpc_in = [rs.randn(b * 1440) * 2 + 1.5 for b in sizes]
+    vit_in = [rs.randn(b * 2, 2 * 70) * 2 for b in sizes]
+    tur_in = [[rs.randn(b, 64) for _ in range(3)] for b in sizes]
+    _lib.viterbi_set_path("cw2")                                    # two-kernel form: takes arena slots 0 and 1 as well
+    try:
+        want_l = [ldpc_bp_decode(x.copy(), p, "MSA", 8) for x in ldpc_in]
+        want_v = [viterbi_decode(x, tr, 20, "soft") for x in vit_in]
+        want_t = [turbo_decode(s, a, b, tr4, 0.8, 3, il) for s, a, b in tur_in]
+        errs = []
+
+        def work(kind):
+            try:
+                for rep in range(6):
+                    for i in range(len(sizes)):
+                        if kind == 0:
+                            d, o = ldpc_bp_decode(ldpc_in[i].copy(), p, "MSA", 8)
+                            ok = np.array_equal(d, want_l[i][0]) and np.array_equal(o, want_l[i][1])
+                        elif kind == 1:
+                            ok = np.array_equal(viterbi_decode(vit_in[i], tr, 20, "soft"), want_v[i])
+                        else:
+                            s, a, b = tur_in[i]
+                            ok = np.array_equal(turbo_decode(s, a, b, tr4, 0.8, 3, il), want_t[i])
+                        if not ok:
+                            errs.append((kind, rep, i))
+            except Exception as e:                                  # noqa: BLE001 -- reported by the main thread
+                errs.append((kind, repr(e)))
+
+        th = [threading.Thread(target=work, args=(k,)) for k in (0, 1, 2, 1, 0)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs[:5]
+    finally:
+        _lib.viterbi_set_path(None)
