@@ -68,6 +68,8 @@ struct IssueGuard {
     int dev;
 };
 
+void issue_lock(int dev, bool lock);     // cpx_release_workspace takes all of them
+
 // roctx range for the lifetime of the object when CPX_TRACE=1 (runtime.hip); a no-op otherwise
 struct TraceRange {
     explicit TraceRange(const char *name);

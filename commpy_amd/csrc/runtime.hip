@@ -185,6 +185,7 @@ IssueGuard::IssueGuard() : dev(0) {
     g_issue_mu[dev].lock();
 }
 IssueGuard::~IssueGuard() { g_issue_mu[dev].unlock(); }
+void issue_lock(int dev, bool lock) { if (lock) g_issue_mu[dev].lock(); else g_issue_mu[dev].unlock(); }
 
 TraceRange::TraceRange(const char *name) : on(roctx().push != nullptr) { if (on) roctx().push(name); }
 TraceRange::~TraceRange() { if (on) roctx().pop(); }
@@ -302,6 +303,11 @@ int cpx_stream_destroy(void *stream) {
 }
 
 int cpx_release_workspace(void) {
+    // no entry point may sit between workspace() and its launches while the blocks are freed: all issue locks, in order
+    struct AllIssueLocks {
+        AllIssueLocks() { for (int d = 0; d < 64; d++) cpx::issue_lock(d, true); }
+        ~AllIssueLocks() { for (int d = 63; d >= 0; d--) cpx::issue_lock(d, false); }
+    } all;
     std::lock_guard<std::mutex> lk(g_ws_mu);
     for (auto &e : g_ws) {
         (void)hipStreamSynchronize(e.st);
