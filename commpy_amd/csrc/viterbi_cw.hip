@@ -200,9 +200,9 @@ __device__ __forceinline__ void cw_step(double (&pm)[1 << LGS], double r0, doubl
 }
 
 // ---- float32 path metrics: the "fp32-fast" mode (cpx_set_precision) -- NOT the parity mode ------------------
-// 'soft' and 'unquantized' metrics in float32: the soft branch metric is the stable form max(r,0) + log(1 + e^-|r|) of the
-// reference's log(e^r + 1) through the hardware exp2/log2, and near-ties between path metrics may resolve differently
-// (measured mismatch rate: DESIGN.md 4.1).  'hard' metrics of 0/1 inputs are Hamming distances <= 2 T, exact in float32
+// 'soft' and 'unquantized' metrics in float32; the soft branch metric is the correlation form (the term common to all
+// branches of a step is dropped: no exp, no log), and near-ties between path metrics may resolve differently (measured
+// mismatch rate: DESIGN.md 4.1).  'hard' metrics of 0/1 inputs are Hamming distances <= 2 T, exact in float32
 // for T < 2^22: identical bits.
 // Same structure as cw_step: in-place butterflies, decision words, first-argmin state; the minimum tree uses v_min3_f32.
 __device__ __forceinline__ float acs_min_f32(unsigned &acc, float x, float y) {
@@ -222,10 +222,12 @@ __device__ __forceinline__ void bit_metrics_f32(int type, double r, float &m0, f
         m0 = (float)(ri ^ 0ll);
         m1 = (float)(ri ^ 1ll);
     } else if (type == CPX_VIT_SOFT) {
-        const float x = (float)r;
-        const float sp = fmaxf(x, 0.0f) + __logf(1.0f + __expf(-fabsf(x)));
-        m0 = sp;
-        m1 = sp - x;
+        // the reference's metrics are m0 = log(e^r + 1), m1 = m0 - r: every branch of a step carries the same
+        // m0(r0) + m0(r1), which cannot change a comparison between paths of equal length -- the fast mode drops it
+        // (correlation metric, SURVEY Appendix C: 0 flipped bits of 263 680 against the reference) and with it the exp and
+        // the log of every received value
+        m0 = 0.0f;
+        m1 = -(float)r;
     } else {
         const float x = (float)r, d0 = x + 1.0f, d1 = x - 1.0f;
         m0 = d0 * d0;
