@@ -262,13 +262,18 @@ int cpx_memset(void *dptr, int value, size_t bytes) {
     return CPX_OK;
 }
 
+// The synchronous copies run ON the library stream and wait for it: they are ordered after every `_dev` call that was given
+// stream = NULL.  (The library stream is non-blocking, so a plain hipMemcpy on the null stream is NOT ordered with it: a
+// cpx_memcpy_d2h right after an asynchronous `_dev` call could read the buffer before the kernel had written it.)
 int cpx_memcpy_h2d(void *dst, const void *src, size_t bytes) {
-    CPX_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    CPX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, lib_stream()));
+    CPX_HIP(hipStreamSynchronize(lib_stream()));
     return CPX_OK;
 }
 
 int cpx_memcpy_d2h(void *dst, const void *src, size_t bytes) {
-    CPX_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    CPX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, lib_stream()));
+    CPX_HIP(hipStreamSynchronize(lib_stream()));
     return CPX_OK;
 }
 

@@ -60,6 +60,8 @@ int cpx_get_precision(void);   /* 0 fp64-parity, 1 fp32-fast */
 int cpx_device_info(char *name, int name_cap, int *compute_units, int64_t *hbm_bytes);
 int cpx_malloc(void **dptr, size_t bytes);
 int cpx_free(void *dptr);
+/* cpx_memset / cpx_memcpy_h2d / cpx_memcpy_d2h are synchronous AND ordered with the library stream: they run after every `_dev`
+ * call that was given stream = NULL has finished (work on a caller's own stream needs cpx_stream_sync first). */
 int cpx_memset(void *dptr, int value, size_t bytes);
 int cpx_memcpy_h2d(void *dst, const void *src, size_t bytes);
 int cpx_memcpy_d2h(void *dst, const void *src, size_t bytes);
