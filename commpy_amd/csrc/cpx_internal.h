@@ -86,6 +86,7 @@ bool trace_enabled();
 // precision mode (cpx_set_precision / CPX_PRECISION): false = fp64-parity (default), true = fp32-fast
 bool precision_fast();
 
+void viterbi_prefer_cw(bool on);   // thread-local: the next dispatches of this thread take the codeword path whatever the batch size
 int viterbi_path_flags();   // bit 0 wave only, bit 1 codeword path forced, bit 2 strict, bit 3 two-kernel form
 
 inline hipStream_t pick_stream(void *s) { return s ? reinterpret_cast<hipStream_t>(s) : lib_stream(); }

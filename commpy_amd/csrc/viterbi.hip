@@ -32,6 +32,7 @@
 #include "demod_dev.h"
 
 #include <algorithm>
+#include <condition_variable>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -793,14 +794,98 @@ int cpx_viterbi_decode_batch_i64(const cpx_trellis *t, const double *coded, int6
     DevBuf din, dout;
     if ((rc = din.alloc(sizeof(double) * (size_t)(B * len)))) return rc;
     if ((rc = dout.alloc(nout))) return rc;
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt > 16) nt = 16;
+    if (nt < 1) nt = 1;
+    auto widen = [&](size_t lo_all, size_t hi_all, unsigned threads) {     // bits64[lo_all, hi_all) = stage[...]
+        auto work = [&](unsigned i) {
+            const size_t n = hi_all - lo_all, lo = lo_all + n * i / threads, hi = lo_all + n * (i + 1) / threads;
+            for (size_t j = lo; j < hi; j++) bits64[j] = stage[j];
+        };
+        std::vector<std::thread> th;
+        for (unsigned i = 1; i < threads; i++) th.emplace_back(work, i);
+        work(0);
+        for (auto &x : th) x.join();
+    };
+    // Large batches: a three-stream pipeline over chunks of codewords.  The pageable upload is what bounds the call (1.08 GB
+    // at 56 GB/s = 19 ms for the config-2 batch; cutting it into up to eight pieces costs nothing, scripts/micro/h2d_probe.py);
+    // decode, download and widening of chunk c run behind the upload of chunk c+1 -- the upload on its own stream (a chunk's
+    // kernels must not sit in front of the next chunk's copy), the download on a third (opposite PCIe direction), the
+    // widening on a worker thread while this thread is blocked inside the next pageable copy.  Measured: 26.2 -> 22.8 ms
+    // for the config-2 batch (2.94 G info-bit/s; 22.1 ms with the last chunk on the state-per-lane kernels, not kept: one
+    // kernel family per call keeps cpx_last_kernel and the precision mode unambiguous).  (Two earlier pipelines lost: chunks on two streams with the
+    // kernels in the upload stream, 44.7 vs 39.2 ms, and host threads copying into pinned staging blocks, 42.6 vs 40.3 ms:
+    // an extra pass over host memory costs more than it hides.)
+    const int64_t min_chunk = 4096;
+    int nch = (int)std::min<int64_t>(8, B / min_chunk);
+    if (nch >= 2 && (size_t)(B * len) * sizeof(double) >= ((size_t)128 << 20)) {
+        static hipStream_t s_up[64] = {}, s_cmp[64] = {}, s_dn[64] = {};     // per device, created once (under `mu`)
+        int dev = 0;
+        CPX_HIP(hipGetDevice(&dev));
+        CPX_REQUIRE(dev >= 0 && dev < 64, CPX_ELIMIT, "viterbi: device index out of range");
+        if (!s_up[dev]) {
+            CPX_HIP(hipStreamCreateWithFlags(&s_up[dev], hipStreamNonBlocking));
+            CPX_HIP(hipStreamCreateWithFlags(&s_cmp[dev], hipStreamNonBlocking));
+            CPX_HIP(hipStreamCreateWithFlags(&s_dn[dev], hipStreamNonBlocking));
+        }
+        std::vector<hipEvent_t> ev_up(nch), ev_cmp(nch), ev_dn(nch);
+        for (int c = 0; c < nch; c++) {
+            CPX_HIP(hipEventCreateWithFlags(&ev_up[c], hipEventDisableTiming));
+            CPX_HIP(hipEventCreateWithFlags(&ev_cmp[c], hipEventDisableTiming));
+            CPX_HIP(hipEventCreateWithFlags(&ev_dn[c], hipEventDisableTiming));
+        }
+        auto cw_lo = [&](int c) { return B * c / nch; };
+        int issued = 0, wrc = CPX_OK;
+        std::mutex qmu;
+        std::condition_variable qcv;
+        std::thread widener([&] {                                  // widens chunk c as soon as its download has landed
+            (void)hipSetDevice(dev);                               // a new host thread starts on device 0
+            for (int c = 0; c < nch; c++) {
+                {
+                    std::unique_lock<std::mutex> ql(qmu);
+                    qcv.wait(ql, [&] { return issued > c || issued < 0; });
+                    if (issued < 0) return;
+                }
+                if (hipEventSynchronize(ev_dn[c]) != hipSuccess) { wrc = CPX_EHIP; return; }
+                CPX_TRACE("widen chunk (worker thread)");
+                widen((size_t)(cw_lo(c) * L), (size_t)(cw_lo(c + 1) * L), nt > 2 ? nt - 1 : 1);
+            }
+        });
+        auto fail = [&](int code) {
+            { std::lock_guard<std::mutex> ql(qmu); issued = -1; }
+            qcv.notify_all();
+            widener.join();
+            (void)hipDeviceSynchronize();
+            for (int c = 0; c < nch; c++) { (void)hipEventDestroy(ev_up[c]); (void)hipEventDestroy(ev_cmp[c]); (void)hipEventDestroy(ev_dn[c]); }
+            return code;
+        };
+        for (int c = 0; c < nch; c++) {
+            const int64_t lo = cw_lo(c), n = cw_lo(c + 1) - lo;
+            {
+                CPX_TRACE("H2D chunk");
+                if (hipMemcpyAsync(din.as<double>() + lo * len, coded + lo * len, sizeof(double) * (size_t)(n * len),
+                                   hipMemcpyHostToDevice, s_up[dev]) != hipSuccess ||
+                    hipEventRecord(ev_up[c], s_up[dev]) != hipSuccess) { set_error("viterbi: upload failed"); return fail(CPX_EHIP); }
+            }
+            if (hipStreamWaitEvent(s_cmp[dev], ev_up[c], 0) != hipSuccess) { set_error("viterbi: stream wait failed"); return fail(CPX_EHIP); }
+            viterbi_prefer_cw(true);                               // see viterbi_cw.hip: the chunk's round hides behind the next upload
+            rc = cpx_viterbi_decode_batch_dev(t, din.as<double>() + lo * len, n, len, L, n_steps, tb_depth, decoding_type,
+                                              dout.as<uint8_t>() + lo * L, s_cmp[dev]);
+            viterbi_prefer_cw(false);
+            if (rc) return fail(rc);
+            if (hipEventRecord(ev_cmp[c], s_cmp[dev]) != hipSuccess || hipStreamWaitEvent(s_dn[dev], ev_cmp[c], 0) != hipSuccess ||
+                hipMemcpyAsync(stage + lo * L, dout.as<uint8_t>() + lo * L, (size_t)(n * L), hipMemcpyDeviceToHost, s_dn[dev]) != hipSuccess ||
+                hipEventRecord(ev_dn[c], s_dn[dev]) != hipSuccess) { set_error("viterbi: download failed"); return fail(CPX_EHIP); }
+            { std::lock_guard<std::mutex> ql(qmu); issued = c + 1; }
+            qcv.notify_all();
+        }
+        widener.join();
+        for (int c = 0; c < nch; c++) { (void)hipEventDestroy(ev_up[c]); (void)hipEventDestroy(ev_cmp[c]); (void)hipEventDestroy(ev_dn[c]); }
+        if (wrc) { set_error("viterbi: download failed"); return wrc; }
+        CPX_HIP(hipStreamSynchronize(s_cmp[dev]));
+        return CPX_OK;
+    }
     hipStream_t st = lib_stream();
-    // (cutting the batch into chunks on two streams to overlap upload and decode was measured: 44.7 ms against
-    // 39.2 ms for B = 65536 -- smaller pageable uploads lose more than the 3 ms of decode they hide.  Round 2 also
-    // measured the other pipeline: 16 host threads copying 128 MB chunks into two pinned staging blocks, DMA of chunk
-    // c-1 and decode of chunk c-2 in flight meanwhile, widening of finished chunks between copies: 42.6 ms against
-    // 40.3 ms.  The runtime's own pageable path already moves the 1.08 GB at ~49 GB/s, i.e. near the PCIe Gen5 rate,
-    // without a staging copy; an extra pass over host memory costs more than the 3 + 1 ms of decode and download it
-    // can hide.)
     {
         CPX_TRACE("H2D coded");
         CPX_HIP(hipMemcpyAsync(din.p, coded, sizeof(double) * (size_t)(B * len), hipMemcpyHostToDevice, st));
@@ -815,17 +900,7 @@ int cpx_viterbi_decode_batch_i64(const cpx_trellis *t, const double *coded, int6
         CPX_HIP(hipStreamSynchronize(st));
     }
     CPX_TRACE("widen to int64 (host threads)");
-    unsigned nt = std::thread::hardware_concurrency();
-    if (nt > 16) nt = 16;
-    if (nt < 1 || nout < (1u << 20)) nt = 1;
-    auto work = [&](unsigned i) {
-        const size_t lo = nout * i / nt, hi = nout * (i + 1) / nt;
-        for (size_t j = lo; j < hi; j++) bits64[j] = stage[j];
-    };
-    std::vector<std::thread> th;
-    for (unsigned i = 1; i < nt; i++) th.emplace_back(work, i);
-    work(0);
-    for (auto &x : th) x.join();
+    widen(0, nout, nout < (1u << 20) ? 1 : nt);
     return CPX_OK;
 }
 

@@ -703,6 +703,12 @@ int viterbi_path_flags() {
     return v;
 }
 
+// Set by the host-buffer pipeline (viterbi.hip) around its per-chunk calls: a chunk of a large batch takes the codeword path
+// whatever its own size (a round costs the same however full it is and hides behind the next chunk's upload; the fused
+// kernel -- and with it the precision mode -- then serves the host API exactly as it serves the device API).
+static thread_local bool tl_prefer_cw = false;
+void viterbi_prefer_cw(bool on) { tl_prefer_cw = on; }
+
 static const char *type_name(int type) { return type == CPX_VIT_HARD ? "hard" : type == CPX_VIT_SOFT ? "soft" : "unquantized"; }
 
 // Returns true when the call was handled here (*rc = status); false -> the caller uses the state-per-lane kernels.
@@ -714,7 +720,7 @@ bool viterbi_codeword_path(const cpx_trellis *t, const double *d_coded, int64_t 
     // where the fused kernel applies
     const int pf = viterbi_path_flags();
     if (pf & 1) return false;
-    const bool forced = pf & 2, strict = pf & 4, two_kernels = pf & 8;
+    const bool forced = (pf & 2) || tl_prefer_cw, strict = pf & 4, two_kernels = pf & 8;
     auto reject = [&](const char *why) {
         if (!strict) return false;
         set_error("viterbi (codeword path): %s", why);

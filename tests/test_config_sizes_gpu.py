@@ -49,8 +49,18 @@ def test_config2_full_batch_vs_oracle_16k(gpu):
     # QPSK soft LLR of a Gray-mapped +-1 component is 4 y / N0; computed in float32 noise to keep host memory modest
     llr = (4.0 / N0) * ((2.0 * coded - 1.0) + np.sqrt(N0 / 2) * rs.standard_normal(coded.shape, ).astype(np.float32))
     llr = np.ascontiguousarray(llr, dtype=np.float64)
-    got = viterbi_decode(llr, tr, None, "soft")
+    # device-resident call: the whole batch in one launch of the fused kernel (what bench.py times)
+    from commpy_amd.channelcoding.convcode import _viterbi_sizes
+    from commpy_amd.devicelink import DeviceBuf
+    lib = _lib.load()
+    L, n_steps, tb = _viterbi_sizes(llr.shape[1], tr, None)
+    d_in, d_out = DeviceBuf.from_array(llr), DeviceBuf(B * L)
+    _lib.check(lib.cpx_viterbi_decode_batch_dev(tr._device_handle(), d_in.ptr, B, llr.shape[1], L, n_steps, tb, 1, d_out.ptr, None))
     assert _lib.viterbi_last_path() == "fused", _lib.last_kernel()
+    got = d_out.to_array((B, L), np.uint8)
+    # host-buffer call (numpy in, int64 out): chunked upload / decode / download pipeline -- same bits
+    got_host = viterbi_decode(llr, tr, None, "soft")
+    assert got_host.dtype == np.int64 and np.array_equal(got_host, got)
     n = 5462
     for lo in (0, B // 2 - n // 2, B - n):
         want = oracle.viterbi_decode_mt(llr[lo:lo + n], tr, None, "soft")
