@@ -104,6 +104,12 @@ struct DevBuf {
     template <class T> T *as() { return reinterpret_cast<T *>(p); }
 };
 
+// a block of the scratch arena (not owned: released by cpx_release_workspace)
+struct ArenaBuf {
+    void *p = nullptr;
+    template <class T> T *as() { return static_cast<T *>(p); }
+};
+
 }  // namespace cpx
 
 // ---- handles -----------------------------------------------------------------------------------

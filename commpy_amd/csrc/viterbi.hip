@@ -791,9 +791,11 @@ int cpx_viterbi_decode_batch_i64(const cpx_trellis *t, const double *coded, int6
         CPX_HIP(hipHostMalloc((void **)&stage, nout, hipHostMallocDefault));
         stage_cap = nout;
     }
-    DevBuf din, dout;
-    if ((rc = din.alloc(sizeof(double) * (size_t)(B * len)))) return rc;
-    if ((rc = dout.alloc(nout))) return rc;
+    // device staging from the scratch arena (slots 2 / 3 of the library stream; this function is serialised by `mu`): a
+    // hipMalloc + hipFree of 1.08 GB per call is about a millisecond of a 23 ms call
+    ArenaBuf din, dout;
+    if ((rc = workspace(lib_stream(), 2, sizeof(double) * (size_t)(B * len), &din.p))) return rc;
+    if ((rc = workspace(lib_stream(), 3, nout, &dout.p))) return rc;
     unsigned nt = std::thread::hardware_concurrency();
     if (nt > 16) nt = 16;
     if (nt < 1) nt = 1;
@@ -811,8 +813,8 @@ int cpx_viterbi_decode_batch_i64(const cpx_trellis *t, const double *coded, int6
     // at 56 GB/s = 19 ms for the config-2 batch; cutting it into up to eight pieces costs nothing, scripts/micro/h2d_probe.py);
     // decode, download and widening of chunk c run behind the upload of chunk c+1 -- the upload on its own stream (a chunk's
     // kernels must not sit in front of the next chunk's copy), the download on a third (opposite PCIe direction), the
-    // widening on a worker thread while this thread is blocked inside the next pageable copy.  Measured: 26.2 -> 22.8 ms
-    // for the config-2 batch (2.94 G info-bit/s; 22.1 ms with the last chunk on the state-per-lane kernels, not kept: one
+    // widening on a worker thread while this thread is blocked inside the next pageable copy.  Measured: 26.2 -> 22.4 ms
+    // for the config-2 batch (3.0 G info-bit/s; 0.7 ms less with the last chunk on the state-per-lane kernels, not kept: one
     // kernel family per call keeps cpx_last_kernel and the precision mode unambiguous).  (Two earlier pipelines lost: chunks on two streams with the
     // kernels in the upload stream, 44.7 vs 39.2 ms, and host threads copying into pinned staging blocks, 42.6 vs 40.3 ms:
     // an extra pass over host memory costs more than it hides.)
