@@ -778,7 +778,7 @@ int cpx_map_decode_batch(const cpx_trellis *t, const double *sys, const double *
     rc = cpx_map_decode_batch_dev(t, ds.as<double>(), dp.as<double>(), dl.as<double>(), B, N, noise_variance, want_bits,
                                   dout.as<double>(), dbits.as<uint8_t>(), st);
     if (rc) return rc;
-    CPX_HIP(hipMemcpyAsync(L_ext, dout.p, nb, hipMemcpyDeviceToHost, st));
+    if ((rc = d2h_pageable(L_ext, dout.p, nb, st))) return rc;
     CPX_HIP(hipMemcpyAsync(bits, dbits.p, (size_t)(B * N), hipMemcpyDeviceToHost, st));
     CPX_HIP(hipStreamSynchronize(st));
     return CPX_OK;

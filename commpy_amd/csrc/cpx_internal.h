@@ -57,7 +57,7 @@ int ldpc_resident_tables(::cpx_ldpc *c, const int32_t *row_ptr, const int32_t *r
                          const int32_t *col_pad_cj);
 void ldpc_resident_free(::cpx_ldpc *c);
 bool ldpc_resident_path(const ::cpx_ldpc *c, double *d_llr, int64_t B, int alg, int n_iters, int8_t *d_dec, double *d_out,
-                        int32_t *d_iters, hipStream_t st, int *rc);
+                        int32_t *d_iters, int *d_clipped, hipStream_t st, int *rc);
 
 // per-device issue lock for entry points that take scratch-arena memory (runtime.hip)
 struct IssueGuard {
@@ -68,6 +68,8 @@ struct IssueGuard {
     int dev;
 };
 
+// blocking download into pageable host memory through pinned staging + host threads (runtime.hip)
+int d2h_pageable(void *dst, const void *d_src, size_t bytes, hipStream_t st);
 void issue_lock(int dev, bool lock);     // cpx_release_workspace takes all of them
 
 // roctx range for the lifetime of the object when CPX_TRACE=1 (runtime.hip); a no-op otherwise

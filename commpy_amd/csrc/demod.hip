@@ -268,7 +268,7 @@ int cpx_demod_soft(const cpx_modem *m, const double *y_re_im, int64_t Ns, double
     hipStream_t st = lib_stream();
     CPX_HIP(hipMemcpyAsync(din.p, y_re_im, sizeof(double) * 2 * (size_t)Ns, hipMemcpyHostToDevice, st));
     if ((rc = cpx_demod_soft_dev(m, din.as<double>(), Ns, noise_var, dout.as<double>(), st))) return rc;
-    CPX_HIP(hipMemcpyAsync(llr, dout.p, out_bytes, hipMemcpyDeviceToHost, st));
+    if ((rc = d2h_pageable(llr, dout.p, out_bytes, st))) return rc;
     CPX_HIP(hipStreamSynchronize(st));
     return CPX_OK;
 }

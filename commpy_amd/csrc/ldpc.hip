@@ -68,7 +68,7 @@ __device__ __forceinline__ void effective(const Ctl *c, int &n_slots, int &buf) 
 
 // L = Q = clip(llr) tile-major; llr clipped in place (ldpc.py:186); slot table; control block
 __global__ __launch_bounds__(LB) void ldpc_init_kernel(double *__restrict__ llr, int64_t B, int n_v, Bufs bf,
-                                                       int32_t *__restrict__ iters) {
+                                                       int32_t *__restrict__ iters, int *__restrict__ clipped) {
     __shared__ double ts[64][65];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;      // 64 x 4
     const int64_t tile = blockIdx.x;
@@ -80,7 +80,10 @@ __global__ __launch_bounds__(LB) void ldpc_init_kernel(double *__restrict__ llr,
         if (b < B && v < n_v) {
             const double raw = llr[b * n_v + v];
             x = clip_nan(raw, -500.0, 500.0);
-            if (x != raw) llr[b * n_v + v] = x;                   // in-place clip (:186); untouched values are not rewritten
+            if (x != raw) {                                       // in-place clip (:186); untouched values are not rewritten
+                llr[b * n_v + v] = x;
+                if (clipped) *clipped = 1;                        // lets the host-buffer entry point skip the copy back
+            }
         }
         ts[r][tx] = x;
     }
@@ -778,9 +781,18 @@ int cpx_ldpc_destroy(cpx_ldpc *c) {
     return CPX_OK;
 }
 
+// d_clipped (may be null): set to 1 when the in-place clip of (:186) changed any value of d_llr
+static int ldpc_decode_impl(const cpx_ldpc *c, double *d_llr, int64_t B, int alg, int n_iters, int8_t *d_dec, double *d_out,
+                            int32_t *d_iters, int *d_clipped, void *stream);
+
 int cpx_ldpc_bp_decode_batch_dev(const cpx_ldpc *c, double *d_llr, int64_t B, int alg, int n_iters, int8_t *d_dec,
                                  double *d_out, int32_t *d_iters, void *stream) {
     CPX_TRACE("cpx_ldpc_bp_decode_batch_dev");
+    return ldpc_decode_impl(c, d_llr, B, alg, n_iters, d_dec, d_out, d_iters, nullptr, stream);
+}
+
+static int ldpc_decode_impl(const cpx_ldpc *c, double *d_llr, int64_t B, int alg, int n_iters, int8_t *d_dec, double *d_out,
+                            int32_t *d_iters, int *d_clipped, void *stream) {
     cpx::IssueGuard issue_guard;
     CPX_REQUIRE(c, CPX_EINVAL, "ldpc: null code");
     if (int rcd = check_handle_device(c->device, "ldpc")) return rcd;
@@ -793,7 +805,7 @@ int cpx_ldpc_bp_decode_batch_dev(const cpx_ldpc *c, double *d_llr, int64_t B, in
     hipStream_t st = pick_stream(stream);
     {   // the whole decoder state of a block in LDS, one persistent launch (ldpc_resident.hip) -- unless it does not fit
         int rcr = CPX_OK;
-        if (ldpc_resident_path(c, d_llr, B, alg, n_iters, d_dec, d_out, d_iters, st, &rcr)) return rcr;
+        if (ldpc_resident_path(c, d_llr, B, alg, n_iters, d_dec, d_out, d_iters, d_clipped, st, &rcr)) return rcr;
     }
     const int64_t E = c->n_edges, nv = c->n_v;
     const int64_t n_tiles = (B + 63) / 64, S = n_tiles * 64;
@@ -817,7 +829,7 @@ int cpx_ldpc_bp_decode_batch_dev(const cpx_ldpc *c, double *d_llr, int64_t B, in
     bf.dst = (int32_t *)p; p += szI;
     bf.ctl = (Ctl *)p;
     hipLaunchKernelGGL(ldpc_init_kernel, dim3((unsigned)n_tiles, (unsigned)((nv + 63) / 64)), dim3(LB), 0, st, d_llr, B,
-                       (int)nv, bf, d_iters);
+                       (int)nv, bf, d_iters, d_clipped);
     // persistent grids: what is resident at once (occupancy x CUs), no more workgroups than wave items, a
     // multiple of 8 (one share per XCD)
     auto pgrid = [&](const void *fn, int64_t items) {
@@ -866,19 +878,34 @@ int cpx_ldpc_bp_decode_batch(const cpx_ldpc *c, double *llr, int64_t B, int alg,
     if (rc) return rc;
     if (B == 0) return CPX_OK;
     const size_t nvb = (size_t)((int64_t)c->n_v * B);
-    DevBuf d_llr, d_dec, d_out, d_it;
+    DevBuf d_llr, d_dec, d_out, d_it, d_flag;
     if ((rc = d_llr.alloc(sizeof(double) * nvb))) return rc;
     if ((rc = d_dec.alloc(nvb))) return rc;
     if ((rc = d_out.alloc(sizeof(double) * nvb))) return rc;
     if ((rc = d_it.alloc(sizeof(int32_t) * (size_t)B))) return rc;
+    if ((rc = d_flag.alloc(sizeof(int)))) return rc;
     hipStream_t st = lib_stream();
-    CPX_HIP(hipMemcpyAsync(d_llr.p, llr, sizeof(double) * nvb, hipMemcpyHostToDevice, st));
-    rc = cpx_ldpc_bp_decode_batch_dev(c, d_llr.as<double>(), B, alg, n_iters, d_dec.as<int8_t>(), d_out.as<double>(),
-                                      d_it.as<int32_t>(), st);
+    CPX_HIP(hipMemsetAsync(d_flag.p, 0, sizeof(int), st));
+    {
+        CPX_TRACE("H2D llr");
+        CPX_HIP(hipMemcpyAsync(d_llr.p, llr, sizeof(double) * nvb, hipMemcpyHostToDevice, st));
+        if (trace_enabled()) CPX_HIP(hipStreamSynchronize(st));
+    }
+    rc = ldpc_decode_impl(c, d_llr.as<double>(), B, alg, n_iters, d_dec.as<int8_t>(), d_out.as<double>(), d_it.as<int32_t>(),
+                          d_flag.as<int>(), st);
     if (rc) return rc;
-    CPX_HIP(hipMemcpyAsync(llr, d_llr.p, sizeof(double) * nvb, hipMemcpyDeviceToHost, st));   // in-place clip (:186)
-    if (dec_word) CPX_HIP(hipMemcpyAsync(dec_word, d_dec.p, nvb, hipMemcpyDeviceToHost, st));
-    if (out_llrs) CPX_HIP(hipMemcpyAsync(out_llrs, d_out.p, sizeof(double) * nvb, hipMemcpyDeviceToHost, st));
+    // in-place clip (:186): the caller's array only changes if a value lay outside +-500 (or is NaN) -- the kernels say so,
+    // and the 8-byte-per-LLR copy back (a third of this call's PCIe traffic) is skipped otherwise
+    int clipped = 0;
+    {
+        CPX_TRACE("decode (wait) + clip flag");
+        CPX_HIP(hipMemcpyAsync(&clipped, d_flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        CPX_HIP(hipStreamSynchronize(st));
+    }
+    CPX_TRACE("D2H results");
+    if (clipped && (rc = d2h_pageable(llr, d_llr.p, sizeof(double) * nvb, st))) return rc;
+    if (dec_word && (rc = d2h_pageable(dec_word, d_dec.p, nvb, st))) return rc;
+    if (out_llrs && (rc = d2h_pageable(out_llrs, d_out.p, sizeof(double) * nvb, st))) return rc;
     if (iters_done) CPX_HIP(hipMemcpyAsync(iters_done, d_it.p, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, st));
     CPX_HIP(hipStreamSynchronize(st));
     return CPX_OK;

@@ -46,6 +46,7 @@ struct ResParams {
     double *stage;           // [B][n_v] a-posteriori LLRs of retired blocks
     int32_t *iters;          // [B] executed iterations, may be null
     int *queue;              // next block to hand out
+    int *clipped;            // set to 1 when the in-place clip changed a value (may be null)
     const int32_t *row_deg;  // [n_c] check degree
     const int32_t *row_q;    // [n_c][cpad] LDS byte offset of Q[variable of the j-th edge]; padding -> the +inf slot
     const int32_t *col_r;    // [n_v][vpad] LDS byte offset of R[q-th edge of the variable], increasing check; padding -> the 0.0 slot
@@ -204,7 +205,10 @@ __global__ __launch_bounds__(1024, 6) void ldpc_resident_kernel(ResParams p) {
         for (int v = tid; v < p.n_v; v += nt) {
             const double raw = in[v];
             const double x = clip_nan(raw, -500.0, 500.0);
-            if (x != raw) in[v] = x;                             // in-place clip (:186); untouched values are not rewritten
+            if (x != raw) {                                      // in-place clip (:186); untouched values are not rewritten
+                in[v] = x;
+                if (p.clipped) *p.clipped = 1;
+            }
             stsd(8 * v, x);                                      // out_llrs = llr (:194)
         }
         for (int e = tid; e < p.n_r; e += nt) stsd(p.roff + 8 * e, 0.0);
@@ -334,7 +338,7 @@ void ldpc_resident_free(cpx_ldpc *c) {
 }
 
 bool ldpc_resident_path(const cpx_ldpc *c, double *d_llr, int64_t B, int alg, int n_iters, int8_t *d_dec, double *d_out,
-                        int32_t *d_iters, hipStream_t st, int *rc) {
+                        int32_t *d_iters, int *d_clipped, hipStream_t st, int *rc) {
     *rc = CPX_OK;
     const int mode = ldpc_path();
     auto reject = [&](const char *why) {
@@ -358,7 +362,7 @@ bool ldpc_resident_path(const cpx_ldpc *c, double *d_llr, int64_t B, int alg, in
     const size_t sz_stage = (sizeof(double) * (size_t)(B * c->n_v) + 255) & ~(size_t)255;
     if ((*rc = workspace(st, 0, sz_stage + 256, (void **)&slab))) return true;
     ResParams p;
-    p.llr = d_llr; p.stage = (double *)slab; p.iters = d_iters; p.queue = (int *)(slab + sz_stage);
+    p.llr = d_llr; p.stage = (double *)slab; p.iters = d_iters; p.queue = (int *)(slab + sz_stage); p.clipped = d_clipped;
     p.row_deg = c->d_res_row_deg; p.row_q = c->d_res_row_q; p.col_r = c->d_res_col_r; p.vgrp = c->d_res_vgrp;
     p.B = B; p.rstride = res_rstride(c); p.n_r = c->n_c * p.rstride; p.n_v = c->n_v; p.n_c = c->n_c; p.cpad = c->cpad; p.vpad = c->vpad;
     p.max_iter = n_iters;

@@ -2,11 +2,13 @@
 // HIP-event timers.  No compute here.
 #include "cpx_internal.h"
 
+#include <algorithm>
 #include <atomic>
 #include <dlfcn.h>
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <utility>
 
 namespace cpx {
@@ -186,6 +188,53 @@ IssueGuard::IssueGuard() : dev(0) {
 }
 IssueGuard::~IssueGuard() { g_issue_mu[dev].unlock(); }
 void issue_lock(int dev, bool lock) { if (lock) g_issue_mu[dev].lock(); else g_issue_mu[dev].unlock(); }
+
+// Download into PAGEABLE host memory, fast: the runtime's own pageable device-to-host path moved a fresh 0.57 GB NumPy result
+// at 24 GB/s (page faults of the destination inside the copy); here the data crosses PCIe into two pinned 64 MB blocks,
+// alternately, and host threads copy a finished block into the caller's array (first touch spread over the cores) while the
+// next one is in flight.  Blocks until the data is in `dst`.
+int d2h_pageable(void *dst, const void *d_src, size_t bytes, hipStream_t st) {
+    constexpr size_t CH = (size_t)64 << 20;
+    if (bytes < 2 * CH) {
+        CPX_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, st));
+        CPX_HIP(hipStreamSynchronize(st));
+        return CPX_OK;
+    }
+    static std::mutex mu;
+    static unsigned char *pin[2] = {nullptr, nullptr};
+    std::lock_guard<std::mutex> lk(mu);
+    for (int i = 0; i < 2; i++)
+        if (!pin[i]) CPX_HIP(hipHostMalloc((void **)&pin[i], CH, hipHostMallocDefault));
+    hipEvent_t ev[2];
+    CPX_HIP(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
+    CPX_HIP(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+    const size_t n = (bytes + CH - 1) / CH;
+    auto issue = [&](size_t c) -> hipError_t {
+        const size_t len = std::min(CH, bytes - c * CH);
+        hipError_t e = hipMemcpyAsync(pin[c & 1], static_cast<const unsigned char *>(d_src) + c * CH, len, hipMemcpyDeviceToHost, st);
+        return e != hipSuccess ? e : hipEventRecord(ev[c & 1], st);
+    };
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt > 8 ? 8 : (nt < 1 ? 1 : nt);
+    hipError_t err = issue(0);
+    for (size_t c = 0; c < n && err == hipSuccess; c++) {
+        if (c + 1 < n) err = issue(c + 1);                        // its pinned block was emptied in the previous round
+        if (err == hipSuccess) err = hipEventSynchronize(ev[c & 1]);
+        if (err != hipSuccess) break;
+        const size_t len = std::min(CH, bytes - c * CH);
+        unsigned char *to = static_cast<unsigned char *>(dst) + c * CH;
+        const unsigned char *from = pin[c & 1];
+        auto work = [&](unsigned i) { const size_t lo = len * i / nt, hi = len * (i + 1) / nt; memcpy(to + lo, from + lo, hi - lo); };
+        std::vector<std::thread> th;
+        for (unsigned i = 1; i < nt; i++) th.emplace_back(work, i);
+        work(0);
+        for (auto &x : th) x.join();
+    }
+    (void)hipEventDestroy(ev[0]);
+    (void)hipEventDestroy(ev[1]);
+    if (err != hipSuccess) { set_error("download failed: %s", hipGetErrorString(err)); (void)hipStreamSynchronize(st); return CPX_EHIP; }
+    return CPX_OK;
+}
 
 TraceRange::TraceRange(const char *name) : on(roctx().push != nullptr) { if (on) roctx().push(name); }
 TraceRange::~TraceRange() { if (on) roctx().pop(); }
