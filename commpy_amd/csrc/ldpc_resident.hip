@@ -22,7 +22,8 @@
 //     iteration exact without a special case: the first variable->check message is R * -1 + 1.0 * Q = -0.0 + Q = Q
 //     bit for bit (:199 vs :244-245);
 //   * min-sum stores the messages themselves (the tiled path stores a 3-word record per check and regenerates them: same
-//     values, fewer bytes, more instructions -- here instructions are what is scarce: the kernels run at ~88 % VALU busy);
+//     values, fewer bytes, more instructions -- with the records the first resident version ran at 88 % VALU busy and
+//     6 080 instructions per block-iteration; this one needs 2 900 and is bound by LDS bandwidth, 82 % busy);
 //   * a final transpose kernel turns the staging buffer [B][n_v] into the reference layout [n_v][B] (:251-253) and
 //     writes dec_word.
 // HBM traffic per block: llr read once per executed iteration (L2 hits after the first), staging written once.
