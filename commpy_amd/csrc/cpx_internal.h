@@ -153,6 +153,8 @@ struct cpx_ldpc {
     int32_t *d_res_row_deg = nullptr;   // [n_c] check degree
     int32_t *d_res_row_q = nullptr;     // [n_c][cpad] offset of Q[variable]; padding -> a +inf slot
     int32_t *d_res_col_r = nullptr;     // [n_v][vpad] offset of R[check][position], increasing check; padding -> a +0.0 slot
+    int32_t *d_res_row_q32 = nullptr;   // the same two tables with 4-byte offsets (fp32-fast mode)
+    int32_t *d_res_col_r32 = nullptr;
     int32_t *d_res_vgrp = nullptr;      // [ceil(n_v/64)] chunks of four entries per group of 64 variables
 };
 

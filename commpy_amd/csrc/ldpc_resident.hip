@@ -233,6 +233,143 @@ __global__ __launch_bounds__(1024, 6) void ldpc_resident_kernel(ResParams p) {
     }
 }
 
+// ---- "fp32-fast" precision mode (cpx_set_precision): the same persistent kernel with float32 state -----------------
+// NOT the parity mode.  Q and R are float (half the LDS: four workgroups per compute unit for (1944,1296)), the channel LLRs are
+// converted on the way in and the a-posteriori LLRs on the way out; sum-product uses the hardware exp2 / log2 / reciprocal
+// (__expf, __logf, __fdividef).  Float32 messages saturate earlier (tanh(m/2) rounds to 1 from |m| ~ 17), so trajectories differ
+// from the float64 decoder's: the contract is the decoded word on blocks that converge and the frame error rate, measured in
+// tests/test_fp32_fast_gpu.py and DESIGN.md 4.3 -- never the 1e-5 LLR criterion.  Tables: the same layout with 4-byte offsets.
+typedef __attribute__((address_space(3))) float lds_f32;
+__device__ __forceinline__ float ldsf(int off) { return *reinterpret_cast<lds_f32 *>((unsigned)off); }
+__device__ __forceinline__ void stsf(int off, float v) { *reinterpret_cast<lds_f32 *>((unsigned)off) = v; }
+__device__ __forceinline__ float clip_nan_f(float v, float lo, float hi) { return (v != v) ? v : fminf(fmaxf(v, lo), hi); }
+
+__device__ __forceinline__ void check_msa_f32(const ResParams &p, int c, int *flag) {
+    const int4 *__restrict__ qv = reinterpret_cast<const int4 *>(p.row_q + (int64_t)c * p.cpad);
+    const int rb = p.roff + 4 * c * p.rstride, nq = p.cpad >> 2;
+    int sx = 0, imin = 0;
+    unsigned neg = 0;
+    float m1 = __builtin_huge_valf(), m2 = __builtin_huge_valf();
+    for (int t = 0; t < nq; t++) {
+        const int4 a = qv[t];
+        const int off[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int j = 4 * t + u;
+            const float q = ldsf(off[u]);                        // padding: +inf, neutral below
+            sx ^= __float_as_int(q);
+            const float m = q - ldsf(rb + 4 * j);
+            const float av = fabsf(m);
+            const bool c1 = av < m1;
+            m2 = fminf(m2, c1 ? m1 : av);
+            m1 = fminf(m1, av);
+            imin = c1 ? j : imin;
+            neg |= (m < 0.0f) ? (1u << j) : 0u;
+        }
+    }
+    if (sx < 0) *flag = 1;
+    const unsigned negp = (__popc(neg) & 1) ? ~neg : neg;
+    const int b1 = __float_as_int(m1);
+    for (int j = 0; j < p.rstride; j++) stsf(rb + 4 * j, __int_as_float(b1 | (int)(((negp >> j) & 1u) << 31)));
+    stsf(rb + 4 * imin, __int_as_float(__float_as_int(m2) | (int)(((negp >> imin) & 1u) << 31)));
+}
+
+__device__ __forceinline__ void check_spa_f32(const ResParams &p, int c, int *flag) {
+    const int deg = p.row_deg[c];
+    const int4 *__restrict__ qv = reinterpret_cast<const int4 *>(p.row_q + (int64_t)c * p.cpad);
+    const int rb = p.roff + 4 * c * p.rstride;
+    int sx = 0;
+    float prod = 1.0f;
+    for (int j0 = 0; __builtin_amdgcn_ballot_w64(j0 < deg) != 0; j0 += 4) {
+        const int4 a = qv[j0 >> 2];
+        const float q[4] = {ldsf(a.x), ldsf(a.y), ldsf(a.z), ldsf(a.w)};
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int j = j0 + u;
+            if (j < deg) {
+                sx ^= __float_as_int(q[u]);
+                const float m = q[u] - ldsf(rb + 4 * j);
+                const float e = __expf(-fabsf(m));
+                const float t = __builtin_copysignf(__fdividef(1.0f - e, 1.0f + e), m);     // tanh(m / 2)
+                prod *= t;
+                stsf(rb + 4 * j, t);
+            }
+        }
+    }
+    if (sx < 0) *flag = 1;
+    for (int j = 0; __builtin_amdgcn_ballot_w64(j < deg) != 0; j++) {
+        if (j < deg) {
+            float x = __fdividef(1.0f, ldsf(rb + 4 * j)) * prod;
+            x = clip_nan_f(x, -1.0f, 1.0f);
+            x = __logf(__fdividef(1.0f + x, 1.0f - x));                                     // 2 atanh(x)
+            stsf(rb + 4 * j, clip_nan_f(x, -500.0f, 500.0f));
+        }
+    }
+}
+
+__device__ __forceinline__ void var_node_f32(const ResParams &p, int v, const double *__restrict__ lrow) {
+    const int trips = p.vgrp[__builtin_amdgcn_readfirstlane(v) >> 6];
+    const int4 *__restrict__ rf = reinterpret_cast<const int4 *>(p.col_r + (int64_t)v * p.vpad);
+    const float l = (float)lrow[v];
+    float msum = 0.0f;
+    for (int t = 0; t < trips; t++) {
+        const int4 a = rf[t];
+        const float r0 = ldsf(a.x), r1 = ldsf(a.y), r2 = ldsf(a.z), r3 = ldsf(a.w);
+        msum += r0; msum += r1; msum += r2; msum += r3;
+    }
+    stsf(4 * v, msum + l);
+}
+
+template <int ALG>
+__global__ __launch_bounds__(1024, 8) void ldpc_resident_f32_kernel(ResParams p) {
+    extern __shared__ __align__(16) char lds[];
+    if ((unsigned)(uintptr_t)lds != 0u) __builtin_trap();
+    int *ctl = reinterpret_cast<int *>(lds + p.ctl_off);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    if (tid == 0) {
+        stsf(4 * p.n_v, __builtin_huge_valf());
+        stsf(p.roff + 4 * p.n_r, 0.0f);
+    }
+    for (;;) {
+        if (tid == 0) {
+            const int t = atomicAdd(p.queue, 1);
+            ctl[2] = t < p.B ? t : -1;
+        }
+        __syncthreads();
+        const int b = ctl[2];
+        if (b < 0) break;
+        if (tid == 0) { ctl[0] = 0; ctl[1] = 0; }
+        double *__restrict__ in = p.llr + (int64_t)b * p.n_v;
+        for (int v = tid; v < p.n_v; v += nt) {
+            const double raw = in[v];
+            const double x = clip_nan(raw, -500.0, 500.0);
+            if (x != raw) {                                      // in-place clip (:186), as in the parity kernel
+                in[v] = x;
+                if (p.clipped) *p.clipped = 1;
+            }
+            stsf(4 * v, (float)x);
+        }
+        for (int e = tid; e < p.n_r; e += nt) stsf(p.roff + 4 * e, 0.0f);
+        __syncthreads();
+        int k = 0;
+        for (; k < p.max_iter; k++) {
+            int *flag = &ctl[k & 1];
+            for (int c = tid; c < p.n_c; c += nt) {
+                if (ALG == CPX_LDPC_MSA) check_msa_f32(p, c, flag);
+                else check_spa_f32(p, c, flag);
+            }
+            __syncthreads();
+            if (!*flag) break;
+            if (tid == 0) ctl[(k + 1) & 1] = 0;
+            for (int v = tid; v < p.n_v; v += nt) var_node_f32(p, v, in);
+            __syncthreads();
+        }
+        double *__restrict__ out = p.stage + (int64_t)b * p.n_v;
+        for (int v = tid; v < p.n_v; v += nt) out[v] = (double)ldsf(4 * v);
+        if (tid == 0 && p.iters) p.iters[b] = k;
+    }
+}
+
 // staging [B][n_v] -> out_llrs [n_v][B], dec_word [n_v][B] (:247-253)
 __global__ __launch_bounds__(256) void ldpc_unstage_kernel(const double *__restrict__ stage, int64_t B, int n_v,
                                                            double *__restrict__ out, int8_t *__restrict__ dec) {
@@ -295,8 +432,15 @@ int launch_resident(const ResParams &p, int grid, int threads, size_t lds, hipSt
     return CPX_OK;
 }
 
+template <int ALG>
+int launch_resident_f32(const ResParams &p, int grid, int threads, size_t lds, hipStream_t st) {
+    hipLaunchKernelGGL((ldpc_resident_f32_kernel<ALG>), dim3((unsigned)grid), dim3((unsigned)threads), lds, st, p);   // < 64 KB of LDS
+    return CPX_OK;
+}
+
 int res_roff(int n_v) { return ((n_v + 2) & ~1) * 8; }            // Q[n_v] + the dummy slot, R 16-byte aligned
 int res_rstride(const cpx_ldpc *c) { return c->max_cdeg | 1; }
+size_t res_lds_bytes_f32(const cpx_ldpc *c) { return (size_t)(res_roff(c->n_v) / 2) + 4 * ((size_t)c->n_c * (c->max_cdeg | 1) + 1 + 4) + 64; }
 size_t res_lds_bytes(const cpx_ldpc *c) { return (size_t)res_roff(c->n_v) + 8 * ((size_t)c->n_c * res_rstride(c) + 1 + 4) + 64; }
 
 }  // namespace
@@ -324,7 +468,11 @@ int ldpc_resident_tables(cpx_ldpc *c, const int32_t *row_ptr, const int32_t *row
             cr[(size_t)v * vpad + q] = roff + 8 * ((cj >> 5) * rs + (cj & 31));
         }
     }
-    struct Up { int32_t **dst; std::vector<int32_t> *src; } ups[] = {{&c->d_res_row_deg, &dg}, {&c->d_res_row_q, &rq},
+    // the float32 mode: same tables with 4-byte offsets (R starts at roff / 2)
+    std::vector<int32_t> rq32(rq.size()), cr32(cr.size());
+    for (size_t i = 0; i < rq.size(); i++) rq32[i] = rq[i] / 2;
+    for (size_t i = 0; i < cr.size(); i++) cr32[i] = roff / 2 + (cr[i] - roff) / 2;
+    struct Up { int32_t **dst; std::vector<int32_t> *src; } ups[] = {{&c->d_res_row_q32, &rq32}, {&c->d_res_col_r32, &cr32}, {&c->d_res_row_deg, &dg}, {&c->d_res_row_q, &rq},
                                                                      {&c->d_res_col_r, &cr}, {&c->d_res_vgrp, &vg}};
     for (auto &u : ups) {
         hipError_t e1 = hipMalloc((void **)u.dst, sizeof(int32_t) * u.src->size());
@@ -335,7 +483,7 @@ int ldpc_resident_tables(cpx_ldpc *c, const int32_t *row_ptr, const int32_t *row
 }
 
 void ldpc_resident_free(cpx_ldpc *c) {
-    (void)hipFree(c->d_res_row_deg); (void)hipFree(c->d_res_row_q); (void)hipFree(c->d_res_col_r); (void)hipFree(c->d_res_vgrp);
+    (void)hipFree(c->d_res_row_deg); (void)hipFree(c->d_res_row_q); (void)hipFree(c->d_res_col_r); (void)hipFree(c->d_res_vgrp); (void)hipFree(c->d_res_row_q32); (void)hipFree(c->d_res_col_r32);
 }
 
 bool ldpc_resident_path(const cpx_ldpc *c, double *d_llr, int64_t B, int alg, int n_iters, int8_t *d_dec, double *d_out,
@@ -350,6 +498,29 @@ bool ldpc_resident_path(const cpx_ldpc *c, double *d_llr, int64_t B, int alg, in
     if (n_iters < 1) return reject("n_iters == 0");
     if (B >= (1ll << 30)) return reject("batch too large");
     if (!c->d_res_row_q) return reject("decoder state of one block exceeds the LDS of a compute unit");
+    if (precision_fast() && n_iters >= 1 && res_lds_bytes_f32(c) <= 64 * 1024) {
+        // "fp32-fast": float32 state (see ldpc_resident_f32_kernel); 512-thread workgroups, as many as the LDS / 2048 threads allow
+        const size_t lds32 = res_lds_bytes_f32(c);
+        const int threads32 = std::min(512, std::max(64, (c->n_c + 63) / 64 * 64));
+        char *slab32 = nullptr;
+        const size_t sz_stage32 = (sizeof(double) * (size_t)(B * c->n_v) + 255) & ~(size_t)255;
+        if ((*rc = workspace(st, 0, sz_stage32 + 256, (void **)&slab32))) return true;
+        ResParams q;
+        q.llr = d_llr; q.stage = (double *)slab32; q.iters = d_iters; q.queue = (int *)(slab32 + sz_stage32); q.clipped = d_clipped;
+        q.row_deg = c->d_res_row_deg; q.row_q = c->d_res_row_q32; q.col_r = c->d_res_col_r32; q.vgrp = c->d_res_vgrp;
+        q.B = B; q.rstride = res_rstride(c); q.n_r = c->n_c * q.rstride; q.n_v = c->n_v; q.n_c = c->n_c; q.cpad = c->cpad; q.vpad = c->vpad;
+        q.max_iter = n_iters; q.roff = res_roff(c->n_v) / 2; q.ctl_off = (int)(lds32 - 64);
+        if (hipMemsetAsync(q.queue, 0, sizeof(int), st) != hipSuccess) { set_error("ldpc: hipMemsetAsync failed"); *rc = CPX_EHIP; return true; }
+        const int per_cu32 = std::max(1, std::min({(int)(LDS_BYTES / lds32), 2048 / threads32, 16}));
+        const int grid32 = (int)std::min<int64_t>((int64_t)device_cus() * per_cu32, B);
+        if (alg == CPX_LDPC_SPA) launch_resident_f32<CPX_LDPC_SPA>(q, grid32, threads32, lds32, st);
+        else launch_resident_f32<CPX_LDPC_MSA>(q, grid32, threads32, lds32, st);
+        hipLaunchKernelGGL(ldpc_unstage_kernel, dim3((unsigned)((B + 63) / 64), (unsigned)((c->n_v + 63) / 64)), dim3(256), 0, st,
+                           q.stage, B, c->n_v, d_out, d_dec);
+        if (hipGetLastError() != hipSuccess) { set_error("ldpc (resident path, f32): launch failed"); *rc = CPX_EHIP; }
+        note_kernel("ldpc_resident_f32_kernel<%s> threads=%d workgroups/CU=%d", alg == CPX_LDPC_MSA ? "MSA" : "SPA", threads32, per_cu32);
+        return true;
+    }
     const size_t lds = res_lds_bytes(c);
     // workgroup size: the check pass in one round (two for > 1024 checks) -- (1944,1296): 704 threads, the variable pass
     // takes three rounds; measured 2.51 ms at 704, 2.75 at 512, 3.38 at 1024 (scripts/micro/ldpc_knobs.py)

@@ -52,9 +52,11 @@ int cpx_get_device(int *device);
 int cpx_last_kernel(char *name, int cap);
 /* Precision mode of the process ("fp64-parity default vs fp32-fast"), initial value from the environment variable
  * CPX_PRECISION.  "fp64-parity" (default): every kernel computes in float64 in the reference's operation order -- the mode all
- * parity claims are made in.  "fp32-fast": kernels that have a float32 variant use it -- today the fused codeword-per-lane
- * Viterbi kernel (float32 path metrics, hardware exp2/log2 branch metrics); NOT bit-exact, measured mismatch rate in
- * DESIGN.md 4.1; every other kernel is unaffected.  cpx_last_kernel shows ",f32" when the variant ran. */
+ * parity claims are made in.  "fp32-fast": kernels that have a float32 variant use it -- the fused codeword-per-lane Viterbi
+ * kernel (float32 path metrics, correlation branch metric; measured mismatch rate in DESIGN.md 4.1) and the LDS-resident LDPC
+ * kernels (float32 messages, hardware exp2 / log2 / reciprocal for sum-product; same decoded words and frame error rate on the
+ * measured workloads) -- NOT bit-exact and NOT under the 1e-5 LLR criterion; every other kernel is unaffected.
+ * cpx_last_kernel shows "f32" in the name when a variant ran. */
 int cpx_set_precision(const char *mode);
 int cpx_get_precision(void);   /* 0 fp64-parity, 1 fp32-fast */
 int cpx_device_info(char *name, int name_cap, int *compute_units, int64_t *hbm_bytes);

@@ -87,3 +87,32 @@ def test_fast_mode_leaves_every_other_kernel_alone(gpu, lib):
     assert np.array_equal(a, b) and np.array_equal(d0, d1) and np.array_equal(o0, o1)
     with pytest.raises(Exception):
         lib.set_precision("fp16")
+
+
+@pytest.mark.parametrize("alg", ["MSA", "SPA"])
+def test_ldpc_fast_mode_decodes_like_the_parity_mode(gpu, lib, alg):
+    """fp32-fast LDPC (float32 state in the LDS-resident kernel): not the 1e-5 LLR contract -- the decoded word of blocks that
+    converge, the frame error rate and the iteration counts must stay those of the float64 decoder."""
+    from commpy_amd.channelcoding import ldpc_bp_decode
+    from helpers import ldpc_params
+    p = ldpc_params("n1944")
+    n, B = 1944, 4096
+    rs = np.random.RandomState(77)
+    sigma = 1 / np.sqrt(10 ** 0.3 * (2.0 / 3) * 2)                                  # Eb/N0 = 3 dB, all-zero codeword
+    llr = (2.0 * (1.0 + sigma * rs.randn(B * n)) / sigma ** 2)
+    d0, o0, i0 = ldpc_bp_decode(llr.copy(), p, alg, 50, return_iterations=True)
+    assert "ldpc_resident_kernel" in lib.last_kernel()
+    lib.set_precision("fp32-fast")
+    d1, o1, i1 = ldpc_bp_decode(llr.copy(), p, alg, 50, return_iterations=True)
+    assert "ldpc_resident_f32_kernel" in lib.last_kernel(), lib.last_kernel()
+    lib.set_precision(None)
+    ok0, ok1 = ~d0.any(axis=0), ~d1.any(axis=0)                                     # decoded to the transmitted (all-zero) word
+    fer0, fer1 = 1 - ok0.mean(), 1 - ok1.mean()
+    both = (i0 < 50) & (i1 < 50)
+    same_word = np.all(d0[:, both] == d1[:, both], axis=0).mean()
+    print("fp32-fast LDPC %s at 3 dB: FER fp64 %.4f, fp32 %.4f; mean iterations %.2f / %.2f; identical dec_word on %.5f of the "
+          "blocks both decoders converge on; sign(out_llrs) agreement %.6f" % (
+              alg, fer0, fer1, i0.mean(), i1.mean(), same_word, np.mean(np.signbit(o0[:, both]) == np.signbit(o1[:, both]))))
+    assert same_word > 0.999
+    assert abs(fer1 - fer0) <= 0.01 + 0.2 * fer0
+    assert abs(i1.mean() - i0.mean()) < 0.5
