@@ -70,21 +70,36 @@ def test_hard_is_identical_and_unquantized_close(gpu, lib, dtype):
 
 
 def test_fast_mode_leaves_every_other_kernel_alone(gpu, lib):
-    """Small batches (state-per-lane kernels), other traceback depths beyond the fused kernel, LDPC, demod: same results."""
-    from commpy_amd.channelcoding import ldpc_bp_decode, viterbi_decode
+    """Small Viterbi batches (state-per-lane kernels), the tiled LDPC path, BCJR and the demodulators have no float32 variant:
+    same results, bit for bit."""
+    from commpy_amd.channelcoding import ldpc_bp_decode, map_decode, viterbi_decode
+    from commpy_amd.modulation import QAMModem
     from helpers import ldpc_params
     tr = make_trellis("k7_133_171")
+    tr4 = make_trellis("rsc_legacy_4")
     rs = np.random.RandomState(2)
     x = rs.randn(40, 2 * 200) * 2
     p = ldpc_params("gallager96")
     l = rs.randn(96 * 7) * 3
-    a = viterbi_decode(x, tr, None, "soft")
-    d0, o0 = ldpc_bp_decode(l.copy(), p, "SPA", 5)
+    md = QAMModem(16)
+    y = md.constellation[rs.randint(0, 16, 300)] + 0.2 * (rs.randn(300) + 1j * rs.randn(300))
+    s_, p_ = rs.randn(50), rs.randn(50)
+
+    def run():
+        lib.ldpc_set_path("tiled")
+        try:
+            d, o = ldpc_bp_decode(l.copy(), p, "SPA", 5)
+        finally:
+            lib.ldpc_set_path(None)
+        return (viterbi_decode(x, tr, None, "soft"), d, o, md.demodulate(y, "soft", 0.1),
+                map_decode(s_, p_, tr4, 0.7, np.zeros(50), "compute")[0])
+
+    a = run()
     lib.set_precision("fp32-fast")
-    b = viterbi_decode(x, tr, None, "soft")
-    d1, o1 = ldpc_bp_decode(l.copy(), p, "SPA", 5)
+    b = run()
     assert "f32" not in lib.last_kernel()
-    assert np.array_equal(a, b) and np.array_equal(d0, d1) and np.array_equal(o0, o1)
+    for u, v in zip(a, b):
+        assert np.array_equal(u, v)
     with pytest.raises(Exception):
         lib.set_precision("fp16")
 
