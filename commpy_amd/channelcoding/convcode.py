@@ -312,7 +312,9 @@ def viterbi_decode(coded_bits, trellis, tb_depth=None, decoding_type='hard'):
     Differences kept on purpose: the caller's array is never modified (the reference overwrites
     the last received codeword with the padding value for 'hard'/'unquantized', convcode.py:724-732);
     an invalid ``decoding_type`` raises ``ValueError`` immediately rather than only when the padding
-    steps are reached (convcode.py:733-734).
+    steps are reached (convcode.py:733-734); a ``tb_depth`` beyond the number of trellis steps + 1 -- where the
+    reference never runs a traceback and returns its uninitialised ``np.empty`` buffer (convcode.py:711, :644) --
+    decodes with one full-length traceback from the best final state instead of returning garbage.
     """
     if decoding_type not in _VIT_TYPES:
         raise ValueError('The available decoding types are "hard", "soft" and "unquantized')
