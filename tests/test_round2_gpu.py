@@ -279,3 +279,24 @@ def test_concurrent_host_threads_share_the_arena_safely(gpu):
         assert not errs, errs[:5]
     finally:
         _lib.viterbi_set_path(None)
+
+
+@pytest.mark.parametrize("m,N0", [(64, 0.1), (64, 0.02), (256, 0.05), (256, 0.02), (16, 0.01)])  # the last: saturates below 600 too
+def test_soft_demod_near_underflow_follows_the_reference(gpu, m, N0):
+    """26 - 35 dB: LLRs of 600 - 745 and +-inf, where sums of e^{-d^2/N0} are down among the denormals.  The factorised
+    (per-axis) sums round differently there, so such symbols are redone point by point in the reference's order
+    (modulation.py:125-137): finiteness pattern equal to the oracle's, values to 1e-9 (found by scripts/fuzz_gpu.py)."""
+    from commpy_amd.modulation import QAMModem
+    md = QAMModem(m)
+    rs = np.random.RandomState(m)
+    ns = 6000
+    y = md.constellation[rs.randint(0, md.m, ns)] + np.sqrt(N0 / 2) * (rs.randn(ns) + 1j * rs.randn(ns))
+    soft = md.demodulate(y, "soft", N0)
+    want = oracle.demodulate(md.constellation, y, "soft", N0)
+    assert np.max(np.abs(want[np.isfinite(want)])) > (600 if m >= 64 else 400)
+    assert np.array_equal(np.isfinite(soft), np.isfinite(want))
+    assert np.array_equal(np.isnan(soft), np.isnan(want))
+    inf = np.isinf(want)
+    assert np.array_equal(soft[inf], want[inf])
+    fin = np.isfinite(want)
+    assert np.max(np.abs(soft[fin] - want[fin])) < 1e-9
