@@ -37,6 +37,7 @@ def main():
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         rsc = [make_trellis("rsc_legacy_4"), make_trellis("rsc_legacy_8")]
+    others = {}
     t_end = time.time() + a.seconds
     n = {"viterbi": 0, "ldpc": 0, "map": 0, "turbo": 0, "demod": 0}
     modems = [QAMModem(4), QAMModem(16), QAMModem(64), QAMModem(256), PSKModem(2), PSKModem(4), PSKModem(8), PSKModem(16)]
@@ -45,7 +46,37 @@ def main():
         kind = rs.choice(["viterbi", "viterbi", "ldpc", "map", "turbo", "demod"])
         n[kind] += 1
         try:
-            if kind == "viterbi":
+            if kind == "viterbi" and rs.rand() < 0.35:
+                # any trellis of the fixture list (k = 2, recursive, 8 .. 128 states: the state-per-lane / wide kernels), decoding
+                # random received values -- no valid codeword needed to compare two decoders
+                name = str(rs.choice(["t57", "rsc_legacy_4", "k2_default", "k2_lsb", "k2_rsc_matrix", "wifi_decimal_133_171",
+                                      "rsc_legacy_8", "rsc_matrix_4", "r13_k4", "k5_23_35", "k8_247_371"]))
+                if name not in others:
+                    with warnings.catch_warnings():
+                        warnings.simplefilter("ignore")
+                        others[name] = make_trellis(name)
+                tr = others[name]
+                dtype = str(rs.choice(["hard", "soft", "unquantized"]))
+                B, steps = int(rs.choice([1, 3, 16, 17, 64, 100])), int(rs.randint(tr.total_memory + 1, 120))
+                length = steps * tr.n
+                L = int(length * tr.k / tr.n)
+                tb = None if rs.rand() < 0.4 else int(rs.randint(2, min(40, L) + 1))
+                n_steps = int((L + tr.total_memory) / tr.k) - 1
+                if (tb if tb is not None else min(5 * tr.total_memory, L)) - 1 > n_steps:
+                    n[kind] -= 1                                   # no traceback ever runs: the reference returns uninitialised memory
+                    continue
+                if dtype == "hard":
+                    rx = rs.randint(0, 2, (B, length)).astype(float)
+                elif dtype == "soft":
+                    rx = rs.randn(B, length) * rs.choice([0.5, 3.0])
+                    rx[rs.rand(*rx.shape) < 0.01] = np.inf
+                else:
+                    rx = rs.choice([-1.0, 1.0], size=(B, length)) + rs.randn(B, length) * 0.7
+                want = oracle.viterbi_decode(rx, tr, tb, dtype)
+                got = viterbi_decode(rx, tr, tb, dtype)
+                if not np.array_equal(got, want):
+                    bad.append(("viterbi-other", name, dtype, B, steps, tb, int(np.sum(got != want))))
+            elif kind == "viterbi":
                 dtype = rs.choice(["hard", "soft", "unquantized"])
                 B, nbits = int(rs.choice([1, 2, 7, 63, 64, 65, 130, 300])), int(rs.randint(1, 400))
                 # tb_depth - 1 > number of steps: the reference never runs a traceback and returns uninitialised memory
