@@ -242,6 +242,11 @@ def ldpc_bp_decode(llr_vec, ldpc_code_params, decoder_algorithm, n_iters, return
     ``(dec_word int8, out_llrs float64)``, each ``(n_vnodes, n_blocks)`` with one block per column,
     squeezed to 1-D for a single block.  ``return_iterations=True`` (extension) appends the int32
     number of executed iterations per block.
+
+    Difference kept on purpose: a NaN among the LLRs of a min-sum ('MSA') decode stays confined to the messages
+    computed from it (the hardware minimum returns the other operand), where NumPy's ``min`` / ``sign`` spread it over
+    the whole block within a few iterations (ldpc.py:229-238); 'SPA' propagates NaN like the reference, and +-inf is
+    clipped to +-500 first by both.
     """
     if decoder_algorithm not in ('SPA', 'MSA'):
         raise NameError('Please input a valid decoder_algorithm string (meanning "SPA" or "MSA").')
