@@ -791,11 +791,13 @@ int cpx_viterbi_decode_batch_i64(const cpx_trellis *t, const double *coded, int6
         CPX_HIP(hipHostMalloc((void **)&stage, nout, hipHostMallocDefault));
         stage_cap = nout;
     }
-    // device staging from the scratch arena (slots 2 / 3 of the library stream; this function is serialised by `mu`): a
+    // device staging from the scratch arena -- slots 6 / 7 of the library stream, used by nothing else (this function is
+    // serialised by `mu`; the blocks are touched from the pipeline's own streams, so they must not be shared with entry points
+    // that rely on the library stream's order): a
     // hipMalloc + hipFree of 1.08 GB per call is about a millisecond of a 23 ms call
     ArenaBuf din, dout;
-    if ((rc = workspace(lib_stream(), 2, sizeof(double) * (size_t)(B * len), &din.p))) return rc;
-    if ((rc = workspace(lib_stream(), 3, nout, &dout.p))) return rc;
+    if ((rc = workspace(lib_stream(), 6, sizeof(double) * (size_t)(B * len), &din.p))) return rc;
+    if ((rc = workspace(lib_stream(), 7, nout, &dout.p))) return rc;
     unsigned nt = std::thread::hardware_concurrency();
     if (nt > 16) nt = 16;
     if (nt < 1) nt = 1;
