@@ -238,31 +238,17 @@ __global__ __launch_bounds__(64) void viterbi_wave_kernel(VitParams p) {
         }
     };
     load_chunk(1, rcur);
-    bool poisoned_before = false, poisoned_now = false;
 
     for (int64_t t_base = 1; t_base <= p.T; t_base += CH) {
         // ---------------- branch-metric table of this chunk ----------------
         {
             double m0[NMAX], m1[NMAX];
-            bool nan_here = false;
 #pragma unroll
             for (int j = 0; j < NMAX; j++) {
                 double r = rcur[j];
-                if (p.type == CPX_VIT_SOFT) {
-                    nan_here |= (j < n) && (r != r);
-                    r = fmin(fmax(r, -500.0), 500.0);                // coded_bits.clip(-500, 500) (:719); NaN: see `poisoned`
-                }
+                if (p.type == CPX_VIT_SOFT) r = fmin(fmax(r, -500.0), 500.0);   // coded_bits.clip(-500, 500) (:719)
                 m0[j] = 0.0; m1[j] = 0.0;
                 if (j < n) bit_metrics(p.type, r, m0[j], m1[j]);
-            }
-            // 'soft' and a NaN among the received values: the reference's clip lets it through, every metric of that step and of
-            // all later ones is NaN, every comparison false, argmin of all-NaN candidates 0 (:633-645): from the first NaN step of
-            // a codeword on, all decisions are "first predecessor" and the traceback starts from state 0.  Lane (g, s) prepared
-            // step s of codeword g: it is poisoned if the codeword was, or if any lane of its group at or below s saw a NaN.
-            if (p.type == CPX_VIT_SOFT) {                        // (kept off the 'hard' / 'unquantized' paths: a chunk is only S steps)
-                const unsigned long long nan_grp = (__ballot(nan_here) >> gshift) & gmask;
-                poisoned_now = poisoned_before || (nan_grp & ((2ull << s) - 1ull)) != 0;
-                poisoned_before = poisoned_before || nan_grp != 0;
             }
             double *row = bm + lane * NC;
             for (int c = 0; c < NC; c++) {
@@ -367,19 +353,6 @@ __global__ __launch_bounds__(64) void viterbi_wave_kernel(VitParams p) {
                 mybest = mine ? bst : mybest;
             }
         }
-        if (p.type == CPX_VIT_SOFT) {
-            // the decision word of a step is shared by the G codewords of the wavefront (bits [g S, g S + S) belong to codeword
-            // g): clear the ranges of the codewords that are poisoned at this lane's step
-            const unsigned long long pb = __ballot(poisoned_now);
-            if (pb) {
-                // bit g S + s of pb: codeword g is poisoned at step s.  One bit per group, multiplied by the group mask, is S bits
-                constexpr unsigned long long REP = (S == 64) ? 1ull : (~0ull / ((1ull << (S & 63)) - 1ull));   // 0x...0101 pattern
-                const unsigned long long zero_bits = ((pb >> s) & REP) * gmask;
-                mydec0 &= ~zero_bits;
-                mydec1 &= ~zero_bits;
-                if (poisoned_now) mybest = 0;
-            }
-        }
         {
             const int slot = (int)((t_base + s) & RM);       // slots of steps beyond T are never read
             dring[slot * PL] = mydec0;                        // identical words from the G codeword slots
@@ -463,27 +436,20 @@ __global__ __launch_bounds__(64) void viterbi_wide_kernel(VitParams p) {
 #pragma unroll
     for (int q = 0; q < SPL; q++) pm[q] = (q == 0 && lane == 0) ? 0.0 : __builtin_huge_val();
     int64_t next_out = 1;
-    bool poisoned = false;                                         // 'soft': a NaN was received in an earlier chunk
-    unsigned long long nan_steps = 0;
 
     for (int64_t t_base = 1; t_base <= p.T; t_base += CH) {
         {   // branch-metric table: lane i prepares step t_base + i
             const int64_t t = t_base + lane;
             const bool have = (t <= p.Lk) && (t <= p.T);
             double m0[CPX_MAX_N], m1[CPX_MAX_N];
-            bool nan_here = false;
 #pragma unroll
             for (int j = 0; j < CPX_MAX_N; j++) {
                 double r = (p.type == CPX_VIT_UNQUANTIZED) ? -1.0 : 0.0;
                 if (have && j < n) r = x[(t - 1) * n + j];
-                if (p.type == CPX_VIT_SOFT) {
-                    nan_here |= (j < n) && (r != r);
-                    r = fmin(fmax(r, -500.0), 500.0);
-                }
+                if (p.type == CPX_VIT_SOFT) r = fmin(fmax(r, -500.0), 500.0);
                 m0[j] = 0.0; m1[j] = 0.0;
                 if (j < n) bit_metrics(p.type, r, m0[j], m1[j]);
             }
-            nan_steps = __ballot(nan_here);                       // bit i: step t_base + i received a NaN (see viterbi_wave_kernel)
             for (int c = 0; c < NC; c++) {
                 double acc = 0.0;
 #pragma unroll
@@ -500,7 +466,6 @@ __global__ __launch_bounds__(64) void viterbi_wide_kernel(VitParams p) {
 #pragma unroll
             for (int q = 0; q < SPL; q++) pmbuf[q * 64 + lane] = pm[q];
             __syncthreads();
-            const bool pz = poisoned || (nan_steps & ((2ull << i) - 1ull)) != 0;   // wave-uniform
             unsigned long long w[SPL][2];
 #pragma unroll
             for (int q = 0; q < SPL; q++) {
@@ -512,8 +477,8 @@ __global__ __launch_bounds__(64) void viterbi_wide_kernel(VitParams p) {
                     if (c < best) { best = c; jb = j; }                        // first minimum wins
                 }
                 pm[q] = best;
-                w[q][0] = pz ? 0ull : __ballot(jb & 1);
-                w[q][1] = (PL == 2 && !pz) ? __ballot(jb & 2) : 0ull;
+                w[q][0] = __ballot(jb & 1);
+                w[q][1] = (PL == 2) ? __ballot(jb & 2) : 0ull;
             }
             double mn = pm[0];
 #pragma unroll
@@ -532,11 +497,10 @@ __global__ __launch_bounds__(64) void viterbi_wide_kernel(VitParams p) {
                     dring[(slot * PL) * SPL + q] = w[q][0];
                     if (PL == 2) dring[(slot * PL + 1) * SPL + q] = w[q][1];
                 }
-                bring[slot] = (unsigned char)((bst < 0 || pz) ? 0 : bst);
+                bring[slot] = (unsigned char)(bst < 0 ? 0 : bst);
             }
             __syncthreads();
         }
-        poisoned = poisoned || nan_steps != 0;
         const int64_t t_done = t_base + nsteps - 1;
         const int64_t s_hi = (t_done >= p.T) ? p.T : (t_done - p.tb + 2);
         auto decision = [&](int64_t tt, int st) {

@@ -66,8 +66,7 @@ __device__ __forceinline__ double vmin(double a, double b) {      // one v_min_f
 // One add-compare-select decision: d = (y < x); result = d ? y : x (first minimum wins, convcode.py:633-642);
 // acc = 2*acc + d shifts the decision bit in.  Two forms:
 //  * acs_min: v_cmp + v_addc + v_min_f64 -- equal to the select whenever neither operand is NaN, which holds for
-//    'hard' (integer metrics) and 'soft' (a NaN input is clipped to -500 for the arithmetic -- metrics are >= 0 or +inf, only
-//    added -- and its effect in the reference, NaN metrics for the rest of the codeword, is applied to the decisions: `poisoned`);
+//    'hard' (integer metrics) and 'soft' (the clip maps a NaN input to -500, metrics are >= 0 or +inf, only added);
 //  * acs_select: v_cmp + 2 v_cndmask + v_addc, the select of viterbi.hip itself -- used for 'unquantized', where a NaN
 //    input reaches the metrics and v_min_f64's NaN rule (return the other operand) would differ.
 __device__ __forceinline__ double acs_min(unsigned &acc, double x, double y) {
@@ -330,11 +329,6 @@ __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_acs_kernel(CwParams
         const int tc = (t < tmax) ? t : tmax;
         return *reinterpret_cast<const double2 *>(x + (int64_t)(tc - 1) * 2);
     };
-    // 'soft' and a NaN among the received values: the reference's clip lets it through (:719), every branch metric of that step
-    // is NaN, so is every path metric from then on, every comparison is false and `argmin` of all-NaN candidates is 0 (:633-645):
-    // from the first NaN step on, all decisions are "first predecessor" and the traceback always starts from state 0.  The
-    // arithmetic below runs on with the NaN clipped to -500 (v_min_f64 needs NaN-free metrics); its decisions are discarded.
-    bool poisoned = false;
     double2 cur[LGS], nxt[LGS];
 #pragma unroll
     for (int u = 0; u < LGS; u++) cur[u] = load(1 + u);
@@ -354,10 +348,9 @@ __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_acs_kernel(CwParams
             constexpr int R = decltype(rtag)::value;
             unsigned long long word;
             int bst;
-            if (TYPE == CPX_VIT_SOFT) poisoned |= (v.x != v.x) || (v.y != v.y);
             cw_step<LGS, G0, G1, TYPE, R>(pm, v.x, v.y, word, bst);
-            d[R * 64] = poisoned ? 0ull : word;                    // see `poisoned`
-            b[R * 64] = (unsigned char)(poisoned ? 0 : bst);
+            d[R * 64] = word;
+            b[R * 64] = (unsigned char)bst;
         };
         if constexpr (LGS >= 1) one(std::integral_constant<int, 0>{}, cur[0]);
         if constexpr (LGS >= 2) one(std::integral_constant<int, 1>{}, cur[1 % LGS]);
@@ -461,7 +454,6 @@ __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_fused_kernel(CwPara
 #pragma unroll
     for (int u = 0; u < LGS; u++) cur[u] = load(1 + u);
     int best_T = 0;                                                               // first-argmin state of step T
-    bool poisoned = false;                                                        // a NaN was received ('soft'): see the ACS kernel
     WalkHook<LGS, HT, RT> walk;                                                        // walk of the previous step (step 0: a dummy)
     walk.pw = mycol;
     walk.st = 0;
@@ -515,10 +507,8 @@ __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_fused_kernel(CwPara
                 const double r0 = have ? cur[R].x : pad, r1 = have ? cur[R].y : pad;
                 unsigned long long word;
                 int bst;
-                if (TYPE == CPX_VIT_SOFT) poisoned |= (r0 != r0) || (r1 != r1);   // see the ACS kernel
                 cw_step<LGS, G0, G1, TYPE, R>(pm, r0, r1, word, bst, walk);      // + hops 0 .. 3/4 H of the walk of step tt - 1
                 walk.finish();
-                if (TYPE == CPX_VIT_SOFT) { word = poisoned ? 0ull : word; bst = poisoned ? 0 : bst; }
                 myrow[g * LGS + R] = (unsigned char)((walk.st >> (LGS - 1)) & 1u);   // input bit of the branch into the state at step tt - 1 - H
                 // ring slot of step tt and its mirror FR_RING slots above; the (at most LGS - 1) steps > T of the last group
                 // write to two dummy slots instead: the ring must keep the words of steps T-H+1 .. T for the final walk

@@ -97,27 +97,3 @@ def test_invalid_arguments(gpu):
         _decode(np.zeros(20), tr, None, "fuzzy")
     out = _decode(np.zeros((0, 20)), tr, None, "hard")
     assert out.shape == (0, 10)
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("name", ["k7_133_171", "t57", "k2_default", "k8_247_371"])
-def test_soft_nan_inputs_follow_the_reference(gpu, name):
-    """The reference's clip lets a NaN LLR through (convcode.py:719): from that step on every metric of the codeword is NaN,
-    every decision "first predecessor", every traceback starts from state 0 (:633-645).  All kernel paths (fused / two-kernel
-    codeword path, state-per-lane, 128-state) against the oracle, which was checked against the live reference on such inputs."""
-    from commpy_amd import _lib
-    from commpy_amd.channelcoding import viterbi_decode
-    tr = make_trellis(name)
-    rs = np.random.RandomState(5)
-    for B, steps in ((1, 40), (70, 130), (64, 64)):
-        rx = rs.randn(B, steps * tr.n) * 3
-        rx[rs.rand(*rx.shape) < 0.004] = np.nan
-        rx[0, rs.randint(0, rx.shape[1])] = np.nan
-        want = oracle.viterbi_decode(rx, tr, None, "soft")
-        for path in ((None, "cw!", "cw2!", "wave") if name == "k7_133_171" else (None,)):
-            _lib.viterbi_set_path(path)
-            try:
-                got = viterbi_decode(rx, tr, None, "soft")
-            finally:
-                _lib.viterbi_set_path(None)
-            assert np.array_equal(got, want), (name, B, steps, path)
