@@ -11,11 +11,11 @@ by default the timed region contains no collective; ``--gather`` adds the one co
 RCCL all-gather of the decoded bits (uint8, 67.5 MB per rank and step) on the decode stream -- to every step.
 Collectives (closing barrier, max over ranks, error-count all-reduce, the optional all-gather) go through the
 engine's own RCCL binding (``cpx_comm_*``, commpy_amd.parallel.RankComm); torch is NOT imported.  ``--comm torch``
-uses torch.distributed instead, and is also what the launcher plumbing falls back to -- loudly, in the JSON line --
-if the RCCL communicator cannot be formed.  Rank 0 prints ONE JSON line with the contract fields plus `roofline`
-(dominant kernel as reported by the library, HIP-event timed on its own stream) and `cpu_baseline` (the C oracle -- a
-port of the reference's algorithm -- timed on the host cores on a bounded sample; the unmodified Python reference is
-not available on the GPU box).
+uses torch.distributed instead (an explicit choice: if the RCCL communicator cannot be formed the run fails).  Rank 0 prints ONE JSON line with the contract fields plus `roofline`
+(dominant kernel as reported by the library, HIP-event timed on its own stream) and `cpu_baseline`: the UNMODIFIED reference
+timed on the host cores when it is present on the box ($CPX_REFERENCE_PATH, /root/reference, importable `commpy`; kind
+"reference"), else the C oracle -- a line-by-line port of the same function -- on >= 4096 distinct codewords (kind "port");
+the NumPy-vectorised restatement rides along as a labelled secondary.
 """
 import argparse
 import ctypes
@@ -33,7 +33,7 @@ MSG_BITS = 1024
 EBN0_DB = 3.0
 ALG_BYTES_PER_CW = 2060 * 8 + 1030 * 1      # float64 LLRs in + uint8 bits out
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: 8.0 TB/s spec
-PMC_FILE = "r02_viterbi_c2_pmc.json"        # written by scripts/collect_pmc.sh from rocprofv3 passes over this script
+PMC_FILE = "r03_viterbi_c2_pmc.json"        # written by scripts/collect_pmc.py from rocprofv3 passes over this script
 
 
 def synth_inputs(B, seed_msg, seed_noise):
@@ -64,23 +64,97 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(tr, llr_sample, budget_s=12.0):
-    """Oracle (C port of convcode.py:661-749) on the host cores: one thread per core decodes its slice of the
-    sample (one C call per pass, GIL released) again and again until budget_s of wall time has elapsed.
-    Bounded sample, reported beside the GPU number."""
+def _find_reference():
+    """Directory that holds the UNMODIFIED reference package `commpy` (veeresht/CommPy), or None.  Looked for in
+    $CPX_REFERENCE_PATH, then /root/reference (the build container; absent on the GPU box), then sys.path."""
+    for cand in (os.environ.get("CPX_REFERENCE_PATH"), "/root/reference"):
+        if cand and os.path.isfile(os.path.join(cand, "commpy", "channelcoding", "convcode.py")):
+            return cand
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("commpy")
+        if spec and spec.origin and os.path.isfile(os.path.join(os.path.dirname(spec.origin), "channelcoding", "convcode.py")):
+            return os.path.dirname(os.path.dirname(spec.origin))
+    except (ImportError, ValueError):
+        pass
+    return None
+
+
+def _reference_worker(job):
+    """One pool process: the reference's own viterbi_decode (convcode.py:661-749) on its share of the codewords; only the
+    decoder calls are timed (imports, Trellis construction and IPC excluded)."""
+    ref_dir, llrs = job
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    import warnings
+    warnings.simplefilter("ignore")
+    if ref_dir not in sys.path:
+        sys.path.insert(0, ref_dir)
+    from commpy.channelcoding import convcode as ref
+    tr = ref.Trellis(np.array([6]), np.array([[0o133, 0o171]]))
+    outs, t = [], 0.0
+    for x in llrs:
+        t0 = time.perf_counter()
+        d = ref.viterbi_decode(x, tr, None, "soft")
+        t += time.perf_counter() - t0
+        outs.append(np.asarray(d, dtype=np.int64))
+    return np.stack(outs), t
+
+
+def cpu_baseline(tr, llr_sample, gpu_bits=None, budget_s=8.0):
+    """The CPU path beside the GPU number, on the host cores of THIS machine, bounded samples of the same workload:
+
+    * kind "reference": the unmodified Python reference (convcode.py:661-749), one process per usable core
+      (multiprocessing, spawn), 8 codewords per core, when the package is present on the box ($CPX_REFERENCE_PATH,
+      /root/reference or an importable `commpy`); its output is compared with the engine's on those codewords;
+    * kind "port" otherwise (the GPU box has no copy of the reference): oracle/cpx_oracle.c, a line-by-line C restatement of
+      the same function, one thread per core over >= 4096 DISTINCT codewords (nothing is cache-hot by construction);
+    * `secondary`: the batch-vectorised NumPy restatement (oracle/np_viterbi.py), single thread -- labelled, never the baseline.
+    """
     import concurrent.futures as cf
     import oracle
+    from oracle import np_viterbi
     oracle.load()
     cores = usable_cores()
-    chunks = [np.ascontiguousarray(llr_sample[i::cores][:8]) for i in range(cores)]
+    res = None
+    ref_dir = _find_reference()
+    if ref_dir:
+        import multiprocessing as mp
+        per = 8
+        n = min(len(llr_sample), cores * per)
+        jobs = [(ref_dir, llr_sample[i:n:cores]) for i in range(cores) if i < n]
+        t0 = time.perf_counter()
+        with mp.get_context("spawn").Pool(len(jobs)) as pool:
+            parts = pool.map(_reference_worker, jobs)
+        wall = time.perf_counter() - t0
+        busy = sum(t for _, t in parts)
+        slowest = max(t for _, t in parts)
+        mism = None
+        if gpu_bits is not None:
+            mism = int(sum(np.sum(out != gpu_bits[i:n:cores][:len(out)]) for i, (out, _) in enumerate(parts)))
+        res = {"value": n * MSG_BITS / slowest, "unit": "info-bits/s", "cores": len(jobs), "kind": "reference",
+               "per_core": n * MSG_BITS / busy,
+               "sample": "%d codewords (K=7 soft, 1024-bit; the first of the timed batch) through the unmodified "
+                         "commpy.channelcoding.viterbi_decode from %s, %d processes x %d codewords; %.1f s of decoder calls "
+                         "in the slowest process (%.1f s wall incl. process start-up and imports, not counted); "
+                         "bits differing from the engine's on these codewords: %s"
+                         % (n, ref_dir, len(jobs), per, slowest, wall, mism)}
+    # the C port: distinct codewords only
+    nd = min(len(llr_sample), 4096)
+    chunks = [np.ascontiguousarray(llr_sample[i:nd:cores]) for i in range(cores)]
     chunks = [c for c in chunks if len(c)]
     deadline = [0.0]
 
     def work(c):
-        done = 0
-        while time.perf_counter() < deadline[0]:          # time-bounded: every pass is ONE C call (GIL released)
-            oracle.viterbi_decode(c, tr, None, "soft")
-            done += len(c)
+        done, pos, step = 0, 0, 8
+        while time.perf_counter() < deadline[0]:                  # time-bounded: every call is ONE C call (GIL released)
+            blk = c[pos:pos + step]
+            if not len(blk):
+                pos = 0                                           # (only a box much faster than expected wraps around)
+                continue
+            oracle.viterbi_decode(blk, tr, None, "soft")
+            done += len(blk)
+            pos += step
         return done
 
     with cf.ThreadPoolExecutor(len(chunks)) as ex:
@@ -88,12 +162,24 @@ def cpu_baseline(tr, llr_sample, budget_s=12.0):
         deadline[0] = t0 + budget_s
         n = sum(ex.map(work, chunks))
         dt = time.perf_counter() - t0
-    reps = n // max(1, sum(len(c) for c in chunks))
-    return {"value": n * MSG_BITS / dt, "unit": "info-bits/s", "cores": len(chunks), "kind": "port",
-            "sample": "%d codeword decodes (K=7 soft, 1024-bit; %d distinct codewords x ~%d passes) through "
-                      "oracle/cpx_oracle.c orc_viterbi_decode on %d threads, %.1f s wall; the unmodified Python "
-                      "reference is absent on the GPU box -- measured in the build container it does ~1.0e3 "
-                      "info-bits/s per core (BASELINE.md)" % (n, sum(len(c) for c in chunks), reps, len(chunks), dt)}
+    port = {"value": n * MSG_BITS / dt, "unit": "info-bits/s", "cores": len(chunks), "kind": "port",
+            "sample": "%d codeword decodes (K=7 soft, 1024-bit) over %d distinct codewords of the timed batch through "
+                      "oracle/cpx_oracle.c orc_viterbi_decode on %d threads, %.1f s wall" % (n, nd, len(chunks), dt)}
+    if res is None:
+        res = port
+        res["sample"] += ("; the unmodified Python reference is not present on this box (set CPX_REFERENCE_PATH to time "
+                          "it) -- measured in the build container it does ~1.0e3 info-bits/s per core (BASELINE.md)")
+    else:
+        res["port"] = port
+    nb = min(len(llr_sample), 256)
+    t0 = time.perf_counter()
+    got = np_viterbi.viterbi_decode_batch(llr_sample[:nb], tr, None, "soft")
+    dt = time.perf_counter() - t0
+    res["secondary"] = {"value": nb * MSG_BITS / dt, "unit": "info-bits/s", "cores": 1,
+                        "kind": "numpy-vectorised restatement (oracle/np_viterbi.py), NOT the reference",
+                        "sample": "%d codewords in one batched call, %.2f s; equal to the C port: %s"
+                                  % (nb, dt, bool(np.array_equal(got, oracle.viterbi_decode(llr_sample[:nb], tr, None, "soft"))))}
+    return res
 
 
 def main():
@@ -120,7 +206,6 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     torch = dist = comm = None
-    comm_note = None
     if distributed and args.comm == "torch":
         # torch first: its bundled HIP runtime (same SONAME) is then shared by libcommpy_amd.so
         import torch
@@ -133,16 +218,10 @@ def main():
     _lib.check(lib.cpx_set_device(local_rank))
     _lib.set_precision(args.precision)
     if distributed and args.comm == "rccl":
+        # the engine's own RCCL binding; if the communicator cannot be formed the run FAILS (a silent switch to
+        # torch.distributed would measure torch's collectives under the engine's name -- use --comm torch for those)
         from commpy_amd.parallel import RankComm
-        try:
-            comm = RankComm(rank, world)
-        except Exception as exc:                      # launcher plumbing only: fall back, and say so in the JSON line
-            comm_note = "RankComm failed (%s: %s); torch.distributed used instead" % (type(exc).__name__, exc)
-            print("bench.py: " + comm_note, file=sys.stderr, flush=True)
-            import torch
-            import torch.distributed as dist
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        comm = RankComm(rank, world)
 
     B = args.batch
     nsym = (MSG_BITS + 6) * 2 // 2                                 # 1030 QPSK symbols per codeword
@@ -316,18 +395,24 @@ def main():
         kavg = float(np.mean(kernel_ms))
         achieved = ALG_BYTES_PER_CW * B / (kavg * 1e-3) / 1e9
         value = world * B * MSG_BITS * args.steps / elapsed
-        # HBM traffic and VALU occupancy of this kernel from the committed rocprofv3 PMC passes (scripts/collect_pmc.sh),
-        # used only when they were taken on the same kernel and batch
+        # HBM traffic and VALU occupancy of this kernel from the committed rocprofv3 PMC passes (scripts/collect_pmc.py).  They
+        # cannot be measured inside this run (counters need the profiler), so they are quoted ONLY when the file was recorded
+        # by a library built from the same Viterbi sources as the one loaded now (cpx_build_id, "viterbi" digest), for the same
+        # kernel and batch; otherwise null.
         traffic = traffic_src = valu = None
+        build = _lib.build_id()
         try:
             with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
                 tj = json.load(f)
             same = (tj.get("batch") == B and kernel_name.split("<")[0] in tj.get("kernel", "?") and
-                    args.precision == "fp64-parity")                     # (the counters were taken in parity mode)   rocprofv3 prints the
-            # template arguments as numbers ("<6, 109u, 79u, 1, 28>"): the kernel's base name and the batch identify it
+                    args.precision == "fp64-parity" and                  # (the counters were taken in parity mode)   rocprofv3 prints the
+                    # template arguments as numbers ("<6, 109u, 79u, 1, 28>"): the kernel's base name and the batch identify it
+                    bool(build.get("viterbi")) and (tj.get("build_id") or {}).get("viterbi") == build.get("viterbi"))
             if same:
                 traffic = tj["traffic_bytes_per_launch"]
-                traffic_src = "profiles/%s (rocprofv3 FETCH_SIZE / WRITE_SIZE passes; gfx950 correction as in the file)" % PMC_FILE
+                traffic_src = ("profiles/%s (rocprofv3 FETCH_SIZE / WRITE_SIZE passes; gfx950 correction as in the file; "
+                               "recorded at git %s with the same Viterbi sources, build id %s)"
+                               % (PMC_FILE, str(tj.get("git_head"))[:12], build.get("viterbi")))
                 valu = tj.get("valu")
         except (OSError, ValueError, KeyError):
             pass
@@ -346,7 +431,7 @@ def main():
                            else "no data-path collective"),
                        "collectives": ("engine RCCL binding (cpx_comm_*)" if comm is not None else
                                        "torch.distributed (nccl)" if dist is not None else "none (single process)")},
-            "ber": ber, "oracle_mismatched_bits": mism, "oracle_sample_codewords": checked,
+            "ber": ber, "oracle_mismatched_bits": mism, "oracle_sample_codewords": checked, "build_id": build,
             "demod_max_abs_err_vs_oracle": demod_err,
             # the kernel is bound by VALU issue, not by HBM: achieved / peak / frac are the HBM figures the
             # contract asks for, `valu` carries the ceiling that actually binds (from the PMC passes in profiles/)
@@ -361,10 +446,8 @@ def main():
         }
         if gather_ok is not None:
             out["gather_own_slot_ok"] = gather_ok
-        if comm_note:
-            out["comm_note"] = comm_note
         if not args.no_cpu_baseline and world == 1:                # reported at N = 1 only; the other ranks would idle
-            out["cpu_baseline"] = cpu_baseline(tr, llr_s)
+            out["cpu_baseline"] = cpu_baseline(tr, llr_s, bits[:ns, :].astype(np.int64))
         else:
             out["cpu_baseline"] = None
     if comm is not None:

@@ -10,7 +10,7 @@ GPU is missing.
     from commpy_amd.channelcoding import Trellis, viterbi_decode, map_decode, turbo_decode, ldpc_bp_decode
     from commpy_amd.modulation import PSKModem, QAMModem
 """
-__version__ = "0.1.0"
+__version__ = "0.3.0"
 
 from commpy_amd import utilities  # noqa: F401
 
@@ -18,8 +18,11 @@ from commpy_amd import utilities  # noqa: F401
 
 def set_precision(mode):
     """Precision mode of the engine: 'fp64-parity' (default: float64 in the reference's operation order, the mode every parity
-    claim is made in) or 'fp32-fast' (float32 variants where a kernel has one -- today the large-batch Viterbi kernel; not
-    bit-exact).  Also settable through the environment variable CPX_PRECISION before the first call."""
+    claim is made in) or 'fp32-fast' (float32 variants where a kernel has one; not bit-exact).  The switch is PROCESS-GLOBAL and affects
+    two decoders: the large-batch Viterbi kernel (float32 path metrics) AND ``ldpc_bp_decode`` (float32 messages,
+    hardware exp / log for sum-product, DESIGN.md 4.3: same decoded words on blocks that converge, NOT the 1e-5 LLR criterion).
+    Enable it around the calls that should use it and reset it (``set_precision(None)``) afterwards.  Also settable through the
+    environment variable CPX_PRECISION before the first call."""
     from commpy_amd import _lib
     _lib.set_precision(mode)
 

@@ -24,6 +24,7 @@ _i8p = POINTER(c_int8)
 SYMBOLS = {
     "cpx_last_error": (c_char_p, []),
     "cpx_version": (c_int, []),
+    "cpx_build_id": (c_char_p, []),
     "cpx_device_count": (c_int, [POINTER(c_int)]),
     "cpx_set_device": (c_int, [c_int]),
     "cpx_get_device": (c_int, [POINTER(c_int)]),
@@ -191,6 +192,13 @@ def last_kernel():
     buf = ctypes.create_string_buffer(200)
     check(load().cpx_last_kernel(buf, 200))
     return buf.value.decode()
+
+
+def build_id():
+    """{'full': sha16, 'viterbi': sha16}: digests of the sources the loaded library was compiled from (cpx_build_id)."""
+    raw = load().cpx_build_id()
+    txt = raw.decode() if raw else ""
+    return dict(part.split(":", 1) for part in txt.split(";") if ":" in part)
 
 
 def set_precision(mode):

@@ -6,6 +6,7 @@ hipcc cross-compiles without a GPU.  Device code is built with -ffp-contract=off
 reproduce the reference's float64 arithmetic operation by operation, and fusing a*b+c into an FMA
 would change the rounding of path metrics / state metrics.
 """
+import hashlib
 import os
 import subprocess
 import sys
@@ -14,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(CSRC, "libcommpy_amd.so")
-SOURCES = ["runtime.hip", "viterbi.hip", "viterbi_cw.hip", "bcjr.hip", "ldpc.hip", "ldpc_resident.hip", "demod.hip", "linksim.hip", "encoders.hip",
+SOURCES = ["runtime.hip", "viterbi.hip", "viterbi_cw.hip", "bcjr.hip", "bcjr_exact.hip", "ldpc.hip", "ldpc_resident.hip", "demod.hip", "linksim.hip", "encoders.hip",
            "comm.hip"]
 
 
@@ -30,6 +31,27 @@ OBJDIR = os.path.join(CSRC, "build")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-result",
          "-I", INCLUDE, "-I", CSRC]
 LINK_LIBS = ["-ldl"]            # librccl is dlopen()ed by comm.hip at the first communicator
+
+
+def _digest(names):
+    h = hashlib.sha256()
+    for n in sorted(names):
+        path = n if os.path.isabs(n) else os.path.join(CSRC, n)
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+# what the Viterbi kernels are compiled from: bench.py only trusts committed rocprofv3 counters of the headline kernel when
+# they were recorded with a library built from exactly these sources (cpx_build_id() of the .so == the id in the PMC file)
+VITERBI_SOURCES = ["viterbi.hip", "viterbi_cw.hip", "cpx_math.h", "cpx_internal.h", "demod_dev.h"]
+
+
+def source_build_id():
+    """'full:<sha16 of every source and header>;viterbi:<sha16 of the Viterbi kernels' sources>' -- also compiled into the
+    library (cpx_build_id), so that a measurement file can be tied to the code that produced it."""
+    return "full:%s;viterbi:%s" % (_digest(SOURCES + HEADERS), _digest(VITERBI_SOURCES))
 
 
 def _stale(target, deps):
@@ -50,13 +72,18 @@ def build_native(force=False, verbose=True):
         return LIB
     os.makedirs(OBJDIR, exist_ok=True)
     hipcc = _hipcc()
+    build_id = source_build_id()
+    id_file = os.path.join(OBJDIR, "build_id.txt")
+    id_changed = not os.path.exists(id_file) or open(id_file).read() != build_id
     jobs, objs = [], []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(OBJDIR, os.path.splitext(s)[0] + ".o")
         objs.append(obj)
-        if force or _stale(obj, [src] + HEADERS):
+        if force or _stale(obj, [src] + HEADERS) or (s == "runtime.hip" and id_changed):
             cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+            if s == "runtime.hip":
+                cmd.insert(-4, '-DCPX_BUILD_ID="%s"' % build_id)      # cpx_build_id()
             if verbose:
                 print(" ".join(cmd), flush=True)
             jobs.append((s, subprocess.Popen(cmd)))
@@ -67,6 +94,8 @@ def build_native(force=False, verbose=True):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(id_file, "w") as f:
+        f.write(build_id)
     return LIB
 
 

@@ -314,10 +314,11 @@ def viterbi_decode(coded_bits, trellis, tb_depth=None, decoding_type='hard'):
     an invalid ``decoding_type`` raises ``ValueError`` immediately rather than only when the padding
     steps are reached (convcode.py:733-734); a ``tb_depth`` beyond the number of trellis steps + 1 -- where the
     reference never runs a traceback and returns its uninitialised ``np.empty`` buffer (convcode.py:711, :644) --
-    decodes with one full-length traceback from the best final state instead of returning garbage; a NaN among
-    'soft' inputs is treated as -500 (the reference's clip lets it through, every metric it touches becomes NaN and
-    all later comparisons on that path are false) -- 'hard' and 'unquantized' inputs, including NaN, +-inf and
-    non-binary values, decode exactly like the reference.
+    decodes with one full-length traceback from the best final state instead of returning garbage.  Abnormal
+    inputs decode exactly like the reference: non-binary 'hard' values, +-inf, and NaN -- which the reference's
+    clip lets through (convcode.py:719): from the first NaN step of a codeword on every metric is NaN, every
+    decision is "first predecessor" and every traceback starts from state 0 (the fast kernels detect the NaN and
+    such codewords are decoded a second time by a NaN-exact kernel).
     """
     if decoding_type not in _VIT_TYPES:
         raise ValueError('The available decoding types are "hard", "soft" and "unquantized')

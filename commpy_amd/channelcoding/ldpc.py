@@ -152,9 +152,13 @@ def get_ldpc_code_params(ldpc_design_filename, compute_matrix=False):
     with open(ldpc_design_filename, 'rb') as f:
         raw = f.read()
     sha = hashlib.sha256(raw).hexdigest()
-    z = _cache_load(sha + '.npz')
+    # the cache entry is keyed by the design file AND by the blob format this engine writes: an entry of another engine
+    # version is simply not found, and a found one is validated (cpx_ldpc_blob_info: magic, sizes, checksum, every index) before
+    # it is trusted -- a blob that fails is dropped and rebuilt, never handed to the decoder
+    entry = '%s.v%d.npz' % (sha, _BLOB_FORMAT)
+    z = _cache_load(entry)
     params = None
-    if z is not None and all(k in z for k in _PARAM_ARRAYS + ('dims', 'blob')):
+    if z is not None and all(k in z for k in _PARAM_ARRAYS + ('dims', 'blob')) and _blob_ok(z['blob']):
         n_v, n_c, mvd, mcd = [int(x) for x in z['dims']]
         params = {'n_vnodes': n_v, 'n_cnodes': n_c, 'max_cnode_deg': mcd, 'max_vnode_deg': mvd}
         for k in _PARAM_ARRAYS:
@@ -164,15 +168,27 @@ def get_ldpc_code_params(ldpc_design_filename, compute_matrix=False):
         params = _parse_design(raw.decode())
         try:
             params['_cpx_blob'] = ldpc_design_blob(params)
-            _cache_store(sha + '.npz', dict({k: params[k] for k in _PARAM_ARRAYS}, blob=params['_cpx_blob'],
-                                            dims=np.array([params['n_vnodes'], params['n_cnodes'],
-                                                           params['max_vnode_deg'], params['max_cnode_deg']])))
+            _cache_store(entry, dict({k: params[k] for k in _PARAM_ARRAYS}, blob=params['_cpx_blob'],
+                                     dims=np.array([params['n_vnodes'], params['n_cnodes'],
+                                                    params['max_vnode_deg'], params['max_cnode_deg']])))
         except (_lib.EngineError, ValueError):                   # library not built / code beyond an engine limit
             pass
     params['_design_sha'] = sha
     if compute_matrix:
         build_matrix(params)
     return params
+
+
+_BLOB_FORMAT = 1        # LdpcBlobHeader.version of csrc/ldpc.hip; part of the cache entry's name
+
+
+def _blob_ok(blob):
+    """True when the engine accepts ``blob`` (host-only check, no GPU needed); False also when the library is missing."""
+    try:
+        b = np.ascontiguousarray(blob, dtype=np.uint8)
+        return _lib.load().cpx_ldpc_blob_info(_lib.ptr(b), b.nbytes, None, None, None, None, None) == 0
+    except (_lib.EngineError, OSError):
+        return False
 
 
 def _edges_from_adjacency(p):
@@ -227,7 +243,13 @@ def _device_code(ldpc_code_params):
                 blob = ldpc_design_blob(ldpc_code_params, _edge_list(ldpc_code_params))
             blob = np.ascontiguousarray(blob, dtype=np.uint8)
             h = ctypes.c_void_p()
-            _lib.check(_lib.load().cpx_ldpc_create_from_blob(_lib.ptr(blob), blob.nbytes, ctypes.byref(h)))
+            rc = _lib.load().cpx_ldpc_create_from_blob(_lib.ptr(blob), blob.nbytes, ctypes.byref(h))
+            if rc == _lib.CPX_EINVAL and blob is not None and ldpc_code_params.get('_cpx_blob') is not None:
+                # a cached blob the engine refuses (format change, damaged file): rebuild from the matrix instead of failing
+                ldpc_code_params.pop('_cpx_blob', None)
+                blob = np.ascontiguousarray(ldpc_design_blob(ldpc_code_params, _edge_list(ldpc_code_params)), dtype=np.uint8)
+                rc = _lib.load().cpx_ldpc_create_from_blob(_lib.ptr(blob), blob.nbytes, ctypes.byref(h))
+            _lib.check(rc)
             return h
         hs = ldpc_code_params['_cpx_ldpc'] = _lib.DeviceHandles(create, 'cpx_ldpc_destroy')
     return hs.get()
@@ -243,10 +265,9 @@ def ldpc_bp_decode(llr_vec, ldpc_code_params, decoder_algorithm, n_iters, return
     squeezed to 1-D for a single block.  ``return_iterations=True`` (extension) appends the int32
     number of executed iterations per block.
 
-    Difference kept on purpose: a NaN among the LLRs of a min-sum ('MSA') decode stays confined to the messages
-    computed from it (the hardware minimum returns the other operand), where NumPy's ``min`` / ``sign`` spread it over
-    the whole block within a few iterations (ldpc.py:229-238); 'SPA' propagates NaN like the reference, and +-inf is
-    clipped to +-500 first by both.
+    Abnormal inputs behave like the reference's: +-inf is clipped to +-500 first; a NaN LLR propagates -- through 'SPA' by
+    itself, through 'MSA' because NumPy's ``min`` / ``sign`` propagate it (ldpc.py:229-238): blocks with a NaN LLR are
+    detected by the fast kernels and decoded a second time by a NaN-exact kernel.
     """
     if decoder_algorithm not in ('SPA', 'MSA'):
         raise NameError('Please input a valid decoder_algorithm string (meanning "SPA" or "MSA").')

@@ -51,6 +51,22 @@ constexpr int XS_ROW = 64 * 2 + 4;   // doubles per step row of the parked branc
                                     // epilogue reads one step per lane: a 1024-byte row stride puts its eight steps on the same banks)
 constexpr int NPAIR = 4;       // (forward, reverse) wave pairs per full-size workgroup: 8 waves = 2 per SIMD of a CU
 
+// ---- outside the reference's representable range: detect and redo --------------------------------------------------------
+// The recursions below are SCALE-FREE in the branch probabilities (a factor common to a trellis step is dropped) and
+// normalise every KNORM steps; the reference carries the absolute gamma = exp(-d^2 / 2 sigma^2) and normalises every step
+// (turbo.py:62-76, :110-111, :155-158).  Wherever every term of the reference stays a normal float64 the two agree to
+// rounding; where its terms underflow (symbol amplitudes of 5 - 20 at sigma^2 <= 0.1, priors of e^-200 meeting a contradicting
+// channel) the reference returns NaN / +-inf LLRs and these kernels would not.  So the fast kernels DETECT, conservatively,
+// every codeword for which that can happen and a literal absolute-scale kernel (bcjr_exact.hip) decodes those again:
+//   (A) a received pair whose worst branch probability is below e^-345:  (|r0| + 1)^2 + (|r1| + 1)^2 > 345 * 2 sigma^2
+//       (also true for NaN / inf);
+//   (C) a normalisation sum of alpha or beta below 1e-150 (or NaN): up to KNORM steps lost 150 decades;
+//   (D) a non-finite LLR;  (E) both a-posteriori sums of a step below 1e-150.
+// (A) bounds what the dropped common factor can be (>= 1e-150 per step), (C) / (E) what the scale-free quantities are, so a
+// codeword that raises none of them has every term of the reference's own recursion above 1e-300.  The priors are NOT
+// scale-free: p0 = 1 / (1 + e^L), p1 = 1 - p0 as the reference computes them (:239-240), exact zeros and cancellation included.
+constexpr double T_A = 345.0, T_SMALL = 1e-150;
+
 struct MapTables {
     const int32_t *next_state, *output;                       // [S][2]
     const int32_t *pred_state, *pred_input, *pred_code;       // [S][2]
@@ -91,11 +107,18 @@ struct Ctx {
     int ilo;
     int o_glo, o_ghi;                 // offsets of gamma(code of the branch to lo / hi) inside an item of `tab`
     // LDS of this wave
-    double *tab;    // [CH][GW][6] (+2 pad per step): gamma[4], prior weights q0, q1 of every (step, codeword) item
+    double *tab;    // [CH][GW][6] (+2 pad per step): gamma[4], priors p0, p1 of every (step, codeword) item
     double *xs;     // [CH][64][2]  per-lane branch products alpha*gamma*beta of the chunk (phase 2)
     double *rw;     // [CH][64]     alpha rows of a partial (last) chunk: the rolled code path keeps them here
     double *xch;    // [64]         exchange buffer (trellises without the DPP fast path)
+    // "detect and redo": lanes that raised a flag (one mask for the whole pass: three masks that resolve the codeword cost six
+    // more SGPRs in kernels that already spill them; a flag therefore sends all GW codewords of the pair to the redo path);
+    // mutable: the helpers take the context by const reference
+    mutable unsigned long long bad;
 };
+
+// v is wave-level: OR the lanes for which `cond` holds into a mask on the scalar unit
+__device__ __forceinline__ void flag_or(unsigned long long &mask, bool cond) { mask |= __ballot(cond); }
 
 template <int LGS>
 __host__ __device__ constexpr size_t wave_lds_doubles(int GW) { return (size_t)CH * (GW * 6 + 2) + (size_t)CH * (XS_ROW + 64) + 64; }
@@ -128,6 +151,14 @@ __device__ __forceinline__ void init_ctx(Ctx<LGS> &c, const MapTables &tb, unsig
     c.xs = p;  p += CH * XS_ROW;
     c.rw = p;  p += CH * 64;
     c.xch = p;
+    c.bad = 0;
+}
+
+// a flag was raised during the pass: flag bytes of all codewords of the pair (both waves of a pair may store the same 1)
+template <int LGS>
+__device__ __forceinline__ void publish_flags(const Ctx<LGS> &c, uint8_t *flags, int ncw) {
+    if (flags && c.bad != 0 && c.lane < ncw) flags[c.lane] = 1;
+    c.bad = 0;
 }
 
 // value of `v` in lane (quad base + idx), idx in 0..3 per lane: 4 quad broadcasts + selects (no LDS)
@@ -188,6 +219,7 @@ struct PassIO {
     int lstride, ncw, N;          // ncw: codewords of the batch this pair really has (<= GW, may be <= 0)
     double nv2;
     double *ckpt;                 // this pair's checkpoint rows [nchunks + 1][64]
+    uint8_t *flags;               // "detect and redo": one byte per codeword of the pair, set to 1 (never cleared here); may be null
 };
 
 __device__ __forceinline__ double ld_off(const double *base, unsigned elem) {
@@ -218,8 +250,9 @@ __device__ __forceinline__ void load_raw(const Ctx<LGS> &c, const PassIO &io, Ra
 //   gamma[c] = exp(-((r0-c0)^2 + (r1-c1)^2)/nv2) = E * (c0 matches sign(r0) ? 1 : Qa) * (c1 matches sign(r1) ? 1 : Qb),
 //     E = exp(-((|r0|-1)^2 + (|r1|-1)^2)/nv2) (dropped), Qa = exp(-4|r0|/nv2), Qb = exp(-4|r1|/nv2): two exps instead
 //     of four, every factor <= 1;
-//   (p0, p1) = (1, e^L)/(1+e^L): q = (1, e^L) for L < 0, (e^-L, 1) otherwise -- one exp of a non-positive argument, no
-//     division; same limits as the reference (p0 -> 0 / p1 -> 0 when e^L overflows / underflows).
+//   (p0, p1) = (1 / (1 + e^L), 1 - p0): the reference's own two operations (round 2 used the scale-free weights (1, e^L) /
+//     (e^-L, 1); they are more accurate than the reference where 1 - p0 cancels -- L < -30 -- and non-zero where its p1 is
+//     exactly 0 -- L < -36.7 --, which is a difference as soon as the channel contradicts such a prior).
 // The row stride P = 6 GW + 2 doubles makes the eight lanes that hold consecutive steps of a codeword hit eight
 // different 16-byte bank groups.  (An entry-major row [6][GW], which makes the recursions' reads conflict-free, was measured:
 // six 8-byte staging stores per item instead of three 16-byte ones and the extra address arithmetic cost more than the
@@ -233,20 +266,27 @@ template <int LGS, bool PRE>
 __device__ __forceinline__ void stage_chunk(const Ctx<LGS> &c, const RawChunk &rc, double nv2) {
     const int GW = c.GW;
     const double k4 = -4.0 / nv2;
+    const double lim = T_A * nv2;
 #pragma unroll
     for (int q = 0; q < 2; q++) {
         const int p = c.lane + 64 * q, gg = p / CH, tl = p % CH;
         if (gg < GW) {
             const double r0 = rc.r0[q], r1 = rc.r1[q], li = rc.li[q];
-            const double qa = PRE ? fabs(r0) : exp(k4 * fabs(r0)), qb = PRE ? fabs(r1) : exp(k4 * fabs(r1)), e = exp(-fabs(li));
+            const double qa = PRE ? fabs(r0) : exp(k4 * fabs(r0)), qb = PRE ? fabs(r1) : exp(k4 * fabs(r1));
+            if (!PRE) {                                           // (A); turbo_decode checks the received values once, at its start
+                const double u0 = fabs(r0) + 1.0, u1 = fabs(r1) + 1.0;
+                flag_or(c.bad, !(u0 * u0 + u1 * u1 <= lim));
+            }
+            // priors exactly as the reference forms them (:239-240): e^L may overflow (p0 = 0), 1 - p0 may cancel to 0
+            const double p0 = 1.0 / (1.0 + exp(li)), p1 = 1.0 - p0;
             // sign of the received value; the sign BIT, so that an underflowed factor stored as -0.0 keeps its sign
-            const bool n0 = PRE ? __double2hiint(r0) < 0 : r0 < 0.0, n1 = PRE ? __double2hiint(r1) < 0 : r1 < 0.0, pos = li >= 0.0;
+            const bool n0 = PRE ? __double2hiint(r0) < 0 : r0 < 0.0, n1 = PRE ? __double2hiint(r1) < 0 : r1 < 0.0;
             const double a0 = n0 ? 1.0 : qa, a1 = n0 ? qa : 1.0;  // systematic bit 0 (c0 = -1) / 1 (c0 = +1)
             const double b0 = n1 ? 1.0 : qb, b1 = n1 ? qb : 1.0;  // parity bit
             double2 *row = reinterpret_cast<double2 *>(c.tab + tl * c.P + gg * 6);
             row[0] = make_double2(a0 * b0, a0 * b1);              // code = 2*sys_bit + parity_bit
             row[1] = make_double2(a1 * b0, a1 * b1);
-            row[2] = make_double2(pos ? e : 1.0, pos ? 1.0 : e);
+            row[2] = make_double2(p0, p1);
         }
     }
     asm volatile("" ::: "memory");
@@ -308,7 +348,11 @@ __device__ __forceinline__ void beta_step(const Ctx<LGS> &c, int tl, double &b, 
         xo[1 - s_lo] = (a_own * g_hi) * hi;
     }
     b = __builtin_fma(hi, w_hi, lo * w_lo);
-    if ((tl & (KNORM - 1)) == 0) b = b * __builtin_amdgcn_rcp(group_sum<LGS>(b));
+    if ((tl & (KNORM - 1)) == 0) {
+        const double sum = group_sum<LGS>(b);
+        flag_or(c.bad, !(sum >= T_SMALL));                        // (C)
+        b = b * __builtin_amdgcn_rcp(sum);
+    }
 }
 
 template <int LGS, bool SR>
@@ -316,7 +360,11 @@ __device__ __forceinline__ void alpha_step(const Ctx<LGS> &c, int tl, double &a,
     double ap0, ap1;
     exchange_pred<LGS, SR>(c, a, ap0, ap1);
     a = __builtin_fma(ap1, w1, ap0 * w0);
-    if ((tl & (KNORM - 1)) == KNORM - 1) a = a * __builtin_amdgcn_rcp(group_sum<LGS>(a));
+    if ((tl & (KNORM - 1)) == KNORM - 1) {
+        const double sum = group_sum<LGS>(a);
+        flag_or(c.bad, !(sum >= T_SMALL));                        // (C)
+        a = a * __builtin_amdgcn_rcp(sum);
+    }
 }
 
 // beta over the `len` staged steps, downwards.  X: also parks the branch products; arow[tl] = alpha of this lane's state
@@ -380,6 +428,7 @@ __device__ __forceinline__ void epilogue(const Ctx<LGS> &c, const PassIO &io, co
 #pragma unroll
             for (int st = 0; st < S; st++) { const double2 v = x[st]; app0 += v.x; app1 += v.y; }
             const double lr = fast_log(app1 / app0);
+            flag_or(c.bad, !(fabs(lr) < __builtin_huge_val()) || !(fmax(app0, app1) >= T_SMALL));   // (D), (E)
             const double L = io.ext ? lr : li[q] + lr;
             const unsigned t = (unsigned)(t_lo + tl);
             st_off(io.Lout, (unsigned)(gg * io.lstride) + t, L);
@@ -482,6 +531,7 @@ __device__ void map_pass(const Ctx<LGS> &c, const PassIO &io) {
         }
         epilogue<LGS>(c, io, li_prev, t_prev, len_prev);
     }
+    publish_flags<LGS>(c, io.flags, io.ncw);
 }
 
 struct MapParams {
@@ -490,6 +540,7 @@ struct MapParams {
     double *Lout;                      // [B][N]
     uint8_t *bits;                     // [B][N]
     double *scratch;                   // per pair: checkpoint rows [nchunks + 1][64]
+    uint8_t *flags;                    // [B] "detect and redo" (zeroed before the launch), may be null
     int64_t B, N;
     double nv2;
     int want_bits, GW;
@@ -512,6 +563,7 @@ __global__ __launch_bounds__(128 * NPAIR) void map_decode_kernel(MapParams p) {
     io.bits = p.bits ? p.bits + o0 : nullptr; io.want_bits = p.want_bits;
     io.ncw = (int)(left < p.GW ? left : p.GW); io.nv2 = p.nv2;
     io.ckpt = p.scratch + pair * (K + 1) * 64;
+    io.flags = p.flags ? p.flags + cw0 : nullptr;
     map_pass<LGS, SR, false>(c, io);                              // L_ext and the hard decisions leave in the pass's epilogue
 }
 
@@ -522,6 +574,7 @@ struct TurboParams {
     uint8_t *bits;                        // [B][N]
     double *ckpt;                         // per pair: checkpoint rows [nchunks + 1][64]
     double *larr;                         // per codeword: A, B, C, Qs, Qsi, Qp1, Qp2 [N] each
+    uint8_t *flags;                       // [B] "detect and redo" (zeroed before the launch), may be null
     int64_t B, N;
     double nv2;
     int n_iter, GW;
@@ -548,6 +601,9 @@ __global__ __launch_bounds__(128 * NPAIR) void turbo_decode_kernel(TurboParams p
     io.ncw = (int)(left < p.GW ? left : p.GW);
     io.want_bits = 0;
     io.ckpt = p.ckpt + pair * (K + 1) * 64;
+    io.flags = p.flags ? p.flags + cw0 : nullptr;
+    // (A) for every received value on its own: |r| > sqrt(T_A nv2 / 2) - 1 bounds (|r0| + 1)^2 + (|r1| + 1)^2 for any pairing
+    const double rmax = sqrt(0.5 * T_A * p.nv2) - 1.0;
     // Between the MAP passes only the interleaver is left to do: a pass writes E = L - L_int directly (`ext`), so
     //   even h: L_int_2 = interlv(E_1)      C[t] = B[perm[t]]         (:318-319)
     //   odd h:  L_int_1 = deinterlv(E_2)    A[perm[t]] = B[t]         (:328-329)
@@ -562,15 +618,19 @@ __global__ __launch_bounds__(128 * NPAIR) void turbo_decode_kernel(TurboParams p
         if (cwg >= p.B) break;
         double *A = A0 + cwg * ls, *qs = QS + cwg * ls, *qsi = QSI + cwg * ls, *qp1 = QP1 + cwg * ls, *qp2 = QP2 + cwg * ls;
         const double *sy = p.sys + cwg * N, *y1 = p.p1 + cwg * N, *y2 = p.p2 + cwg * N;
+        bool far = false;
 #pragma unroll 2
         for (int64_t t = lane; t < N; t += 64) {
             A[t] = p.Lint ? p.Lint[cwg * N + t] : 0.0;             // L_int_1 (:305-308)
-            qp1[t] = signed_q(y1[t], k4);
-            qp2[t] = signed_q(y2[t], k4);
-            const double v = signed_q(sy[t], k4);
+            const double r1 = y1[t], r2 = y2[t], rs = sy[t];
+            far = far || !(fabs(r1) <= rmax) || !(fabs(r2) <= rmax) || !(fabs(rs) <= rmax);
+            qp1[t] = signed_q(r1, k4);
+            qp2[t] = signed_q(r2, k4);
+            const double v = signed_q(rs, k4);
             qs[t] = v;
             if (in_lds) buf[t] = v;
         }
+        if (p.flags && __ballot(far) != 0 && lane == 0) p.flags[cwg] = 1;
         // sys_symbols_i = interlv(sys) (:310), once: through LDS -- coalesced read, LDS gather, coalesced write.  (Reading
         // sys[perm[t]] in every second MAP pass fetched a 64-byte line per 8-byte value: 8 of the 17 GB a launch read.)
         asm volatile("" ::: "memory");
@@ -705,6 +765,13 @@ int cpx_map_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const do
     p.B = B; p.N = N; p.nv2 = 2 * noise_variance; p.want_bits = want_bits;
     CPX_REQUIRE(nblocks < (1ll << 31), CPX_ELIMIT, "map_decode: batch too large");
     if ((rc = workspace(st, 0, sizeof(double) * (size_t)(nblocks * np * (K + 1) * 64), (void **)&p.scratch))) return rc;
+    // "detect and redo": one flag byte per codeword (scratch-arena slot 3), zeroed here, set by the kernel, consumed by the
+    // absolute-scale redo launch below; blocks too long for that path's scratch are decoded by the fast kernel alone
+    p.flags = nullptr;
+    if (bcjr_exact_supported(t->S, N, 0)) {
+        if ((rc = workspace(st, 3, (size_t)B, (void **)&p.flags))) return rc;
+        CPX_HIP(hipMemsetAsync(p.flags, 0, (size_t)B, st));
+    }
     dim3 grid((unsigned)nblocks), block(128 * np);
     switch (p.tb.lgS) {
 #define CASE(LG) case LG: hipLaunchKernelGGL((map_decode_kernel<LG, false>), grid, block, sizeof(double) * 2 * np * wave_lds_doubles<LG>(GW), st, p); break;
@@ -717,6 +784,7 @@ int cpx_map_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const do
         default: set_error("map_decode: unsupported state count"); return CPX_ELIMIT;
     }
     CPX_HIP(hipGetLastError());
+    if (p.flags && (rc = bcjr_exact_map(t, d_sys, d_par, d_L_int, B, N, p.nv2, want_bits, d_L_ext, d_bits, p.flags, st))) return rc;
     note_kernel("map_decode_kernel<%d,%s> (%d wave pairs per workgroup, %d codewords per pair)", p.tb.lgS, (p.tb.lgS == 2 && p.tb.sr4) ? "true" : "false", np, GW);
     return CPX_OK;
 }
@@ -743,6 +811,11 @@ int cpx_turbo_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const 
     CPX_REQUIRE(nblocks < (1ll << 31), CPX_ELIMIT, "turbo_decode: batch too large");
     if ((rc = workspace(st, 0, sizeof(double) * (size_t)(nblocks * np * (K + 1) * 64), (void **)&p.ckpt))) return rc;
     if ((rc = workspace(st, 1, sizeof(double) * (size_t)(B * 7 * N), (void **)&p.larr))) return rc;
+    p.flags = nullptr;                                             // "detect and redo", as in cpx_map_decode_batch_dev
+    if (bcjr_exact_supported(t->S, N, 1)) {
+        if ((rc = workspace(st, 3, (size_t)B, (void **)&p.flags))) return rc;
+        CPX_HIP(hipMemsetAsync(p.flags, 0, (size_t)B, st));
+    }
     dim3 grid((unsigned)nblocks), block(128 * np);
     switch (p.tb.lgS) {
 #define CASE(LG) case LG: hipLaunchKernelGGL((turbo_decode_kernel<LG, false>), grid, block, sizeof(double) * 2 * np * wave_lds_doubles<LG>(GW), st, p); break;
@@ -755,6 +828,7 @@ int cpx_turbo_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const 
         default: set_error("turbo_decode: unsupported state count"); return CPX_ELIMIT;
     }
     CPX_HIP(hipGetLastError());
+    if (p.flags && (rc = bcjr_exact_turbo(t, d_sys, d_p1, d_p2, d_L_int_or_null, d_perm, B, N, p.nv2, n_iter, d_bits, p.flags, st))) return rc;
     note_kernel("turbo_decode_kernel<%d,%s> (%d wave pairs per workgroup, %d codewords per pair)", p.tb.lgS, (p.tb.lgS == 2 && p.tb.sr4) ? "true" : "false", np, GW);
     return CPX_OK;
 }

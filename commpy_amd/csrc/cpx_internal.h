@@ -49,15 +49,25 @@ int workspace(hipStream_t stream, int slot, size_t bytes, void **out);
     } while (0)
 
 // codeword-per-lane Viterbi path (viterbi_cw.hip): true when it handled the call (*rc = status)
+// nanflags ('soft' only, else null): [B] bytes, set to 1 for every codeword that received a NaN (viterbi.hip re-decodes those)
 bool viterbi_codeword_path(const ::cpx_trellis *t, const double *d_coded, int64_t B, int64_t len, int64_t L, int64_t T,
-                           int tb, int type, uint8_t *d_bits, hipStream_t st, int *rc);
+                           int tb, int type, uint8_t *d_bits, uint8_t *nanflags, hipStream_t st, int *rc);
 
 // LDS-resident LDPC path (ldpc_resident.hip): true when it handled the call (*rc = status)
 int ldpc_resident_tables(::cpx_ldpc *c, const int32_t *row_ptr, const int32_t *row_pad, const int32_t *col_ptr,
                          const int32_t *col_pad_cj);
 void ldpc_resident_free(::cpx_ldpc *c);
+// nanflags (min-sum only, else null): [B] bytes, written for every block: 1 = a NaN among its LLRs (ldpc.hip decodes it again)
 bool ldpc_resident_path(const ::cpx_ldpc *c, double *d_llr, int64_t B, int alg, int n_iters, int8_t *d_dec, double *d_out,
-                        int32_t *d_iters, int *d_clipped, hipStream_t st, int *rc);
+                        int32_t *d_iters, int *d_clipped, uint8_t *nanflags, hipStream_t st, int *rc);
+
+// absolute-scale BCJR / turbo redo path (bcjr_exact.hip): decodes the codewords whose flag byte is set, overwriting the outputs
+bool bcjr_exact_supported(int S, int64_t N, int turbo);
+int bcjr_exact_map(const ::cpx_trellis *t, const double *sys, const double *par, const double *Lin, int64_t B, int64_t N, double nv2,
+                   int want_bits, double *Lout, uint8_t *bits, const uint8_t *flags, hipStream_t st);
+int bcjr_exact_turbo(const ::cpx_trellis *t, const double *sys, const double *p1, const double *p2, const double *Lint_or_null,
+                     const int32_t *perm, int64_t B, int64_t N, double nv2, int n_iter, uint8_t *bits, const uint8_t *flags,
+                     hipStream_t st);
 
 // per-device issue lock for entry points that take scratch-arena memory (runtime.hip)
 struct IssueGuard {

@@ -68,7 +68,8 @@ __device__ __forceinline__ void effective(const Ctl *c, int &n_slots, int &buf) 
 
 // L = Q = clip(llr) tile-major; llr clipped in place (ldpc.py:186); slot table; control block
 __global__ __launch_bounds__(LB) void ldpc_init_kernel(double *__restrict__ llr, int64_t B, int n_v, Bufs bf,
-                                                       int32_t *__restrict__ iters, int *__restrict__ clipped) {
+                                                       int32_t *__restrict__ iters, int *__restrict__ clipped,
+                                                       uint8_t *__restrict__ nanflags /* min-sum: [B], zeroed; else null */) {
     __shared__ double ts[64][65];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;      // 64 x 4
     const int64_t tile = blockIdx.x;
@@ -81,8 +82,12 @@ __global__ __launch_bounds__(LB) void ldpc_init_kernel(double *__restrict__ llr,
             const double raw = llr[b * n_v + v];
             x = clip_nan(raw, -500.0, 500.0);
             if (x != raw) {                                       // in-place clip (:186); untouched values are not rewritten
-                llr[b * n_v + v] = x;
-                if (clipped) *clipped = 1;                        // lets the host-buffer entry point skip the copy back
+                if (x == x) {
+                    llr[b * n_v + v] = x;
+                    if (clipped) *clipped = 1;                    // lets the host-buffer entry point skip the copy back
+                } else if (nanflags) {
+                    nanflags[b] = 1;                              // min-sum: the block is decoded again, NaN-exact (ldpc_msa_exact_kernel)
+                }
             }
         }
         ts[r][tx] = x;
@@ -557,6 +562,103 @@ __global__ __launch_bounds__(LB) void ldpc_final_kernel(Bufs bf, int n_v, int64_
     }
 }
 
+// ---- min-sum with a NaN among the LLRs: detect and redo ---------------------------------------------------------------
+// NumPy's `min` and `sign` PROPAGATE a NaN (ldpc.py:229-238): a NaN message makes every other message of its check NaN, the
+// next variable pass (:243-245) spreads that over every neighbour, and within a few iterations the block's whole connected
+// component is NaN -- with dec_word = signbit(NaN) deciding the syndrome test (:205) and thereby the iteration count.  The
+// fast kernels' minimum (v_min_f64 returns the other operand) confines a NaN to the messages computed from it.  They only
+// DETECT a NaN LLR while loading a block (one flag byte per block) and this kernel decodes the flagged blocks again, a
+// literal restatement of the reference's loop with NaN-propagating minimum and sign.  No NaN in the batch: every
+// workgroup reads its share of the flag bytes and exits.
+// NaN signs: every NaN here is a propagated copy of an input NaN (the clip bounds the values, no operation of the loop creates
+// one), and neither x86 nor gfx950 changes the sign of a NaN it propagates; with inputs of ONE NaN sign (np.nan) results are
+// the reference's bit for bit; with mixed signs, which NaN an operation of two NaNs returns is unspecified on both sides.
+struct MsaExactParams {
+    const double *llr;        // [B][n_v], already clipped in place
+    const uint8_t *flags;     // [B]
+    double *out;              // [n_v][B]
+    int8_t *dec;              // [n_v][B]
+    int32_t *iters;           // [B] or null
+    double *scratch;          // per workgroup: M[E], tot[n_v]
+    const int32_t *edge_var, *row_ptr, *col_ptr, *col_edge;
+    int64_t B, E;
+    int n_v, n_c, n_iters;
+};
+
+__global__ __launch_bounds__(256) void ldpc_msa_exact_kernel(MsaExactParams p) {
+    __shared__ int any;
+    __shared__ unsigned char flagged[256];
+    const int tid = threadIdx.x;
+    double *M = p.scratch + (int64_t)blockIdx.x * (p.E + p.n_v);
+    double *tot = M + p.E;
+    const int64_t per = (p.B + gridDim.x - 1) / gridDim.x;        // contiguous share of the blocks
+    const int64_t lo = (int64_t)blockIdx.x * per, hi = (lo + per < p.B) ? lo + per : p.B;
+    for (int64_t base = lo; base < hi; base += 256) {
+        __syncthreads();
+        flagged[tid] = (base + tid < hi) ? p.flags[base + tid] : 0;
+        __syncthreads();
+        for (int i = 0; i < 256 && base + i < hi; i++) {
+            if (!flagged[i]) continue;                            // workgroup-uniform
+            const int64_t b = base + i;
+            const double *l = p.llr + b * p.n_v;
+            for (int64_t e = tid; e < p.E; e += 256) M[e] = 1.0 * l[p.edge_var[e]];          // H.multiply(llr) (:199)
+            for (int v = tid; v < p.n_v; v += 256) tot[v] = l[v];                             // out_llrs = llr (:194)
+            __syncthreads();
+            int it = 0;
+            for (; it < p.n_iters; it++) {
+                if (tid == 0) any = 0;
+                __syncthreads();
+                for (int c = tid; c < p.n_c; c += 256) {          // H . dec_word % 2 (:205), dec_word = signbit(out_llrs)
+                    int par = 0;
+                    for (int e = p.row_ptr[c]; e < p.row_ptr[c + 1]; e++) par ^= __builtin_signbit(tot[p.edge_var[e]]) ? 1 : 0;
+                    if (par) any = 1;
+                }
+                __syncthreads();
+                if (!any) break;
+                for (int c = tid; c < p.n_c; c += 256) {          // (:231-238)
+                    const int b0 = p.row_ptr[c], deg = p.row_ptr[c + 1] - b0;
+                    double row[MAXDEG];
+                    for (int j = 0; j < deg; j++) row[j] = M[b0 + j];
+                    for (int j = 0; j < deg; j++) {
+                        double sp = 1.0, mn = __builtin_huge_val();
+                        for (int q = 0; q < deg; q++) {
+                            if (q == j) continue;
+                            const double v = row[q];
+                            double sg = (double)((v > 0.0) - (v < 0.0));          // np.sign; sign(NaN) = that NaN
+                            if (v != v) sg = v;
+                            sp *= sg;                                             // .prod()
+                            const double av = fabs(v);
+                            if (av < mn || av != av) mn = av;                     // .min() propagates NaN
+                        }
+                        M[b0 + j] = sp * mn;
+                    }
+                }
+                __syncthreads();
+                for (int v = tid; v < p.n_v; v += 256) {          // (:243-248)
+                    double msum = 0.0;
+                    for (int q = p.col_ptr[v]; q < p.col_ptr[v + 1]; q++) msum += M[p.col_edge[q]];   // sum(0): increasing check
+                    const double t = msum + l[v];
+                    for (int q = p.col_ptr[v]; q < p.col_ptr[v + 1]; q++) {
+                        const int e = p.col_edge[q];
+                        double m = M[e] * -1.0;                   // data *= -1 (:244)
+                        m += 1.0 * t;                             // data += H.multiply(msg_sum + llr).data (:245)
+                        M[e] = m;
+                    }
+                    tot[v] = t;
+                }
+                __syncthreads();
+            }
+            for (int v = tid; v < p.n_v; v += 256) {
+                const double x = tot[v];
+                p.out[(int64_t)v * p.B + b] = x;
+                p.dec[(int64_t)v * p.B + b] = (int8_t)(__builtin_signbit(x) ? 1 : 0);
+            }
+            if (tid == 0 && p.iters) p.iters[b] = it;
+            __syncthreads();
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -644,6 +746,25 @@ static int blob_view(const void *blob, size_t nbytes, LdpcBlobView &v) {
     for (size_t i = 0; i < v.n_col_pad; i++)
         CPX_REQUIRE(v.col_pad_edge[i] >= 0 && v.col_pad_edge[i] < E && (v.col_pad_cj[i] >> 5) >= 0 &&
                     (v.col_pad_cj[i] >> 5) < h->n_c, CPX_EINVAL, "ldpc blob: padded column entry out of range");
+    // (check, position) pairs become LDS addresses of the resident path (roff + 8 (check * rstride + position)): a position
+    // must lie inside ITS check's row, and the views must describe the same graph as the edge list (FNV is no protection
+    // against a deliberately edited cache file)
+    for (int64_t e = 0; e < E; e++) {
+        const int c = v.edge_check[e];
+        CPX_REQUIRE(e >= v.row_ptr[c] && e < v.row_ptr[c + 1], CPX_EINVAL, "ldpc blob: edge list and row pointers disagree");
+    }
+    for (int c = 0; c < h->n_c; c++)
+        for (int j = 0; j < v.row_ptr[c + 1] - v.row_ptr[c]; j++)
+            CPX_REQUIRE(v.row_pad[(size_t)c * h->cpad + j] == v.edge_var[v.row_ptr[c] + j], CPX_EINVAL,
+                        "ldpc blob: padded rows and edge list disagree");
+    for (int q = 0; q < h->n_v; q++)
+        for (int i = v.col_ptr[q]; i < v.col_ptr[q + 1]; i++) {
+            const int e = v.col_edge[i], cj = v.col_cj[i], c = cj >> 5, pos = cj & 31;
+            CPX_REQUIRE(v.edge_var[e] == q && v.edge_check[e] == c && pos == e - v.row_ptr[c], CPX_EINVAL,
+                        "ldpc blob: column view and edge list disagree");
+            const size_t k = (size_t)q * h->vpad + (size_t)(i - v.col_ptr[q]);
+            CPX_REQUIRE(v.col_pad_edge[k] == e && v.col_pad_cj[k] == cj, CPX_EINVAL, "ldpc blob: padded columns and column view disagree");
+        }
     return CPX_OK;
 }
 
@@ -803,10 +924,40 @@ static int ldpc_decode_impl(const cpx_ldpc *c, double *d_llr, int64_t B, int alg
     CPX_REQUIRE(d_llr && d_dec && d_out, CPX_EINVAL, "ldpc: null device pointer");
     CPX_REQUIRE(B <= (1ll << 30), CPX_ELIMIT, "ldpc: batch too large");
     hipStream_t st = pick_stream(stream);
+    // min-sum: one flag byte per block, set by the kernels that load the LLRs when they meet a NaN; flagged blocks are
+    // decoded again by ldpc_msa_exact_kernel (scratch-arena slots 4 / 5)
+    uint8_t *nanflags = nullptr;
+    const unsigned g_ex = (unsigned)std::min<int64_t>(B, 2 * device_cus());
+    auto msa_redo = [&]() -> int {
+        if (!nanflags) return CPX_OK;
+        MsaExactParams q;
+        void *sc = nullptr;
+        if (int rcs = workspace(st, 5, sizeof(double) * (size_t)g_ex * (size_t)(c->n_edges + c->n_v), &sc)) return rcs;
+        q.llr = d_llr; q.flags = nanflags; q.out = d_out; q.dec = d_dec; q.iters = d_iters; q.scratch = static_cast<double *>(sc);
+        q.edge_var = c->d_edge_var; q.row_ptr = c->d_row_ptr; q.col_ptr = c->d_col_ptr; q.col_edge = c->d_col_edge;
+        q.B = B; q.E = c->n_edges; q.n_v = c->n_v; q.n_c = c->n_c; q.n_iters = n_iters;
+        hipLaunchKernelGGL(ldpc_msa_exact_kernel, dim3(g_ex), dim3(256), 0, st, q);
+        CPX_HIP(hipGetLastError());
+        return CPX_OK;
+    };
+    if (alg == CPX_LDPC_MSA) {
+        void *w = nullptr;
+        if (int rcf = workspace(st, 4, (size_t)B, &w)) return rcf;
+        nanflags = static_cast<uint8_t *>(w);
+    }
     {   // the whole decoder state of a block in LDS, one persistent launch (ldpc_resident.hip) -- unless it does not fit
         int rcr = CPX_OK;
-        if (ldpc_resident_path(c, d_llr, B, alg, n_iters, d_dec, d_out, d_iters, d_clipped, st, &rcr)) return rcr;
+        if (ldpc_resident_path(c, d_llr, B, alg, n_iters, d_dec, d_out, d_iters, d_clipped, nanflags, st, &rcr)) {
+            if (rcr == CPX_OK) {
+                char name[160];
+                snprintf(name, sizeof(name), "%s", last_kernel_name());
+                rcr = msa_redo();
+                note_kernel("%s", name);
+            }
+            return rcr;
+        }
     }
+    if (nanflags) CPX_HIP(hipMemsetAsync(nanflags, 0, (size_t)B, st));
     const int64_t E = c->n_edges, nv = c->n_v;
     const int64_t n_tiles = (B + 63) / 64, S = n_tiles * 64;
     const int64_t RR = alg == CPX_LDPC_MSA ? 3 * (int64_t)c->n_c : E;      // rows of R per tile (records / edges)
@@ -829,7 +980,7 @@ static int ldpc_decode_impl(const cpx_ldpc *c, double *d_llr, int64_t B, int alg
     bf.dst = (int32_t *)p; p += szI;
     bf.ctl = (Ctl *)p;
     hipLaunchKernelGGL(ldpc_init_kernel, dim3((unsigned)n_tiles, (unsigned)((nv + 63) / 64)), dim3(LB), 0, st, d_llr, B,
-                       (int)nv, bf, d_iters, d_clipped);
+                       (int)nv, bf, d_iters, d_clipped, nanflags);
     // persistent grids: what is resident at once (occupancy x CUs), no more workgroups than wave items, a
     // multiple of 8 (one share per XCD)
     auto pgrid = [&](const void *fn, int64_t items) {
@@ -866,6 +1017,7 @@ static int ldpc_decode_impl(const cpx_ldpc *c, double *d_llr, int64_t B, int alg
     }
     hipLaunchKernelGGL(ldpc_final_kernel, dim3(g_vn), dim3(LB), 0, st, bf, (int)nv, B, d_out, d_dec);
     CPX_HIP(hipGetLastError());
+    if (int rcx = msa_redo()) return rcx;
     note_kernel("ldpc_cn_%s_kernel + ldpc_vn_%s_kernel (tiled)", alg == CPX_LDPC_MSA ? "msa" : "spa", alg == CPX_LDPC_MSA ? "msa" : "spa");
     return CPX_OK;
 }

@@ -48,6 +48,7 @@ struct ResParams {
     int32_t *iters;          // [B] executed iterations, may be null
     int *queue;              // next block to hand out
     int *clipped;            // set to 1 when the in-place clip changed a value (may be null)
+    uint8_t *nanflags;       // min-sum: [B], 1 = a NaN among the block's LLRs (decoded again by ldpc_msa_exact_kernel); else null
     const int32_t *row_deg;  // [n_c] check degree
     const int32_t *row_q;    // [n_c][cpad] LDS byte offset of Q[variable of the j-th edge]; padding -> the +inf slot
     const int32_t *col_r;    // [n_v][vpad] LDS byte offset of R[q-th edge of the variable], increasing check; padding -> the 0.0 slot
@@ -192,6 +193,7 @@ __global__ __launch_bounds__(1024, 6) void ldpc_resident_kernel(ResParams p) {
     if (tid == 0) {
         stsd(8 * p.n_v, __builtin_huge_val());                   // dummy Q (row padding)
         stsd(p.roff + 8 * p.n_r, 0.0);                           // dummy R (column padding)
+        ctl[3] = 0;                                              // "a NaN among the LLRs of the current block"
     }
     for (;;) {
         if (tid == 0) {
@@ -207,8 +209,12 @@ __global__ __launch_bounds__(1024, 6) void ldpc_resident_kernel(ResParams p) {
             const double raw = in[v];
             const double x = clip_nan(raw, -500.0, 500.0);
             if (x != raw) {                                      // in-place clip (:186); untouched values are not rewritten
-                in[v] = x;
-                if (p.clipped) *p.clipped = 1;
+                if (x == x) {
+                    in[v] = x;
+                    if (p.clipped) *p.clipped = 1;
+                } else {
+                    ctl[3] = 1;                                  // NaN: min-sum decodes the block again (see ResParams::nanflags)
+                }
             }
             stsd(8 * v, x);                                      // out_llrs = llr (:194)
         }
@@ -229,7 +235,11 @@ __global__ __launch_bounds__(1024, 6) void ldpc_resident_kernel(ResParams p) {
         }
         double *__restrict__ out = p.stage + (int64_t)b * p.n_v;
         for (int v = tid; v < p.n_v; v += nt) out[v] = ldsd(8 * v);          // the same thread reloads these entries for the next block
-        if (tid == 0 && p.iters) p.iters[b] = k;
+        if (tid == 0) {
+            if (p.iters) p.iters[b] = k;
+            if (p.nanflags) p.nanflags[b] = (uint8_t)ctl[3];
+            ctl[3] = 0;                                          // the next block's loads come after the barrier of its queue pop
+        }
     }
 }
 
@@ -329,6 +339,7 @@ __global__ __launch_bounds__(1024, 8) void ldpc_resident_f32_kernel(ResParams p)
     if (tid == 0) {
         stsf(4 * p.n_v, __builtin_huge_valf());
         stsf(p.roff + 4 * p.n_r, 0.0f);
+        ctl[3] = 0;
     }
     for (;;) {
         if (tid == 0) {
@@ -344,8 +355,12 @@ __global__ __launch_bounds__(1024, 8) void ldpc_resident_f32_kernel(ResParams p)
             const double raw = in[v];
             const double x = clip_nan(raw, -500.0, 500.0);
             if (x != raw) {                                      // in-place clip (:186), as in the parity kernel
-                in[v] = x;
-                if (p.clipped) *p.clipped = 1;
+                if (x == x) {
+                    in[v] = x;
+                    if (p.clipped) *p.clipped = 1;
+                } else {
+                    ctl[3] = 1;
+                }
             }
             stsf(4 * v, (float)x);
         }
@@ -366,7 +381,11 @@ __global__ __launch_bounds__(1024, 8) void ldpc_resident_f32_kernel(ResParams p)
         }
         double *__restrict__ out = p.stage + (int64_t)b * p.n_v;
         for (int v = tid; v < p.n_v; v += nt) out[v] = (double)ldsf(4 * v);
-        if (tid == 0 && p.iters) p.iters[b] = k;
+        if (tid == 0) {
+            if (p.iters) p.iters[b] = k;
+            if (p.nanflags) p.nanflags[b] = (uint8_t)ctl[3];
+            ctl[3] = 0;
+        }
     }
 }
 
@@ -487,7 +506,7 @@ void ldpc_resident_free(cpx_ldpc *c) {
 }
 
 bool ldpc_resident_path(const cpx_ldpc *c, double *d_llr, int64_t B, int alg, int n_iters, int8_t *d_dec, double *d_out,
-                        int32_t *d_iters, int *d_clipped, hipStream_t st, int *rc) {
+                        int32_t *d_iters, int *d_clipped, uint8_t *nanflags, hipStream_t st, int *rc) {
     *rc = CPX_OK;
     const int mode = ldpc_path();
     auto reject = [&](const char *why) {
@@ -506,7 +525,7 @@ bool ldpc_resident_path(const cpx_ldpc *c, double *d_llr, int64_t B, int alg, in
         const size_t sz_stage32 = (sizeof(double) * (size_t)(B * c->n_v) + 255) & ~(size_t)255;
         if ((*rc = workspace(st, 0, sz_stage32 + 256, (void **)&slab32))) return true;
         ResParams q;
-        q.llr = d_llr; q.stage = (double *)slab32; q.iters = d_iters; q.queue = (int *)(slab32 + sz_stage32); q.clipped = d_clipped;
+        q.llr = d_llr; q.stage = (double *)slab32; q.iters = d_iters; q.queue = (int *)(slab32 + sz_stage32); q.clipped = d_clipped; q.nanflags = nanflags;
         q.row_deg = c->d_res_row_deg; q.row_q = c->d_res_row_q32; q.col_r = c->d_res_col_r32; q.vgrp = c->d_res_vgrp;
         q.B = B; q.rstride = res_rstride(c); q.n_r = c->n_c * q.rstride; q.n_v = c->n_v; q.n_c = c->n_c; q.cpad = c->cpad; q.vpad = c->vpad;
         q.max_iter = n_iters; q.roff = res_roff(c->n_v) / 2; q.ctl_off = (int)(lds32 - 64);
@@ -534,7 +553,7 @@ bool ldpc_resident_path(const cpx_ldpc *c, double *d_llr, int64_t B, int alg, in
     const size_t sz_stage = (sizeof(double) * (size_t)(B * c->n_v) + 255) & ~(size_t)255;
     if ((*rc = workspace(st, 0, sz_stage + 256, (void **)&slab))) return true;
     ResParams p;
-    p.llr = d_llr; p.stage = (double *)slab; p.iters = d_iters; p.queue = (int *)(slab + sz_stage); p.clipped = d_clipped;
+    p.llr = d_llr; p.stage = (double *)slab; p.iters = d_iters; p.queue = (int *)(slab + sz_stage); p.clipped = d_clipped; p.nanflags = nanflags;
     p.row_deg = c->d_res_row_deg; p.row_q = c->d_res_row_q; p.col_r = c->d_res_col_r; p.vgrp = c->d_res_vgrp;
     p.B = B; p.rstride = res_rstride(c); p.n_r = c->n_c * p.rstride; p.n_v = c->n_v; p.n_c = c->n_c; p.cpad = c->cpad; p.vpad = c->vpad;
     p.max_iter = n_iters;

@@ -107,7 +107,13 @@ extern "C" {
 
 const char *cpx_last_error(void) { return g_err; }
 
-int cpx_version(void) { return 200; }  // 0.2.0
+int cpx_version(void) { return 300; }  // 0.3.0
+
+#ifndef CPX_BUILD_ID
+#define CPX_BUILD_ID "unknown"
+#endif
+// "full:<sha16>;viterbi:<sha16>": digests of the sources this library was compiled from (commpy_amd/build.py)
+const char *cpx_build_id(void) { return CPX_BUILD_ID; }
 
 int cpx_device_count(int *n) {
     CPX_REQUIRE(n, CPX_EINVAL, "cpx_device_count: null pointer");

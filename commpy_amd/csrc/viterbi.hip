@@ -54,7 +54,20 @@ struct VitParams {
     const double *axes;    // separable constellations: [2][sqrt(M)], else null
     int64_t nsym;
     int M, nb, nh;         // nh: log2(sqrt(M)) for separable constellations, 0 = generic scan
+    // 'soft' only: one byte per wavefront-sized work item (`blk` of wave_body / the codeword of viterbi_wide_kernel), set
+    // when one of its received values is NaN -- see "NaN among 'soft' inputs" below; null otherwise
+    uint8_t *nanflags;
 };
+
+// ---- NaN among 'soft' inputs: detect and redo ---------------------------------------------------------------------
+// The reference's clip lets a NaN through (convcode.py:719): every branch metric of that step is NaN, so is every path
+// metric from then on, every comparison is false and `argmin` of all-NaN candidates is 0 (:633-645) -- from the first NaN
+// step of a codeword on, ALL decisions are "first predecessor" and EVERY traceback starts from state 0.  Carrying that
+// rule in the hot loops cost the fused kernel 2 % and the state-per-lane kernels 4 - 7 % (round 2) for an input no
+// demodulator produces, so the fast kernels only DETECT it -- one unordered compare per received pair, OR-ed into a
+// per-item flag byte; their arithmetic runs on with the NaN clipped to -500 -- and a second launch re-decodes the flagged
+// items with the NaN-exact instantiation (NANX) of the state-per-lane body.  With no NaN in the batch that launch is
+// ceil(items / 64) wavefronts that read 64 flag bytes each and exit.
 
 // ---- cross-lane helpers -------------------------------------------------------------------------
 template <int CTRL>
@@ -167,9 +180,10 @@ __device__ __forceinline__ void bit_metrics(int type, double r, double &m0, doub
 //     and the input on every branch into s is s >> (LGS-1), so the traceback needs no table lookups;
 // N_T: outputs per trellis step when known at compile time (2, 3), 0 = run-time n <= CPX_MAX_N.
 // DM: the input is symbols to be hard-demodulated in the kernel (run-time n only, 'hard' metrics).
-template <int LGS, int I_T, bool SR, int N_T, bool DM = false>
-__global__ __launch_bounds__(64) void viterbi_wave_kernel(VitParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// NANX: the NaN-exact instantiation (redo launch only); the fast one returns whether a NaN was received ('soft').
+// blk: the work item -- codewords blk * G .. blk * G + G - 1.
+template <int LGS, int I_T, bool SR, int N_T, bool DM, bool NANX>
+__device__ __forceinline__ bool wave_body(const VitParams &p, const int64_t blk, unsigned char *smem) {
     constexpr int PL = (I_T == 2) ? 1 : 2;          // decision bit planes
     constexpr int S = 1 << LGS, G = 64 >> LGS, CH = S;
     constexpr int NMAX = N_T ? N_T : CPX_MAX_N;
@@ -184,7 +198,7 @@ __global__ __launch_bounds__(64) void viterbi_wave_kernel(VitParams p) {
     unsigned short *ptab = reinterpret_cast<unsigned short *>(dring + (size_t)p.RS * PL);  // [S*I]
     unsigned char *bring = reinterpret_cast<unsigned char *>(ptab + S * I_T);   // [RS][G]
 
-    const int64_t cw = (int64_t)blockIdx.x * G + g;
+    const int64_t cw = blk * G + g;
     const bool valid_cw = cw < p.B;
     const double *x = p.coded + (valid_cw ? cw : 0) * p.len;
 
@@ -238,17 +252,35 @@ __global__ __launch_bounds__(64) void viterbi_wave_kernel(VitParams p) {
         }
     };
     load_chunk(1, rcur);
+    unsigned long long nan_any = 0;                          // fast instantiation: lanes that received a NaN ('soft')
+    bool poisoned_before = false, poisoned_now = false;      // NANX: see "NaN among 'soft' inputs"
 
     for (int64_t t_base = 1; t_base <= p.T; t_base += CH) {
         // ---------------- branch-metric table of this chunk ----------------
         {
             double m0[NMAX], m1[NMAX];
+            bool nan_here = false;
 #pragma unroll
             for (int j = 0; j < NMAX; j++) {
                 double r = rcur[j];
-                if (p.type == CPX_VIT_SOFT) r = fmin(fmax(r, -500.0), 500.0);   // coded_bits.clip(-500, 500) (:719)
+                if (p.type == CPX_VIT_SOFT) {
+                    nan_here |= (j < n) && (r != r);
+                    r = fmin(fmax(r, -500.0), 500.0);                // coded_bits.clip(-500, 500) (:719); a NaN becomes -500
+                }
                 m0[j] = 0.0; m1[j] = 0.0;
                 if (j < n) bit_metrics(p.type, r, m0[j], m1[j]);
+            }
+            if (!DM && p.type == CPX_VIT_SOFT) {                     // (a chunk is S steps: off the 'hard' / 'unquantized' paths)
+                const unsigned long long nb = __ballot(nan_here);
+                if constexpr (NANX) {
+                    // lane (g, s) prepared step s of codeword g: the step is poisoned if the codeword was, or if a lane of its
+                    // group at or below s saw a NaN
+                    const unsigned long long nan_grp = (nb >> gshift) & gmask;
+                    poisoned_now = poisoned_before || (nan_grp & ((2ull << s) - 1ull)) != 0;
+                    poisoned_before = poisoned_before || nan_grp != 0;
+                } else {
+                    nan_any |= nb;
+                }
             }
             double *row = bm + lane * NC;
             for (int c = 0; c < NC; c++) {
@@ -353,6 +385,19 @@ __global__ __launch_bounds__(64) void viterbi_wave_kernel(VitParams p) {
                 mybest = mine ? bst : mybest;
             }
         }
+        if constexpr (NANX) {
+            // the decision word of a step is shared by the G codewords of the wavefront (bits [g S, g S + S) belong to codeword
+            // g): clear the ranges of the codewords that are poisoned at this lane's step -- "first predecessor" everywhere
+            const unsigned long long pb = __ballot(poisoned_now);
+            if (pb) {
+                // bit g S + s of pb: codeword g is poisoned at step s.  One bit per group, multiplied by the group mask, is S bits
+                constexpr unsigned long long REP = (S == 64) ? 1ull : (~0ull / ((1ull << (S & 63)) - 1ull));   // 0x...0101 pattern
+                const unsigned long long zero_bits = ((pb >> s) & REP) * gmask;
+                mydec0 &= ~zero_bits;
+                mydec1 &= ~zero_bits;
+                if (poisoned_now) mybest = 0;                // argmin of all-NaN metrics (:645)
+            }
+        }
         {
             const int slot = (int)((t_base + s) & RM);       // slots of steps beyond T are never read
             dring[slot * PL] = mydec0;                        // identical words from the G codeword slots
@@ -398,6 +443,28 @@ __global__ __launch_bounds__(64) void viterbi_wave_kernel(VitParams p) {
         }
         __syncthreads();
     }
+    return nan_any != 0;
+}
+
+template <int LGS, int I_T, bool SR, int N_T, bool DM = false>
+__global__ __launch_bounds__(64) void viterbi_wave_kernel(VitParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const bool nan = wave_body<LGS, I_T, SR, N_T, DM, false>(p, (int64_t)blockIdx.x, smem);
+    if (!DM && p.nanflags && threadIdx.x == 0) p.nanflags[blockIdx.x] = nan ? 1 : 0;
+}
+
+// Redo launch: wavefront w owns the work items 64 w .. 64 w + 63 of the launch it follows and re-decodes the flagged ones,
+// one after the other, with the NaN-exact body.  N_T = 0 (run-time n): this kernel's speed does not matter.
+template <int LGS, int I_T, bool SR>
+__global__ __launch_bounds__(64) void viterbi_wave_redo_kernel(VitParams p, int64_t nitems) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int64_t item = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    unsigned long long todo = __ballot(item < nitems && p.nanflags[item] != 0);
+    while (todo) {
+        const int b = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        wave_body<LGS, I_T, SR, 0, false, true>(p, (int64_t)blockIdx.x * 64 + b, smem);
+    }
 }
 
 // ---- S > 64 (total_memory 7: 128 states): SPL = S/64 states per lane, one codeword per wavefront ----
@@ -406,9 +473,8 @@ __global__ __launch_bounds__(64) void viterbi_wave_kernel(VitParams p) {
 // else (branch-metric table, decision ring, sliding traceback, first-argmin rule) is as above.
 // Table-driven traceback only.  The reference cannot build larger trellises (Trellis overflows int8
 // for total_memory >= 8 on NumPy 2), so 128 states is the practical maximum.
-template <int SPL, int I_T>
-__global__ __launch_bounds__(64) void viterbi_wide_kernel(VitParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+template <int SPL, int I_T, bool NANX>
+__device__ __forceinline__ bool wide_body(const VitParams &p, const int64_t cw, unsigned char *smem) {
     constexpr int PL = (I_T == 2) ? 1 : 2;
     constexpr int S = 64 * SPL, CH = 64;
     const int lane = threadIdx.x;
@@ -420,7 +486,6 @@ __global__ __launch_bounds__(64) void viterbi_wide_kernel(VitParams p) {
     unsigned short *ptab = reinterpret_cast<unsigned short *>(dring + (size_t)p.RS * PL * SPL);   // [S*I]
     unsigned char *bring = reinterpret_cast<unsigned char *>(ptab + S * I_T);        // [RS]
 
-    const int64_t cw = blockIdx.x;
     const double *x = p.coded + cw * p.len;
     int pst[SPL][I_T], pcode[SPL][I_T];
 #pragma unroll
@@ -436,19 +501,30 @@ __global__ __launch_bounds__(64) void viterbi_wide_kernel(VitParams p) {
 #pragma unroll
     for (int q = 0; q < SPL; q++) pm[q] = (q == 0 && lane == 0) ? 0.0 : __builtin_huge_val();
     int64_t next_out = 1;
+    unsigned long long nan_any = 0;                                // fast instantiation: a NaN was received ('soft')
+    bool poisoned = false;                                         // NANX: a NaN was received in an earlier chunk (see wave_body)
+    unsigned long long nan_steps = 0;
 
     for (int64_t t_base = 1; t_base <= p.T; t_base += CH) {
         {   // branch-metric table: lane i prepares step t_base + i
             const int64_t t = t_base + lane;
             const bool have = (t <= p.Lk) && (t <= p.T);
             double m0[CPX_MAX_N], m1[CPX_MAX_N];
+            bool nan_here = false;
 #pragma unroll
             for (int j = 0; j < CPX_MAX_N; j++) {
                 double r = (p.type == CPX_VIT_UNQUANTIZED) ? -1.0 : 0.0;
                 if (have && j < n) r = x[(t - 1) * n + j];
-                if (p.type == CPX_VIT_SOFT) r = fmin(fmax(r, -500.0), 500.0);
+                if (p.type == CPX_VIT_SOFT) {
+                    nan_here |= (j < n) && (r != r);
+                    r = fmin(fmax(r, -500.0), 500.0);
+                }
                 m0[j] = 0.0; m1[j] = 0.0;
                 if (j < n) bit_metrics(p.type, r, m0[j], m1[j]);
+            }
+            if (p.type == CPX_VIT_SOFT) {
+                nan_steps = __ballot(nan_here);                   // bit i: step t_base + i received a NaN
+                nan_any |= nan_steps;
             }
             for (int c = 0; c < NC; c++) {
                 double acc = 0.0;
@@ -466,6 +542,7 @@ __global__ __launch_bounds__(64) void viterbi_wide_kernel(VitParams p) {
 #pragma unroll
             for (int q = 0; q < SPL; q++) pmbuf[q * 64 + lane] = pm[q];
             __syncthreads();
+            const bool pz = NANX && (poisoned || (nan_steps & ((2ull << i) - 1ull)) != 0);   // wave-uniform: step t is poisoned
             unsigned long long w[SPL][2];
 #pragma unroll
             for (int q = 0; q < SPL; q++) {
@@ -477,8 +554,8 @@ __global__ __launch_bounds__(64) void viterbi_wide_kernel(VitParams p) {
                     if (c < best) { best = c; jb = j; }                        // first minimum wins
                 }
                 pm[q] = best;
-                w[q][0] = __ballot(jb & 1);
-                w[q][1] = (PL == 2) ? __ballot(jb & 2) : 0ull;
+                w[q][0] = pz ? 0ull : __ballot(jb & 1);
+                w[q][1] = (PL == 2 && !pz) ? __ballot(jb & 2) : 0ull;
             }
             double mn = pm[0];
 #pragma unroll
@@ -497,10 +574,11 @@ __global__ __launch_bounds__(64) void viterbi_wide_kernel(VitParams p) {
                     dring[(slot * PL) * SPL + q] = w[q][0];
                     if (PL == 2) dring[(slot * PL + 1) * SPL + q] = w[q][1];
                 }
-                bring[slot] = (unsigned char)(bst < 0 ? 0 : bst);
+                bring[slot] = (unsigned char)((bst < 0 || pz) ? 0 : bst);
             }
             __syncthreads();
         }
+        poisoned = poisoned || nan_steps != 0;
         const int64_t t_done = t_base + nsteps - 1;
         const int64_t s_hi = (t_done >= p.T) ? p.T : (t_done - p.tb + 2);
         auto decision = [&](int64_t tt, int st) {
@@ -525,6 +603,26 @@ __global__ __launch_bounds__(64) void viterbi_wide_kernel(VitParams p) {
             next_out = (next_out + CH <= s_hi + 1) ? next_out + CH : s_hi + 1;
         }
         __syncthreads();
+    }
+    return nan_any != 0;
+}
+
+template <int SPL, int I_T>
+__global__ __launch_bounds__(64) void viterbi_wide_kernel(VitParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const bool nan = wide_body<SPL, I_T, false>(p, (int64_t)blockIdx.x, smem);
+    if (p.nanflags && threadIdx.x == 0) p.nanflags[blockIdx.x] = nan ? 1 : 0;
+}
+
+template <int SPL, int I_T>
+__global__ __launch_bounds__(64) void viterbi_wide_redo_kernel(VitParams p, int64_t nitems) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int64_t item = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    unsigned long long todo = __ballot(item < nitems && p.nanflags[item] != 0);
+    while (todo) {
+        const int b = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        wide_body<SPL, I_T, true>(p, (int64_t)blockIdx.x * 64 + b, smem);
     }
 }
 
@@ -598,6 +696,65 @@ int cpx_trellis_destroy(cpx_trellis *t) {
     return CPX_OK;
 }
 
+// shift-register structure (feed-forward, k = 1): predecessor j of state s is ((s << 1) & (S - 1)) | j, input s >> (lgS - 1)
+static bool shift_register(const cpx_trellis *t) {
+    int lgS = 0;
+    while ((1 << lgS) < t->S) lgS++;
+    if (!(t->I == 2 && t->k == 1 && lgS >= 1)) return false;
+    for (int s2 = 0; s2 < t->S; s2++)
+        for (int j = 0; j < 2; j++)
+            if (t->pred_state[s2 * 2 + j] != (((s2 << 1) & (t->S - 1)) | j) || t->pred_input[s2 * 2 + j] != (s2 >> (lgS - 1)))
+                return false;
+    return true;
+}
+
+// ring size and dynamic LDS of the state-per-lane kernels for this trellis and p.tb (sets p.RS)
+static int wave_lds(const cpx_trellis *t, VitParams &p, size_t *lds) {
+    const int PL = (t->I == 2) ? 1 : 2;
+    if (t->S > 64) {
+        const int SPL = t->S / 64;
+        p.RS = next_pow2(64 + p.tb);
+        *lds = sizeof(double) * 64 * p.NC + sizeof(double) * t->S + sizeof(unsigned long long) * p.RS * PL * SPL +
+               sizeof(unsigned short) * t->S * t->I + (size_t)p.RS;
+    } else {
+        const int S = t->S, G = 64 / S, CH = S;
+        p.RS = next_pow2(CH + p.tb);
+        *lds = sizeof(double) * 64 * p.NC + sizeof(double) * (64 + 8) + sizeof(unsigned long long) * p.RS * PL +
+               sizeof(unsigned short) * S * t->I + (size_t)p.RS * G;
+    }
+    CPX_REQUIRE(*lds <= 64 * 1024, CPX_ELIMIT, "viterbi: tb_depth %d needs %zu B of LDS (> 64 KiB)", p.tb, *lds);
+    return CPX_OK;
+}
+
+// The redo launch behind a 'soft' decode (see "NaN among 'soft' inputs"): `nitems` flag bytes at p.nanflags, one per work
+// item of the state-per-lane body for this trellis (64 / S codewords; one codeword for 64 and 128 states).
+static int launch_redo(const cpx_trellis *t, VitParams p, int64_t nitems, hipStream_t st) {
+    size_t lds = 0;
+    if (int rcl = wave_lds(t, p, &lds)) return rcl;
+    const int64_t nw = (nitems + 63) / 64;
+    CPX_REQUIRE(nw < (1ll << 31), CPX_ELIMIT, "viterbi: batch too large");
+    const dim3 grid((unsigned)nw), block(64);
+    if (t->S > 64) {
+        if (t->I == 2) hipLaunchKernelGGL((viterbi_wide_redo_kernel<2, 2>), grid, block, lds, st, p, nitems);
+        else hipLaunchKernelGGL((viterbi_wide_redo_kernel<2, 4>), grid, block, lds, st, p, nitems);
+    } else {
+        const bool sr = shift_register(t);
+#define REDO_CASE(LG)                                                                                              \
+    case LG:                                                                                                       \
+        if (t->I == 4) hipLaunchKernelGGL((viterbi_wave_redo_kernel<LG, 4, false>), grid, block, lds, st, p, nitems);   \
+        else if (sr) hipLaunchKernelGGL((viterbi_wave_redo_kernel<LG, 2, true>), grid, block, lds, st, p, nitems);      \
+        else hipLaunchKernelGGL((viterbi_wave_redo_kernel<LG, 2, false>), grid, block, lds, st, p, nitems);             \
+        break;
+        switch (p.lgS) {
+            REDO_CASE(1) REDO_CASE(2) REDO_CASE(3) REDO_CASE(4) REDO_CASE(5) REDO_CASE(6)
+            default: set_error("viterbi: unsupported number of states %d", t->S); return CPX_ELIMIT;
+        }
+#undef REDO_CASE
+    }
+    CPX_HIP(hipGetLastError());
+    return CPX_OK;
+}
+
 struct DemodSrc {                  // fused hard demodulation: symbols instead of decoder input
     const cpx_modem *m;
     const double *d_y;             // [B][nsym][2]
@@ -621,6 +778,25 @@ static int viterbi_dispatch(const cpx_trellis *t, const double *d_coded, const D
     if (n_steps <= 0 || n_steps * t->k < L) CPX_HIP(hipMemsetAsync(d_bits, 0, (size_t)(B * L), st));
     if (n_steps <= 0) return CPX_OK;
     note_kernel("");
+    // 'soft': one flag byte per work item of the launches below (see "NaN among 'soft' inputs"); scratch-arena slot 3
+    uint8_t *nanflags = nullptr;
+    if (decoding_type == CPX_VIT_SOFT && !dm) {
+        void *w = nullptr;
+        if (int rcw = workspace(st, 3, (size_t)B + 64, &w)) return rcw;
+        nanflags = static_cast<uint8_t *>(w);
+    }
+    // parameters of the state-per-lane kernels for `nb` codewords starting at (`coded`, `bits`); `flags`: their flag bytes
+    auto wave_params = [&](VitParams &p, const double *coded, uint8_t *bits, int64_t nb, uint8_t *flags) {
+        p.coded = coded; p.bits = bits;
+        p.pred_state = t->d_pred_state; p.pred_input = t->d_pred_input; p.pred_code = t->d_pred_code;
+        p.B = nb; p.len = len; p.L = L; p.T = n_steps; p.Lk = L / t->k;
+        p.k = t->k; p.n = t->n; p.I = t->I; p.NC = 1 << t->n; p.type = decoding_type; p.tb = tb_depth;
+        p.ysym = nullptr; p.cst = nullptr; p.axes = nullptr; p.nsym = 0; p.M = 0; p.nb = 1; p.nh = 0;
+        p.nanflags = flags;
+        int lg = 0;
+        while ((1 << lg) < t->S) lg++;
+        p.lgS = lg;
+    };
     if (!dm) {   // large batches of the standard rate-1/2 codes: one codeword per lane (viterbi_cw.hip).  That path runs in rounds
         // of one wavefront of 64 codewords per SIMD, each as long as a full one; a last round that would fill less than 45 % of
         // the chip is cheaper on the wave kernels below, whose time is proportional to the batch (config 2: 54 us per 1000
@@ -630,8 +806,16 @@ static int viterbi_dispatch(const cpx_trellis *t, const double *d_coded, const D
         int64_t Bcw = B;
         if (!(viterbi_path_flags() & 2) && B > round && 20 * (B % round) < 9 * round) Bcw = B / round * round;
         int rc_cw = CPX_OK;
-        if (viterbi_codeword_path(t, d_coded, Bcw, len, L, n_steps, tb_depth, decoding_type, d_bits, st, &rc_cw)) {
-            if (rc_cw != CPX_OK || Bcw == B) return rc_cw;
+        if (viterbi_codeword_path(t, d_coded, Bcw, len, L, n_steps, tb_depth, decoding_type, d_bits, nanflags, st, &rc_cw)) {
+            if (rc_cw != CPX_OK) return rc_cw;
+            if (nanflags) {
+                // codeword path: one flag per codeword; the redo decodes a flagged codeword with one wavefront (64 states)
+                VitParams q;
+                wave_params(q, d_coded, d_bits, Bcw, nanflags);
+                if (int rcr = launch_redo(t, q, Bcw, st)) return rcr;
+                nanflags += Bcw;
+            }
+            if (Bcw == B) return CPX_OK;
             d_coded += Bcw * len;
             d_bits += Bcw * L;
             B -= Bcw;
@@ -639,11 +823,7 @@ static int viterbi_dispatch(const cpx_trellis *t, const double *d_coded, const D
     }
 
     VitParams p;
-    p.coded = d_coded; p.bits = d_bits;
-    p.pred_state = t->d_pred_state; p.pred_input = t->d_pred_input; p.pred_code = t->d_pred_code;
-    p.B = B; p.len = len; p.L = L; p.T = n_steps; p.Lk = L / t->k;
-    p.k = t->k; p.n = t->n; p.I = t->I; p.NC = 1 << t->n; p.type = decoding_type; p.tb = tb_depth;
-    p.ysym = nullptr; p.cst = nullptr; p.axes = nullptr; p.nsym = 0; p.M = 0; p.nb = 1; p.nh = 0;
+    wave_params(p, d_coded, d_bits, B, nanflags);
     if (dm) {
         p.ysym = reinterpret_cast<const double2 *>(dm->d_y);
         p.cst = reinterpret_cast<const double2 *>(dm->m->d_const);
@@ -651,37 +831,23 @@ static int viterbi_dispatch(const cpx_trellis *t, const double *d_coded, const D
         p.nsym = dm->nsym; p.M = dm->m->M; p.nb = dm->m->nbits; p.nh = dm->m->separable ? dm->m->nbits / 2 : 0;
         CPX_REQUIRE(t->S <= 64, CPX_ELIMIT, "demod_hard_viterbi: trellises above 64 states take the two-call path");
     }
-    int lgS = 0;
-    while ((1 << lgS) < t->S) lgS++;
-    p.lgS = lgS;
-    const int PL = (t->I == 2) ? 1 : 2;
+    const int lgS = p.lgS;
+    size_t lds = 0;
+    if (int rcl = wave_lds(t, p, &lds)) return rcl;
     if (t->S > 64) {                                             // 128 states: two states per lane
-        const int SPL = t->S / 64;
-        p.RS = next_pow2(64 + tb_depth);
-        size_t ldsw = sizeof(double) * 64 * p.NC + sizeof(double) * t->S + sizeof(unsigned long long) * p.RS * PL * SPL +
-                      sizeof(unsigned short) * t->S * t->I + (size_t)p.RS;
-        CPX_REQUIRE(ldsw <= 64 * 1024, CPX_ELIMIT, "viterbi: tb_depth %d needs %zu B of LDS (> 64 KiB)", tb_depth, ldsw);
         CPX_REQUIRE(B < (1ll << 31), CPX_ELIMIT, "viterbi: batch too large");
-        if (t->I == 2) hipLaunchKernelGGL((viterbi_wide_kernel<2, 2>), dim3((unsigned)B), dim3(64), ldsw, st, p);
-        else hipLaunchKernelGGL((viterbi_wide_kernel<2, 4>), dim3((unsigned)B), dim3(64), ldsw, st, p);
+        if (t->I == 2) hipLaunchKernelGGL((viterbi_wide_kernel<2, 2>), dim3((unsigned)B), dim3(64), lds, st, p);
+        else hipLaunchKernelGGL((viterbi_wide_kernel<2, 4>), dim3((unsigned)B), dim3(64), lds, st, p);
         CPX_HIP(hipGetLastError());
+        if (p.nanflags) if (int rcr = launch_redo(t, p, B, st)) return rcr;
         note_kernel("viterbi_wide_kernel<2,%d>", t->I);
         return CPX_OK;
     }
-    const int S = t->S, G = 64 / S, CH = S;
-    p.RS = next_pow2(CH + tb_depth);
-    size_t lds = sizeof(double) * 64 * p.NC + sizeof(double) * (64 + 8) + sizeof(unsigned long long) * p.RS * PL +
-                 sizeof(unsigned short) * S * t->I + (size_t)p.RS * G;
-    CPX_REQUIRE(lds <= 64 * 1024, CPX_ELIMIT, "viterbi: tb_depth %d needs %zu B of LDS (> 64 KiB)", tb_depth, lds);
+    const int S = t->S, G = 64 / S;
     const int64_t nblocks = (B + G - 1) / G;
     CPX_REQUIRE(nblocks < (1ll << 31), CPX_ELIMIT, "viterbi: batch too large");
     dim3 grid((unsigned)nblocks), block(64);
-    // shift-register structure => arithmetic traceback (no predecessor table lookups)
-    bool sr = (t->I == 2 && t->k == 1 && lgS >= 1);
-    for (int s2 = 0; s2 < S && sr; s2++)
-        for (int j = 0; j < 2; j++)
-            if (t->pred_state[s2 * 2 + j] != (((s2 << 1) & (S - 1)) | j) || t->pred_input[s2 * 2 + j] != (s2 >> (lgS - 1)))
-                sr = false;
+    const bool sr = shift_register(t);                       // => arithmetic traceback (no predecessor table lookups)
 #define VIT_LAUNCH(LG, IT, SRV)                                                                             \
     do {                                                                                                    \
         if (dm) hipLaunchKernelGGL((viterbi_wave_kernel<LG, IT, SRV, 0, true>), grid, block, lds, st, p);    \
@@ -702,6 +868,7 @@ static int viterbi_dispatch(const cpx_trellis *t, const double *d_coded, const D
 #undef VIT_CASE
 #undef VIT_LAUNCH
     CPX_HIP(hipGetLastError());
+    if (p.nanflags) if (int rcr = launch_redo(t, p, nblocks, st)) return rcr;
     {
         char first[160];                                         // a leading round on the codeword path, if any
         snprintf(first, sizeof(first), "%s", last_kernel_name());
@@ -785,6 +952,10 @@ int cpx_viterbi_decode_batch_i64(const cpx_trellis *t, const double *coded, int6
     static uint8_t *stage = nullptr;
     static size_t stage_cap = 0;
     std::lock_guard<std::mutex> lk(mu);
+    // the arena blocks below are touched from this function's own three streams: hold the device's issue lock for the whole
+    // call, so that cpx_release_workspace (which takes every issue lock, then synchronises the library stream only) cannot
+    // free them while copies and kernels of the pipeline are still in flight
+    cpx::IssueGuard issue_guard;
     if (stage_cap < nout) {
         if (stage) (void)hipHostFree(stage);
         stage = nullptr; stage_cap = 0;
@@ -832,11 +1003,18 @@ int cpx_viterbi_decode_batch_i64(const cpx_trellis *t, const double *coded, int6
             CPX_HIP(hipStreamCreateWithFlags(&s_cmp[dev], hipStreamNonBlocking));
             CPX_HIP(hipStreamCreateWithFlags(&s_dn[dev], hipStreamNonBlocking));
         }
-        std::vector<hipEvent_t> ev_up(nch), ev_cmp(nch), ev_dn(nch);
-        for (int c = 0; c < nch; c++) {
-            CPX_HIP(hipEventCreateWithFlags(&ev_up[c], hipEventDisableTiming));
-            CPX_HIP(hipEventCreateWithFlags(&ev_cmp[c], hipEventDisableTiming));
-            CPX_HIP(hipEventCreateWithFlags(&ev_dn[c], hipEventDisableTiming));
+        std::vector<hipEvent_t> ev_up(nch, nullptr), ev_cmp(nch, nullptr), ev_dn(nch, nullptr);
+        bool ev_ok = true;
+        for (int c = 0; c < nch && ev_ok; c++)
+            ev_ok = hipEventCreateWithFlags(&ev_up[c], hipEventDisableTiming) == hipSuccess &&
+                    hipEventCreateWithFlags(&ev_cmp[c], hipEventDisableTiming) == hipSuccess &&
+                    hipEventCreateWithFlags(&ev_dn[c], hipEventDisableTiming) == hipSuccess;
+        if (!ev_ok) {                                              // nothing is in flight yet: release what was created
+            for (int c = 0; c < nch; c++)
+                for (hipEvent_t e : {ev_up[c], ev_cmp[c], ev_dn[c]})
+                    if (e) (void)hipEventDestroy(e);
+            set_error("viterbi: hipEventCreate failed");
+            return CPX_EHIP;
         }
         auto cw_lo = [&](int c) { return B * c / nch; };
         int issued = 0, wrc = CPX_OK;

@@ -91,9 +91,18 @@ struct CwParams {
     unsigned long long *dec;      // [groups][T][64]  decision word of step t of the lane's codeword
     unsigned char *best;          // [groups][T][64]  first-argmin state
     uint8_t *bits;                // [B][L]
+    uint8_t *nanflags;            // 'soft': [B], 1 = the codeword received a NaN (re-decoded by viterbi.hip's redo launch)
     int64_t B, len, L, T, Lk, Tp;   // Tp: T rounded up to whole groups of log2(S) steps (row count of dec/best)
     int type, tb;
 };
+
+// 'soft': the reference's clip lets a NaN through and the codeword's metrics are NaN from that step on (convcode.py:719,
+// :633-645).  The kernels here only DETECT that -- one unordered compare of the step's two received values, OR-ed into a
+// lane mask on the scalar unit -- and go on with the NaN clipped to -500; flagged codewords are decoded again by the
+// NaN-exact state-per-lane kernel (viterbi.hip, "NaN among 'soft' inputs").
+__device__ __forceinline__ void nan_or(unsigned long long &mask, double r0, double r1) {
+    asm("v_cmp_u_f64 vcc, %1, %2\n\ts_or_b64 %0, %0, vcc" : "+s"(mask) : "v"(r0), "v"(r1) : "vcc");
+}
 
 // Per-bit metrics of one received value (convcode.py:575-587) -- identical to viterbi.hip
 __device__ __forceinline__ void bit_metrics_cw(int type, double r, double &m0, double &m1) {
@@ -332,6 +341,7 @@ __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_acs_kernel(CwParams
     double2 cur[LGS], nxt[LGS];
 #pragma unroll
     for (int u = 0; u < LGS; u++) cur[u] = load(1 + u);
+    unsigned long long nanmask = 0;                                               // 'soft': lanes that received a NaN
     // groups of LGS steps; a partial last group simply runs on (steps > T see padding, their rows are never read)
     for (int t = 1; t <= T; t += LGS) {
 #pragma unroll
@@ -348,6 +358,7 @@ __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_acs_kernel(CwParams
             constexpr int R = decltype(rtag)::value;
             unsigned long long word;
             int bst;
+            if constexpr (TYPE == CPX_VIT_SOFT) nan_or(nanmask, v.x, v.y);
             cw_step<LGS, G0, G1, TYPE, R>(pm, v.x, v.y, word, bst);
             d[R * 64] = word;
             b[R * 64] = (unsigned char)bst;
@@ -361,6 +372,8 @@ __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_acs_kernel(CwParams
 #pragma unroll
         for (int u = 0; u < LGS; u++) cur[u] = nxt[u];
     }
+    if constexpr (TYPE == CPX_VIT_SOFT)
+        if (valid) p.nanflags[cw] = (uint8_t)((nanmask >> lane) & 1ull);
 }
 
 // ---- fused variant: add-compare-select AND sliding traceback in one kernel, no workspace in HBM -------------------------
@@ -454,6 +467,7 @@ __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_fused_kernel(CwPara
 #pragma unroll
     for (int u = 0; u < LGS; u++) cur[u] = load(1 + u);
     int best_T = 0;                                                               // first-argmin state of step T
+    unsigned long long nanmask = 0;                                               // 'soft': lanes that received a NaN
     WalkHook<LGS, HT, RT> walk;                                                        // walk of the previous step (step 0: a dummy)
     walk.pw = mycol;
     walk.st = 0;
@@ -507,6 +521,7 @@ __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_fused_kernel(CwPara
                 const double r0 = have ? cur[R].x : pad, r1 = have ? cur[R].y : pad;
                 unsigned long long word;
                 int bst;
+                if constexpr (TYPE == CPX_VIT_SOFT) nan_or(nanmask, cur[R].x, cur[R].y);   // (steps > tmax re-read step tmax)
                 cw_step<LGS, G0, G1, TYPE, R>(pm, r0, r1, word, bst, walk);      // + hops 0 .. 3/4 H of the walk of step tt - 1
                 walk.finish();
                 myrow[g * LGS + R] = (unsigned char)((walk.st >> (LGS - 1)) & 1u);   // input bit of the branch into the state at step tt - 1 - H
@@ -541,6 +556,8 @@ __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_fused_kernel(CwPara
         }
         flush(tc0, n);
     }
+    if constexpr (TYPE == CPX_VIT_SOFT)
+        if (valid) p.nanflags[cw] = (uint8_t)((nanmask >> lane) & 1ull);
     // the last H output steps: one walk from best[T]; the state before hop h is the state of step T - h
     if (valid) {
         const int qT = T & (FR_RING - 1);
@@ -713,7 +730,7 @@ static const char *type_name(int type) { return type == CPX_VIT_HARD ? "hard" : 
 
 // Returns true when the call was handled here (*rc = status); false -> the caller uses the state-per-lane kernels.
 bool viterbi_codeword_path(const cpx_trellis *t, const double *d_coded, int64_t B, int64_t len, int64_t L, int64_t T,
-                           int tb, int type, uint8_t *d_bits, hipStream_t st, int *rc) {
+                           int tb, int type, uint8_t *d_bits, uint8_t *nanflags, hipStream_t st, int *rc) {
     *rc = CPX_OK;
     // path override (cpx_viterbi_set_path / CPX_VITERBI_PATH): "wave" = state-per-lane kernels; "cw" = this path whatever
     // the batch size; "cw!" = fail instead of falling back; a '2' anywhere ("cw2", "cw2!") = the two-kernel form even
@@ -738,7 +755,8 @@ bool viterbi_codeword_path(const cpx_trellis *t, const double *d_coded, int64_t 
     if (groups >= (1ll << 31) || T >= (1ll << 31) - 64) return reject("batch too large / block too long");
     CwParams p;
     p.coded = d_coded; p.bits = d_bits; p.B = B; p.len = len; p.L = L; p.T = T; p.Lk = L;   // k = 1
-    p.type = type; p.tb = tb;
+    p.type = type; p.tb = tb; p.nanflags = nanflags;
+    if (type == CPX_VIT_SOFT && !nanflags) return reject("'soft' needs the NaN flag array");
     // float32 path metrics when the caller selected "fp32-fast" (cpx_set_precision) -- fused kernel only.  ('hard' metrics
     // of 0/1 inputs are Hamming distances <= 2 T, exact in float32: there the fast mode returns identical bits.)
     const bool f32 = precision_fast() && T < (1ll << 22);

@@ -103,31 +103,55 @@ def reduce_counters(counters, comm=None):
 
 
 # ---- id exchange for one-process-per-GPU launches ------------------------------------------------------------------
-def exchange_unique_id(rank, world, make_id, path=None, timeout=180.0):
+_comm_seq = 0                      # communicators formed by this process so far: all ranks create them in the same order
+
+
+def _launcher_start_time():
+    """Start time of the parent process (the launcher all ranks of one torch.distributed.run share), 0.0 if unknown."""
+    try:
+        return os.stat('/proc/%d' % os.getppid()).st_ctime
+    except OSError:
+        return 0.0
+
+
+def _default_id_path(seq):
+    return os.path.join(tempfile.gettempdir(), 'cpx_comm_%d_%s_%s_%d.id' % (
+        os.getppid(), os.environ.get('MASTER_PORT', '0'), os.environ.get('TORCHELASTIC_RUN_ID', 'none'), seq))
+
+
+def exchange_unique_id(rank, world, make_id, path=None, timeout=180.0, seq=0):
     """Rank 0 calls ``make_id() -> bytes`` and publishes the result; every rank returns the same bytes.
 
     Single-node launches only (the bench contract): the id travels through a file.  Its default name holds the
-    launcher's pid (all ranks of one ``torch.distributed.run`` share their parent) and ``MASTER_PORT``, so concurrent
-    or earlier launches never collide; the write is atomic (temporary file + rename)."""
+    launcher's pid (all ranks of one ``torch.distributed.run`` share their parent), ``MASTER_PORT``, the elastic run id
+    and ``seq`` -- the number of communicators this job has formed before -- so every communicator of every launch has
+    its own file.  A file left behind by a crashed earlier launch that happens to have the same name is not trusted:
+    rank 0 removes it before it creates the id, and the other ranks only accept a file written after their launcher
+    started.  The write is atomic (temporary file + rename)."""
     if world == 1:
         return make_id()
     if path is None:
-        path = os.path.join(tempfile.gettempdir(), 'cpx_comm_%d_%s_%s.id' % (
-            os.getppid(), os.environ.get('MASTER_PORT', '0'), os.environ.get('TORCHELASTIC_RUN_ID', 'none')))
+        path = _default_id_path(seq)
     if rank == 0:
+        try:
+            os.remove(path)                                   # a stale id must never be read as this communicator's
+        except OSError:
+            pass
         blob = make_id()
         fd, tmp = tempfile.mkstemp(dir=os.path.dirname(path))
         with os.fdopen(fd, 'wb') as f:
             f.write(blob)
         os.replace(tmp, path)
         return blob
+    fresh_after = _launcher_start_time() - 2.0
     deadline = time.time() + timeout
     while True:
         try:
-            with open(path, 'rb') as f:
-                blob = f.read()
-            if blob:
-                return blob
+            if os.stat(path).st_mtime >= fresh_after:
+                with open(path, 'rb') as f:
+                    blob = f.read()
+                if blob:
+                    return blob
         except OSError:
             pass
         if time.time() > deadline:
@@ -161,8 +185,11 @@ class RankComm:
             _lib.check(self.lib.cpx_comm_unique_id(buf))
             return buf.raw
 
-        uid = exchange_unique_id(self.rank, self.world, make_id, id_path, timeout)
-        self._id_path = id_path
+        global _comm_seq
+        seq, _comm_seq = _comm_seq, _comm_seq + 1
+        uid = exchange_unique_id(self.rank, self.world, make_id, id_path, timeout, seq)
+        self._id_path = id_path if id_path is not None else _default_id_path(seq)
+        self._own_path = id_path is None
         self.h = ctypes.c_void_p()
         _lib.check(self.lib.cpx_comm_init_rank(uid, self.world, self.rank, ctypes.byref(self.h)))
 
@@ -206,10 +233,9 @@ class RankComm:
         if getattr(self, 'h', None):
             self.lib.cpx_comm_destroy(self.h)
             self.h = ctypes.c_void_p()
-            if self.rank == 0 and self.world > 1 and self._id_path is None:
+            if self.rank == 0 and self.world > 1 and self._own_path:
                 try:
-                    os.remove(os.path.join(tempfile.gettempdir(), 'cpx_comm_%d_%s_%s.id' % (
-                        os.getppid(), os.environ.get('MASTER_PORT', '0'), os.environ.get('TORCHELASTIC_RUN_ID', 'none'))))
+                    os.remove(self._id_path)
                 except OSError:
                     pass
 
@@ -244,9 +270,16 @@ class DeviceGroup:
             _lib.check(self.lib.cpx_stream_create(ctypes.byref(s)))
             self.streams.append(s)
         _lib.check(self.lib.cpx_set_device(self._home))
-        self.h = ctypes.c_void_p()
-        devs = (ctypes.c_int * self.G)(*self.devices)
-        _lib.check(self.lib.cpx_comm_init_all(devs, self.G, ctypes.byref(self.h)))
+        self.h = ctypes.c_void_p()                    # RCCL communicator: formed by the first collective (`_comm`)
+        self._closed = False
+
+    def _comm(self):
+        """The group's RCCL communicator (ncclCommInitAll), created on first use: a group that never gathers or reduces --
+        one device, or gather=False -- does not need librccl at all."""
+        if not self.h:
+            devs = (ctypes.c_int * self.G)(*self.devices)
+            _lib.check(self.lib.cpx_comm_init_all(devs, self.G, ctypes.byref(self.h)))
+        return self.h
 
     # -- plumbing ----------------------------------------------------------------------------------------------------
     def each(self, fn):
@@ -284,12 +317,12 @@ class DeviceGroup:
 
     def allgather_dev(self, d_send, d_recv, bytes_per_rank):
         """``d_send[i]`` / ``d_recv[i]``: device pointers on device i; asynchronous on the group's streams."""
-        _lib.check(self.lib.cpx_comm_allgather_u8(self.h, _ptrs(d_send), _ptrs(d_recv), int(bytes_per_rank),
+        _lib.check(self.lib.cpx_comm_allgather_u8(self._comm(), _ptrs(d_send), _ptrs(d_recv), int(bytes_per_rank),
                                                   _ptrs(self.streams)))
 
     def allreduce_dev(self, d_send, d_recv, count, dtype='i64', op='sum'):
         fn = self.lib.cpx_comm_allreduce_i64 if dtype == 'i64' else self.lib.cpx_comm_allreduce_f64
-        _lib.check(fn(self.h, _ptrs(d_send), _ptrs(d_recv), int(count), _OPS[op], _ptrs(self.streams)))
+        _lib.check(fn(self._comm(), _ptrs(d_send), _ptrs(d_recv), int(count), _OPS[op], _ptrs(self.streams)))
 
     def allreduce_counters(self, per_device_counters):
         """Sum one int64 counter array per device over the group with an RCCL all-reduce; returns the total (read back
@@ -298,6 +331,8 @@ class DeviceGroup:
         arrs = [np.ascontiguousarray(c, dtype=np.int64) for c in per_device_counters]
         if len(arrs) != self.G or any(a.shape != arrs[0].shape for a in arrs):
             raise ValueError('allreduce_counters: one equally shaped array per device')
+        if self.G == 1:
+            return arrs[0].copy()                      # nothing to reduce: no communicator, no device round trip
         bufs = self.each(lambda i, dev, st: DeviceBuf.from_array(arrs[i]))
         self.allreduce_dev([b.ptr for b in bufs], [b.ptr for b in bufs], arrs[0].size)
         self.sync()
@@ -427,13 +462,16 @@ class DeviceGroup:
         return total[0] / total[1].astype(float), total[0], total[1]
 
     def close(self):
-        if getattr(self, 'h', None):
+        if getattr(self, '_closed', True):
+            return
+        self._closed = True
+        if self.h:
             self.lib.cpx_comm_destroy(self.h)
             self.h = ctypes.c_void_p()
-            for d, s in zip(self.devices, self.streams):
-                self.lib.cpx_set_device(d)
-                self.lib.cpx_stream_destroy(s)
-            self.lib.cpx_set_device(self._home)
+        for d, s in zip(self.devices, self.streams):
+            self.lib.cpx_set_device(d)
+            self.lib.cpx_stream_destroy(s)
+        self.lib.cpx_set_device(self._home)
 
     def __del__(self):
         try:

@@ -44,6 +44,10 @@ typedef struct cpx_modem cpx_modem;
 /* ---- runtime ---------------------------------------------------------------------------------*/
 const char *cpx_last_error(void);
 int cpx_version(void);
+/* "full:<sha16>;viterbi:<sha16>" -- digests of the sources this library was compiled from (commpy_amd/build.py).  Measurement
+ * files (profiles/...pmc.json) carry the id of the library that produced them; bench.py only quotes their counters when the
+ * "viterbi" part equals the loaded library's. */
+const char *cpx_build_id(void);
 int cpx_device_count(int *n);
 int cpx_set_device(int device);
 int cpx_get_device(int *device);

@@ -96,8 +96,22 @@ def main():
             kern[k].setdefault("dispatches_counted", n)
         shutil.rmtree(d, ignore_errors=True)
 
+    # ---- provenance: which code produced these numbers (bench.py refuses counters of another build) ----
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        head = subprocess.run(["git", "rev-parse", "HEAD"], cwd=root, capture_output=True, text=True, timeout=20).stdout.strip() or None
+    except Exception:
+        head = None                                    # the GPU box receives the tree without .git
+    try:
+        sys.path.insert(0, root)
+        from commpy_amd import _lib
+        build_id = _lib.build_id()
+    except Exception:
+        build_id = None
+
     # ---- derived ----
     res = {"name": a.name, "command": " ".join(cmd), "batch": a.batch, "fetch_scale": a.fetch_scale,
+           "git_head": head, "build_id": build_id,
            "units": "FETCH_SIZE / WRITE_SIZE in KiB per dispatch; SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* in quad-cycles "
                     "summed over waves; GRBM_GUI_ACTIVE in cycles summed over the 8 XCDs",
            "kernels": {}}

@@ -1,6 +1,6 @@
-"""Viterbi on inputs nobody should send: non-binary 'hard' values, +-inf / NaN / 1e200 in 'unquantized', +-inf / +-500 / +-0 in 'soft',
-four trellises, all kernel paths, against the oracle (= the reference, checked).  NaN in 'soft' is excluded: the engine treats it as -500,
-the reference propagates it (documented in viterbi_decode)."""
+"""Viterbi on inputs nobody should send: non-binary 'hard' values, +-inf / NaN / 1e200 in 'unquantized', +-inf / NaN / +-500 / +-0 in
+'soft', five trellises (k = 1 and 2, 4 to 128 states), all kernel paths, against the oracle (= the reference, checked on these cases).
+A smaller draw of the same cases is part of the suite: tests/test_viterbi_gpu.py::test_abnormal_inputs_all_types_vs_oracle."""
 import sys, numpy as np
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 import oracle
@@ -9,7 +9,7 @@ from commpy_amd import _lib
 from commpy_amd.channelcoding import viterbi_decode
 rs = np.random.RandomState(0)
 bad = 0; n = 0
-for name in ("k7_133_171", "t57", "k2_default", "rsc_legacy_8"):
+for name in ("k7_133_171", "t57", "k2_default", "rsc_legacy_8", "k8_247_371"):
     tr = make_trellis(name)
     for trial in range(60):
         B, steps = int(rs.choice([1, 5, 64, 70])), int(rs.randint(20, 150))
@@ -23,10 +23,10 @@ for name in ("k7_133_171", "t57", "k2_default", "rsc_legacy_8"):
                     rx[rs.rand(B, length) < 0.004] = v
             else:
                 rx = rs.randn(B, length) * 4
-                for v in (np.inf, -np.inf, 1e200, 499.99999, -500.0, 0.0, -0.0):
+                for v in (np.inf, -np.inf, np.nan, 1e200, 499.99999, -500.0, 0.0, -0.0):
                     rx[rs.rand(B, length) < 0.004] = v
             want = oracle.viterbi_decode(rx, tr, None, dtype)
-            for path in ((None, "cw!", "wave") if name == "k7_133_171" else (None,)):
+            for path in ((None, "cw!", "cw2!", "wave") if name == "k7_133_171" else (None,)):
                 _lib.viterbi_set_path(path)
                 got = viterbi_decode(rx, tr, None, dtype)
                 n += 1

@@ -297,3 +297,87 @@ def test_demod_full_size_identity(gpu):
     soft = md.demodulate(y, "soft", N0)
     assert soft.shape == (nsym * 6,) and np.all(np.isfinite(soft) | np.isinf(soft))
     assert np.array_equal(soft > 0, bits == 1)
+
+
+# ------------------------------------------------------------------ BCJR outside the reference's representable range
+def _pattern_equal(a, b):
+    """Same NaN positions, same +-inf positions (and signs)."""
+    return (np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(np.isposinf(a), np.isposinf(b)) and
+            np.array_equal(np.isneginf(a), np.isneginf(b)))
+
+
+@pytest.mark.parametrize("tname", ["rsc_legacy_4", "rsc_legacy_8"])
+def test_map_decode_extreme_regimes_follow_the_reference(gpu, tname):
+    """Promoted from scripts/micro/map_extreme.py.  Symbol amplitudes of 5 - 20 at sigma^2 <= 0.1 and priors of |L| up to 200:
+    the terms of the reference's absolute-scale recursion underflow (turbo.py:62-76, :238-240), a column sum becomes 0 and the
+    LLRs NaN, or app0 = 0 and the LLR +-inf.  The fast kernels flag every codeword for which that can happen and a literal
+    absolute-scale kernel decodes it again (csrc/bcjr_exact.hip): NaN / +-inf pattern identical to the oracle (= the
+    reference, checked on these regimes), finite values within 1e-5 + 1e-9 |L|, decisions equal."""
+    from commpy_amd.channelcoding import map_decode
+    tr = make_trellis(tname)
+    rs = np.random.RandomState(7)
+    n_nonfinite = 0
+    for amp in (1.0, 5.0, 20.0):
+        for nv in (0.02, 0.1, 1.0):
+            for lsc in (0.0, 5.0, 60.0):
+                B, N = 6, int(rs.randint(5, 120))
+                s_ = (rs.choice([-1.0, 1.0], size=(B, N)) + rs.randn(B, N) * 0.5) * amp
+                p_ = (rs.choice([-1.0, 1.0], size=(B, N)) + rs.randn(B, N) * 0.5) * amp
+                L = rs.randn(B, N) * lsc
+                Le, bits = map_decode(s_, p_, tr, nv, L, "decode")
+                for b in range(B):
+                    Lo, bo = oracle.map_decode(s_[b], p_[b], tr, nv, L[b], "decode")
+                    key = (tname, amp, nv, lsc, b)
+                    assert _pattern_equal(Le[b], Lo), key
+                    fin = np.isfinite(Lo)
+                    n_nonfinite += int(np.sum(~fin))
+                    assert np.all(np.abs(Le[b][fin] - Lo[fin]) <= TOL + 1e-9 * np.abs(Lo[fin])), key
+                    assert not np.any((bits[b] != bo) & ~(np.abs(Lo) <= TOL)), key      # NaN / inf positions included
+    assert n_nonfinite > 500                                       # the regimes really are outside the reference's range
+
+
+def test_map_decode_nonfinite_inputs_follow_the_reference(gpu):
+    """NaN / +-inf among the received values or the a-priori LLRs: e^inf = inf gives p0 = 0, p1 = 1 (turbo.py:239-240); a NaN
+    poisons the column sums from its step on, in both directions."""
+    from commpy_amd.channelcoding import map_decode
+    tr = make_trellis("rsc_legacy_4")
+    rs = np.random.RandomState(8)
+    B, N = 8, 60
+    s_ = rs.choice([-1.0, 1.0], size=(B, N)) + rs.randn(B, N) * 0.7
+    p_ = rs.choice([-1.0, 1.0], size=(B, N)) + rs.randn(B, N) * 0.7
+    L = rs.randn(B, N) * 2
+    s_[1, 17] = np.nan
+    p_[2, 3] = np.inf
+    L[3, 30] = np.inf
+    L[4, 31] = -np.inf
+    L[5, 0] = np.nan
+    L[6, 10] = 800.0
+    L[6, 11] = -800.0
+    Le, bits = map_decode(s_, p_, tr, 0.5, L, "decode")
+    for b in range(B):
+        Lo, bo = oracle.map_decode(s_[b], p_[b], tr, 0.5, L[b], "decode")
+        assert _pattern_equal(Le[b], Lo), b
+        fin = np.isfinite(Lo)
+        assert np.all(np.abs(Le[b][fin] - Lo[fin]) <= TOL + 1e-9 * np.abs(Lo[fin])), b
+        assert not np.any((bits[b] != bo) & ~(np.abs(Lo) <= TOL)), b
+
+
+def test_turbo_decode_extreme_regimes_follow_the_reference(gpu):
+    """turbo_decode where the reference's MAP passes underflow (high amplitude at low noise variance, huge L_int): decoded bits
+    equal the oracle's -- the flagged codewords go through the absolute-scale turbo kernel (csrc/bcjr_exact.hip)."""
+    from commpy_amd.channelcoding import RandInterlv, turbo_decode
+    tr = make_trellis("rsc_legacy_4")
+    rs = np.random.RandomState(9)
+    n = 0
+    for amp, nv, lsc in ((5.0, 0.02, 0.0), (20.0, 0.1, 0.0), (1.0, 0.1, 60.0), (5.0, 1.0, 5.0), (1.0, 0.004, 0.0)):
+        B, N = 20, int(rs.randint(40, 200))
+        il = RandInterlv(N, 77)
+        s_, p1, p2 = ((rs.choice([-1.0, 1.0], size=(B, N)) + rs.randn(B, N) * 0.5) * amp for _ in range(3))
+        L = rs.randn(B, N) * lsc if lsc else None
+        for iters in (1, 3):
+            dec = turbo_decode(s_, p1, p2, tr, nv, iters, il, L)
+            for b in range(0, B, 3):
+                want = oracle.turbo_decode(s_[b], p1[b], p2[b], tr, nv, iters, il, None if L is None else L[b])
+                assert np.array_equal(dec[b], want), (amp, nv, lsc, iters, b)
+                n += 1
+    assert n >= 60

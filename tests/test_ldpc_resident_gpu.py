@@ -130,3 +130,27 @@ def test_auto_falls_back_to_tiled_for_codes_beyond_lds(gpu, paths):
     paths.ldpc_set_path("resident")
     with pytest.raises(Exception):
         ldpc_bp_decode(llr.copy(), dict(p), "MSA", 3)
+
+
+@pytest.mark.parametrize("name,n,iters", [("n1944", 1944, 12), ("gallager96", 96, 30), ("wimax1440", 1440, 8)])
+def test_min_sum_nan_llrs_follow_the_reference(gpu, paths, name, n, iters):
+    """NumPy's min / sign propagate a NaN (ldpc.py:229-238): within a few iterations the whole block is NaN and dec_word =
+    signbit(NaN) decides the syndrome test.  The fast kernels only detect a NaN LLR; flagged blocks are decoded again by the
+    literal ldpc_msa_exact_kernel (csrc/ldpc.hip).  Both paths against the oracle: iteration counts, dec_word, out_llrs and its
+    NaN pattern -- np.nan inputs (one NaN sign; see the kernel's note on mixed signs)."""
+    p = ldpc_params(name)
+    rs = np.random.RandomState(21)
+    B = 70
+    llr = _staggered(rs, B, n, 0.5, [1.0, 2.5, 4.0, 30.0])
+    blocks = [0, 3, 5, 64, 69]
+    for b in blocks:
+        llr[b * n + rs.randint(n, size=1 + (b % 3))] = np.nan
+    llr[5 * n:6 * n] = np.nan                                       # a block of nothing but NaN
+    do, oo, io = oracle.ldpc_bp_decode(llr.copy(), p, "MSA", iters, True)
+    assert np.isnan(oo[:, blocks]).any(axis=0).all() and not np.isnan(np.delete(oo, blocks, axis=1)).any()
+    for path in ("resident", "tiled"):
+        d, o, i, x, _ = _decode(paths, path, llr, p, "MSA", iters)
+        assert np.array_equal(i, io), path
+        assert np.array_equal(o, oo, equal_nan=True), path
+        assert np.array_equal(d, do), path
+        assert np.array_equal(x, llr, equal_nan=True), path         # nothing to clip: the input is unchanged

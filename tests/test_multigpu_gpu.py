@@ -1,0 +1,113 @@
+"""Multi-GPU paths on REAL devices: skipped when fewer than two GPUs are visible (the build and test boxes have one; the
+driver's scaling node has eight).  They exist so that the first hardware run of the N > 1 paths cannot fall over on
+something a two-device run would have shown:
+
+  * one process per GPU (the bench.py / torch.distributed.run form): two spawned processes form an RCCL communicator
+    through cpx_comm_init_rank (commpy_amd.parallel.RankComm, id exchange through its per-communicator file) and check
+    allgather_rows / allreduce / sharded_decode / reduce_counters against the single-process result;
+  * one process, several GPUs (commpy_amd.parallel.DeviceGroup over devices [0, 1]): BASELINE config 4 (LDPC, dec_word
+    all-gathered, out_llrs left sharded) and config 5 (Wifi80211 sweep, counters all-reduced).
+
+The shard arithmetic, padding and id exchange are also covered without any GPU by tests/test_parallel_gloo.py.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _need_two(gpu):
+    from commpy_amd import _lib
+    if _lib.device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+
+
+def _rank_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import numpy as np
+    from helpers import make_trellis
+    from commpy_amd.channelcoding import conv_encode_batch, viterbi_decode
+    from commpy_amd.parallel import RankComm, reduce_counters, shard_bounds, sharded_decode
+    ok = True
+    comm = RankComm(rank, world, device=rank)
+    try:
+        # ragged rows (7 = 4 + 3), uint8 and float64 payloads
+        rows = np.arange(7 * 5, dtype=np.uint8).reshape(7, 5)
+        a, b = shard_bounds(7, rank, world)
+        ok = ok and np.array_equal(comm.allgather_rows(rows[a:b], 7), rows)
+        f = np.linspace(0.0, 1.0, 12).reshape(6, 2)
+        ok = ok and np.array_equal(comm.allgather_rows(f[rank * 3:(rank + 1) * 3], 6), f)
+        ok = ok and np.array_equal(comm.allreduce(np.array([rank + 1, 10], np.int64)), [3, 20])
+        ok = ok and np.array_equal(comm.allreduce(np.array([float(rank), 2.5]), "max"), [1.0, 2.5])
+        comm.barrier()
+        # a second communicator of the same job must not read the first one's id file
+        comm2 = RankComm(rank, world, device=rank)
+        ok = ok and np.array_equal(comm2.allreduce(np.array([1], np.int64)), [2])
+        comm2.close()
+        # sharded decode: every rank decodes its rows on its own GPU, one all-gather reassembles the batch
+        tr = make_trellis("k7_133_171")
+        rs = np.random.RandomState(2)
+        msgs = rs.randint(0, 2, (37, 96))
+        llr = 6.0 * (2.0 * conv_encode_batch(msgs, tr) - 1) + 4.0 * rs.randn(37, 204)
+        want = viterbi_decode(llr, tr, None, "soft")
+        got = sharded_decode(lambda x: viterbi_decode(x, tr, None, "soft").astype(np.uint8), [llr], comm)
+        ok = ok and np.array_equal(got, want)
+        lo, hi = shard_bounds(37, rank, world)
+        errs = int(np.sum(want[lo:hi, :96] != msgs[lo:hi]))
+        tot = reduce_counters(np.array([errs, (hi - lo) * 96], np.int64), comm)
+        ok = ok and tot[0] == int(np.sum(want[:, :96] != msgs)) and tot[1] == 37 * 96
+    finally:
+        comm.close()
+    q.put((rank, bool(ok)))
+
+
+def test_rank_comm_two_processes(gpu):
+    _need_two(gpu)
+    import multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        res = sorted(q.get(timeout=300) for _ in procs)
+    finally:
+        for p in procs:
+            p.join(60)
+            if p.is_alive():
+                p.terminate()
+    assert res == [(0, True), (1, True)]
+
+
+def test_device_group_two_devices_config4_and_config5(gpu):
+    _need_two(gpu)
+    from helpers import golden, ldpc_params
+    from commpy_amd.channelcoding import ldpc_bp_decode
+    from commpy_amd.parallel import DeviceGroup
+    grp = DeviceGroup([0, 1])
+    try:
+        g = golden("ldpc_c4x")
+        p = ldpc_params("n1944")
+        for alg in ("MSA", "SPA"):
+            d1, o1 = ldpc_bp_decode(g["e9__llr"].copy(), p, alg, 50)
+            for gather in (True, False):
+                dec, out = grp.ldpc_bp_decode(g["e9__llr"].copy(), p, alg, 50, gather=gather)
+                assert np.array_equal(dec, d1) and np.array_equal(out, o1), (alg, gather)
+        tot = grp.allreduce_counters([np.array([3 + i, 10], np.int64) for i in range(2)])
+        assert tot[0] == 7 and tot[1] == 20
+        ber, errs, bits = grp.wifi_ber_sweep(5, np.array([14.0, 40.0]), 600 * 400, generator_matrix=[[0o133, 0o171]])
+        assert bits[0] >= 600 * 400 and errs[1] == 0 and 0 < ber[0] < 0.5
+    finally:
+        grp.close()

@@ -107,6 +107,10 @@ def test_sharded_decode_world2_gloo(tmp_path):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    # a stale id file of a crashed earlier launch sits where this launch will publish its id: it must never be read
+    stale = tmp_path / "id"
+    stale.write_bytes(b"\xff" * 128)
+    os.utime(stale, (1.0e9, 1.0e9))
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
@@ -132,3 +136,5 @@ def test_default_id_path_is_per_launch():
     """Ranks of one launcher share their parent pid; two launches (or ports) never see each other's id file."""
     from commpy_amd.parallel import exchange_unique_id
     assert exchange_unique_id(0, 1, lambda: b"x" * 128) == b"x" * 128                # world 1: no file at all
+    from commpy_amd import parallel
+    assert parallel._default_id_path(0) != parallel._default_id_path(1)              # one file per communicator of a job

@@ -97,3 +97,67 @@ def test_invalid_arguments(gpu):
         _decode(np.zeros(20), tr, None, "fuzzy")
     out = _decode(np.zeros((0, 20)), tr, None, "hard")
     assert out.shape == (0, 10)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["k7_133_171", "t57", "k2_default", "k8_247_371"])
+def test_soft_nan_inputs_follow_the_reference(gpu, name):
+    """The reference's clip lets a NaN LLR through (convcode.py:719): from that step on every metric of the codeword is NaN,
+    every decision "first predecessor", every traceback starts from state 0 (:633-645).  The fast kernels only detect the NaN;
+    flagged codewords are decoded again by the NaN-exact instantiation (csrc/viterbi.hip, "NaN among 'soft' inputs").  All
+    kernel paths (fused / two-kernel codeword path, state-per-lane, 128-state) against the oracle, which was checked against
+    the live reference on such inputs."""
+    from commpy_amd import _lib
+    from commpy_amd.channelcoding import viterbi_decode
+    tr = make_trellis(name)
+    rs = np.random.RandomState(5)
+    for B, steps in ((1, 40), (70, 130), (64, 64), (200, 33)):
+        rx = rs.randn(B, steps * tr.n) * 3
+        rx[rs.rand(*rx.shape) < 0.004] = np.nan
+        rx[0, rs.randint(0, rx.shape[1])] = np.nan
+        if B > 100:
+            rx[100:] = rs.randn(B - 100, steps * tr.n) * 3          # whole wavefronts / redo groups without a NaN
+        want = oracle.viterbi_decode(rx, tr, None, "soft")
+        for path in ((None, "cw!", "cw2!", "wave") if name == "k7_133_171" else (None,)):
+            _lib.viterbi_set_path(path)
+            try:
+                got = viterbi_decode(rx, tr, None, "soft")
+            finally:
+                _lib.viterbi_set_path(None)
+            assert np.array_equal(got, want), (name, B, steps, path)
+
+
+@pytest.mark.gpu
+def test_abnormal_inputs_all_types_vs_oracle(gpu):
+    """Inputs nobody should send (promoted from scripts/micro/vit_weird.py): non-binary 'hard' values, +-inf / NaN / 1e200 in
+    'unquantized', +-inf / NaN / +-500 / +-0 in 'soft'; five trellises (k = 1 and 2, 4 to 128 states), every kernel path."""
+    from commpy_amd import _lib
+    from commpy_amd.channelcoding import viterbi_decode
+    rs = np.random.RandomState(0)
+    n_cases = 0
+    for name in ("k7_133_171", "t57", "k2_default", "rsc_legacy_8", "k8_247_371"):
+        tr = make_trellis(name)
+        for trial in range(12):
+            B, steps = int(rs.choice([1, 5, 64, 70])), int(rs.randint(20, 150))
+            length = steps * tr.n
+            for dtype in ("hard", "unquantized", "soft"):
+                if dtype == "hard":
+                    rx = rs.choice([0.0, 1.0, 2.0, -1.0, 0.5, 1.9, 3.0, -0.3], size=(B, length), p=[.4, .4, .04, .04, .03, .03, .03, .03])
+                elif dtype == "unquantized":
+                    rx = rs.choice([-1.0, 1.0], size=(B, length)) + rs.randn(B, length) * 0.6
+                    for v in (np.inf, -np.inf, np.nan, 1e200, -1e200, 0.0):
+                        rx[rs.rand(B, length) < 0.004] = v
+                else:
+                    rx = rs.randn(B, length) * 4
+                    for v in (np.inf, -np.inf, np.nan, 1e200, 499.99999, -500.0, 0.0, -0.0):
+                        rx[rs.rand(B, length) < 0.004] = v
+                want = oracle.viterbi_decode(rx, tr, None, dtype)
+                for path in ((None, "cw!", "cw2!", "wave") if name == "k7_133_171" else (None,)):
+                    _lib.viterbi_set_path(path)
+                    try:
+                        got = viterbi_decode(rx, tr, None, dtype)
+                    finally:
+                        _lib.viterbi_set_path(None)
+                    n_cases += 1
+                    assert np.array_equal(got, want), (name, dtype, B, steps, path, int(np.sum(got != want)))
+    assert n_cases >= 250
