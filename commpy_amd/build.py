@@ -26,7 +26,7 @@ def _hipcc():
     return "hipcc"
 
 
-HEADERS = [os.path.join(CSRC, h) for h in ("cpx_internal.h", "cpx_math.h", "demod_dev.h", "ldpc_dev.h")] + [os.path.join(INCLUDE, "commpy_amd.h")]
+HEADERS = [os.path.join(CSRC, h) for h in ("cpx_internal.h", "cpx_math.h", "demod_dev.h", "ldpc_dev.h", "viterbi_cw_asm.h")] + [os.path.join(INCLUDE, "commpy_amd.h")]
 OBJDIR = os.path.join(CSRC, "build")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-result",
          "-I", INCLUDE, "-I", CSRC]
@@ -45,7 +45,7 @@ def _digest(names):
 
 # what the Viterbi kernels are compiled from: bench.py only trusts committed rocprofv3 counters of the headline kernel when
 # they were recorded with a library built from exactly these sources (cpx_build_id() of the .so == the id in the PMC file)
-VITERBI_SOURCES = ["viterbi.hip", "viterbi_cw.hip", "cpx_math.h", "cpx_internal.h", "demod_dev.h"]
+VITERBI_SOURCES = ["viterbi.hip", "viterbi_cw.hip", "viterbi_cw_asm.h", "cpx_math.h", "cpx_internal.h", "demod_dev.h"]
 
 
 def source_build_id():

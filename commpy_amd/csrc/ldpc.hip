@@ -598,7 +598,7 @@ __global__ __launch_bounds__(256) void ldpc_msa_exact_kernel(MsaExactParams p) {
         flagged[tid] = (base + tid < hi) ? p.flags[base + tid] : 0;
         __syncthreads();
         for (int i = 0; i < 256 && base + i < hi; i++) {
-            if (!flagged[i]) continue;                            // workgroup-uniform
+            if (!__builtin_amdgcn_readfirstlane((int)flagged[i])) continue;   // workgroup-uniform: a SCALAR branch around the barriers below
             const int64_t b = base + i;
             const double *l = p.llr + b * p.n_v;
             for (int64_t e = tid; e < p.E; e += 256) M[e] = 1.0 * l[p.edge_var[e]];          // H.multiply(llr) (:199)
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(256) void ldpc_msa_exact_kernel(MsaExactParams p) {
                     if (par) any = 1;
                 }
                 __syncthreads();
-                if (!any) break;
+                if (!__builtin_amdgcn_readfirstlane(any)) break;     // uniform (scalar) exit
                 for (int c = tid; c < p.n_c; c += 256) {          // (:231-238)
                     const int b0 = p.row_ptr[c], deg = p.row_ptr[c + 1] - b0;
                     double row[MAXDEG];

@@ -190,20 +190,25 @@ __global__ __launch_bounds__(1024, 6) void ldpc_resident_kernel(ResParams p) {
     if ((unsigned)(uintptr_t)lds != 0u) __builtin_trap();        // the tables hold absolute LDS addresses (see ldsd)
     int *ctl = reinterpret_cast<int *>(lds + p.ctl_off);         // [0], [1]: "unsatisfied" flag of even / odd iterations; [2]: block
     const int tid = threadIdx.x, nt = blockDim.x;
+    // Control flow around the barriers is kept UNIFORM on purpose: the block index and the syndrome flag are read through
+    // readfirstlane (scalar loop exits), and everything only thread 0 does -- retiring a block, taking the next one from the
+    // queue -- sits in ONE if-block in the middle of the loop body, followed by a barrier.  With a thread-0 block at the end of
+    // the body and another at its start the structuriser turned the loop inside out (lanes 1..63 of wave 0 went round to the
+    // next s_barrier while lane 0 was still retiring): wave 0 met the barrier twice per block and the kernel hung.
+    auto pop = [&]() {                                           // thread 0 only
+        const int t = atomicAdd(p.queue, 1);
+        ctl[2] = t < p.B ? t : -1;
+    };
     if (tid == 0) {
         stsd(8 * p.n_v, __builtin_huge_val());                   // dummy Q (row padding)
         stsd(p.roff + 8 * p.n_r, 0.0);                           // dummy R (column padding)
+        ctl[0] = 0; ctl[1] = 0;                                  // "unsatisfied" flags of the first block
         ctl[3] = 0;                                              // "a NaN among the LLRs of the current block"
+        pop();
     }
-    for (;;) {
-        if (tid == 0) {
-            const int t = atomicAdd(p.queue, 1);
-            ctl[2] = t < p.B ? t : -1;
-        }
-        __syncthreads();
-        const int b = ctl[2];
-        if (b < 0) break;
-        if (tid == 0) { ctl[0] = 0; ctl[1] = 0; }
+    __syncthreads();
+    int b = __builtin_amdgcn_readfirstlane(ctl[2]);
+    while (b >= 0) {
         double *__restrict__ in = p.llr + (int64_t)b * p.n_v;
         for (int v = tid; v < p.n_v; v += nt) {
             const double raw = in[v];
@@ -228,7 +233,7 @@ __global__ __launch_bounds__(1024, 6) void ldpc_resident_kernel(ResParams p) {
                 else check_spa(p, c, flag);
             }
             __syncthreads();
-            if (!*flag) break;                                   // zero syndrome: the block keeps the Q it has (:205-206)
+            if (!__builtin_amdgcn_readfirstlane(*flag)) break;   // zero syndrome: the block keeps the Q it has (:205-206)
             if (tid == 0) ctl[(k + 1) & 1] = 0;
             for (int v = tid; v < p.n_v; v += nt) var_node(p, v, in);
             __syncthreads();
@@ -238,8 +243,12 @@ __global__ __launch_bounds__(1024, 6) void ldpc_resident_kernel(ResParams p) {
         if (tid == 0) {
             if (p.iters) p.iters[b] = k;
             if (p.nanflags) p.nanflags[b] = (uint8_t)ctl[3];
-            ctl[3] = 0;                                          // the next block's loads come after the barrier of its queue pop
+            ctl[3] = 0;
+            ctl[0] = 0; ctl[1] = 0;                              // (a thread that has yet to read a flag of this block reads the 0 that sent the others here)
+            pop();
         }
+        __syncthreads();
+        b = __builtin_amdgcn_readfirstlane(ctl[2]);
     }
 }
 
@@ -336,20 +345,20 @@ __global__ __launch_bounds__(1024, 8) void ldpc_resident_f32_kernel(ResParams p)
     if ((unsigned)(uintptr_t)lds != 0u) __builtin_trap();
     int *ctl = reinterpret_cast<int *>(lds + p.ctl_off);
     const int tid = threadIdx.x, nt = blockDim.x;
+    auto pop = [&]() {                                           // thread 0 only (control flow: see ldpc_resident_kernel)
+        const int t = atomicAdd(p.queue, 1);
+        ctl[2] = t < p.B ? t : -1;
+    };
     if (tid == 0) {
         stsf(4 * p.n_v, __builtin_huge_valf());
         stsf(p.roff + 4 * p.n_r, 0.0f);
+        ctl[0] = 0; ctl[1] = 0;
         ctl[3] = 0;
+        pop();
     }
-    for (;;) {
-        if (tid == 0) {
-            const int t = atomicAdd(p.queue, 1);
-            ctl[2] = t < p.B ? t : -1;
-        }
-        __syncthreads();
-        const int b = ctl[2];
-        if (b < 0) break;
-        if (tid == 0) { ctl[0] = 0; ctl[1] = 0; }
+    __syncthreads();
+    int b = __builtin_amdgcn_readfirstlane(ctl[2]);
+    while (b >= 0) {
         double *__restrict__ in = p.llr + (int64_t)b * p.n_v;
         for (int v = tid; v < p.n_v; v += nt) {
             const double raw = in[v];
@@ -374,7 +383,7 @@ __global__ __launch_bounds__(1024, 8) void ldpc_resident_f32_kernel(ResParams p)
                 else check_spa_f32(p, c, flag);
             }
             __syncthreads();
-            if (!*flag) break;
+            if (!__builtin_amdgcn_readfirstlane(*flag)) break;
             if (tid == 0) ctl[(k + 1) & 1] = 0;
             for (int v = tid; v < p.n_v; v += nt) var_node_f32(p, v, in);
             __syncthreads();
@@ -385,7 +394,11 @@ __global__ __launch_bounds__(1024, 8) void ldpc_resident_f32_kernel(ResParams p)
             if (p.iters) p.iters[b] = k;
             if (p.nanflags) p.nanflags[b] = (uint8_t)ctl[3];
             ctl[3] = 0;
+            ctl[0] = 0; ctl[1] = 0;
+            pop();
         }
+        __syncthreads();
+        b = __builtin_amdgcn_readfirstlane(ctl[2]);
     }
 }
 

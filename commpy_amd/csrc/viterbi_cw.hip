@@ -27,6 +27,7 @@
 // Measured on MI355X for BASELINE config 2 (B = 65536, K = 7, soft): see DESIGN.md 4.1.
 #include "cpx_internal.h"
 #include "cpx_math.h"
+#include "viterbi_cw_asm.h"
 
 #include <atomic>
 #include <cstdlib>
@@ -101,7 +102,11 @@ struct CwParams {
 // lane mask on the scalar unit -- and go on with the NaN clipped to -500; flagged codewords are decoded again by the
 // NaN-exact state-per-lane kernel (viterbi.hip, "NaN among 'soft' inputs").
 __device__ __forceinline__ void nan_or(unsigned long long &mask, double r0, double r1) {
-    asm("v_cmp_u_f64 vcc, %1, %2\n\ts_or_b64 %0, %0, vcc" : "+s"(mask) : "v"(r0), "v"(r1) : "vcc");
+#ifdef CPX_AB_NO_NAN_DETECT                                         // A/B builds only (experiments/README.md): what the detection costs
+    (void)mask; (void)r0; (void)r1;
+    return;
+#endif
+    asm("v_cmp_u_f64 vcc, %1, %2\n\ts_or_b64 %0, %0, vcc" : "+s"(mask) : "v"(r0), "v"(r1) : "vcc", "scc");
 }
 
 // Per-bit metrics of one received value (convcode.py:575-587) -- identical to viterbi.hip
@@ -177,17 +182,40 @@ __device__ __forceinline__ void cw_step(double (&pm)[1 << LGS], double r0, doubl
     hook.template at<2>();
     // first-argmin state (:645): the minimum (v_min_f64 tree, as viterbi.hip's cross-lane tree) and the first state equal to it
     double m0 = pm[0], m1 = pm[1 % S], m2 = pm[2 % S], m3 = pm[3 % S];
+    if constexpr (S == 64) {
+        // 60 v_min_f64 as three statements of four interleaved chains (viterbi_cw_asm.h: one statement per instruction cost an
+        // s_nop per dependent pair and serialised the chains)
+#define CPX_V4(a) "v"(pm[a]), "v"(pm[(a) + 1]), "v"(pm[(a) + 2]), "v"(pm[(a) + 3])
+        asm(CPX_MIN_BLOCK24 : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3)
+            : CPX_V4(4), CPX_V4(8), CPX_V4(12), CPX_V4(16), CPX_V4(20), CPX_V4(24));
+        asm(CPX_MIN_BLOCK24 : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3)
+            : CPX_V4(28), CPX_V4(32), CPX_V4(36), CPX_V4(40), CPX_V4(44), CPX_V4(48));
+        asm(CPX_MIN_BLOCK12 : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3) : CPX_V4(52), CPX_V4(56), CPX_V4(60));
+#undef CPX_V4
+    } else {
 #pragma unroll
-    for (int s = 4; s < S; s += 4) {
-        m0 = vmin(m0, pm[s]); m1 = vmin(m1, pm[s + 1]); m2 = vmin(m2, pm[s + 2]); m3 = vmin(m3, pm[s + 3]);
+        for (int s = 4; s < S; s += 4) {
+            m0 = vmin(m0, pm[s]); m1 = vmin(m1, pm[s + 1]); m2 = vmin(m2, pm[s + 2]); m3 = vmin(m3, pm[s + 3]);
+        }
     }
     const double mn = vmin(vmin(m0, m1), vmin(m2, m3));
     hook.template at<3>();
     int bst = 0;
-    if constexpr (S % 4 == 0) {
-        // first state equal to the minimum, scanned downwards four states at a time: four compares into four SGPR pairs,
-        // then the four selects.  A select right behind its float64 compare needs two wait states on gfx950 (the compiler
-        // pads every pair with s_nop 1); here three instructions always sit between a compare and its select (-4 %).
+    if constexpr (S == 64) {
+        // first state equal to the minimum, scanned downwards (a later, lower state overwrites): per four states four compares
+        // into four SGPR pairs, then the four selects with inline-constant state numbers -- three instructions always sit
+        // between a float64 compare and the select that reads its mask (back to back the pair needs two wait states).  Three
+        // statements of 24 / 24 / 16 states (30 operands is the limit of one).
+        unsigned long long k0, k1, k2, k3;
+#define CPX_S4(a) "v"(pm[rotl<LGS>((a), R + 1)]), "v"(pm[rotl<LGS>((a) - 1, R + 1)]), "v"(pm[rotl<LGS>((a) - 2, R + 1)]), "v"(pm[rotl<LGS>((a) - 3, R + 1)])
+        asm(CPX_SCAN_BLOCK0 : "+v"(bst), "=&s"(k0), "=&s"(k1), "=&s"(k2), "=&s"(k3)
+            : "v"(mn), CPX_S4(63), CPX_S4(59), CPX_S4(55), CPX_S4(51), CPX_S4(47), CPX_S4(43));
+        asm(CPX_SCAN_BLOCK1 : "+v"(bst), "=&s"(k0), "=&s"(k1), "=&s"(k2), "=&s"(k3)
+            : "v"(mn), CPX_S4(39), CPX_S4(35), CPX_S4(31), CPX_S4(27), CPX_S4(23), CPX_S4(19));
+        asm(CPX_SCAN_BLOCK2 : "+v"(bst), "=&s"(k0), "=&s"(k1), "=&s"(k2), "=&s"(k3)
+            : "v"(mn), CPX_S4(15), CPX_S4(11), CPX_S4(7), CPX_S4(3));
+#undef CPX_S4
+    } else if constexpr (S % 4 == 0) {
 #pragma unroll
         for (int s = S - 4; s >= 0; s -= 4) {
             unsigned long long k0, k1, k2, k3;

@@ -12,7 +12,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd $R
 if [[ $SEC == *t* ]]; then
-  timeout 1500 python -m pytest tests -m gpu -q --durations=8 2>&1 | tail -120 | tee $OUT/pytest_gpu.txt
+  timeout 900 python -m pytest tests -m gpu -q -x --timeout 120 --timeout-method=thread --durations=8 2>&1 | tail -120 | tee $OUT/pytest_gpu.txt
 fi
 if [[ $SEC == *s* ]]; then
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee $OUT/smoke.txt
