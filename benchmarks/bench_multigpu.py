@@ -68,7 +68,7 @@ def config4(grp, B_total, ebn0=9.0):
                 b = bufs[i]
                 mine = ctypes.c_void_p(b["dec"].ptr.value + i * rows * n)
                 _lib.check(lib.cpx_memcpy_d2d_async(b["neg"].ptr, b["llr"].ptr, B * n * 8, st))    # the decoder clips in place
-                _lib.check(lib.cpx_ldpc_bp_decode_batch_dev(_device_code(p), b["neg"].ptr, B, alg, 50, mine, b["out"].ptr,
+                _lib.check(lib.cpx_ldpc_bp_decode_batch_bm_dev(_device_code(p), b["neg"].ptr, B, alg, 50, mine, b["out"].ptr,
                                                             b["it"].ptr, st))
                 return mine
             mine = grp.each(launch)
@@ -89,7 +89,7 @@ def config4(grp, B_total, ebn0=9.0):
         full = grp.each(lambda i, dev, st: bufs[i]["dec"].to_array((grp.G, rows * n), np.int8) if i == 0 else None)[0]
         fer = []
         for g in range(grp.G):
-            dec = full[g, :n * counts[g]].reshape(n, counts[g]).T
+            dec = full[g, :n * counts[g]].reshape(counts[g], n)       # block-major shards: one block per row
             fer.append(float(np.mean((dec != sent_its[g][0]).any(axis=1))))
         its = np.concatenate([s[1] for s in sent_its])
         print(json.dumps({"benchmark": "config 4 sharded: (1944,1296) LDPC %s, 64-QAM soft demod at Eb/N0 = %.0f dB, <= 50 its, "

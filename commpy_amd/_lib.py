@@ -81,6 +81,9 @@ SYMBOLS = {
     "cpx_ldpc_bp_decode_batch": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "cpx_ldpc_bp_decode_batch_dev": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                              c_void_p]),
+    "cpx_ldpc_bp_decode_batch_bm": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "cpx_ldpc_bp_decode_batch_bm_dev": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                                c_void_p]),
     "cpx_modem_create": (c_int, [c_void_p, c_int, POINTER(c_void_p)]),
     "cpx_modem_destroy": (c_int, [c_void_p]),
     "cpx_demod_soft": (c_int, [c_void_p, c_void_p, c_int64, c_double, c_void_p]),

@@ -278,19 +278,21 @@ def ldpc_bp_decode(llr_vec, ldpc_code_params, decoder_algorithm, n_iters, return
         raise ValueError('llr_vec length must be a multiple of the block length')
     n_blocks = llr.size // n_v
     code = _device_code(ldpc_code_params)
-    dec = np.zeros((n_v, n_blocks), dtype=np.int8)
-    out = np.zeros((n_v, n_blocks))
+    # block-major result buffers: the reference's results are F-ordered views of exactly this memory (ldpc.py:251-253,
+    # `reshape(-1, n_blocks, order='F')`), so `.T` below returns its shape, dtype, values and strides without any transposition
+    dec = np.zeros((n_blocks, n_v), dtype=np.int8)
+    out = np.zeros((n_blocks, n_v))
     its = np.zeros(n_blocks, dtype=np.int32)
     if n_blocks:
         work = llr if llr.flags.writeable and llr.flags.c_contiguous else llr.copy()
-        _lib.check(lib.cpx_ldpc_bp_decode_batch(code, _lib.ptr(work), n_blocks, 0 if decoder_algorithm == 'SPA' else 1,
-                                                int(n_iters), _lib.ptr(dec), _lib.ptr(out), _lib.ptr(its)))
+        _lib.check(lib.cpx_ldpc_bp_decode_batch_bm(code, _lib.ptr(work), n_blocks, 0 if decoder_algorithm == 'SPA' else 1,
+                                                   int(n_iters), _lib.ptr(dec), _lib.ptr(out), _lib.ptr(its)))
         if isinstance(llr_vec, np.ndarray) and llr_vec.dtype == np.float64 and work is not llr_vec:
             try:
                 llr_vec[...] = work.reshape(llr_vec.shape)        # in-place clip (ldpc.py:186)
             except ValueError:
                 pass
-    dec, out = dec.squeeze(), out.squeeze()                        # (ldpc.py:251-253)
+    dec, out = dec.T.squeeze(), out.T.squeeze()                    # (ldpc.py:251-253)
     return (dec, out, its) if return_iterations else (dec, out)
 
 

@@ -58,8 +58,9 @@ int ldpc_resident_tables(::cpx_ldpc *c, const int32_t *row_ptr, const int32_t *r
                          const int32_t *col_pad_cj);
 void ldpc_resident_free(::cpx_ldpc *c);
 // nanflags (min-sum only, else null): [B] bytes, written for every block: 1 = a NaN among its LLRs (ldpc.hip decodes it again)
+// block_major: d_dec / d_out are [B][n_v] (one block per row) instead of [n_v][B]
 bool ldpc_resident_path(const ::cpx_ldpc *c, double *d_llr, int64_t B, int alg, int n_iters, int8_t *d_dec, double *d_out,
-                        int32_t *d_iters, int *d_clipped, uint8_t *nanflags, hipStream_t st, int *rc);
+                        int block_major, int32_t *d_iters, int *d_clipped, uint8_t *nanflags, hipStream_t st, int *rc);
 
 // absolute-scale BCJR / turbo redo path (bcjr_exact.hip): decodes the codewords whose flag byte is set, overwriting the outputs
 bool bcjr_exact_supported(int S, int64_t N, int turbo);
@@ -68,6 +69,9 @@ int bcjr_exact_map(const ::cpx_trellis *t, const double *sys, const double *par,
 int bcjr_exact_turbo(const ::cpx_trellis *t, const double *sys, const double *p1, const double *p2, const double *Lint_or_null,
                      const int32_t *perm, int64_t B, int64_t N, double nv2, int n_iter, uint8_t *bits, const uint8_t *flags,
                      hipStream_t st);
+
+// CPX_LDPC_SPA=exact: sum-product check rows always by the exact-order sequence (ldpc_dev.h)
+bool ldpc_spa_exact();
 
 // per-device issue lock for entry points that take scratch-arena memory (runtime.hip)
 struct IssueGuard {

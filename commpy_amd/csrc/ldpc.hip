@@ -120,13 +120,15 @@ __global__ __launch_bounds__(LB) void ldpc_init_kernel(double *__restrict__ llr,
     for (int idx = blockIdx.x >> 3;; idx += jstride)
 
 // ---- sum-product (:209-227): R keeps one float64 per edge --------------------------------------------------
+// The row of ldpc_dev.h: one division per edge, rows near saturation by the exact-order sequence -- the same operations in
+// the same order as check_spa of the LDS-resident path (results are bit-identical between the two paths).
 template <int DEG>
 __device__ __forceinline__ void cn_spa_row(double *__restrict__ Rrow, const double *__restrict__ Qt,
-                                           const int32_t *__restrict__ ev, int deg, int k, int32_t *st) {
-    // DEG > 0: exact degree, fully unrolled, row in registers;  DEG == 0: any degree, tanh values parked in R
+                                           const int32_t *__restrict__ ev, int deg, int k, int32_t *st, int spa_exact) {
+    // DEG > 0: exact degree, fully unrolled, row in registers;  DEG == 0: any degree, the row's e values parked in R
     double v[DEG > 0 ? DEG : 1];
     int sx = 0;
-    double prod = 1.0;
+    double U = 1.0, W = 1.0, emax = 0.0;
 #define CPX_SPA_IN(j)                                                                                 \
     {                                                                                                 \
         const double q = Qt[(int64_t)ev[j] * 64];                                                     \
@@ -136,30 +138,43 @@ __device__ __forceinline__ void cn_spa_row(double *__restrict__ Rrow, const doub
             m = ntload(&Rrow[(int64_t)(j) * 64]) * -1.0;     /* data *= -1 (:244) */                   \
             m += 1.0 * q;                                    /* data += H.multiply(msg_sum + llr).data (:245) */ \
         }                                                                                             \
-        m = tanh_half(m);                                    /* data *= .5; tanh (:210-211) */         \
-        prod *= m;                                           /* row product (reference: exp2(sum(log2)) :217-219) */ \
-        if (DEG > 0) v[DEG > 0 ? (j) : 0] = m; else Rrow[(int64_t)(j) * 64] = m;                       \
+        double se, u, w;                                                                              \
+        spa_in(m, se, u, w);                                 /* e = exp(-|m|): tanh(m / 2) = u / w (:210-211) */ \
+        U *= u; W *= w;                                      /* row product (reference: exp2(sum(log2)) :217-219) */ \
+        emax = fmax(emax, fabs(se));                                                                  \
+        if (DEG > 0) v[DEG > 0 ? (j) : 0] = se; else Rrow[(int64_t)(j) * 64] = se;                     \
     }
-#define CPX_SPA_OUT(j, t)                                                                             \
-    {                                                                                                 \
-        double x = (1.0 / (t)) * prod;                       /* data = 1/data; multiply(msg_products) (:222-223) */ \
-        x = clip_nan(x, -1.0, 1.0);                          /* (:224) */                              \
-        x = atanh_twice(x);                                  /* (:225-226) */                          \
-        ntstore(clip_nan(x, -500.0, 500.0), &Rrow[(int64_t)(j) * 64]);   /* (:227) */                  \
-    }
+#define CPX_SPA_SE(j) (DEG > 0 ? v[DEG > 0 ? (j) : 0] : Rrow[(int64_t)(j) * 64])
     if (DEG > 0) {
 #pragma unroll
         for (int j = 0; j < DEG; j++) CPX_SPA_IN(j)
-        if (sx < 0) *st = k + 1;                                 // odd row: iteration k is executed (:205)
-#pragma unroll
-        for (int j = 0; j < DEG; j++) CPX_SPA_OUT(j, v[DEG > 0 ? j : 0])
     } else {
         for (int j = 0; j < deg; j++) CPX_SPA_IN(j)
-        if (sx < 0) *st = k + 1;
-        for (int j = 0; j < deg; j++) CPX_SPA_OUT(j, Rrow[(int64_t)j * 64])
+    }
+    if (sx < 0) *st = k + 1;                                     // odd row: iteration k is executed (:205)
+    const bool near = spa_exact || spa_row_near(U, W, emax);
+    if constexpr (DEG > 0) {
+        if (!near) {
+#pragma unroll
+            for (int j = 0; j < DEG; j++) ntstore(spa_out_fast(U, W, CPX_SPA_SE(j)), &Rrow[(int64_t)j * 64]);
+        } else {                                                 // near saturation: the exact-order sequence (ldpc_dev.h)
+            double prod = 1.0;
+#pragma unroll
+            for (int j = 0; j < DEG; j++) prod *= spa_exact_t(CPX_SPA_SE(j));
+#pragma unroll
+            for (int j = 0; j < DEG; j++) ntstore(spa_out_exact(spa_exact_t(CPX_SPA_SE(j)), prod), &Rrow[(int64_t)j * 64]);
+        }
+    } else {
+        if (!near) {
+            for (int j = 0; j < deg; j++) ntstore(spa_out_fast(U, W, CPX_SPA_SE(j)), &Rrow[(int64_t)j * 64]);
+        } else {
+            double prod = 1.0;
+            for (int j = 0; j < deg; j++) prod *= spa_exact_t(CPX_SPA_SE(j));
+            for (int j = 0; j < deg; j++) ntstore(spa_out_exact(spa_exact_t(CPX_SPA_SE(j)), prod), &Rrow[(int64_t)j * 64]);
+        }
     }
 #undef CPX_SPA_IN
-#undef CPX_SPA_OUT
+#undef CPX_SPA_SE
 }
 
 // ---- min-sum (:229-238): a row is kept as a record (MsaRec, ldpc_dev.h) -------------------------------------
@@ -210,7 +225,7 @@ __device__ __forceinline__ void cn_msa_row(const MsaRec &o, double *__restrict__
 // Sum-product check pass of iteration k: syndrome bit + check-node update.  RR = E rows of R per tile.
 __global__ __launch_bounds__(LB) void ldpc_cn_spa_kernel(Bufs bf, int n_v, int n_c, int64_t RR,
                                                          const int32_t *__restrict__ row_ptr,
-                                                         const int32_t *__restrict__ row_pad, int cpad, int k) {
+                                                         const int32_t *__restrict__ row_pad, int cpad, int k, int spa_exact) {
     int n_slots, buf;
     effective(bf.ctl, n_slots, buf);
     const int n_tiles = n_slots >> 6;
@@ -233,7 +248,7 @@ __global__ __launch_bounds__(LB) void ldpc_cn_spa_kernel(Bufs bf, int n_v, int n
         const double *__restrict__ Qt = Q + tile * n_v * 64 + lane;
         if (st < k) continue;                                     // frozen, retired or padding
         double *__restrict__ Rrow = R + (tile * RR + e0) * 64 + lane;
-        CPX_DEG_SWITCH(cn_spa_row, Rrow, Qt, ev, deg, k, &state[slot])
+        CPX_DEG_SWITCH(cn_spa_row, Rrow, Qt, ev, deg, k, &state[slot], spa_exact)
     }
 }
 
@@ -489,8 +504,9 @@ __global__ __launch_bounds__(1024) void ldpc_scan_kernel(Bufs bf, int k, int pat
 
 // Move pass (only when requested): columns of continuing slots go to their dense position in the other buffer
 // set; frozen slots are retired to the caller's out_llrs / dec_word ([n_v][B], reference layout :251-253).
+// (sv, sb): element strides of out / dec per variable and per block -- (B, 1) for the [n_v][B] layout, (1, n_v) for block-major
 __global__ __launch_bounds__(LB) void ldpc_move_kernel(Bufs bf, int n_v, int64_t E /* rows of R per tile */, int k, int64_t B,
-                                                       double *__restrict__ out, int8_t *__restrict__ dec) {
+                                                       double *__restrict__ out, int8_t *__restrict__ dec, int64_t sv, int64_t sb) {
     const Ctl *ctl = bf.ctl;
     if (!ctl->do_move) return;
     const int buf = ctl->buf, n_tiles = ctl->n_slots >> 6;
@@ -528,8 +544,8 @@ __global__ __launch_bounds__(LB) void ldpc_move_kernel(Bufs bf, int n_v, int64_t
                 if (go) {
                     bf.Q[buf ^ 1][(dt * n_v + v) * 64 + dl] = x[u];
                 } else {
-                    out[v * B + o] = x[u];                                            // (:247)
-                    dec[v * B + o] = (int8_t)(__builtin_signbit(x[u]) ? 1 : 0);       // (:248)
+                    out[v * sv + o * sb] = x[u];                                      // (:247)
+                    dec[v * sv + o * sb] = (int8_t)(__builtin_signbit(x[u]) ? 1 : 0); // (:248)
                 }
             } else if (row < E + 2 * (int64_t)n_v) {
                 if (go) bf.L[buf ^ 1][(dt * n_v + (row - E - n_v)) * 64 + dl] = x[u];
@@ -543,7 +559,7 @@ __global__ __launch_bounds__(LB) void ldpc_move_kernel(Bufs bf, int n_v, int64_t
 
 // End of the decode: every slot still in the working set is retired.
 __global__ __launch_bounds__(LB) void ldpc_final_kernel(Bufs bf, int n_v, int64_t B, double *__restrict__ out,
-                                                        int8_t *__restrict__ dec) {
+                                                        int8_t *__restrict__ dec, int64_t sv, int64_t sb) {
     int n_slots, buf;
     effective(bf.ctl, n_slots, buf);
     const int n_tiles = n_slots >> 6;
@@ -557,8 +573,8 @@ __global__ __launch_bounds__(LB) void ldpc_final_kernel(Bufs bf, int n_v, int64_
         if (bf.state[buf][slot] < 0) continue;
         const double x = bf.Q[buf][(tile * n_v + v) * 64 + lane];
         const int64_t o = bf.orig[buf][slot];
-        out[v * B + o] = x;
-        dec[v * B + o] = (int8_t)(__builtin_signbit(x) ? 1 : 0);
+        out[v * sv + o * sb] = x;
+        dec[v * sv + o * sb] = (int8_t)(__builtin_signbit(x) ? 1 : 0);
     }
 }
 
@@ -576,8 +592,9 @@ __global__ __launch_bounds__(LB) void ldpc_final_kernel(Bufs bf, int n_v, int64_
 struct MsaExactParams {
     const double *llr;        // [B][n_v], already clipped in place
     const uint8_t *flags;     // [B]
-    double *out;              // [n_v][B]
-    int8_t *dec;              // [n_v][B]
+    double *out;              // element (v, b) at v * sv + b * sb: [n_v][B] or block-major [B][n_v]
+    int8_t *dec;
+    int64_t sv, sb;
     int32_t *iters;           // [B] or null
     double *scratch;          // per workgroup: M[E], tot[n_v]
     const int32_t *edge_var, *row_ptr, *col_ptr, *col_edge;
@@ -650,8 +667,8 @@ __global__ __launch_bounds__(256) void ldpc_msa_exact_kernel(MsaExactParams p) {
             }
             for (int v = tid; v < p.n_v; v += 256) {
                 const double x = tot[v];
-                p.out[(int64_t)v * p.B + b] = x;
-                p.dec[(int64_t)v * p.B + b] = (int8_t)(__builtin_signbit(x) ? 1 : 0);
+                p.out[(int64_t)v * p.sv + b * p.sb] = x;
+                p.dec[(int64_t)v * p.sv + b * p.sb] = (int8_t)(__builtin_signbit(x) ? 1 : 0);
             }
             if (tid == 0 && p.iters) p.iters[b] = it;
             __syncthreads();
@@ -903,17 +920,24 @@ int cpx_ldpc_destroy(cpx_ldpc *c) {
 }
 
 // d_clipped (may be null): set to 1 when the in-place clip of (:186) changed any value of d_llr
+// block_major: d_dec / d_out are [B][n_v] instead of [n_v][B]
 static int ldpc_decode_impl(const cpx_ldpc *c, double *d_llr, int64_t B, int alg, int n_iters, int8_t *d_dec, double *d_out,
-                            int32_t *d_iters, int *d_clipped, void *stream);
+                            int block_major, int32_t *d_iters, int *d_clipped, void *stream);
 
 int cpx_ldpc_bp_decode_batch_dev(const cpx_ldpc *c, double *d_llr, int64_t B, int alg, int n_iters, int8_t *d_dec,
                                  double *d_out, int32_t *d_iters, void *stream) {
     CPX_TRACE("cpx_ldpc_bp_decode_batch_dev");
-    return ldpc_decode_impl(c, d_llr, B, alg, n_iters, d_dec, d_out, d_iters, nullptr, stream);
+    return ldpc_decode_impl(c, d_llr, B, alg, n_iters, d_dec, d_out, 0, d_iters, nullptr, stream);
+}
+
+int cpx_ldpc_bp_decode_batch_bm_dev(const cpx_ldpc *c, double *d_llr, int64_t B, int alg, int n_iters, int8_t *d_dec,
+                                    double *d_out, int32_t *d_iters, void *stream) {
+    CPX_TRACE("cpx_ldpc_bp_decode_batch_bm_dev");
+    return ldpc_decode_impl(c, d_llr, B, alg, n_iters, d_dec, d_out, 1, d_iters, nullptr, stream);
 }
 
 static int ldpc_decode_impl(const cpx_ldpc *c, double *d_llr, int64_t B, int alg, int n_iters, int8_t *d_dec, double *d_out,
-                            int32_t *d_iters, int *d_clipped, void *stream) {
+                            int block_major, int32_t *d_iters, int *d_clipped, void *stream) {
     cpx::IssueGuard issue_guard;
     CPX_REQUIRE(c, CPX_EINVAL, "ldpc: null code");
     if (int rcd = check_handle_device(c->device, "ldpc")) return rcd;
@@ -924,6 +948,7 @@ static int ldpc_decode_impl(const cpx_ldpc *c, double *d_llr, int64_t B, int alg
     CPX_REQUIRE(d_llr && d_dec && d_out, CPX_EINVAL, "ldpc: null device pointer");
     CPX_REQUIRE(B <= (1ll << 30), CPX_ELIMIT, "ldpc: batch too large");
     hipStream_t st = pick_stream(stream);
+    const int64_t sv = block_major ? 1 : B, sb = block_major ? (int64_t)c->n_v : 1;    // strides of d_out / d_dec (variable, block)
     // min-sum: one flag byte per block, set by the kernels that load the LLRs when they meet a NaN; flagged blocks are
     // decoded again by ldpc_msa_exact_kernel (scratch-arena slots 4 / 5)
     uint8_t *nanflags = nullptr;
@@ -935,7 +960,7 @@ static int ldpc_decode_impl(const cpx_ldpc *c, double *d_llr, int64_t B, int alg
         if (int rcs = workspace(st, 5, sizeof(double) * (size_t)g_ex * (size_t)(c->n_edges + c->n_v), &sc)) return rcs;
         q.llr = d_llr; q.flags = nanflags; q.out = d_out; q.dec = d_dec; q.iters = d_iters; q.scratch = static_cast<double *>(sc);
         q.edge_var = c->d_edge_var; q.row_ptr = c->d_row_ptr; q.col_ptr = c->d_col_ptr; q.col_edge = c->d_col_edge;
-        q.B = B; q.E = c->n_edges; q.n_v = c->n_v; q.n_c = c->n_c; q.n_iters = n_iters;
+        q.B = B; q.E = c->n_edges; q.n_v = c->n_v; q.n_c = c->n_c; q.n_iters = n_iters; q.sv = sv; q.sb = sb;
         hipLaunchKernelGGL(ldpc_msa_exact_kernel, dim3(g_ex), dim3(256), 0, st, q);
         CPX_HIP(hipGetLastError());
         return CPX_OK;
@@ -947,7 +972,7 @@ static int ldpc_decode_impl(const cpx_ldpc *c, double *d_llr, int64_t B, int alg
     }
     {   // the whole decoder state of a block in LDS, one persistent launch (ldpc_resident.hip) -- unless it does not fit
         int rcr = CPX_OK;
-        if (ldpc_resident_path(c, d_llr, B, alg, n_iters, d_dec, d_out, d_iters, d_clipped, nanflags, st, &rcr)) {
+        if (ldpc_resident_path(c, d_llr, B, alg, n_iters, d_dec, d_out, block_major, d_iters, d_clipped, nanflags, st, &rcr)) {
             if (rcr == CPX_OK) {
                 char name[160];
                 snprintf(name, sizeof(name), "%s", last_kernel_name());
@@ -999,7 +1024,7 @@ static int ldpc_decode_impl(const cpx_ldpc *c, double *d_llr, int64_t B, int alg
     for (int it = 0; it < n_iters; it++) {
         if (alg == CPX_LDPC_SPA) {
             hipLaunchKernelGGL(ldpc_cn_spa_kernel, dim3(g_cn), dim3(LB), 0, st, bf, (int)nv, c->n_c, RR,
-                               c->d_row_ptr, c->d_row_pad, c->cpad, it);
+                               c->d_row_ptr, c->d_row_pad, c->cpad, it, ldpc_spa_exact() ? 1 : 0);
             hipLaunchKernelGGL(ldpc_vn_spa_kernel, dim3(g_vn), dim3(LB), 0, st, bf, (int)nv, RR, c->d_col_ptr,
                                c->d_col_pad_edge, c->vpad, it, d_iters);
         } else {
@@ -1012,19 +1037,18 @@ static int ldpc_decode_impl(const cpx_ldpc *c, double *d_llr, int64_t B, int alg
         }
         if (S > 64 && it + 1 < n_iters) {
             hipLaunchKernelGGL(ldpc_scan_kernel, dim3(1), dim3(1024), 0, st, bf, it, alg == CPX_LDPC_MSA ? 1 : 0);
-            hipLaunchKernelGGL(ldpc_move_kernel, dim3(g_mv), dim3(LB), 0, st, bf, (int)nv, RR, it, B, d_out, d_dec);
+            hipLaunchKernelGGL(ldpc_move_kernel, dim3(g_mv), dim3(LB), 0, st, bf, (int)nv, RR, it, B, d_out, d_dec, sv, sb);
         }
     }
-    hipLaunchKernelGGL(ldpc_final_kernel, dim3(g_vn), dim3(LB), 0, st, bf, (int)nv, B, d_out, d_dec);
+    hipLaunchKernelGGL(ldpc_final_kernel, dim3(g_vn), dim3(LB), 0, st, bf, (int)nv, B, d_out, d_dec, sv, sb);
     CPX_HIP(hipGetLastError());
     if (int rcx = msa_redo()) return rcx;
     note_kernel("ldpc_cn_%s_kernel + ldpc_vn_%s_kernel (tiled)", alg == CPX_LDPC_MSA ? "msa" : "spa", alg == CPX_LDPC_MSA ? "msa" : "spa");
     return CPX_OK;
 }
 
-int cpx_ldpc_bp_decode_batch(const cpx_ldpc *c, double *llr, int64_t B, int alg, int n_iters, int8_t *dec_word,
-                             double *out_llrs, int32_t *iters_done) {
-    CPX_TRACE("cpx_ldpc_bp_decode_batch");
+static int ldpc_decode_host(const cpx_ldpc *c, double *llr, int64_t B, int alg, int n_iters, int8_t *dec_word,
+                            double *out_llrs, int32_t *iters_done, int block_major) {
     CPX_REQUIRE(c && (llr || B == 0), CPX_EINVAL, "ldpc: null pointer");
     int rc = ensure_device();
     if (rc) return rc;
@@ -1043,8 +1067,8 @@ int cpx_ldpc_bp_decode_batch(const cpx_ldpc *c, double *llr, int64_t B, int alg,
         CPX_HIP(hipMemcpyAsync(d_llr.p, llr, sizeof(double) * nvb, hipMemcpyHostToDevice, st));
         if (trace_enabled()) CPX_HIP(hipStreamSynchronize(st));
     }
-    rc = ldpc_decode_impl(c, d_llr.as<double>(), B, alg, n_iters, d_dec.as<int8_t>(), d_out.as<double>(), d_it.as<int32_t>(),
-                          d_flag.as<int>(), st);
+    rc = ldpc_decode_impl(c, d_llr.as<double>(), B, alg, n_iters, d_dec.as<int8_t>(), d_out.as<double>(), block_major,
+                          d_it.as<int32_t>(), d_flag.as<int>(), st);
     if (rc) return rc;
     // in-place clip (:186): the caller's array only changes if a value lay outside +-500 (or is NaN) -- the kernels say so,
     // and the 8-byte-per-LLR copy back (a third of this call's PCIe traffic) is skipped otherwise
@@ -1061,6 +1085,18 @@ int cpx_ldpc_bp_decode_batch(const cpx_ldpc *c, double *llr, int64_t B, int alg,
     if (iters_done) CPX_HIP(hipMemcpyAsync(iters_done, d_it.p, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, st));
     CPX_HIP(hipStreamSynchronize(st));
     return CPX_OK;
+}
+
+int cpx_ldpc_bp_decode_batch(const cpx_ldpc *c, double *llr, int64_t B, int alg, int n_iters, int8_t *dec_word,
+                             double *out_llrs, int32_t *iters_done) {
+    CPX_TRACE("cpx_ldpc_bp_decode_batch");
+    return ldpc_decode_host(c, llr, B, alg, n_iters, dec_word, out_llrs, iters_done, 0);
+}
+
+int cpx_ldpc_bp_decode_batch_bm(const cpx_ldpc *c, double *llr, int64_t B, int alg, int n_iters, int8_t *dec_word,
+                                double *out_llrs, int32_t *iters_done) {
+    CPX_TRACE("cpx_ldpc_bp_decode_batch_bm");
+    return ldpc_decode_host(c, llr, B, alg, n_iters, dec_word, out_llrs, iters_done, 1);
 }
 
 }  // extern "C"

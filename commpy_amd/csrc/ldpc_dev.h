@@ -33,6 +33,48 @@ __device__ __forceinline__ double tanh_half(double v) {
 }
 __device__ __forceinline__ double atanh_twice(double x) { return fast_log((1.0 + x) / (1.0 - x)); }
 
+// ---- sum-product check node with ONE division per edge, exact redo near saturation ----------------------------------------
+// The reference's row (:209-227) costs three float64 divisions per edge in this engine's exact-order form: tanh(m/2) as
+// (1 - e) / (1 + e), the reciprocal 1 / t, and (1 + x) / (1 - x) inside 2 atanh(x).  Algebraically, with e_j = exp(-|m_j|),
+// u_j = sign(m_j) (1 - e_j), w_j = 1 + e_j, U = prod u_j, W = prod w_j:
+//     x_j = P / t_j = (U / W) (w_j / u_j)     and     (1 + x_j) / (1 - x_j) = (W u_j + U w_j) / (W u_j - U w_j)
+// -- one division per edge (measured in round 2: 8.1 instead of 9.6 ms for config 4's share at 3 dB, identical dec_word and
+// iteration counts, <= 3e-7 from the exact-order row up to |LLR| = 26).  It was not shipped then because of ONE regime: where
+// |x| is within a few ulp of 1 the reference's result is decided by how ITS sequence fl(fl(1 / t) P) rounds -- clip to 1 gives
+// atanh = inf -> 500, one ulp below gives 37.4 -- and the rearranged row rounds differently there.  Now a row is first tested
+// for that regime, cheaply and conservatively: the largest |x_j| of a row belongs to the edge with the smallest |m_j|, so
+//     near  <=>  not ( |U| w* < |W| |u*| (1 - 2^-32) ),      (u*, w*) of that edge; also true for NaN / inf / t = 0
+// and a near row is evaluated by the exact-order sequence (spa_exact_t + the caller's second loop), bit for bit what the engine
+// did for every row before.  Rows that are not near have |x_j| < 1 - 2^-32 for every edge: messages below 22.9, no clip binds.
+// Why 2^-32 and not "a few ulp": 2 atanh(x) turns a relative error eps of x into eps / (1 - |x|) of the message.  The
+// exact-order sequence shares its roundings with the reference's (the two agree far better than that bound); the rearranged
+// row does not, its eps ~ 1e-15 is independent: 1 - |x| >= 2^-32 keeps the difference below 4e-6, inside the 1e-5 contract
+// (at 2^-44 it reached 1e-2 on messages of 26 - 31).
+__device__ __forceinline__ void spa_in(double m, double &se, double &u, double &w) {
+    const double e = exp(-fabs(m));
+    se = __builtin_copysign(e, m);                                // what the row keeps per edge: e with the sign of m
+    u = __builtin_copysign(1.0 - e, m);
+    w = 1.0 + e;
+}
+__device__ __forceinline__ bool spa_row_near(double U, double W, double emax) {
+    return !(fabs(U) * (1.0 + emax) < fabs(W) * (1.0 - emax) * (1.0 - 0x1p-32));
+}
+__device__ __forceinline__ double spa_out_fast(double U, double W, double se) {
+    const double e = fabs(se);
+    const double n1 = W * __builtin_copysign(1.0 - e, se), n2 = U * (1.0 + e);
+    return fast_log((n1 + n2) / (n1 - n2));                       // 2 atanh(x), |x| < 1 - 2^-32: no clip binds
+}
+__device__ __forceinline__ double spa_exact_t(double se) {        // == tanh_half(m) of the edge, from its stored e
+    const double e = fabs(se);
+    return __builtin_copysign((1.0 - e) / (1.0 + e), se);
+}
+__device__ __forceinline__ double spa_out_exact(double t, double prod) {
+    double x = (1.0 / t) * prod;                                  // data = 1/data; multiply(msg_products) (:222-223)
+    x = clip_nan(x, -1.0, 1.0);                                   // (:224)
+    x = atanh_twice(x);                                           // (:225-226)
+    return clip_nan(x, -500.0, 500.0);                            // (:227)
+}
+
 // ---- min-sum (:229-238): the messages of a row are (+-) one of TWO magnitudes, so the row is kept as a record
 //   rec[0] = min1 = smallest |v->c message| of the row, rec[1] = min2 = second smallest (ties: a later equal
 //   value), rec[2] = meta: bits 0..7 position of min1, bit 8 parity of the negatives, bits 32..63 negative mask.

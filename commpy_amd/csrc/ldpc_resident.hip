@@ -44,7 +44,10 @@ constexpr size_t LDS_BYTES = 160 * 1024;
 
 struct ResParams {
     double *llr;             // [B][n_v], clipped in place (:186)
-    double *stage;           // [B][n_v] a-posteriori LLRs of retired blocks
+    double *out;             // [B][n_v] a-posteriori LLRs of retired blocks, one block per ROW: the caller's block-major out_llrs, or
+                             // the staging buffer that ldpc_unstage_kernel transposes into the [n_v][B] layout
+    int8_t *dec;             // [B][n_v] dec_word of retired blocks (block-major outputs), or null (the transpose kernel writes it)
+    int spa_exact;           // sum-product: every row by the exact-order sequence (CPX_LDPC_SPA=exact; A/B and strict runs)
     int32_t *iters;          // [B] executed iterations, may be null
     int *queue;              // next block to hand out
     int *clipped;            // set to 1 when the in-place clip changed a value (may be null)
@@ -126,44 +129,44 @@ __device__ __forceinline__ void check_msa(const ResParams &p, int c, int *flag) 
     stsd(rb + 8 * imin, __hiloint2double(__double2hiint(m2) | (int)(((negp >> imin) & 1u) << 31), __double2loint(m2)));
 }
 
-// ---- sum-product check node (:209-227); the tanh values of the row are parked in the row's own R entries ----------
-// (A row with ONE division per edge -- e = exp(-|m|), u = sign(m)(1 - e), w = 1 + e, U = prod u, W = prod w,
-//  message = log((W u_j + U w_j) / (W u_j - U w_j)) instead of tanh / reciprocal / atanh with three -- was built and measured:
-//  8.1 instead of 9.6 ms at 3 dB, identical dec_word and iterations, <= 3e-7 from the tiled path and the oracle up to
-//  |LLR| = 26.  It was NOT kept: above |LLR| ~ 36, where x = prod tanh is within a few ulp of 1, the reference's own result
-//  is set by how fl(1/t) * P rounds (clip to 1 -> 500, one ulp below -> 37.4); the rearranged row rounds differently there and
-//  a message can come out as 40 where the reference has 500.  Parity with the reference's rounding sequence is worth more
-//  than 15 %.)
+// ---- sum-product check node (:209-227): one division per edge, exact-order redo of rows near saturation (ldpc_dev.h);
+// the row keeps e_j = exp(-|m_j|) with the sign of m_j in its own R entries between the two loops --------------------------
 __device__ __forceinline__ void check_spa(const ResParams &p, int c, int *flag) {
     const int deg = p.row_deg[c];
     const int4 *__restrict__ qv = reinterpret_cast<const int4 *>(p.row_q + (int64_t)c * p.cpad);
     const int rb = p.roff + 8 * c * p.rstride;
     int sx = 0;
-    double prod = 1.0;
+    double U = 1.0, W = 1.0, emax = 0.0;
     for (int j0 = 0; __builtin_amdgcn_ballot_w64(j0 < deg) != 0; j0 += 4) {
         const int4 a = qv[j0 >> 2];
         const double q[4] = {ldsd(a.x), ldsd(a.y), ldsd(a.z), ldsd(a.w)};
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int j = j0 + u;
+        for (int u4 = 0; u4 < 4; u4++) {
+            const int j = j0 + u4;
             if (j < deg) {
-                sx ^= __double2hiint(q[u]);                      // dec_word = out_llrs < 0 (:193, :248)
+                sx ^= __double2hiint(q[u4]);                     // dec_word = out_llrs < 0 (:193, :248)
                 double m = ldsd(rb + 8 * j) * -1.0;              // data *= -1 (:244); first pass: 0 * -1 = -0.0
-                m += 1.0 * q[u];                                 // data += H.multiply(msg_sum + llr).data (:245); first pass (:199)
-                m = tanh_half(m);                                // data *= .5; tanh (:210-211)
-                prod *= m;                                       // row product (reference: exp2(sum(log2)) :217-219)
-                stsd(rb + 8 * j, m);
+                m += 1.0 * q[u4];                                // data += H.multiply(msg_sum + llr).data (:245); first pass (:199)
+                double se, u, w;
+                spa_in(m, se, u, w);                             // e = exp(-|m|): tanh(m / 2) = u / w (:210-211)
+                U *= u; W *= w;                                  // row product (reference: exp2(sum(log2)) :217-219)
+                emax = fmax(emax, fabs(se));                     // the edge with the smallest |m| (NaN: spa_row_near sees U)
+                stsd(rb + 8 * j, se);
             }
         }
     }
     if (sx < 0) *flag = 1;
-    for (int j = 0; __builtin_amdgcn_ballot_w64(j < deg) != 0; j++) {
-        if (j < deg) {
-            double x = (1.0 / ldsd(rb + 8 * j)) * prod;          // data = 1/data; multiply(msg_products) (:222-223)
-            x = clip_nan(x, -1.0, 1.0);                          // (:224)
-            x = atanh_twice(x);                                  // (:225-226)
-            stsd(rb + 8 * j, clip_nan(x, -500.0, 500.0));        // (:227)
-        }
+    const bool near = p.spa_exact || spa_row_near(U, W, emax);   // see ldpc_dev.h: near rows take the exact-order sequence
+    if (__builtin_amdgcn_ballot_w64(!near) != 0) {
+        for (int j = 0; __builtin_amdgcn_ballot_w64(j < deg) != 0; j++)
+            if (j < deg && !near) stsd(rb + 8 * j, spa_out_fast(U, W, ldsd(rb + 8 * j)));
+    }
+    if (__builtin_amdgcn_ballot_w64(near) != 0) {
+        double prod = 1.0;
+        for (int j = 0; __builtin_amdgcn_ballot_w64(j < deg) != 0; j++)
+            if (j < deg && near) prod *= spa_exact_t(ldsd(rb + 8 * j));
+        for (int j = 0; __builtin_amdgcn_ballot_w64(j < deg) != 0; j++)
+            if (j < deg && near) stsd(rb + 8 * j, spa_out_exact(spa_exact_t(ldsd(rb + 8 * j)), prod));
     }
 }
 
@@ -238,8 +241,20 @@ __global__ __launch_bounds__(1024, 6) void ldpc_resident_kernel(ResParams p) {
             for (int v = tid; v < p.n_v; v += nt) var_node(p, v, in);
             __syncthreads();
         }
-        double *__restrict__ out = p.stage + (int64_t)b * p.n_v;
-        for (int v = tid; v < p.n_v; v += nt) out[v] = ldsd(8 * v);          // the same thread reloads these entries for the next block
+        // Retire: the a-posteriori LLRs (and, for block-major outputs, their sign bits) as one contiguous row -- the layout the
+        // reference's own results have in memory (ldpc.py:251-253 reshapes with order='F': one block per column of an F-ordered
+        // array IS one block per contiguous row).  Not waited for: the next block's loads queue behind these stores.
+        double *__restrict__ orow = p.out + (int64_t)b * p.n_v;
+        if (p.dec) {
+            int8_t *__restrict__ drow = p.dec + (int64_t)b * p.n_v;
+            for (int v = tid; v < p.n_v; v += nt) {
+                const double x = ldsd(8 * v);                            // the same thread reloads these entries for the next block
+                orow[v] = x;                                     // (:247)
+                drow[v] = (int8_t)(__builtin_signbit(x) ? 1 : 0);    // (:248)
+            }
+        } else {
+            for (int v = tid; v < p.n_v; v += nt) orow[v] = ldsd(8 * v);
+        }
         if (tid == 0) {
             if (p.iters) p.iters[b] = k;
             if (p.nanflags) p.nanflags[b] = (uint8_t)ctl[3];
@@ -388,13 +403,25 @@ __global__ __launch_bounds__(1024, 8) void ldpc_resident_f32_kernel(ResParams p)
             for (int v = tid; v < p.n_v; v += nt) var_node_f32(p, v, in);
             __syncthreads();
         }
-        double *__restrict__ out = p.stage + (int64_t)b * p.n_v;
-        for (int v = tid; v < p.n_v; v += nt) out[v] = (double)ldsf(4 * v);
+        // Retire: the a-posteriori LLRs (and, for block-major outputs, their sign bits) as one contiguous row -- the layout the
+        // reference's own results have in memory (ldpc.py:251-253 reshapes with order='F': one block per column of an F-ordered
+        // array IS one block per contiguous row).  Not waited for: the next block's loads queue behind these stores.
+        double *__restrict__ orow = p.out + (int64_t)b * p.n_v;
+        if (p.dec) {
+            int8_t *__restrict__ drow = p.dec + (int64_t)b * p.n_v;
+            for (int v = tid; v < p.n_v; v += nt) {
+                const double x = (double)ldsf(4 * v);                            // the same thread reloads these entries for the next block
+                orow[v] = x;                                     // (:247)
+                drow[v] = (int8_t)(__builtin_signbit(x) ? 1 : 0);    // (:248)
+            }
+        } else {
+            for (int v = tid; v < p.n_v; v += nt) orow[v] = (double)ldsf(4 * v);
+        }
         if (tid == 0) {
             if (p.iters) p.iters[b] = k;
             if (p.nanflags) p.nanflags[b] = (uint8_t)ctl[3];
             ctl[3] = 0;
-            ctl[0] = 0; ctl[1] = 0;
+            ctl[0] = 0; ctl[1] = 0;                              // (a thread that has yet to read a flag of this block reads the 0 that sent the others here)
             pop();
         }
         __syncthreads();
@@ -474,10 +501,14 @@ int res_roff(int n_v) { return ((n_v + 2) & ~1) * 8; }            // Q[n_v] + th
 int res_rstride(const cpx_ldpc *c) { return c->max_cdeg | 1; }
 size_t res_lds_bytes_f32(const cpx_ldpc *c) { return (size_t)(res_roff(c->n_v) / 2) + 4 * ((size_t)c->n_c * (c->max_cdeg | 1) + 1 + 4) + 64; }
 size_t res_lds_bytes(const cpx_ldpc *c) { return (size_t)res_roff(c->n_v) + 8 * ((size_t)c->n_c * res_rstride(c) + 1 + 4) + 64; }
-
 }  // namespace
 
 namespace cpx {
+
+bool ldpc_spa_exact() {
+    static const bool v = [] { const char *e = getenv("CPX_LDPC_SPA"); return e && strcmp(e, "exact") == 0; }();
+    return v;
+}
 
 // Offset tables of the resident path, built once per handle from the blob's tables (host pointers).
 int ldpc_resident_tables(cpx_ldpc *c, const int32_t *row_ptr, const int32_t *row_pad, const int32_t *col_ptr,
@@ -519,7 +550,7 @@ void ldpc_resident_free(cpx_ldpc *c) {
 }
 
 bool ldpc_resident_path(const cpx_ldpc *c, double *d_llr, int64_t B, int alg, int n_iters, int8_t *d_dec, double *d_out,
-                        int32_t *d_iters, int *d_clipped, uint8_t *nanflags, hipStream_t st, int *rc) {
+                        int block_major, int32_t *d_iters, int *d_clipped, uint8_t *nanflags, hipStream_t st, int *rc) {
     *rc = CPX_OK;
     const int mode = ldpc_path();
     auto reject = [&](const char *why) {
@@ -530,65 +561,56 @@ bool ldpc_resident_path(const cpx_ldpc *c, double *d_llr, int64_t B, int alg, in
     if (n_iters < 1) return reject("n_iters == 0");
     if (B >= (1ll << 30)) return reject("batch too large");
     if (!c->d_res_row_q) return reject("decoder state of one block exceeds the LDS of a compute unit");
-    if (precision_fast() && n_iters >= 1 && res_lds_bytes_f32(c) <= 64 * 1024) {
-        // "fp32-fast": float32 state (see ldpc_resident_f32_kernel); 512-thread workgroups, as many as the LDS / 2048 threads allow
-        const size_t lds32 = res_lds_bytes_f32(c);
-        const int threads32 = std::min(512, std::max(64, (c->n_c + 63) / 64 * 64));
-        char *slab32 = nullptr;
-        const size_t sz_stage32 = (sizeof(double) * (size_t)(B * c->n_v) + 255) & ~(size_t)255;
-        if ((*rc = workspace(st, 0, sz_stage32 + 256, (void **)&slab32))) return true;
-        ResParams q;
-        q.llr = d_llr; q.stage = (double *)slab32; q.iters = d_iters; q.queue = (int *)(slab32 + sz_stage32); q.clipped = d_clipped; q.nanflags = nanflags;
-        q.row_deg = c->d_res_row_deg; q.row_q = c->d_res_row_q32; q.col_r = c->d_res_col_r32; q.vgrp = c->d_res_vgrp;
-        q.B = B; q.rstride = res_rstride(c); q.n_r = c->n_c * q.rstride; q.n_v = c->n_v; q.n_c = c->n_c; q.cpad = c->cpad; q.vpad = c->vpad;
-        q.max_iter = n_iters; q.roff = res_roff(c->n_v) / 2; q.ctl_off = (int)(lds32 - 64);
-        if (hipMemsetAsync(q.queue, 0, sizeof(int), st) != hipSuccess) { set_error("ldpc: hipMemsetAsync failed"); *rc = CPX_EHIP; return true; }
-        const int per_cu32 = std::max(1, std::min({(int)(LDS_BYTES / lds32), 2048 / threads32, 16}));
-        const int grid32 = (int)std::min<int64_t>((int64_t)device_cus() * per_cu32, B);
-        if (alg == CPX_LDPC_SPA) launch_resident_f32<CPX_LDPC_SPA>(q, grid32, threads32, lds32, st);
-        else launch_resident_f32<CPX_LDPC_MSA>(q, grid32, threads32, lds32, st);
-        hipLaunchKernelGGL(ldpc_unstage_kernel, dim3((unsigned)((B + 63) / 64), (unsigned)((c->n_v + 63) / 64)), dim3(256), 0, st,
-                           q.stage, B, c->n_v, d_out, d_dec);
-        if (hipGetLastError() != hipSuccess) { set_error("ldpc (resident path, f32): launch failed"); *rc = CPX_EHIP; }
-        note_kernel("ldpc_resident_f32_kernel<%s> threads=%d workgroups/CU=%d", alg == CPX_LDPC_MSA ? "MSA" : "SPA", threads32, per_cu32);
-        return true;
-    }
-    const size_t lds = res_lds_bytes(c);
-    // workgroup size: the check pass in one round (two for > 1024 checks) -- (1944,1296): 704 threads, the variable pass
-    // takes three rounds; measured 2.51 ms at 704, 2.75 at 512, 3.38 at 1024 (scripts/micro/ldpc_knobs.py)
+    const bool f32 = precision_fast() && res_lds_bytes_f32(c) <= 64 * 1024;   // "fp32-fast": float32 state (ldpc_resident_f32_kernel)
+    const size_t lds = f32 ? res_lds_bytes_f32(c) : res_lds_bytes(c);
+    // workgroup size.  float64: the check pass in one round (two for > 1024 checks) -- (1944,1296): 704 threads, the variable
+    // pass takes three rounds; measured 2.51 ms at 704, 2.75 at 512, 3.38 at 1024 (scripts/micro/ldpc_knobs.py).  float32: 512.
     const int rounds = (c->n_c + 1023) / 1024;
-    int threads = std::min(1024, std::max(64, ((c->n_c + rounds - 1) / rounds + 63) / 64 * 64));
+    int threads = f32 ? std::min(512, std::max(64, (c->n_c + 63) / 64 * 64))
+                      : std::min(1024, std::max(64, ((c->n_c + rounds - 1) / rounds + 63) / 64 * 64));
     if (const char *e = getenv("CPX_LDPC_THREADS")) {             // experiment knob
         const int t = atoi(e);
-        if (t >= 64 && t <= 1024 && t % 64 == 0) threads = t;
+        if (!f32 && t >= 64 && t <= 1024 && t % 64 == 0) threads = t;
     }
+    // Outputs.  Block-major (one block per row, the memory layout of the reference's own results): retired blocks go straight
+    // to the caller's arrays.  [n_v][B]: they go to a staging buffer and ldpc_unstage_kernel transposes it.
     char *slab = nullptr;
-    const size_t sz_stage = (sizeof(double) * (size_t)(B * c->n_v) + 255) & ~(size_t)255;
+    const size_t sz_stage = block_major ? 0 : (sizeof(double) * (size_t)(B * c->n_v) + 255) & ~(size_t)255;
     if ((*rc = workspace(st, 0, sz_stage + 256, (void **)&slab))) return true;
     ResParams p;
-    p.llr = d_llr; p.stage = (double *)slab; p.iters = d_iters; p.queue = (int *)(slab + sz_stage); p.clipped = d_clipped; p.nanflags = nanflags;
-    p.row_deg = c->d_res_row_deg; p.row_q = c->d_res_row_q; p.col_r = c->d_res_col_r; p.vgrp = c->d_res_vgrp;
+    p.llr = d_llr; p.iters = d_iters; p.queue = (int *)(slab + sz_stage); p.clipped = d_clipped; p.nanflags = nanflags;
+    p.out = block_major ? d_out : (double *)slab;
+    p.dec = block_major ? d_dec : nullptr;
+    p.spa_exact = (!f32 && ldpc_spa_exact()) ? 1 : 0;
+    p.row_deg = c->d_res_row_deg; p.vgrp = c->d_res_vgrp;
+    p.row_q = f32 ? c->d_res_row_q32 : c->d_res_row_q;
+    p.col_r = f32 ? c->d_res_col_r32 : c->d_res_col_r;
     p.B = B; p.rstride = res_rstride(c); p.n_r = c->n_c * p.rstride; p.n_v = c->n_v; p.n_c = c->n_c; p.cpad = c->cpad; p.vpad = c->vpad;
     p.max_iter = n_iters;
-    p.roff = res_roff(c->n_v); p.ctl_off = (int)(lds - 64);
+    p.roff = f32 ? res_roff(c->n_v) / 2 : res_roff(c->n_v);
+    p.ctl_off = (int)(lds - 64);
     if (hipMemsetAsync(p.queue, 0, sizeof(int), st) != hipSuccess) { set_error("ldpc: hipMemsetAsync failed"); *rc = CPX_EHIP; return true; }
     // persistent grid: as many workgroups as fit a compute unit (LDS, 2048 threads, 16 workgroups), no more than blocks
     const int per_cu = std::max(1, std::min({(int)(LDS_BYTES / lds), 2048 / threads, 16}));
     const int grid = (int)std::min<int64_t>((int64_t)device_cus() * per_cu, B);
     const int cq = c->cpad / 4;
     int lrc;
-    if (alg == CPX_LDPC_SPA) lrc = launch_resident<CPX_LDPC_SPA, 0>(p, grid, threads, lds, st);
+    if (f32) lrc = alg == CPX_LDPC_SPA ? launch_resident_f32<CPX_LDPC_SPA>(p, grid, threads, lds, st)
+                                       : launch_resident_f32<CPX_LDPC_MSA>(p, grid, threads, lds, st);
+    else if (alg == CPX_LDPC_SPA) lrc = launch_resident<CPX_LDPC_SPA, 0>(p, grid, threads, lds, st);
     else if (cq == 1) lrc = launch_resident<CPX_LDPC_MSA, 1>(p, grid, threads, lds, st);
     else if (cq == 2) lrc = launch_resident<CPX_LDPC_MSA, 2>(p, grid, threads, lds, st);
     else if (cq == 3) lrc = launch_resident<CPX_LDPC_MSA, 3>(p, grid, threads, lds, st);
     else if (cq == 4) lrc = launch_resident<CPX_LDPC_MSA, 4>(p, grid, threads, lds, st);
     else lrc = launch_resident<CPX_LDPC_MSA, 0>(p, grid, threads, lds, st);
     if (lrc) { *rc = lrc; return true; }
-    hipLaunchKernelGGL(ldpc_unstage_kernel, dim3((unsigned)((B + 63) / 64), (unsigned)((c->n_v + 63) / 64)), dim3(256), 0, st,
-                       p.stage, B, c->n_v, d_out, d_dec);
+    if (!block_major)
+        hipLaunchKernelGGL(ldpc_unstage_kernel, dim3((unsigned)((B + 63) / 64), (unsigned)((c->n_v + 63) / 64)), dim3(256), 0, st,
+                           p.out, B, c->n_v, d_out, d_dec);
     if (hipGetLastError() != hipSuccess) { set_error("ldpc (resident path): launch failed"); *rc = CPX_EHIP; }
-    note_kernel("ldpc_resident_kernel<%s,%d> threads=%d workgroups/CU=%d", alg == CPX_LDPC_MSA ? "MSA" : "SPA",
-                alg == CPX_LDPC_MSA && cq <= 4 ? cq : 0, threads, per_cu);
+    if (f32) note_kernel("ldpc_resident_f32_kernel<%s> threads=%d workgroups/CU=%d", alg == CPX_LDPC_MSA ? "MSA" : "SPA", threads, per_cu);
+    else note_kernel("ldpc_resident_kernel<%s,%d> threads=%d workgroups/CU=%d", alg == CPX_LDPC_MSA ? "MSA" : "SPA",
+                     alg == CPX_LDPC_MSA && cq <= 4 ? cq : 0, threads, per_cu);
     return true;
 }
 

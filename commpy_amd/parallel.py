@@ -424,24 +424,26 @@ class DeviceGroup:
             mine = ctypes.c_void_p(d_dec.ptr.value + (i * rows * n_v if gather else 0))
             if cnt:
                 _lib.check(lib.cpx_memcpy_h2d_async(d_llr.ptr, _lib.ptr(llr[lo:hi]), cnt * n_v * 8, st))
-                _lib.check(lib.cpx_ldpc_bp_decode_batch_dev(_device_code(ldpc_code_params), d_llr.ptr, cnt, alg, int(n_iters),
-                                                            mine, d_out.ptr, None, st))
+                # block-major outputs: a shard is `cnt` contiguous rows, the gathered array is [B][n_v] = the memory of the
+                # reference's F-ordered result (ldpc.py:251-253); no transposition on the device
+                _lib.check(lib.cpx_ldpc_bp_decode_batch_bm_dev(_device_code(ldpc_code_params), d_llr.ptr, cnt, alg, int(n_iters),
+                                                               mine, d_out.ptr, None, st))
             return d_llr, d_out, d_dec, mine
 
         bufs = self.each(launch)
         if gather and self.G > 1:
             self.allgather_dev([b[3] for b in bufs], [b[2].ptr for b in bufs], rows * n_v)
         self.sync()
-        outs = self.each(lambda i, dev, st: bufs[i][1].to_array((n_v, counts[i]), np.float64) if counts[i] else np.zeros((n_v, 0)))
+        outs = self.each(lambda i, dev, st: bufs[i][1].to_array((counts[i], n_v), np.float64) if counts[i] else np.zeros((0, n_v)))
         if gather:
-            raw = self.each(lambda i, dev, st: bufs[i][2].to_array((self.G, rows * n_v), np.int8) if i == 0 else None)[0]
-            decs = [raw[g, :n_v * counts[g]].reshape(n_v, counts[g]) for g in range(self.G)]
+            raw = self.each(lambda i, dev, st: bufs[i][2].to_array((self.G, rows, n_v), np.int8) if i == 0 else None)[0]
+            decs = [raw[g, :counts[g]] for g in range(self.G)]
         else:
-            decs = self.each(lambda i, dev, st: bufs[i][2].to_array((rows * n_v,), np.int8)[:n_v * counts[i]].reshape(n_v, counts[i]))
+            decs = self.each(lambda i, dev, st: bufs[i][2].to_array((rows, n_v), np.int8)[:counts[i]])
         for b in bufs:
             for d in b[:3]:
                 d.free()
-        return np.concatenate(decs, axis=1).squeeze(), np.concatenate(outs, axis=1).squeeze()
+        return np.concatenate(decs, axis=0).T.squeeze(), np.concatenate(outs, axis=0).T.squeeze()
 
     def wifi_ber_sweep(self, mcs, snrs_db, n_bits, send_chunk=600, frame_aggregation=1, generator_matrix=None, seed=1):
         """BASELINE config 5: BER of an 802.11 MCS over AWGN per SNR point, ``n_bits`` information bits per point split

@@ -207,6 +207,17 @@ int cpx_ldpc_bp_decode_batch(const cpx_ldpc *c, double *llr, int64_t B, int alg,
 int cpx_ldpc_bp_decode_batch_dev(const cpx_ldpc *c, double *d_llr, int64_t B, int alg, int n_iters,
                                  int8_t *d_dec_word, double *d_out_llrs, int32_t *d_iters_done,
                                  void *stream);
+/* The same decode with BLOCK-MAJOR outputs: dec_word [B][n_v] int8 and out_llrs [B][n_v] float64, one block per ROW.  This
+ * is the memory the reference's own results live in: ldpc.py:251-253 returns `x.reshape(-1, n_blocks, order='F')`, an
+ * F-ordered (n_v, n_blocks) VIEW of a buffer in which every block is contiguous -- so the Python layer wraps these arrays as
+ * `dec.T` / `out.T` and returns objects with the reference's shape, dtype, values AND strides, and no transposition pass exists
+ * anywhere (the [n_v][B] entry points above cost one: a staging buffer written, read back and written again).  HBM traffic of a
+ * block is then SURVEY 8d's resident model exactly: llr in, out_llrs and dec_word out, 17 n_v bytes. */
+int cpx_ldpc_bp_decode_batch_bm(const cpx_ldpc *c, double *llr, int64_t B, int alg, int n_iters,
+                                int8_t *dec_word, double *out_llrs, int32_t *iters_done);
+int cpx_ldpc_bp_decode_batch_bm_dev(const cpx_ldpc *c, double *d_llr, int64_t B, int alg, int n_iters,
+                                    int8_t *d_dec_word, double *d_out_llrs, int32_t *d_iters_done,
+                                    void *stream);
 /* Two implementations of the same arithmetic (identical results, tests/test_ldpc_resident_gpu.py): the LDS-resident
  * path (csrc/ldpc_resident.hip: the decoder state of a block lives in the LDS of one compute unit, one persistent launch,
  * blocks retire and are replaced individually) whenever that state fits, else the tiled HBM path (csrc/ldpc.hip).

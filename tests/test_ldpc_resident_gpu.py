@@ -154,3 +154,43 @@ def test_min_sum_nan_llrs_follow_the_reference(gpu, paths, name, n, iters):
         assert np.array_equal(o, oo, equal_nan=True), path
         assert np.array_equal(d, do), path
         assert np.array_equal(x, np.clip(llr, -500, 500), equal_nan=True), path      # in-place clip (:186); np.clip lets NaN through
+
+
+@pytest.mark.parametrize("path", ["resident", "tiled"])
+def test_block_major_outputs_equal_the_column_layout(gpu, paths, path):
+    """cpx_ldpc_bp_decode_batch_bm[_dev] (dec_word / out_llrs [B][n_v], one block per row -- the memory behind the reference's
+    F-ordered result, ldpc.py:251-253) against the [n_v][B] entry point: identical values and iteration counts for both
+    algorithms, NaN blocks (min-sum's exact redo kernel writes through the same strides) and a ragged batch; and the Python
+    function returns arrays with the reference's shape AND strides."""
+    import ctypes
+    from commpy_amd.channelcoding import ldpc_bp_decode
+    from commpy_amd.channelcoding.ldpc import _device_code
+    from commpy_amd.devicelink import DeviceBuf
+    lib = paths.load()
+    p = ldpc_params("wimax1440")
+    n, B = 1440, 131
+    rs = np.random.RandomState(17)
+    llr = _staggered(rs, B, n, 0.5, [1.0, 2.5, 4.0, 30.0])
+    llr[7 * n + 11] = np.nan
+    llr[130 * n + 5] = np.nan
+    paths.ldpc_set_path(path)
+    code = _device_code(p)
+    for alg, name, iters in ((1, "MSA", 12), (0, "SPA", 6)):
+        res = []
+        for fn in (lib.cpx_ldpc_bp_decode_batch_dev, lib.cpx_ldpc_bp_decode_batch_bm_dev):
+            d_llr = DeviceBuf.from_array(llr)
+            d_dec, d_out, d_it = DeviceBuf(B * n), DeviceBuf(B * n * 8), DeviceBuf(B * 4)
+            paths.check(fn(code, d_llr.ptr, B, alg, iters, d_dec.ptr, d_out.ptr, d_it.ptr, None))
+            paths.check(lib.cpx_stream_sync(None))
+            res.append((d_dec, d_out, d_it))
+        dec_c, out_c = res[0][0].to_array((n, B), np.int8), res[0][1].to_array((n, B), np.float64)
+        dec_b, out_b = res[1][0].to_array((B, n), np.int8), res[1][1].to_array((B, n), np.float64)
+        assert np.array_equal(res[0][2].to_array((B,), np.int32), res[1][2].to_array((B,), np.int32)), name
+        assert np.array_equal(dec_b.T, dec_c) and np.array_equal(out_b.T, out_c, equal_nan=True), name
+        for r in res:
+            for d in r:
+                d.free()
+        dec, out = ldpc_bp_decode(llr.copy(), p, name, iters)
+        assert dec.shape == (n, B) and out.shape == (n, B) and dec.dtype == np.int8 and out.dtype == np.float64
+        assert dec.flags.f_contiguous and out.flags.f_contiguous and out.strides == (8, 8 * n)     # the reference's reshape(order='F')
+        assert np.array_equal(dec, dec_c) and np.array_equal(out, out_c, equal_nan=True), name
