@@ -208,19 +208,40 @@ struct RawChunk {
 // that retires through the same in-order counter as the prefetches, i.e. it waits for the HBM round trip issued just before
 // it (the "exposed memory time" of the round-2 ablations).
 struct PassIO {
-    const double *sys;            // systematic values, stride sstride per codeword
-    const double *par;            // parity values, stride pstride
-    uint8_t *bits;                // map_decode: hard decisions [.][N] (L > 0 in 'decode' mode), or null
+    // The four arrays of a pass as RAW BUFFERS that start at the pair's first codeword and are 2 GiB long; a lane's byte offset
+    // is (codeword-in-pair * stride + step) * 8 < 2^31 (checked on the host), and a lane that has nothing to load or store uses
+    // offset OOB = 2^31: the hardware returns 0 for that load and drops that store.  No branch around a memory operation
+    // is left in the pass, and that is the point: with `if (in range) load` the compiler cannot know how many operations are in
+    // flight behind the checkpoint load that starts a recursion, so it waited for ALL of them (s_waitcnt vmcnt(0)) -- i.e. for
+    // the HBM round trip of the prefetch issued just before, once per chunk.  With unconditional operations it counts.
+    __amdgpu_buffer_rsrc_t rsys, rpar, rlin, rout;   // systematic, parity, L_int, output (L_int + log(app1/app0), or with `ext` the log alone)
+    __amdgpu_buffer_rsrc_t rbits;                    // map_decode: hard decisions [.][N] (L > 0 in 'decode' mode); zero-length if unwanted
+    unsigned osys, opar, olin, oout;                 // scalar byte offsets added to the lane offsets (turbo: the array inside the slab)
     int want_bits;
-    int sstride, pstride;         // per-codeword strides (elements); 16 codewords x stride x 8 B < 4 GiB (checked on the host)
-    const double *Lin;            // L_int, stride lstride per codeword
-    double *Lout;                 // L_int + log(app1/app0) -- or, with `ext`, log(app1/app0) alone --, stride lstride
+    int sstride, pstride;         // per-codeword strides (elements)
     bool ext;                     // turbo: write L - L_int, the quantity the next half-iteration interleaves (:318, :328)
     int lstride, ncw, N;          // ncw: codewords of the batch this pair really has (<= GW, may be <= 0)
     double nv2;
     double *ckpt;                 // this pair's checkpoint rows [nchunks + 1][64]
     uint8_t *flags;               // "detect and redo": one byte per codeword of the pair, set to 1 (never cleared here); may be null
 };
+constexpr unsigned OOB = 0x80000000u;
+typedef unsigned bcjr_v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pass_buffer(const void *base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
+}
+// all ones if this lane's item (codeword slot gg, step tl of the chunk) exists, else 0 -- plain integer arithmetic: from
+// `cond ? offset : OOB` the compiler built a branch with the loads inside, which is the uncounted wait again
+__device__ __forceinline__ unsigned item_mask(int gg, int ncw, int tl, int len) {
+    return (unsigned)(((gg - ncw) & (tl - len)) >> 31);
+}
+__device__ __forceinline__ unsigned item_off(unsigned m, unsigned byte_off) { return (byte_off & m) | (OOB & ~m); }
+__device__ __forceinline__ double buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double v) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(bcjr_v2u, v), r, voff, soff, 0);
+}
 
 __device__ __forceinline__ double ld_off(const double *base, unsigned elem) {
     return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + (elem * 8u));
@@ -235,12 +256,10 @@ __device__ __forceinline__ void load_raw(const Ctx<LGS> &c, const PassIO &io, Ra
     for (int q = 0; q < 2; q++) {
         const int p = c.lane + 64 * q, gg = p / CH, tl = p % CH;
         const unsigned t = (unsigned)(t0 + tl);                   // 0-based step index
-        rc.r0[q] = 0.0; rc.r1[q] = 0.0; rc.li[q] = 0.0;
-        if (gg < io.ncw && tl < len) {
-            rc.r0[q] = ld_off(io.sys, (unsigned)(gg * io.sstride) + t);
-            rc.r1[q] = ld_off(io.par, (unsigned)(gg * io.pstride) + t);
-            rc.li[q] = ld_off(io.Lin, (unsigned)(gg * io.lstride) + t);
-        }
+        const unsigned m = item_mask(gg, io.ncw, tl, len);        // no such item: zeros
+        rc.r0[q] = buf_ld(io.rsys, item_off(m, ((unsigned)(gg * io.sstride) + t) * 8u), io.osys);
+        rc.r1[q] = buf_ld(io.rpar, item_off(m, ((unsigned)(gg * io.pstride) + t) * 8u), io.opar);
+        rc.li[q] = buf_ld(io.rlin, item_off(m, ((unsigned)(gg * io.lstride) + t) * 8u), io.olin);
     }
 }
 
@@ -415,25 +434,26 @@ __device__ __forceinline__ void alpha_chunk(const Ctx<LGS> &c, double &a, int le
 }
 
 // time-parallel epilogue of a phase-2 chunk: app sums in state order, L = L_int + log(app1/app0) (:145)
-template <int LGS>
+template <int LGS, bool BITS>
 __device__ __forceinline__ void epilogue(const Ctx<LGS> &c, const PassIO &io, const double (&li)[2], int t_lo, int len) {
     constexpr int S = Ctx<LGS>::S;
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int q = 0; q < 2; q++) {
         const int p = c.lane + 64 * q, gg = p / CH, tl = p % CH;
-        if (gg < io.ncw && tl < len) {
-            const double2 *x = reinterpret_cast<const double2 *>(c.xs + tl * XS_ROW + gg * S * 2);
-            double app0 = 0.0, app1 = 0.0;
+        const unsigned m = item_mask(gg, io.ncw, tl, len);        // no such item: computes on whatever LDS holds, stores nowhere
+        const bool ok = m != 0;
+        const double2 *x = reinterpret_cast<const double2 *>(c.xs + tl * XS_ROW + (gg < c.GW ? gg : 0) * S * 2);
+        double app0 = 0.0, app1 = 0.0;
 #pragma unroll
-            for (int st = 0; st < S; st++) { const double2 v = x[st]; app0 += v.x; app1 += v.y; }
-            const double lr = fast_log(app1 / app0);
-            flag_or(c.bad, !(fabs(lr) < __builtin_huge_val()) || !(fmax(app0, app1) >= T_SMALL));   // (D), (E)
-            const double L = io.ext ? lr : li[q] + lr;
-            const unsigned t = (unsigned)(t_lo + tl);
-            st_off(io.Lout, (unsigned)(gg * io.lstride) + t, L);
-            if (io.bits) io.bits[(unsigned)(gg * io.N) + t] = (uint8_t)((io.want_bits && L > 0) ? 1 : 0);   // (:148-152)
-        }
+        for (int st = 0; st < S; st++) { const double2 v = x[st]; app0 += v.x; app1 += v.y; }
+        const double lr = fast_log(app1 / app0);
+        flag_or(c.bad, ok && (!(fabs(lr) < __builtin_huge_val()) || !(fmax(app0, app1) >= T_SMALL)));   // (D), (E)
+        const double L = io.ext ? lr : li[q] + lr;
+        const unsigned t = (unsigned)(t_lo + tl);
+        buf_st(io.rout, item_off(m, ((unsigned)(gg * io.lstride) + t) * 8u), io.oout, L);
+        if (BITS) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)((io.want_bits && L > 0) ? 1 : 0), io.rbits,
+                                             item_off(m, (unsigned)(gg * io.N) + t), 0, 0);               // (:148-152)
     }
     asm volatile("" ::: "memory");
 }
@@ -457,79 +477,90 @@ __device__ void map_pass(const Ctx<LGS> &c, const PassIO &io) {
     // checkpoint row k (state vector at time k*CH), this lane's entry
     auto ck_ld = [&](int k) { return ld_off(io.ckpt, (unsigned)(k * 64 + c.lane)); };
     auto ck_st = [&](int k, double v) { st_off(io.ckpt, (unsigned)(k * 64 + c.lane), v); };
-    RawChunk cur, nxt;
     double arow[CH];                                              // alpha of this lane's state at the chunk's steps
 #pragma unroll
     for (int tl = 0; tl < CH; tl++) arow[tl] = 0.0;
+    // Either wave walks ALL K chunks in one direction -- F: 0 .. K-1, R: K-1 .. 0 -- first on its own recursion only (phase 1),
+    // then on both (phase 2); `seq(i)` is the i-th chunk of the walk.  The received values of a chunk are requested TWO chunks
+    // ahead: two register sets X / Y alternate (the loops below are unrolled by two, so that no set is ever copied -- a copy would
+    // wait for the load it copies).  Measured on config 3, same box (experiments/README.md): one set 4.90 ms, two sets 4.85 ms,
+    // two sets + counted waits (PassIO) 4.80 ms -- the pass is NOT limited by its loads: rocprofv3 has the two waves of a SIMD
+    // issuing VALU 53 % of the time, 22 % of the wave cycles in s_waitcnt and 29 % ready-but-not-issued.
+    auto seq = [&](int i) { return c.fwd ? i : K - 1 - i; };
+    // (past the end of the walk the last chunk is requested again: an `if` around the loads would bring the uncounted wait back)
+    auto fetch = [&](RawChunk &S, int i) { const int k = seq(i < K ? i : K - 1); load_raw<LGS>(c, io, S, k * CH, clen(k)); };
+    RawChunk X, Y;
+    fetch(X, 0);
+    fetch(Y, 1);
+    // runs step(i, set) for i = i0 .. i1-1, alternating X, Y; an odd count ends with the sets swapped by value (once per phase)
+    auto run = [&](int i0, int i1, auto &&step) {
+        int i = i0;
+        for (; i + 1 < i1; i += 2) {
+            step(i, X);
+            step(i + 1, Y);
+        }
+        if (i < i1) {
+            step(i, X);
+            const RawChunk t = X; X = Y; Y = t;
+        }
+    };
     // Phase 2 of either wave, one chunk: alpha over the chunk (kept per step), then beta over it with the branch products,
     // then the epilogue.  One of the two recursions continues the wave's own chain, the other starts from the partner's
     // checkpoint and is discarded afterwards.  The checkpoint is loaded at the TOP of the iteration, before the prefetch
-    // of the next chunk is issued: loads return in order, so the chain then only waits for that one load (with the
-    // checkpoint prefetched an iteration earlier the compiler had to put a full vmcnt(0) in front of the chain, i.e.
-    // the chain waited for the HBM round trip of the prefetch issued just before it: +1000 cycles per chunk).
+    // of a later chunk is issued: loads return in order, so the chain then only waits for that one load.
+    // The epilogue of a chunk runs at the top of the NEXT iteration, after that iteration's checkpoint load has been
+    // issued: loads and stores retire through one in-order counter, so with the LLR stores issued BEFORE the
+    // checkpoint load the chain waited for their write acknowledgements as well.
+    double li_prev[2] = {0.0, 0.0};
+    int t_prev = 0;
+    int len_prev = 0;                                             // first iteration of phase 2: nothing to write
     if (c.fwd) {
         // ---------------- phase 1: alpha over chunks 0 .. K1-1, checkpoint before every chunk ----------------
         double a = (c.s == 0) ? 1.0 : 0.0;                        // f_state_metrics[0][0] = 1 (:221)
-        if (K1 > 0) load_raw<LGS>(c, io, cur, 0, clen(0));
-        for (int k = 0; k < K1; k++) {
-            ck_st(k, a);                                          // alpha at time k*CH (read by R in phase 2)
-            stage_chunk<LGS, PRE>(c, cur, io.nv2);
-            if (k + 1 < K1) load_raw<LGS>(c, io, nxt, (k + 1) * CH, clen(k + 1));
+        run(0, K1, [&](int i, RawChunk &S) {
+            ck_st(i, a);                                          // alpha at time i*CH (read by R in phase 2)
+            stage_chunk<LGS, PRE>(c, S, io.nv2);
+            fetch(S, i + 2);
             alpha_chunk<LGS, SR, false>(c, a, CH, arow);          // chunks below K1 are full
-            cur = nxt;
-        }
-        load_raw<LGS>(c, io, cur, K1 * CH, clen(K1));             // first chunk of phase 2 (K1 < K always)
+        });
         pair_sync();
         // ---------------- phase 2: chunks K1 .. K-1: own alpha, beta from R's checkpoint, combine ----------------
-        // The epilogue of a chunk runs at the top of the NEXT iteration, after that iteration's checkpoint load has been
-        // issued: loads and stores retire through one in-order counter, so with the LLR stores issued BEFORE the
-        // checkpoint load the chain waited for their write acknowledgements as well (ablation: the stores cost 0.7 of the
-        // 5.3 ms of a config-3 launch, the loads 1.0).
-        double li_prev[2] = {0.0, 0.0};
-        int t_prev = 0;
-        int len_prev = 0;                                         // first iteration: nothing to write
-        for (int k = K1; k < K; k++) {
+        run(K1, K, [&](int k, RawChunk &S) {
             const int len = clen(k);
             double b = ck_ld(k + 1);                              // beta at the upper boundary of chunk k
-            epilogue<LGS>(c, io, li_prev, t_prev, len_prev);
-            stage_chunk<LGS, PRE>(c, cur, io.nv2);
-            if (k + 1 < K) load_raw<LGS>(c, io, nxt, (k + 1) * CH, clen(k + 1));
+            epilogue<LGS, !PRE>(c, io, li_prev, t_prev, len_prev);
+            stage_chunk<LGS, PRE>(c, S, io.nv2);
+            li_prev[0] = S.li[0]; li_prev[1] = S.li[1];
+            fetch(S, k + 2);
             alpha_chunk<LGS, SR, true>(c, a, len, arow);
             beta_chunk<LGS, SR, true>(c, b, len, arow);
-            li_prev[0] = cur.li[0]; li_prev[1] = cur.li[1];
             t_prev = k * CH; len_prev = len;
-            cur = nxt;
-        }
-        epilogue<LGS>(c, io, li_prev, t_prev, len_prev);
+        });
+        epilogue<LGS, !PRE>(c, io, li_prev, t_prev, len_prev);
     } else {
         // ---------------- phase 1: beta over chunks K-1 .. K1, checkpoint before every chunk ----------------
         double b = 1.0;                                           // b_state_metrics[:, N] = 1 (:225)
-        load_raw<LGS>(c, io, cur, (K - 1) * CH, clen(K - 1));
-        for (int k = K - 1; k >= K1; --k) {
+        run(0, K - K1, [&](int i, RawChunk &S) {
+            const int k = K - 1 - i;
             ck_st(k + 1, b);                                      // beta at the upper boundary of chunk k (read by F)
-            stage_chunk<LGS, PRE>(c, cur, io.nv2);
-            if (k > K1) load_raw<LGS>(c, io, nxt, (k - 1) * CH, CH);
+            stage_chunk<LGS, PRE>(c, S, io.nv2);
+            fetch(S, i + 2);
             beta_chunk<LGS, SR, false>(c, b, clen(k), arow);
-            cur = nxt;
-        }
-        if (K1 > 0) load_raw<LGS>(c, io, cur, (K1 - 1) * CH, CH);
+        });
         pair_sync();
         // ---------------- phase 2: chunks K1-1 .. 0 (all full): alpha from F's checkpoint, own beta, combine ----------------
-        double li_prev[2] = {0.0, 0.0};
-        int t_prev = 0;
-        int len_prev = 0;
-        for (int k = K1 - 1; k >= 0; --k) {
+        run(K - K1, K, [&](int i, RawChunk &S) {
+            const int k = K - 1 - i;
             double a = ck_ld(k);                                  // alpha at the lower boundary of chunk k
-            epilogue<LGS>(c, io, li_prev, t_prev, len_prev);      // of the previous chunk (see the forward wave)
-            stage_chunk<LGS, PRE>(c, cur, io.nv2);
-            if (k > 0) load_raw<LGS>(c, io, nxt, (k - 1) * CH, CH);
+            epilogue<LGS, !PRE>(c, io, li_prev, t_prev, len_prev);      // of the previous chunk (see the forward wave)
+            stage_chunk<LGS, PRE>(c, S, io.nv2);
+            li_prev[0] = S.li[0]; li_prev[1] = S.li[1];
+            fetch(S, i + 2);
             alpha_chunk<LGS, SR, true>(c, a, CH, arow);           // arow[tl] = alpha at time k*CH + tl
             beta_chunk<LGS, SR, true>(c, b, CH, arow);
-            li_prev[0] = cur.li[0]; li_prev[1] = cur.li[1];
             t_prev = k * CH; len_prev = CH;
-            cur = nxt;
-        }
-        epilogue<LGS>(c, io, li_prev, t_prev, len_prev);
+        });
+        epilogue<LGS, !PRE>(c, io, li_prev, t_prev, len_prev);
     }
     publish_flags<LGS>(c, io.flags, io.ncw);
 }
@@ -559,9 +590,13 @@ __global__ __launch_bounds__(128 * NPAIR) void map_decode_kernel(MapParams p) {
     const int64_t left = p.B - cw0;
     PassIO io;
     io.N = (int)p.N; io.sstride = io.pstride = io.lstride = io.N; io.ext = false;
-    io.sys = p.sys + o0; io.par = p.par + o0; io.Lin = p.Lin + o0; io.Lout = p.Lout + o0;
-    io.bits = p.bits ? p.bits + o0 : nullptr; io.want_bits = p.want_bits;
     io.ncw = (int)(left < p.GW ? left : p.GW); io.nv2 = p.nv2;
+    const unsigned span = io.ncw > 0 ? OOB : 0u;                  // a pair past the end of the batch: everything out of range
+    io.rsys = pass_buffer(p.sys + o0, span); io.rpar = pass_buffer(p.par + o0, span);
+    io.rlin = pass_buffer(p.Lin + o0, span); io.rout = pass_buffer(p.Lout + o0, span);
+    io.rbits = pass_buffer(p.bits ? p.bits + o0 : nullptr, p.bits ? span : 0u);
+    io.osys = io.opar = io.olin = io.oout = 0u;
+    io.want_bits = p.want_bits;
     io.ckpt = p.scratch + pair * (K + 1) * 64;
     io.flags = p.flags ? p.flags + cw0 : nullptr;
     map_pass<LGS, SR, false>(c, io);                              // L_ext and the hard decisions leave in the pass's epilogue
@@ -573,131 +608,125 @@ struct TurboParams {
     const int32_t *perm;                  // [N]
     uint8_t *bits;                        // [B][N]
     double *ckpt;                         // per pair: checkpoint rows [nchunks + 1][64]
-    double *larr;                         // per codeword: A, B, C, Qs, Qsi, Qp1, Qp2 [N] each
+    // The slab: per codeword seven arrays [N] -- A (L_int_1), B (a pass's output), C (L_int_2) and the signed channel factors
+    // (signed_q) of sys, interlv(sys) (:310), non_sys_1, non_sys_2 -- rows [B][7][N].  (A CHUNKED slab, [pair][array][chunk][GW][8]:
+    // the GW x 8 values a pass reads per array and chunk as ONE contiguous 1 KB line, was built and measured in round 3: the
+    // pass kernel did not move (337 us either way -- it is not the number of 64-byte segments that costs) and the stage
+    // kernels, whose per-codeword accesses become strided, lost 11 us each: 4.87 instead of 4.82 ms.  experiments/README.md.)
+    double *larr;
     uint8_t *flags;                       // [B] "detect and redo" (zeroed before the launch), may be null
     int64_t B, N;
     double nv2;
     int n_iter, GW;
 };
+// element t of array `a` (0 .. 6) of codeword cw
+__device__ __forceinline__ int64_t slab_off(const TurboParams &p, int a, int64_t cw, int64_t t) {
+    return (cw * 7 + a) * p.N + t;
+}
 
+// ---- turbo_decode as a SEQUENCE of launches (round 3) ------------------------------------------------------------------------
+// One launch per MAP pass (the pass of map_decode_kernel, reading the chunked slab) and one small launch per stage between
+// passes.  Round 2 ran everything in ONE persistent launch; inlined into that kernel's iteration loop the pass needed more
+// than 256 VGPRs -- 18 to 23 of them spilled, and a scratch reload retires through the same in-order counter as the prefetches,
+// i.e. it waits for the HBM round trip issued just before it (rocprofv3, round 2: 61 % of the wave cycles parked in s_waitcnt
+// where the stand-alone pass has 33 %).  As its own kernel the pass keeps the register allocation of map_decode_kernel (224
+// VGPRs, no scratch); a kernel boundary costs ~2 us, 25 of them per decode.  Measured, same box: 5.24 ms (persistent) -> 4.82 ms
+// (launch per pass, row slab) -> chunked slab: see DESIGN.md 4.2.
 template <int LGS, bool SR>
-__global__ __launch_bounds__(128 * NPAIR) void turbo_decode_kernel(TurboParams p) {
+__global__ __launch_bounds__(128 * NPAIR) void turbo_pass_kernel(TurboParams p, int second) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Ctx<LGS> c;
     init_ctx<LGS>(c, p.tb, smem, p.GW);
-    // wave-uniform by construction; readfirstlane tells the compiler, so that everything derived from it (the pair's base
-    // pointers, codeword counts) lives in SGPRs and the loads take the `saddr + 32-bit voffset` form
     const int64_t pair = (int64_t)blockIdx.x * (blockDim.x >> 7) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 7));
     const int64_t N = p.N, K = (N + CH - 1) / CH, cw0 = pair * p.GW;
-    // per-codeword arrays in one slab [B][7][N]: A (L_int_1), B (a pass's output), C (L_int_2) and the signed channel
-    // factors (signed_q) of sys, interlv(sys) (:310), non_sys_1 and non_sys_2
-    double *A0 = p.larr, *B0 = p.larr + N, *C0 = p.larr + 2 * N;
-    double *QS = p.larr + 3 * N, *QSI = p.larr + 4 * N, *QP1 = p.larr + 5 * N, *QP2 = p.larr + 6 * N;
-    const int64_t ls = 7 * N;
-    const double k4 = -4.0 / p.nv2;
-    const int64_t left = p.B - cw0, o0 = cw0 * ls;               // the pair's codewords start at element o0 of every slab array
+    const int64_t left = p.B - cw0;
     PassIO io;
-    io.lstride = io.sstride = io.pstride = (int)ls; io.N = (int)N; io.nv2 = p.nv2; io.bits = nullptr;
+    const int64_t ls = 7 * N;
+    io.lstride = io.sstride = io.pstride = (int)ls;
+    io.N = (int)N; io.nv2 = p.nv2; io.want_bits = 0;
     io.ncw = (int)(left < p.GW ? left : p.GW);
-    io.want_bits = 0;
     io.ckpt = p.ckpt + pair * (K + 1) * 64;
     io.flags = p.flags ? p.flags + cw0 : nullptr;
-    // (A) for every received value on its own: |r| > sqrt(T_A nv2 / 2) - 1 bounds (|r0| + 1)^2 + (|r1| + 1)^2 for any pairing
-    const double rmax = sqrt(0.5 * T_A * p.nv2) - 1.0;
-    // Between the MAP passes only the interleaver is left to do: a pass writes E = L - L_int directly (`ext`), so
-    //   even h: L_int_2 = interlv(E_1)      C[t] = B[perm[t]]         (:318-319)
-    //   odd h:  L_int_1 = deinterlv(E_2)    A[perm[t]] = B[t]         (:328-329)
-    // A codeword's array (8 KB for N = 1024) is permuted THROUGH LDS -- coalesced read, LDS scatter / gather, coalesced
-    // write -- one codeword per wave at a time, the two waves of the pair taking alternate codewords.  (Round 1 gathered
-    // from HBM: every 8-byte element fetched a 64-byte line, 2 x 8-fold read amplification per stage, 1.5 of 8.4 ms.)
-    const int lane = c.lane, GW = p.GW, w2 = (threadIdx.x >> 6) & 1;
-    double *buf = c.tab;                                           // the wave's whole LDS region, free between passes
-    const bool in_lds = N <= (int64_t)wave_lds_doubles<LGS>(GW);
-    for (int g = w2; g < GW; g += 2) {
-        const int64_t cwg = cw0 + g;
-        if (cwg >= p.B) break;
-        double *A = A0 + cwg * ls, *qs = QS + cwg * ls, *qsi = QSI + cwg * ls, *qp1 = QP1 + cwg * ls, *qp2 = QP2 + cwg * ls;
+    io.ext = true;                                                // the pass writes E = L - L_int (:318, :328)
+    double *base = p.larr + cw0 * ls;                              // the pair's first codeword
+    //   first  half-iteration: [L_ext_1, _] = map_decode(sys,   non_sys_1, trellis, nv, L_int_1, 'compute')   (:315)
+    //   second half-iteration: [L_2, bits]  = map_decode(sys_i, non_sys_2, trellis, nv, L_int_2, mode)        (:326)
+    io.rsys = io.rpar = io.rlin = io.rout = pass_buffer(base, io.ncw > 0 ? OOB : 0u);
+    io.rbits = pass_buffer(nullptr, 0u);
+    const unsigned nb = (unsigned)N * 8u;
+    io.osys = __builtin_amdgcn_readfirstlane((second ? 4u : 3u) * nb);
+    io.opar = __builtin_amdgcn_readfirstlane((second ? 6u : 5u) * nb);
+    io.olin = __builtin_amdgcn_readfirstlane((second ? 2u : 0u) * nb);
+    io.oout = nb;
+    map_pass<LGS, SR, true>(c, io);
+}
+
+// mode 0: slab initialisation (:305-310) + flag (A);  1: L_int_2 = interlv(E_1) (:318-319);  2: L_int_1 = deinterlv(E_2)
+// (:328-329);  3: decoded_bits = deinterlv(L_2 > 0) (:148-152, :331).  One wavefront per codeword, four per workgroup; `lds_n`
+// doubles of LDS per wavefront when a codeword's array fits -- the permutations then go THROUGH LDS: coalesced read, LDS
+// scatter / gather, coalesced write (round 1 gathered from HBM: a 64-byte line per 8-byte element) -- else 0.
+__global__ __launch_bounds__(256) void turbo_stage_kernel(TurboParams p, int mode, int lds_n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t cwg = (int64_t)blockIdx.x * 4 + wv;
+    if (cwg >= p.B) return;
+    const int64_t N = p.N;
+    double *buf = reinterpret_cast<double *>(smem) + (size_t)wv * lds_n;
+    const bool in_lds = lds_n >= N;
+    auto at = [&](int a, int64_t t) -> double & { return p.larr[slab_off(p, a, cwg, t)]; };
+    if (mode == 0) {
+        const double k4 = -4.0 / p.nv2;
+        // (A) of "detect and redo" for every received value on its own: |r| > sqrt(T_A nv2 / 2) - 1 bounds
+        // (|r0| + 1)^2 + (|r1| + 1)^2 for any pairing
+        const double rmax = sqrt(0.5 * T_A * p.nv2) - 1.0;
         const double *sy = p.sys + cwg * N, *y1 = p.p1 + cwg * N, *y2 = p.p2 + cwg * N;
         bool far = false;
 #pragma unroll 2
         for (int64_t t = lane; t < N; t += 64) {
-            A[t] = p.Lint ? p.Lint[cwg * N + t] : 0.0;             // L_int_1 (:305-308)
+            at(0, t) = p.Lint ? p.Lint[cwg * N + t] : 0.0;         // L_int_1 (:305-308)
             const double r1 = y1[t], r2 = y2[t], rs = sy[t];
             far = far || !(fabs(r1) <= rmax) || !(fabs(r2) <= rmax) || !(fabs(rs) <= rmax);
-            qp1[t] = signed_q(r1, k4);
-            qp2[t] = signed_q(r2, k4);
+            at(5, t) = signed_q(r1, k4);
+            at(6, t) = signed_q(r2, k4);
             const double v = signed_q(rs, k4);
-            qs[t] = v;
+            at(3, t) = v;
             if (in_lds) buf[t] = v;
         }
         if (p.flags && __ballot(far) != 0 && lane == 0) p.flags[cwg] = 1;
-        // sys_symbols_i = interlv(sys) (:310), once: through LDS -- coalesced read, LDS gather, coalesced write.  (Reading
-        // sys[perm[t]] in every second MAP pass fetched a 64-byte line per 8-byte value: 8 of the 17 GB a launch read.)
-        asm volatile("" ::: "memory");
+        asm volatile("" ::: "memory");                             // LDS operations of one wave execute in order
         if (in_lds) {
 #pragma unroll 4
-            for (int64_t t = lane; t < N; t += 64) qsi[t] = buf[p.perm[t]];
-            asm volatile("" ::: "memory");
+            for (int64_t t = lane; t < N; t += 64) at(4, t) = buf[p.perm[t]];               // interlv(sys) (:310)
         } else {
 #pragma unroll 2
-            for (int64_t t = lane; t < N; t += 64) qsi[t] = signed_q(sy[p.perm[t]], k4);
+            for (int64_t t = lane; t < N; t += 64) at(4, t) = signed_q(sy[p.perm[t]], k4);
         }
-    }
-    pair_sync();
-    io.ext = true;
-    // 2 n_iter half-iterations through ONE map_pass call site (two inlined copies of the unrolled pass spill registers):
-    //   even h: [L_ext_1, _] = map_decode(sys, non_sys_1, trellis, nv, L_int_1, 'compute')          (:315)
-    //   odd h:  [L_2, bits] = map_decode(sys_i, non_sys_2, trellis, nv, L_int_2, mode)              (:326)
-    for (int h = 0; h < 2 * p.n_iter; h++) {
-        const bool second = h & 1;
-        io.sys = (second ? QSI : QS) + o0;
-        io.par = (second ? QP2 : QP1) + o0;
-        io.Lin = (second ? C0 : A0) + o0;
-        io.Lout = B0 + o0;
-        map_pass<LGS, SR, true>(c, io);
-        pair_sync();
-        if (h == 2 * p.n_iter - 1) break;                          // the last E_2 only feeds the decisions below
-        for (int g = w2; g < GW; g += 2) {
-            const int64_t cwg = cw0 + g;
-            if (cwg >= p.B) break;
-            const double *src = B0 + cwg * ls;
-            double *dst = (second ? A0 : C0) + cwg * ls;
-            if (in_lds) {
-                asm volatile("" ::: "memory");
-                if (!second) {
+    } else if (mode == 1) {
+        if (in_lds) {
 #pragma unroll 4
-                    for (int64_t t = lane; t < N; t += 64) buf[t] = src[t];
-                } else {
+            for (int64_t t = lane; t < N; t += 64) buf[t] = at(1, t);
+            asm volatile("" ::: "memory");
 #pragma unroll 4
-                    for (int64_t t = lane; t < N; t += 64) buf[p.perm[t]] = src[t];
-                }
-                asm volatile("" ::: "memory");                    // LDS operations of one wave execute in order
-                if (!second) {
+            for (int64_t t = lane; t < N; t += 64) at(2, t) = buf[p.perm[t]];
+        } else {
 #pragma unroll 4
-                    for (int64_t t = lane; t < N; t += 64) dst[t] = buf[p.perm[t]];
-                } else {
-#pragma unroll 4
-                    for (int64_t t = lane; t < N; t += 64) dst[t] = buf[t];
-                }
-                asm volatile("" ::: "memory");
-            } else if (!second) {
-#pragma unroll 4
-                for (int64_t t = lane; t < N; t += 64) dst[t] = src[p.perm[t]];
-            } else {
-#pragma unroll 4
-                for (int64_t t = lane; t < N; t += 64) dst[p.perm[t]] = src[t];
-            }
+            for (int64_t t = lane; t < N; t += 64) at(2, t) = at(1, p.perm[t]);
         }
-        pair_sync();
-    }
-    // decoded_bits = deinterlv(L_2 > 0), L_2 = L_int_2 + log(app1/app0) of the last MAP2          (:148-152, :331)
-    for (int g = w2; g < GW; g += 2) {
-        const int64_t cwg = cw0 + g;
-        if (cwg >= p.B) break;
-        const double *Bb = B0 + cwg * ls, *C = C0 + cwg * ls;
+    } else if (mode == 2) {
+        if (in_lds) {
+#pragma unroll 4
+            for (int64_t t = lane; t < N; t += 64) buf[p.perm[t]] = at(1, t);
+            asm volatile("" ::: "memory");
+#pragma unroll 4
+            for (int64_t t = lane; t < N; t += 64) at(0, t) = buf[t];
+        } else {
+#pragma unroll 4
+            for (int64_t t = lane; t < N; t += 64) at(0, p.perm[t]) = at(1, t);
+        }
+    } else {
 #pragma unroll 4
         for (int64_t t = lane; t < N; t += 64)
-            p.bits[cwg * N + p.perm[t]] = (uint8_t)((p.n_iter > 0 && C[t] + Bb[t] > 0) ? 1 : 0);
+            p.bits[cwg * N + p.perm[t]] = (uint8_t)((p.n_iter > 0 && at(2, t) + at(1, t) > 0) ? 1 : 0);
     }
 }
 
@@ -753,7 +782,7 @@ int cpx_map_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const do
     int rc = fill_tables(t, p.tb);
     if (rc) return rc;
     CPX_REQUIRE(B >= 0 && N >= 0, CPX_EINVAL, "map_decode: negative size");
-    CPX_REQUIRE(N < (1ll << 24), CPX_ELIMIT, "map_decode: blocks of 2^24 steps or more are not supported (32-bit lane offsets)");
+    CPX_REQUIRE(N < (1ll << 24), CPX_ELIMIT, "map_decode: blocks of 2^24 steps or more are not supported (31-bit lane offsets over 16 codewords)");
     if (B == 0 || N == 0) return CPX_OK;
     hipStream_t st = pick_stream(stream);
     const int GW = pick_gw(t->S, B);
@@ -798,7 +827,7 @@ int cpx_turbo_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const 
     int rc = fill_tables(t, p.tb);
     if (rc) return rc;
     CPX_REQUIRE(B >= 0 && N >= 0 && n_iter >= 0, CPX_EINVAL, "turbo_decode: negative size");
-    CPX_REQUIRE(N < (1ll << 22), CPX_ELIMIT, "turbo_decode: blocks of 2^22 steps or more are not supported (32-bit lane offsets)");
+    CPX_REQUIRE(N < (1ll << 21), CPX_ELIMIT, "turbo_decode: blocks of 2^21 steps or more are not supported (31-bit lane offsets into a 16-codeword slab)");
     if (B == 0 || N == 0) return CPX_OK;
     hipStream_t st = pick_stream(stream);
     const int GW = pick_gw(t->S, B);
@@ -817,19 +846,38 @@ int cpx_turbo_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const 
         CPX_HIP(hipMemsetAsync(p.flags, 0, (size_t)B, st));
     }
     dim3 grid((unsigned)nblocks), block(128 * np);
-    switch (p.tb.lgS) {
-#define CASE(LG) case LG: hipLaunchKernelGGL((turbo_decode_kernel<LG, false>), grid, block, sizeof(double) * 2 * np * wave_lds_doubles<LG>(GW), st, p); break;
-        case 2:
-            if (p.tb.sr4) hipLaunchKernelGGL((turbo_decode_kernel<2, true>), grid, block, sizeof(double) * 2 * np * wave_lds_doubles<2>(GW), st, p);
-            else hipLaunchKernelGGL((turbo_decode_kernel<2, false>), grid, block, sizeof(double) * 2 * np * wave_lds_doubles<2>(GW), st, p);
-            break;
-        CASE(1) CASE(3) CASE(4)
+    // one launch per MAP pass, one small launch per stage (see turbo_pass_kernel)
+    const int lds_n = (N * 8 * 4 <= 64 * 1024) ? (int)N : 0;
+    CPX_REQUIRE((B + 3) / 4 < (1ll << 31), CPX_ELIMIT, "turbo_decode: batch too large");
+    const dim3 sgrid((unsigned)((B + 3) / 4)), sblock(256);
+    const size_t slds = (size_t)lds_n * 8 * 4;
+    auto stage = [&](int mode) { hipLaunchKernelGGL(turbo_stage_kernel, sgrid, sblock, slds, st, p, mode, lds_n); };
+    auto pass = [&](int second) -> int {
+        switch (p.tb.lgS) {
+#define CASE(LG) case LG: hipLaunchKernelGGL((turbo_pass_kernel<LG, false>), grid, block, sizeof(double) * 2 * np * wave_lds_doubles<LG>(GW), st, p, second); break;
+            case 2:
+                if (p.tb.sr4) hipLaunchKernelGGL((turbo_pass_kernel<2, true>), grid, block, sizeof(double) * 2 * np * wave_lds_doubles<2>(GW), st, p, second);
+                else hipLaunchKernelGGL((turbo_pass_kernel<2, false>), grid, block, sizeof(double) * 2 * np * wave_lds_doubles<2>(GW), st, p, second);
+                break;
+            CASE(1) CASE(3) CASE(4)
 #undef CASE
-        default: set_error("turbo_decode: unsupported state count"); return CPX_ELIMIT;
+            default: set_error("turbo_decode: unsupported state count"); return CPX_ELIMIT;
+        }
+        return CPX_OK;
+    };
+    stage(0);
+    for (int h = 0; h < 2 * n_iter; h++) {
+        if ((rc = pass(h & 1))) return rc;
+        if (h < 2 * n_iter - 1) stage(1 + (h & 1));
     }
+    stage(3);
     CPX_HIP(hipGetLastError());
+    note_kernel("turbo_pass_kernel<%d,%s> x %d + turbo_stage_kernel (%d wave pairs per workgroup, %d codewords per pair)", p.tb.lgS,
+                (p.tb.lgS == 2 && p.tb.sr4) ? "true" : "false", 2 * n_iter, np, GW);
+    char kname[200];
+    snprintf(kname, sizeof(kname), "%s", last_kernel_name());
     if (p.flags && (rc = bcjr_exact_turbo(t, d_sys, d_p1, d_p2, d_L_int_or_null, d_perm, B, N, p.nv2, n_iter, d_bits, p.flags, st))) return rc;
-    note_kernel("turbo_decode_kernel<%d,%s> (%d wave pairs per workgroup, %d codewords per pair)", p.tb.lgS, (p.tb.lgS == 2 && p.tb.sr4) ? "true" : "false", np, GW);
+    note_kernel("%s", kname);
     return CPX_OK;
 }
 

@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--fetch-scale", type=float, default=2.0)
     ap.add_argument("--batch", type=int, default=None, help="recorded in the JSON (bench.py checks it)")
     ap.add_argument("--timeout", type=int, default=600)
+    ap.add_argument("--groups", default=None, help='counter passes instead of the default ones: "A,B;C,D" = two passes')
     ap.add_argument("cmd", nargs=argparse.REMAINDER)
     a = ap.parse_args()
     cmd = a.cmd[1:] if a.cmd and a.cmd[0] == "--" else a.cmd
@@ -77,7 +78,7 @@ def main():
     shutil.rmtree(d, ignore_errors=True)
 
     # ---- counter passes ----
-    for grp in GROUPS:
+    for grp in ([g.split(",") for g in a.groups.split(";")] if a.groups else GROUPS):
         tag = "_".join(grp)[:40]
         d = os.path.join(out, a.name + "_pmc_" + tag)
         shutil.rmtree(d, ignore_errors=True)

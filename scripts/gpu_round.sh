@@ -41,7 +41,7 @@ if [[ $SEC == *v* ]]; then
       python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | tail -40
 fi
 if [[ $SEC == *u* ]]; then
-  timeout 1500 python scripts/collect_pmc.py --out $OUT --name turbo_c3 --match _decode_kernel --fetch-scale 1 -- \
+  timeout 1500 python scripts/collect_pmc.py --out $OUT --name turbo_c3 --match _kernel --fetch-scale 1 -- \
       python $R/benchmarks/bench_kernels.py --which turbo,map 2>&1 | tail -60
 fi
 if [[ $SEC == *m* ]]; then
