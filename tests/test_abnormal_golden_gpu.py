@@ -1,0 +1,70 @@
+"""The HIP path against tests/golden/abnormal.npz: what the LIVE reference returns for inputs outside its representable
+range (NaN among Viterbi / min-sum LLRs, MAP recursions that underflow, non-finite MAP inputs, turbo in those regimes).
+The fast kernels only detect these inputs; flagged codewords / blocks are decoded again by literal kernels (DESIGN.md
+"detect and redo").  Integer outputs bit-exact, LLRs: same NaN / +-inf pattern, finite values within 1e-5."""
+import numpy as np
+import pytest
+
+from helpers import Perm, ldpc_params, make_trellis
+from test_oracle_golden import abnormal_cases, same_nonfinite_pattern
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def test_viterbi_nan_inputs(gpu):
+    from commpy_amd import _lib
+    from commpy_amd.channelcoding import viterbi_decode
+    g, names = abnormal_cases("vit_")
+    for key in names:
+        tname = key[4:key.rindex("_")]
+        tr = make_trellis(tname)
+        for path in ((None, "cw!", "cw2!", "wave") if tname == "k7_133_171" else (None,)):
+            _lib.viterbi_set_path(path)
+            try:
+                got = viterbi_decode(g[key + "__rx"], tr, None, "soft")
+            finally:
+                _lib.viterbi_set_path(None)
+            assert np.array_equal(got, g[key + "__dec"]), (key, path)
+
+
+def test_min_sum_nan_llrs(gpu):
+    from commpy_amd import _lib
+    from commpy_amd.channelcoding import ldpc_bp_decode
+    g, names = abnormal_cases("msa_")
+    for key in names:
+        p = ldpc_params(key[4:])
+        for path in ("resident", "tiled"):
+            _lib.ldpc_set_path(path)
+            try:
+                dec, out = ldpc_bp_decode(g[key + "__llr"].copy(), p, "MSA", int(g[key + "__iters"]))
+            finally:
+                _lib.ldpc_set_path(None)
+            assert out.shape == g[key + "__out"].shape
+            assert np.array_equal(out, g[key + "__out"], equal_nan=True), (key, path)
+            assert np.array_equal(dec, g[key + "__dec"]), (key, path)
+
+
+def test_map_decode_regimes(gpu):
+    from commpy_amd.channelcoding import map_decode
+    g, names = abnormal_cases("map_")
+    for nm in names:
+        key, tname = nm.split("|")
+        tr = make_trellis(tname)
+        Le, bits = map_decode(g[key + "__sys"], g[key + "__par"], tr, float(g[key + "__nv"]), g[key + "__Lint"], "decode")
+        ref, rbits = g[key + "__L"], g[key + "__bits"]
+        assert same_nonfinite_pattern(Le, ref), key
+        fin = np.isfinite(ref)
+        assert np.all(np.abs(Le[fin] - ref[fin]) <= TOL + 1e-9 * np.abs(ref[fin])), key
+        assert not np.any((bits != rbits) & ~(np.abs(ref) <= TOL)), key       # NaN / inf positions included
+
+
+def test_turbo_decode_regimes(gpu):
+    from commpy_amd.channelcoding import turbo_decode
+    g, names = abnormal_cases("tur_")
+    tr = make_trellis("rsc_legacy_4")
+    for key in names:
+        nv, iters, has_L = g[key + "__par"]
+        dec = turbo_decode(g[key + "__sys"], g[key + "__p1"], g[key + "__p2"], tr, float(nv), int(iters),
+                           Perm(g[key + "__perm"]), g[key + "__Lint"] if has_L else None)
+        assert np.array_equal(dec, g[key + "__dec"]), key

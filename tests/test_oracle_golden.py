@@ -112,6 +112,25 @@ def test_viterbi_config2_768_reference_codewords():
     assert 3e-2 < np.mean(c2x_case("e1")[1][:, :1024] != c2x_case("e1")[2]) < 8e-2      # the 1 dB set really has errors
 
 
+def c2u_case():
+    """(llr float64 [256, 2060] exactly as the reference modem returned them, reference bits [256, 1030], messages) of viterbi_c2u.npz."""
+    g = golden("viterbi_c2u")
+    return g["llr"], np.unpackbits(g["dec"], axis=1)[:, :1030], np.unpackbits(g["msg"], axis=1)[:, :1024]
+
+
+def test_viterbi_config2_256_unquantised_reference_codewords():
+    """256 live-reference codewords at 3 dB whose inputs are the reference modem's float64 LLRs, not rounded: bit-exact,
+    through the C oracle and through the batch-vectorised NumPy restatement."""
+    from oracle.np_viterbi import viterbi_decode_batch
+    tr = TableTrellis("k7_133_171")
+    llr, dec, msg = c2u_case()
+    assert np.mean(llr * 256 == np.rint(llr * 256)) < 0.01           # really unquantised
+    got = oracle.viterbi_decode(llr, tr, None, "soft")
+    assert np.array_equal(got, dec), int(np.sum(got != dec))
+    got_np = viterbi_decode_batch(llr[:32], tr, None, "soft")
+    assert np.array_equal(got_np, dec[:32]), int(np.sum(got_np != dec[:32]))
+
+
 def test_turbo_config3_48_reference_codewords():
     """Config-3 shape through the live reference: N = 1024, RandInterlv(1024, 1234), 6 iterations, 1.5 dB."""
     g = golden("turbo_c3x")
@@ -154,3 +173,69 @@ def test_ldpc_config4_chain_reference_blocks():
                 assert np.max(dev[mag <= 26.0]) < 1e-5
                 assert np.all(dev[mag > 26.0] <= 1e-2 * mag[mag > 26.0])
         assert not np.all(np.all(g[tag + "__dec_MSA"] == g[tag + "__code"], axis=1)) or tag == "e9"   # 8 dB: a mix
+
+
+# ---- inputs outside the reference's representable range (tests/golden/abnormal.npz, live reference) ---------------------
+def abnormal_cases(prefix):
+    g = golden("abnormal")
+    return g, [str(n) for n in g["names"] if str(n).startswith(prefix)]
+
+
+def same_nonfinite_pattern(a, b):
+    return (np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(np.isposinf(a), np.isposinf(b)) and
+            np.array_equal(np.isneginf(a), np.isneginf(b)))
+
+
+def test_abnormal_viterbi_nan_inputs():
+    g, names = abnormal_cases("vit_")
+    assert len(names) == 4
+    for key in names:
+        tr = TableTrellis(key[4:key.rindex("_")])
+        got = oracle.viterbi_decode(g[key + "__rx"], tr, None, "soft")
+        assert np.array_equal(got, g[key + "__dec"]), key
+        assert np.isnan(g[key + "__rx"]).any()
+
+
+def test_abnormal_min_sum_nan_llrs():
+    from helpers import ldpc_params
+    g, names = abnormal_cases("msa_")
+    assert len(names) == 2
+    for key in names:
+        p = ldpc_params(key[4:])
+        dec, out = oracle.ldpc_bp_decode(g[key + "__llr"].copy(), p, "MSA", int(g[key + "__iters"]))
+        assert np.array_equal(np.isnan(out), np.isnan(g[key + "__out"])), key
+        assert np.array_equal(out, g[key + "__out"], equal_nan=True), key
+        assert np.array_equal(dec, g[key + "__dec"]), key
+        assert np.isnan(g[key + "__out"]).any()
+
+
+def test_abnormal_map_decode_regimes():
+    g, names = abnormal_cases("map_")
+    assert len(names) == 55
+    nonfinite = 0
+    for nm in names:
+        key, tname = nm.split("|")
+        tr = TableTrellis(tname)
+        s_, p_, L, nv = g[key + "__sys"], g[key + "__par"], g[key + "__Lint"], float(g[key + "__nv"])
+        for b in range(s_.shape[0]):
+            Lo, bo = oracle.map_decode(s_[b], p_[b], tr, nv, L[b], "decode")
+            ref = g[key + "__L"][b]
+            assert same_nonfinite_pattern(Lo, ref), (key, b)
+            fin = np.isfinite(ref)
+            nonfinite += int(np.sum(~fin))
+            assert np.all(np.abs(Lo[fin] - ref[fin]) <= 1e-9 + 1e-9 * np.abs(ref[fin])), (key, b)
+            assert np.array_equal(bo, g[key + "__bits"][b]), (key, b)
+    assert nonfinite > 300
+
+
+def test_abnormal_turbo_decode_regimes():
+    from helpers import Perm
+    g, names = abnormal_cases("tur_")
+    assert len(names) == 10
+    tr = TableTrellis("rsc_legacy_4")
+    for key in names:
+        nv, iters, has_L = g[key + "__par"]
+        for b in range(g[key + "__sys"].shape[0]):
+            got = oracle.turbo_decode(g[key + "__sys"][b], g[key + "__p1"][b], g[key + "__p2"][b], tr, float(nv), int(iters),
+                                      Perm(g[key + "__perm"]), g[key + "__Lint"][b] if has_L else None)
+            assert np.array_equal(got, g[key + "__dec"][b]), (key, b)
