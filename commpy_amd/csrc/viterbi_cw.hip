@@ -415,10 +415,17 @@ __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_acs_kernel(CwParams
 // store per codeword and half-tile.  HBM traffic is the algorithmic one again (the two-kernel path moves 9 B per
 // codeword-step through a workspace and back).
 constexpr int FR_RING = 32, FR_CHUNK = 96, FR_OBPAD = 100;     // ring slots (mirrored), steps per flush (a multiple of LGS), tile row bytes
+// Traceback depths above the default (tb_depth 31 .. 48 for K = 7) run the same kernel on a ring of FR_RING_DEEP slots that is
+// NOT mirrored -- the same LDS per wave (64 slots once instead of 32 twice) --: a walk's words then wrap around the ring and
+// every hop forms its own LDS address, ((q - h) mod 64) * 512 + lane * 8: one more vector add per hop (+6 % per step with 46
+// hops).  Round 2 sent these depths to the two-kernel form (1.66 x the time: decision words through HBM and back).
+constexpr int FR_RING_DEEP = 64;
 
-template <int LGS>
+// slots of one wave: the ring (twice if mirrored) + one dummy slot per copy for steps > T
+template <int RING, bool MIR> constexpr int fused_slots() { return MIR ? 2 * RING + 2 : RING + 1; }
+template <int RING, bool MIR>
 constexpr size_t fused_wave_lds() {
-    return (size_t)(2 * FR_RING + 2) * 64 * 8 + (size_t)64 * FR_OBPAD;   // ring + two dummy slots for steps > T, staging tile
+    return (size_t)fused_slots<RING, MIR>() * 64 * 8 + (size_t)64 * FR_OBPAD;   // ring + dummy slot(s), staging tile
 }
 
 // The traceback walk of one step, cut into four batches of hops that cw_step's hook runs between the phases of the NEXT
@@ -427,17 +434,23 @@ constexpr size_t fused_wave_lds() {
 // of the step: +0.5 ms).  sched_barrier pins the batches where they are put.
 // RT: the number of hops is a run-time value hr <= H (traceback depths below the default): hops h >= hr leave the state alone
 // (one v_cndmask each, +4 % per step); their LDS reads still go to valid, older ring slots.
-template <int LGS, int H, bool RT = false>
+template <int LGS, int H, bool RT = false, int RING = FR_RING, bool MIR = true>
 struct WalkHook {
     static constexpr int NB = 4, PER = (H + NB - 1) / NB;
-    const unsigned long long *pw;           // ring pointer of the walked step t': word of step t' - h at pw[(FR_RING - h) * 64]
+    // MIR: ring pointer of the walked step t': word of step t' - h at pw[(RING - h) * 64].  Not mirrored: pw = this lane's
+    // column, q = ring slot of step t' (wave-uniform), word of step t' - h at pw[((q - h) mod RING) * 64].
+    const unsigned long long *pw;
+    int q;
     mutable unsigned st;                    // state of the walk
     int hr;                                 // hops to execute (RT only)
     mutable unsigned long long buf[PER];
+    __device__ __forceinline__ unsigned long long word(int h) const {
+        return MIR ? pw[(RING - h) * 64] : pw[((q - h) & (RING - 1)) * 64];
+    }
     template <int B> __device__ __forceinline__ void issue() const {
 #pragma unroll
         for (int i = 0; i < PER; i++)
-            if (B * PER + i < H) buf[i] = pw[(FR_RING - (B * PER + i)) * 64];
+            if (B * PER + i < H) buf[i] = word(B * PER + i);
     }
     template <int B> __device__ __forceinline__ void hops() const {
 #pragma unroll
@@ -464,10 +477,10 @@ struct WalkHook {
     }
 };
 
-template <int LGS, unsigned G0, unsigned G1, int TYPE, int HT, bool RT = false, class F = double>
+template <int LGS, unsigned G0, unsigned G1, int TYPE, int HT, bool RT = false, class F = double, int RING = FR_RING, bool MIR = true>
 __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_fused_kernel(CwParams p) {
     constexpr int S = 1 << LGS, FR_GROUPS = FR_CHUNK / LGS, CHUNK = FR_GROUPS * LGS;
-    static_assert(HT >= 0 && HT + 1 <= FR_RING && CHUNK + 1 <= FR_OBPAD, "ring / tile too small");
+    static_assert(HT >= 0 && HT + 1 <= RING && (RING & (RING - 1)) == 0 && CHUNK + 1 <= FR_OBPAD, "ring / tile too small");
     const int H = RT ? p.tb - 2 : HT;                                              // hops of a walk = tb_depth - 2
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -476,8 +489,8 @@ __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_fused_kernel(CwPara
     if (grp * 64 >= p.B) return;                                                   // whole wave beyond the batch
     const bool valid = cw < p.B;
     const double *x = p.coded + (valid ? cw : 0) * p.len;
-    unsigned long long *ring = reinterpret_cast<unsigned long long *>(smem + (size_t)wv * fused_wave_lds<LGS>());
-    unsigned char *obuf = reinterpret_cast<unsigned char *>(ring + (2 * FR_RING + 2) * 64);
+    unsigned long long *ring = reinterpret_cast<unsigned long long *>(smem + (size_t)wv * fused_wave_lds<RING, MIR>());
+    unsigned char *obuf = reinterpret_cast<unsigned char *>(ring + fused_slots<RING, MIR>() * 64);
     unsigned long long *mycol = ring + lane;                                       // slot s of this lane's codeword: mycol[s * 64]
     unsigned char *myrow = obuf + lane * FR_OBPAD;
 
@@ -496,8 +509,9 @@ __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_fused_kernel(CwPara
     for (int u = 0; u < LGS; u++) cur[u] = load(1 + u);
     int best_T = 0;                                                               // first-argmin state of step T
     unsigned long long nanmask = 0;                                               // 'soft': lanes that received a NaN
-    WalkHook<LGS, HT, RT> walk;                                                        // walk of the previous step (step 0: a dummy)
+    WalkHook<LGS, HT, RT, RING, MIR> walk;                                             // walk of the previous step (step 0: a dummy)
     walk.pw = mycol;
+    walk.q = 0;
     walk.st = 0;
     walk.hr = H;
 
@@ -553,17 +567,23 @@ __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_fused_kernel(CwPara
                 cw_step<LGS, G0, G1, TYPE, R>(pm, r0, r1, word, bst, walk);      // + hops 0 .. 3/4 H of the walk of step tt - 1
                 walk.finish();
                 myrow[g * LGS + R] = (unsigned char)((walk.st >> (LGS - 1)) & 1u);   // input bit of the branch into the state at step tt - 1 - H
-                // ring slot of step tt and its mirror FR_RING slots above; the (at most LGS - 1) steps > T of the last group
+                // ring slot of step tt and (mirrored ring) its copy RING slots above; the (at most LGS - 1) steps > T of the last group
                 // write to two dummy slots instead: the ring must keep the words of steps T-H+1 .. T for the final walk
                 const bool live = tt <= T;
-                const int q = tt & (FR_RING - 1);
+                const int q = tt & (RING - 1);
                 unsigned long long *wb = mycol + q * 64;
-                unsigned long long *w0 = live ? wb : mycol + (2 * FR_RING) * 64;
-                unsigned long long *w1 = live ? wb + FR_RING * 64 : mycol + (2 * FR_RING + 1) * 64;
-                *w0 = word;
-                *w1 = word;
+                if constexpr (MIR) {
+                    unsigned long long *w0 = live ? wb : mycol + (2 * RING) * 64;
+                    unsigned long long *w1 = live ? wb + RING * 64 : mycol + (2 * RING + 1) * 64;
+                    *w0 = word;
+                    *w1 = word;
+                    walk.pw = wb;                                                 // next: the walk of this step
+                } else {
+                    unsigned long long *w0 = live ? wb : mycol + RING * 64;
+                    *w0 = word;
+                    walk.q = q;
+                }
                 best_T = (tt == T) ? bst : best_T;
-                walk.pw = wb;                                                     // next: the walk of this step
                 walk.st = (unsigned)bst;
             };
             if constexpr (LGS >= 1) one(std::integral_constant<int, 0>{});
@@ -578,7 +598,7 @@ __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_fused_kernel(CwPara
         int n = ngroups * LGS;
         if (tc0 + CHUNK > T) {                                                     // last chunk: finish the pending walk (of its last step)
             unsigned st = walk.st;
-            for (int h = 0; h < H; h++) st = tb_hop<LGS>(walk.pw[(FR_RING - h) * 64], st);
+            for (int h = 0; h < H; h++) st = tb_hop<LGS>(walk.word(h), st);
             myrow[n] = (unsigned char)((st >> (LGS - 1)) & 1u);
             n++;
         }
@@ -588,13 +608,13 @@ __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_fused_kernel(CwPara
         if (valid) p.nanflags[cw] = (uint8_t)((nanmask >> lane) & 1ull);
     // the last H output steps: one walk from best[T]; the state before hop h is the state of step T - h
     if (valid) {
-        const int qT = T & (FR_RING - 1);
+        const int qT = T & (RING - 1);
         unsigned st = (unsigned)best_T;
         for (int h = 0; h < H; h++) {
             const int so = T - h;
             if (so < 1) break;
             if (so - 1 < p.L) p.bits[cw * p.L + so - 1] = (uint8_t)((st >> (LGS - 1)) & 1u);
-            st = tb_hop<LGS>(mycol[(qT + FR_RING - h) * 64], st);
+            st = tb_hop<LGS>(mycol[((qT - h) & (RING - 1)) * 64], st);
         }
     }
 }
@@ -692,10 +712,14 @@ void launch(const CwParams &p, size_t tb_lds, hipStream_t st) {
 // (convcode.py:701); every smaller depth runs it with a run-time hop count
 template <int LGS> constexpr int fused_tb() { return 5 * LGS; }
 
-template <int LGS, unsigned G0, unsigned G1, int TYPE, bool RT, class F>
+// ... and up to this depth on the deep ring (run-time hop count, float64 metrics only)
+template <int LGS> constexpr int fused_tb_deep() { return 8 * LGS; }
+
+template <int LGS, unsigned G0, unsigned G1, int TYPE, bool RT, class F, bool DEEP = false>
 int launch_fused_typed(const CwParams &p, hipStream_t st) {
-    auto *fn = viterbi_cw_fused_kernel<LGS, G0, G1, TYPE, fused_tb<LGS>() - 2, RT, F>;
-    const size_t lds = ACS_WAVES * fused_wave_lds<LGS>();
+    constexpr int RING = DEEP ? FR_RING_DEEP : FR_RING;
+    auto *fn = viterbi_cw_fused_kernel<LGS, G0, G1, TYPE, (DEEP ? fused_tb_deep<LGS>() : fused_tb<LGS>()) - 2, RT, F, RING, !DEEP>;
+    const size_t lds = ACS_WAVES * fused_wave_lds<RING, !DEEP>();
     static bool raised[64] = {};                                 // > 64 KiB of dynamic LDS is opt-in, once per kernel and device
     static std::mutex raised_mu;                                 // host threads may launch concurrently (ctypes drops the GIL)
     int dev = 0;
@@ -716,6 +740,11 @@ int launch_fused_typed(const CwParams &p, hipStream_t st) {
 // the default depth runs the compile-time walk; smaller depths the same kernel with a run-time hop count
 template <int LGS, unsigned G0, unsigned G1, class F>
 int launch_fused(const CwParams &p, hipStream_t st) {
+    if (p.tb > fused_tb<LGS>()) {
+        if (p.type == CPX_VIT_HARD) return launch_fused_typed<LGS, G0, G1, CPX_VIT_HARD, true, double, true>(p, st);
+        if (p.type == CPX_VIT_SOFT) return launch_fused_typed<LGS, G0, G1, CPX_VIT_SOFT, true, double, true>(p, st);
+        return launch_fused_typed<LGS, G0, G1, CPX_VIT_UNQUANTIZED, true, double, true>(p, st);
+    }
     const bool rt = p.tb != fused_tb<LGS>();
     if (p.type == CPX_VIT_HARD) return rt ? launch_fused_typed<LGS, G0, G1, CPX_VIT_HARD, true, F>(p, st) : launch_fused_typed<LGS, G0, G1, CPX_VIT_HARD, false, F>(p, st);
     if (p.type == CPX_VIT_SOFT) return rt ? launch_fused_typed<LGS, G0, G1, CPX_VIT_SOFT, true, F>(p, st) : launch_fused_typed<LGS, G0, G1, CPX_VIT_SOFT, false, F>(p, st);
@@ -790,11 +819,14 @@ bool viterbi_codeword_path(const cpx_trellis *t, const double *d_coded, int64_t 
     const bool f32 = precision_fast() && T < (1ll << 22);
 #define CPX_TRY(LG, GA, GB)                                                                                         \
     if (tables_match<LG, GA, GB>(t)) {                                                                              \
-        if (tb >= 2 && tb <= fused_tb<LG>() && !two_kernels &&                                                      \
+        if (tb >= 2 && tb <= fused_tb_deep<LG>() && !two_kernels &&                                                 \
             (f32 ? launch_fused<LG, GA, GB, float>(p, st) : launch_fused<LG, GA, GB, double>(p, st))) {                 \
+            const bool deep = tb > fused_tb<LG>();                                                                  \
             if (hipGetLastError() != hipSuccess) { set_error("viterbi (fused codeword path): launch failed"); *rc = CPX_EHIP; } \
-            note_kernel("viterbi_cw_fused_kernel<%d,0%o,0%o,%s,%d%s%s>", LG, GA, GB, type_name(type), fused_tb<LG>() - 2,     \
-                        tb == fused_tb<LG>() ? "" : ",runtime hops", f32 ? ",f32" : "");                               \
+            note_kernel("viterbi_cw_fused_kernel<%d,0%o,0%o,%s,%d%s%s>", LG, GA, GB, type_name(type),                    \
+                        (deep ? fused_tb_deep<LG>() : fused_tb<LG>()) - 2,                                            \
+                        deep ? ",runtime hops,64-slot ring" : tb == fused_tb<LG>() ? "" : ",runtime hops",              \
+                        (f32 && !deep) ? ",f32" : "");                                                              \
             return true;                                                                                            \
         }                                                                                                           \
         void *w0 = nullptr, *w1 = nullptr;                                                                          \
@@ -813,6 +845,8 @@ bool viterbi_codeword_path(const cpx_trellis *t, const double *d_coded, int64_t 
     // (133,171) -> (155,117).
     CPX_TRY(6, 0155u, 0117u)      // K = 7 (133,171), commpy default format: 802.11 / BASELINE configs 2 and 5
     CPX_TRY(6, 0117u, 0155u)      // K = 7 (171,133)
+    CPX_TRY(6, 0133u, 0171u)      // K = 7 (133,171) written with polynomial_format='LSB' (convcode.py:216-222)
+    CPX_TRY(6, 0171u, 0133u)      // K = 7 (171,133), 'LSB'
     // Wifi80211 as shipped: its generators are written in DECIMAL, (133, 171), and dec2bitarray wraps them to (5, 43)
     // (wifi80211.py:49, utilities.py:81-85) -- 0000101 / 0101011, bit-reversed 0120 / 0152.  The reference's
     // own link simulation (BASELINE config 5 with default arguments) decodes this 64-state code.

@@ -1,6 +1,6 @@
 """The codeword-per-lane Viterbi path (csrc/viterbi_cw.hip) against the reference goldens, the CPU oracle and the
 state-per-lane kernels -- bit-exact for every decoding type.  cpx_viterbi_set_path forces a path: "cw!" = codeword path or
-fail (the fused single kernel when tb_depth = 30, else ACS + traceback kernels), "cw2!" = always the two-kernel form,
+fail (the fused single kernel for tb_depth <= 48, else ACS + traceback kernels), "cw2!" = always the two-kernel form,
 "wave" = state-per-lane kernels."""
 import os
 
@@ -99,7 +99,35 @@ def test_random_batches_vs_oracle(gpu, dtype, B, nbits, tb):
         assert np.array_equal(_decode(rx, tr, tb, dtype, path), want), (dtype, B, nbits, tb, path)
 
 
-@pytest.mark.parametrize("gm,fmt", [([[0o133, 0o171]], "MSB"), ([[0o171, 0o133]], "MSB")])
+@pytest.mark.parametrize("dtype", ["hard", "soft", "unquantized"])
+@pytest.mark.parametrize("tb", [31, 36, 47, 48, 49])
+def test_deep_traceback_stays_in_the_fused_kernel(gpu, dtype, tb):
+    """tb_depth 31 .. 48 (K = 7): the fused kernel on its 64-slot ring (round 2: two-kernel form); 49 and above: two kernels.
+    Ragged batch, block lengths around the flush period, a NaN codeword ('soft'), against the oracle and the other paths."""
+    from commpy_amd import _lib
+    from commpy_amd.channelcoding import conv_encode_batch
+    tr = make_trellis("k7_133_171")
+    for B, nbits in ((70, 96), (5, 200), (129, 50), (64, 1024 if tb == 48 else 97)):
+        rs = np.random.RandomState(100 * tb + nbits)
+        coded = conv_encode_batch(rs.randint(0, 2, (B, nbits)), tr).astype(float)
+        if dtype == "hard":
+            rx = np.where(rs.rand(*coded.shape) < 0.08, 1 - coded, coded)
+        elif dtype == "soft":
+            rx = 4.0 * coded - 2 + rs.randn(*coded.shape) * 2.0
+            rx[B // 2, rs.randint(rx.shape[1])] = np.nan
+        else:
+            rx = 2.0 * coded - 1 + rs.randn(*coded.shape) * 0.8
+        want = oracle.viterbi_decode(rx, tr, tb, dtype)
+        got = _decode(rx, tr, tb, dtype, "cw!")
+        note = _lib.last_kernel()
+        assert ("64-slot ring" in note) == (tb <= 48) and ("viterbi_cw_acs_kernel" in note) == (tb > 48), note
+        assert np.array_equal(got, want), (dtype, tb, B, nbits, "cw!")
+        for path in ("cw2!", "wave"):
+            assert np.array_equal(_decode(rx, tr, tb, dtype, path), want), (dtype, tb, B, nbits, path)
+
+
+@pytest.mark.parametrize("gm,fmt", [([[0o133, 0o171]], "MSB"), ([[0o171, 0o133]], "MSB"), ([[0o133, 0o171]], "LSB"),
+                                    ([[0o171, 0o133]], "LSB")])
 def test_all_instantiated_generators(gpu, gm, fmt):
     from commpy_amd.channelcoding import Trellis, conv_encode_batch
     try:
