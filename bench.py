@@ -64,6 +64,21 @@ def usable_cores():
     return n
 
 
+def _git_head():
+    """Commit the tree was taken from: `git rev-parse` here, .git_head (scripts/run_gpu_round.sh) on the GPU box, else None."""
+    import subprocess
+    try:
+        h = subprocess.run(["git", "rev-parse", "HEAD"], cwd=ROOT, capture_output=True, text=True, timeout=20).stdout.strip()
+        if h:
+            return h
+    except Exception:
+        pass
+    try:
+        return open(os.path.join(ROOT, ".git_head")).read().strip() or None
+    except OSError:
+        return None
+
+
 def _find_reference():
     """Directory that holds the UNMODIFIED reference package `commpy` (veeresht/CommPy), or None.  Looked for in
     $CPX_REFERENCE_PATH, then /root/reference (the build container; absent on the GPU box), then sys.path."""
@@ -431,14 +446,17 @@ def main():
                            else "no data-path collective"),
                        "collectives": ("engine RCCL binding (cpx_comm_*)" if comm is not None else
                                        "torch.distributed (nccl)" if dist is not None else "none (single process)")},
-            "ber": ber, "oracle_mismatched_bits": mism, "oracle_sample_codewords": checked, "build_id": build,
+            "ber": ber, "oracle_mismatched_bits": mism, "oracle_sample_codewords": checked, "build_id": build, "git_head": _git_head(),
             "demod_max_abs_err_vs_oracle": demod_err,
             # the kernel is bound by VALU issue, not by HBM: achieved / peak / frac are the HBM figures the
             # contract asks for, `valu` carries the ceiling that actually binds (from the PMC passes in profiles/)
             "roofline": {"bound": "valu", "kernel": kernel_name, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src,
-                         "kernel_ms_avg": kavg,
+                         "kernel_ms_avg": kavg, "kernel_ms_min": float(np.min(kernel_ms)),
+                         "kernel_ms_median": float(np.median(kernel_ms)),
+                         "kernel_ms_scope": "HIP events around one decode call on its stream: the decoder kernel plus the "
+                                            "NaN-redo launch that follows it (~4 us when nothing is flagged)",
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_CW * B,
                          "valu": valu,
                          "note": "serial float64 add-compare-select recursion: VALU-issue bound (valu.busy_frac), the HBM "

@@ -102,7 +102,12 @@ def main():
     try:
         head = subprocess.run(["git", "rev-parse", "HEAD"], cwd=root, capture_output=True, text=True, timeout=20).stdout.strip() or None
     except Exception:
-        head = None                                    # the GPU box receives the tree without .git
+        head = None
+    if not head:                                       # the GPU box receives the tree without .git: scripts/run_gpu_round.sh
+        try:                                           # stamps the commit (and whether the tree was dirty) into .git_head
+            head = open(os.path.join(root, ".git_head")).read().strip() or None
+        except OSError:
+            head = None
     try:
         sys.path.insert(0, root)
         from commpy_amd import _lib

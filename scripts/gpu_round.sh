@@ -4,7 +4,7 @@
 #   sections: t(ests) s(moke) b(ench.py) d(ist: torchrun N=1 over the engine's RCCL binding) k(ernel benches)
 #             l(ink + host-api + multi-GPU benches) v(iterbi PMC passes) u(turbo/map PMC passes) m(demod PMC passes)
 #             x(ldpc PMC passes) r(octx marker trace of the host-API benchmark, CPX_TRACE=1)
-TAG=${1:-r02}
+TAG=${1:-r03}
 SEC=${2:-tsbdklvu}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
