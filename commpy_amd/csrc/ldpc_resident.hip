@@ -68,9 +68,6 @@ struct ResParams {
 typedef __attribute__((address_space(3))) double lds_f64;
 __device__ __forceinline__ double ldsd(int off) { return *reinterpret_cast<lds_f64 *>((unsigned)off); }
 __device__ __forceinline__ void stsd(int off, double v) { *reinterpret_cast<lds_f64 *>((unsigned)off) = v; }
-__device__ __forceinline__ void min_in_place(double &acc, double v) {   // one v_min_f64, no copy (fmin adds two canonicalising v_max)
-    asm("v_min_f64 %0, %0, %1" : "+v"(acc) : "v"(v));
-}
 
 // ---- min-sum check node (:229-238 after :244-245): m_j = Q[v_j] - R_j;  R_j <- prod_{i != j} sign(m_i) * min_{i != j} |m_i| ----
 // CQ > 0: rows of at most 4 CQ entries, fully unrolled.  The messages are written from (min1, min2, argmin, signs), exactly
@@ -80,42 +77,56 @@ __device__ __forceinline__ void check_msa(const ResParams &p, int c, int *flag) 
     const int4 *__restrict__ qv = reinterpret_cast<const int4 *>(p.row_q + (int64_t)c * p.cpad);
     const int rb = p.roff + 8 * c * p.rstride;
     int sx = 0, imin = 0;
-    unsigned neg = 0;
+    unsigned neg = 0;                                            // sign bits, shifted in from the right: edge j ends at bit N - 1 - j
     double m1 = __builtin_huge_val(), m2 = __builtin_huge_val();
     constexpr int NQ = CQ > 0 ? CQ : 1;
-#define CPX_MSA_IN(j, qoff)                                                                            \
+    // One edge: seven instructions.  |m| never exists as a value -- the compare and the min / max take it as an operand modifier --;
+    // the second minimum needs no select: the candidate is the LARGER of (first minimum so far, |m|) either way; the sign goes into
+    // `neg` with one v_alignbit (the sign BIT: a message of -0.0 counts as negative, which only changes the sign of zero messages
+    // -- never observable: a column sum starts from +0.0 and a row with a zero sends +-0.0 to everyone else).  Round 2 spent 14:
+    // |m| materialised (and + mov), a 64-bit select for the second minimum, compare / select / or for the sign, with s_nops between.
+#define CPX_MSA_IN(j, q, JC)                                                                              \
     {                                                                                                  \
-        const double q = ldsd(qoff);                                                                   \
-        sx ^= __double2hiint(q);                                 /* dec_word = out_llrs < 0 (:193, :248) */ \
-        const double m = ldsd(rb + 8 * (j)) * -1.0 + q;          /* data * -1 + 1.0 * (msg_sum + llr) (:244-245); first pass -0.0 + q (:199) */ \
-        const double a = fabs(m);                                                                      \
-        const bool c1 = a < m1;                                                                        \
-        min_in_place(m2, c1 ? m1 : a);                                                                 \
-        min_in_place(m1, a);                                                                           \
-        imin = c1 ? (j) : imin;                                                                        \
-        neg |= (m < 0.0) ? (1u << (j)) : 0u;                                                           \
+        const double m = ldsd(rb + 8 * (j)) * -1.0 + (q);        /* data * -1 + 1.0 * (msg_sum + llr) (:244-245); first pass -0.0 + q (:199) */ \
+        double big;                                                                                    \
+        /* one statement: three instructions sit between the float64 compare and the select that reads its mask (back to back */ \
+        /* the pair costs two wait states), and the old first minimum is read by compare and max before the min overwrites it */ \
+        asm("v_cmp_lt_f64 vcc, |%5|, %0\n\tv_max_f64 %4, %0, |%5|\n\tv_min_f64 %0, %0, |%5|\n\t"               \
+            "v_alignbit_b32 %2, %2, %6, 31\n\tv_cndmask_b32_e64 %3, %3, %7, vcc\n\tv_min_f64 %1, %1, %4"      \
+            : "+v"(m1), "+v"(m2), "+v"(neg), "+v"(imin), "=&v"(big)                                     \
+              : "v"(m), "v"(__double2hiint(m)), JC(j) : "vcc");                                        \
     }
+    // four edges: the gathers, the syndrome parity of their sign words (dec_word = out_llrs < 0, :193, :248) as two 3-input xors
+#define CPX_MSA_IN4(t, a, JC)                                                                            \
+    {                                                                                                  \
+        const double q0 = ldsd((a).x), q1 = ldsd((a).y), q2 = ldsd((a).z), q3 = ldsd((a).w);           \
+        asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(sx) : "v"(__double2hiint(q0)), "v"(__double2hiint(q1))); \
+        asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(sx) : "v"(__double2hiint(q2)), "v"(__double2hiint(q3))); \
+        CPX_MSA_IN(4 * (t) + 0, q0, JC) CPX_MSA_IN(4 * (t) + 1, q1, JC) CPX_MSA_IN(4 * (t) + 2, q2, JC) CPX_MSA_IN(4 * (t) + 3, q3, JC) \
+    }
+    int N;                                                       // entries shifted into `neg`
     if (CQ > 0) {
         int4 a[NQ];
 #pragma unroll
         for (int t = 0; t < NQ; t++) a[t] = qv[t];
 #pragma unroll
-        for (int t = 0; t < NQ; t++) {
-            CPX_MSA_IN(4 * t + 0, a[t].x) CPX_MSA_IN(4 * t + 1, a[t].y) CPX_MSA_IN(4 * t + 2, a[t].z) CPX_MSA_IN(4 * t + 3, a[t].w)
-        }
+        for (int t = 0; t < NQ; t++) CPX_MSA_IN4(t, a[t], "n")    // edge number: an inline constant
+        N = 4 * NQ;
     } else {
         const int nq = p.cpad >> 2;
         for (int t = 0; t < nq; t++) {
             const int4 a = qv[t];
-            CPX_MSA_IN(4 * t + 0, a.x) CPX_MSA_IN(4 * t + 1, a.y) CPX_MSA_IN(4 * t + 2, a.z) CPX_MSA_IN(4 * t + 3, a.w)
+            CPX_MSA_IN4(t, a, "v")                               // ... a register
         }
+        N = 4 * nq;
     }
+#undef CPX_MSA_IN4
 #undef CPX_MSA_IN
     if (sx < 0) *flag = 1;                                       // odd row: this iteration is executed (:205)
     // every entry of the row (padding included: its slot is never gathered) gets +-min1, then the argmin's own entry +-min2
-    const unsigned negp = (__popc(neg) & 1) ? ~neg : neg;        // bit j: sign of the product of the OTHER messages
+    const unsigned negp = (__popc(neg) & 1) ? ~neg : neg;        // bit N-1-j: sign of the product of the OTHER messages
     const int h1 = __double2hiint(m1), l1 = __double2loint(m1);
-#define CPX_MSA_OUT(j) stsd(rb + 8 * (j), __hiloint2double(h1 | (int)(((negp >> (j)) & 1u) << 31), l1));
+#define CPX_MSA_OUT(j) stsd(rb + 8 * (j), __hiloint2double(h1 | (int)((negp << (32 - N + (j))) & 0x80000000u), l1));
     if (CQ > 0) {
 #pragma unroll
         for (int j = 0; j < 4 * NQ - 4; j++) CPX_MSA_OUT(j)      // rstride > 4 (NQ - 1): these positions always belong to the row
@@ -126,7 +137,7 @@ __device__ __forceinline__ void check_msa(const ResParams &p, int c, int *flag) 
         for (int j = 0; j < p.rstride; j++) CPX_MSA_OUT(j)
     }
 #undef CPX_MSA_OUT
-    stsd(rb + 8 * imin, __hiloint2double(__double2hiint(m2) | (int)(((negp >> imin) & 1u) << 31), __double2loint(m2)));
+    stsd(rb + 8 * imin, __hiloint2double(__double2hiint(m2) | (int)((negp << (32 - N + imin)) & 0x80000000u), __double2loint(m2)));
 }
 
 // ---- sum-product check node (:209-227): one division per edge, exact-order redo of rows near saturation (ldpc_dev.h);
@@ -204,7 +215,11 @@ __global__ __launch_bounds__(1024, 6) void ldpc_resident_kernel(ResParams p) {
     };
     if (tid == 0) {
         stsd(8 * p.n_v, __builtin_huge_val());                   // dummy Q (row padding)
-        stsd(p.roff + 8 * p.n_r, 0.0);                           // dummy R (column padding)
+        // dummy R (column padding) and the slack behind it: the padded entries of the LAST row read up to three slots past its
+        // stride.  They must hold numbers: a padded entry is m = -R + inf, and min-sum's check node (v_max / v_min return the
+        // other operand for a NaN) is only right when that is +inf, never NaN (uninitialised LDS: a wrong second minimum and
+        // a flipped row parity whenever the previous kernel had left a NaN pattern there)
+        for (int i = 0; i < 5; i++) stsd(p.roff + 8 * (p.n_r + i), 0.0);
         ctl[0] = 0; ctl[1] = 0;                                  // "unsatisfied" flags of the first block
         ctl[3] = 0;                                              // "a NaN among the LLRs of the current block"
         pop();
