@@ -39,7 +39,7 @@ def main():
                 for rep in range(3):
                     _lib.check(lib.cpx_memcpy_h2d(d_llr, _lib.ptr(llr), llr.nbytes))
                     lib.cpx_timer_start(tm, None)
-                    _lib.check(lib.cpx_ldpc_bp_decode_batch_dev(code, d_llr, B, alg, 50, d_dec, d_out, d_it, None))
+                    _lib.check(lib.cpx_ldpc_bp_decode_batch_bm_dev(code, d_llr, B, alg, 50, d_dec, d_out, d_it, None))
                     lib.cpx_timer_stop(tm, None)
                     v = ctypes.c_float()
                     lib.cpx_timer_elapsed_ms(tm, ctypes.byref(v))
