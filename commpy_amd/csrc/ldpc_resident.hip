@@ -72,8 +72,9 @@ __device__ __forceinline__ void stsd(int off, double v) { *reinterpret_cast<lds_
 // ---- min-sum check node (:229-238 after :244-245): m_j = Q[v_j] - R_j;  R_j <- prod_{i != j} sign(m_i) * min_{i != j} |m_i| ----
 // CQ > 0: rows of at most 4 CQ entries, fully unrolled.  The messages are written from (min1, min2, argmin, signs), exactly
 // sign(other).prod() * abs(other).min(): a zero among the others makes the minimum zero by itself.
+// `held`: the row's offset table already in registers (CQ > 0, see the kernel), else null
 template <int CQ>
-__device__ __forceinline__ void check_msa(const ResParams &p, int c, int *flag) {
+__device__ __forceinline__ void check_msa(const ResParams &p, int c, int *flag, const int4 *held = nullptr) {
     const int4 *__restrict__ qv = reinterpret_cast<const int4 *>(p.row_q + (int64_t)c * p.cpad);
     const int rb = p.roff + 8 * c * p.rstride;
     int sx = 0, imin = 0;
@@ -108,7 +109,7 @@ __device__ __forceinline__ void check_msa(const ResParams &p, int c, int *flag) 
     if (CQ > 0) {
         int4 a[NQ];
 #pragma unroll
-        for (int t = 0; t < NQ; t++) a[t] = qv[t];
+        for (int t = 0; t < NQ; t++) a[t] = held ? held[t] : qv[t];
 #pragma unroll
         for (int t = 0; t < NQ; t++) CPX_MSA_IN4(t, a[t], "n")    // edge number: an inline constant
         N = 4 * NQ;
@@ -182,15 +183,21 @@ __device__ __forceinline__ void check_spa(const ResParams &p, int c, int *flag) 
 }
 
 // ---- variable node, both algorithms: column sum in increasing check order + llr (:243-247) ----------
-__device__ __forceinline__ void var_node(const ResParams &p, int v, const double *__restrict__ lrow) {
+// `a0`, `l`: the first four column entries and the channel LLR of the variable, requested by the caller one round ahead (the
+// first round's before the barrier that ends the check pass): a variable of degree <= 4 -- most of them -- starts its LDS gathers
+// without waiting for memory.
+__device__ __forceinline__ void var_node(const ResParams &p, int v, int4 a0, double l) {
     const int trips = p.vgrp[__builtin_amdgcn_readfirstlane(v) >> 6];      // the lanes of a wavefront hold 64 consecutive variables
     const int4 *__restrict__ rf = reinterpret_cast<const int4 *>(p.col_r + (int64_t)v * p.vpad);
-    const double l = lrow[v];
     double msum = 0.0;
-    for (int t = 0; t < trips; t++) {
+    {
+        const double r0 = ldsd(a0.x), r1 = ldsd(a0.y), r2 = ldsd(a0.z), r3 = ldsd(a0.w);
+        msum += r0; msum += r1; msum += r2; msum += r3;          // message_matrix.sum(0); padding adds +0.0 to a sum that is never -0.0
+    }
+    for (int t = 1; t < trips; t++) {
         const int4 a = rf[t];
         const double r0 = ldsd(a.x), r1 = ldsd(a.y), r2 = ldsd(a.z), r3 = ldsd(a.w);
-        msum += r0; msum += r1; msum += r2; msum += r3;          // message_matrix.sum(0); padding adds +0.0 to a sum that is never -0.0
+        msum += r0; msum += r1; msum += r2; msum += r3;
         // (skipping the entries nobody in the wavefront has -- wave-uniform branches around the reads, same for the 12th row
         //  position in check_msa -- saves 10 % of the LDS traffic and measured 3.55 instead of 2.30 ms: the branches fence the
         //  scheduler and every read waits alone)
@@ -225,6 +232,18 @@ __global__ __launch_bounds__(1024, 6) void ldpc_resident_kernel(ResParams p) {
         pop();
     }
     __syncthreads();
+    // Min-sum with unrolled rows, all checks in one round (thread = check for the whole launch): the row's table of Q addresses
+    // stays in registers.  Read from memory in every check pass it was three dependent 16-byte loads in front of the first LDS
+    // gather of every wave and iteration, and 31 KB per block-iteration through the vector L1.
+    constexpr int HQ = (ALG == CPX_LDPC_MSA && CQ > 0 && CQ <= 3) ? CQ : 1;   // (rows of 13 .. 16 entries: the 16 registers would spill)
+    const bool held_rows = ALG == CPX_LDPC_MSA && CQ > 0 && CQ <= 3 && p.n_c <= nt;
+    int4 hq[HQ];
+#pragma unroll
+    for (int t = 0; t < HQ; t++) hq[t] = make_int4(0, 0, 0, 0);
+    if (held_rows && tid < p.n_c) {
+#pragma unroll
+        for (int t = 0; t < HQ; t++) hq[t] = reinterpret_cast<const int4 *>(p.row_q + (int64_t)tid * p.cpad)[t];
+    }
     int b = __builtin_amdgcn_readfirstlane(ctl[2]);
     while (b >= 0) {
         double *__restrict__ in = p.llr + (int64_t)b * p.n_v;
@@ -246,14 +265,39 @@ __global__ __launch_bounds__(1024, 6) void ldpc_resident_kernel(ResParams p) {
         int k = 0;
         for (; k < p.max_iter; k++) {
             int *flag = &ctl[k & 1];
-            for (int c = tid; c < p.n_c; c += nt) {
-                if (ALG == CPX_LDPC_MSA) check_msa<CQ>(p, c, flag);
-                else check_spa(p, c, flag);
+            if (ALG == CPX_LDPC_MSA && held_rows) {
+                if (tid < p.n_c) check_msa<CQ>(p, tid, flag, hq);
+            } else {
+                for (int c = tid; c < p.n_c; c += nt) {
+                    if (ALG == CPX_LDPC_MSA) check_msa<CQ>(p, c, flag);
+                    else check_spa(p, c, flag);
+                }
+            }
+            // min-sum: the variable pass's first table entries and channel LLR are requested before the barrier (see var_node);
+            // every variable has a padded table row, so the address is valid for tid < n_v -- else entry 0 is read and not used.
+            // (Sum-product sits at its 80-register cap: the six extra registers spilled and cost 1 %; it loads in the loop.)
+            constexpr bool AHEAD = ALG == CPX_LDPC_MSA;
+            int4 nx = make_int4(0, 0, 0, 0);
+            double nl = 0.0;
+            if (AHEAD) {
+                nx = reinterpret_cast<const int4 *>(p.col_r + (int64_t)(tid < p.n_v ? tid : 0) * p.vpad)[0];
+                nl = in[tid < p.n_v ? tid : 0];
             }
             __syncthreads();
             if (!__builtin_amdgcn_readfirstlane(*flag)) break;   // zero syndrome: the block keeps the Q it has (:205-206)
             if (tid == 0) ctl[(k + 1) & 1] = 0;
-            for (int v = tid; v < p.n_v; v += nt) var_node(p, v, in);
+            for (int v = tid; v < p.n_v; v += nt) {
+                if (AHEAD) {
+                    const int4 a0 = nx;
+                    const double l = nl;
+                    const int vn = v + nt < p.n_v ? v + nt : v;  // (the last round requests its own entry again: no branch around loads)
+                    nx = reinterpret_cast<const int4 *>(p.col_r + (int64_t)vn * p.vpad)[0];
+                    nl = in[vn];
+                    var_node(p, v, a0, l);
+                } else {
+                    var_node(p, v, reinterpret_cast<const int4 *>(p.col_r + (int64_t)v * p.vpad)[0], in[v]);
+                }
+            }
             __syncthreads();
         }
         // Retire: the a-posteriori LLRs (and, for block-major outputs, their sign bits) as one contiguous row -- the layout the
