@@ -280,9 +280,11 @@ __device__ __forceinline__ void load_raw(const Ctx<LGS> &c, const PassIO &io, Ra
 // launch (signed_q below) and a pass reads copysign(Qa, r0), copysign(Qb, r1) where it would read r0, r1: one exp per item
 // and pass -- the prior -- instead of three.
 __device__ __forceinline__ double signed_q(double r, double k4) { return __builtin_copysign(exp(k4 * fabs(r)), r); }
+// P(bit = 0) from the a-priori LLR, as the reference writes it (turbo.py:239)
+__device__ __forceinline__ double prior0(double L) { return 1.0 / (1.0 + exp(L)); }
 
 template <int LGS, bool PRE>
-__device__ __forceinline__ void stage_chunk(const Ctx<LGS> &c, const RawChunk &rc, double nv2) {
+__device__ __forceinline__ void stage_chunk(const Ctx<LGS> &c, const RawChunk &rc, double nv2, int ncw) {
     const int GW = c.GW;
     const double k4 = -4.0 / nv2;
     const double lim = T_A * nv2;
@@ -296,8 +298,12 @@ __device__ __forceinline__ void stage_chunk(const Ctx<LGS> &c, const RawChunk &r
                 const double u0 = fabs(r0) + 1.0, u1 = fabs(r1) + 1.0;
                 flag_or(c.bad, !(u0 * u0 + u1 * u1 <= lim));
             }
-            // priors exactly as the reference forms them (:239-240): e^L may overflow (p0 = 0), 1 - p0 may cancel to 0
-            const double p0 = 1.0 / (1.0 + exp(li)), p1 = 1.0 - p0;
+            // priors exactly as the reference forms them (:239-240): e^L may overflow (p0 = 0), 1 - p0 may cancel to 0.
+            // PRE (turbo_decode): the stage kernel that produced L_int has already evaluated prior0(L_int) -- the same two operations,
+            // in a kernel that waits for memory -- and the slab holds THAT; a pass never needs L_int itself (it writes L - L_int).
+            // That is an exp and a division per item and staging, a quarter of a pass's instructions.  (A codeword slot past the end
+            // of the batch reads zeros: it gets the prior of L_int = 0.)
+            const double p0 = PRE ? (gg < ncw ? li : 0.5) : prior0(li), p1 = 1.0 - p0;
             // sign of the received value; the sign BIT, so that an underflowed factor stored as -0.0 keeps its sign
             const bool n0 = PRE ? __double2hiint(r0) < 0 : r0 < 0.0, n1 = PRE ? __double2hiint(r1) < 0 : r1 < 0.0;
             const double a0 = n0 ? 1.0 : qa, a1 = n0 ? qa : 1.0;  // systematic bit 0 (c0 = -1) / 1 (c0 = +1)
@@ -519,7 +525,7 @@ __device__ void map_pass(const Ctx<LGS> &c, const PassIO &io) {
         double a = (c.s == 0) ? 1.0 : 0.0;                        // f_state_metrics[0][0] = 1 (:221)
         run(0, K1, [&](int i, RawChunk &S) {
             ck_st(i, a);                                          // alpha at time i*CH (read by R in phase 2)
-            stage_chunk<LGS, PRE>(c, S, io.nv2);
+            stage_chunk<LGS, PRE>(c, S, io.nv2, io.ncw);
             fetch(S, i + 2);
             alpha_chunk<LGS, SR, false>(c, a, CH, arow);          // chunks below K1 are full
         });
@@ -529,7 +535,7 @@ __device__ void map_pass(const Ctx<LGS> &c, const PassIO &io) {
             const int len = clen(k);
             double b = ck_ld(k + 1);                              // beta at the upper boundary of chunk k
             epilogue<LGS, !PRE>(c, io, li_prev, t_prev, len_prev);
-            stage_chunk<LGS, PRE>(c, S, io.nv2);
+            stage_chunk<LGS, PRE>(c, S, io.nv2, io.ncw);
             li_prev[0] = S.li[0]; li_prev[1] = S.li[1];
             fetch(S, k + 2);
             alpha_chunk<LGS, SR, true>(c, a, len, arow);
@@ -543,7 +549,7 @@ __device__ void map_pass(const Ctx<LGS> &c, const PassIO &io) {
         run(0, K - K1, [&](int i, RawChunk &S) {
             const int k = K - 1 - i;
             ck_st(k + 1, b);                                      // beta at the upper boundary of chunk k (read by F)
-            stage_chunk<LGS, PRE>(c, S, io.nv2);
+            stage_chunk<LGS, PRE>(c, S, io.nv2, io.ncw);
             fetch(S, i + 2);
             beta_chunk<LGS, SR, false>(c, b, clen(k), arow);
         });
@@ -553,7 +559,7 @@ __device__ void map_pass(const Ctx<LGS> &c, const PassIO &io) {
             const int k = K - 1 - i;
             double a = ck_ld(k);                                  // alpha at the lower boundary of chunk k
             epilogue<LGS, !PRE>(c, io, li_prev, t_prev, len_prev);      // of the previous chunk (see the forward wave)
-            stage_chunk<LGS, PRE>(c, S, io.nv2);
+            stage_chunk<LGS, PRE>(c, S, io.nv2, io.ncw);
             li_prev[0] = S.li[0]; li_prev[1] = S.li[1];
             fetch(S, i + 2);
             alpha_chunk<LGS, SR, true>(c, a, CH, arow);           // arow[tl] = alpha at time k*CH + tl
@@ -608,7 +614,8 @@ struct TurboParams {
     const int32_t *perm;                  // [N]
     uint8_t *bits;                        // [B][N]
     double *ckpt;                         // per pair: checkpoint rows [nchunks + 1][64]
-    // The slab: per codeword seven arrays [N] -- A (L_int_1), B (a pass's output), C (L_int_2) and the signed channel factors
+    // The slab: per codeword seven arrays [N] -- A (prior0 of L_int_1; from the last interleave on: L_int_2 itself, for the final
+    // decision), B (a pass's output), C (prior0 of L_int_2: a pass reads the PRIOR, see stage_chunk) and the signed channel factors
     // (signed_q) of sys, interlv(sys) (:310), non_sys_1, non_sys_2 -- rows [B][7][N].  (A CHUNKED slab, [pair][array][chunk][GW][8]:
     // the GW x 8 values a pass reads per array and chunk as ONE contiguous 1 KB line, was built and measured in round 3: the
     // pass kernel did not move (337 us either way -- it is not the number of 64-byte segments that costs) and the stage
@@ -662,10 +669,11 @@ __global__ __launch_bounds__(128 * NPAIR) void turbo_pass_kernel(TurboParams p, 
 }
 
 // mode 0: slab initialisation (:305-310) + flag (A);  1: L_int_2 = interlv(E_1) (:318-319);  2: L_int_1 = deinterlv(E_2)
-// (:328-329);  3: decoded_bits = deinterlv(L_2 > 0) (:148-152, :331).  One wavefront per codeword, four per workgroup; `lds_n`
+// (:328-329) -- each stored as prior0(L_int), the only thing a pass uses it for --;  3: decoded_bits = deinterlv(L_2 > 0)
+// (:148-152, :331).  One wavefront per codeword, four per workgroup; `lds_n`
 // doubles of LDS per wavefront when a codeword's array fits -- the permutations then go THROUGH LDS: coalesced read, LDS
 // scatter / gather, coalesced write (round 1 gathered from HBM: a 64-byte line per 8-byte element) -- else 0.
-__global__ __launch_bounds__(256) void turbo_stage_kernel(TurboParams p, int mode, int lds_n) {
+__global__ __launch_bounds__(256) void turbo_stage_kernel(TurboParams p, int mode, int lds_n, int keep_l) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t cwg = (int64_t)blockIdx.x * 4 + wv;
@@ -683,7 +691,7 @@ __global__ __launch_bounds__(256) void turbo_stage_kernel(TurboParams p, int mod
         bool far = false;
 #pragma unroll 2
         for (int64_t t = lane; t < N; t += 64) {
-            at(0, t) = p.Lint ? p.Lint[cwg * N + t] : 0.0;         // L_int_1 (:305-308)
+            at(0, t) = prior0(p.Lint ? p.Lint[cwg * N + t] : 0.0); // prior of L_int_1 (:305-308, :239)
             const double r1 = y1[t], r2 = y2[t], rs = sy[t];
             far = far || !(fabs(r1) <= rmax) || !(fabs(r2) <= rmax) || !(fabs(rs) <= rmax);
             at(5, t) = signed_q(r1, k4);
@@ -707,10 +715,18 @@ __global__ __launch_bounds__(256) void turbo_stage_kernel(TurboParams p, int mod
             for (int64_t t = lane; t < N; t += 64) buf[t] = at(1, t);
             asm volatile("" ::: "memory");
 #pragma unroll 4
-            for (int64_t t = lane; t < N; t += 64) at(2, t) = buf[p.perm[t]];
+            for (int64_t t = lane; t < N; t += 64) {
+                const double L = buf[p.perm[t]];
+                at(2, t) = prior0(L);
+                if (keep_l) at(0, t) = L;                           // the last L_int_2 itself, for the final decision (mode 3)
+            }
         } else {
 #pragma unroll 4
-            for (int64_t t = lane; t < N; t += 64) at(2, t) = at(1, p.perm[t]);
+            for (int64_t t = lane; t < N; t += 64) {
+                const double L = at(1, p.perm[t]);
+                at(2, t) = prior0(L);
+                if (keep_l) at(0, t) = L;
+            }
         }
     } else if (mode == 2) {
         if (in_lds) {
@@ -718,15 +734,15 @@ __global__ __launch_bounds__(256) void turbo_stage_kernel(TurboParams p, int mod
             for (int64_t t = lane; t < N; t += 64) buf[p.perm[t]] = at(1, t);
             asm volatile("" ::: "memory");
 #pragma unroll 4
-            for (int64_t t = lane; t < N; t += 64) at(0, t) = buf[t];
+            for (int64_t t = lane; t < N; t += 64) at(0, t) = prior0(buf[t]);
         } else {
 #pragma unroll 4
-            for (int64_t t = lane; t < N; t += 64) at(0, p.perm[t]) = at(1, t);
+            for (int64_t t = lane; t < N; t += 64) at(0, p.perm[t]) = prior0(at(1, t));
         }
     } else {
 #pragma unroll 4
         for (int64_t t = lane; t < N; t += 64)
-            p.bits[cwg * N + p.perm[t]] = (uint8_t)((p.n_iter > 0 && at(2, t) + at(1, t) > 0) ? 1 : 0);
+            p.bits[cwg * N + p.perm[t]] = (uint8_t)((p.n_iter > 0 && at(0, t) + at(1, t) > 0) ? 1 : 0);   // L_2 = L_int_2 + E_2 (array 0: see mode 1)
     }
 }
 
@@ -851,7 +867,7 @@ int cpx_turbo_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const 
     CPX_REQUIRE((B + 3) / 4 < (1ll << 31), CPX_ELIMIT, "turbo_decode: batch too large");
     const dim3 sgrid((unsigned)((B + 3) / 4)), sblock(256);
     const size_t slds = (size_t)lds_n * 8 * 4;
-    auto stage = [&](int mode) { hipLaunchKernelGGL(turbo_stage_kernel, sgrid, sblock, slds, st, p, mode, lds_n); };
+    auto stage = [&](int mode, int keep_l = 0) { hipLaunchKernelGGL(turbo_stage_kernel, sgrid, sblock, slds, st, p, mode, lds_n, keep_l); };
     auto pass = [&](int second) -> int {
         switch (p.tb.lgS) {
 #define CASE(LG) case LG: hipLaunchKernelGGL((turbo_pass_kernel<LG, false>), grid, block, sizeof(double) * 2 * np * wave_lds_doubles<LG>(GW), st, p, second); break;
@@ -868,7 +884,7 @@ int cpx_turbo_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const 
     stage(0);
     for (int h = 0; h < 2 * n_iter; h++) {
         if ((rc = pass(h & 1))) return rc;
-        if (h < 2 * n_iter - 1) stage(1 + (h & 1));
+        if (h < 2 * n_iter - 1) stage(1 + (h & 1), h == 2 * n_iter - 2);   // the last interleave also keeps L_int_2 itself
     }
     stage(3);
     CPX_HIP(hipGetLastError());
