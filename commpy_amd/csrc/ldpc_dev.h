@@ -64,12 +64,22 @@ __device__ __forceinline__ double spa_out_fast(double U, double W, double se) {
     const double n1 = W * __builtin_copysign(1.0 - e, se), n2 = U * (1.0 + e);
     return fast_log((n1 + n2) / (n1 - n2));                       // 2 atanh(x), |x| < 1 - 2^-32: no clip binds
 }
+// NaN signs.  An LLR of exactly 0 is a case the reference expects (ldpc.py:214: "Runtime Warnings are expected when llr = 0"):
+// tanh(0) = 0, 1 / 0 = inf, inf * 0 = NaN, and from there the block fills with NaN -- but dec_word = signbit(out_llrs) (:193,
+// :248) and the early-termination test (:205) read the SIGN of those NaNs.  What NumPy on x86 does, and this path reproduces
+// (tests/golden/abnormal.npz, spaz_*): an invalid operation GENERATES a negative NaN (x86's default, 0xFFF8...; gfx950's is
+// positive); np.tanh and the complex log2 / exp2 product return a POSITIVE NaN for a NaN argument whatever its sign; every other
+// operation of the loop passes a NaN on with its sign.  A NaN never takes the fast row (spa_row_near sees U or W).
 __device__ __forceinline__ double spa_exact_t(double se) {        // == tanh_half(m) of the edge, from its stored e
     const double e = fabs(se);
-    return __builtin_copysign((1.0 - e) / (1.0 + e), se);
+    const double t = __builtin_copysign((1.0 - e) / (1.0 + e), se);
+    return se == se ? t : __builtin_nan("");                      // np.tanh(NaN) is +NaN
 }
 __device__ __forceinline__ double spa_out_exact(double t, double prod) {
     double x = (1.0 / t) * prod;                                  // data = 1/data; multiply(msg_products) (:222-223)
+    // generated here (inf * 0): negative.  Propagated: t and prod come out of tanh / the product, i.e. positive.  atanh, * 2 and
+    // the clips (:224-227) pass either on.
+    if (x != x) return (t == t && prod == prod) ? -__builtin_nan("") : __builtin_nan("");
     x = clip_nan(x, -1.0, 1.0);                                   // (:224)
     x = atanh_twice(x);                                           // (:225-226)
     return clip_nan(x, -500.0, 500.0);                            // (:227)

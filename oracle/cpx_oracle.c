@@ -343,7 +343,10 @@ int orc_ldpc_bp_decode(double *llr, int64_t n_blocks, int n_v, int n_c, int64_t 
             for (int c = 0; c < n_c; c++) if (syn[c] % 2 != 0) { all_even = 0; break; }
             if (all_even) break;                                                        /* :205-206 */
             if (alg == 0) {
-                for (int64_t e = 0; e < n_edges; e++) { M[e] *= .5; M[e] = tanh(M[e]); } /* :210-211 */
+                /* NaN signs (an LLR of 0 is an expected input, :214): NumPy's tanh and its complex log2 / exp2 product return a POSITIVE
+                 * NaN for a NaN argument (glibc keeps the argument's sign); inf * 0 generates x86's negative NaN in both; pinned by
+                 * tests/golden/abnormal.npz (spaz_*) */
+                for (int64_t e = 0; e < n_edges; e++) { M[e] *= .5; M[e] = tanh(M[e]); if (isnan(M[e])) M[e] = NAN; } /* :210-211 */
                 for (int c = 0; c < n_c; c++) lsum[c] = 0;
                 for (int64_t e = 0; e < n_edges; e++) {                                  /* :217-218 */
                     double complex lg = clog(M[e] + 0.0 * CI);     /* numpy nc_log2: clog then *LOG2E on both parts */
@@ -355,6 +358,7 @@ int orc_ldpc_bp_decode(double *llr, int64_t n_blocks, int n_v, int n_c, int64_t 
                     double complex a = (creal(lsum[c]) * 0.693147180559945309417232121458176568) +
                                        (cimag(lsum[c]) * 0.693147180559945309417232121458176568) * CI;
                     prod[c] = creal(cexp(a));
+                    if (isnan(prod[c])) prod[c] = NAN;
                 }
                 for (int64_t e = 0; e < n_edges; e++) {
                     double v = 1 / M[e];                                                 /* :222 */

@@ -708,6 +708,22 @@ def gen_abnormal():
         out[key + "__llr"], out[key + "__dec"], out[key + "__out"] = llr, np.asarray(dec).astype(np.int8), np.asarray(oll)
         out[key + "__iters"] = np.array(iters)
         names.append(key)
+    # ---- sum-product with LLRs of exactly 0 (punctured bits): "Runtime Warnings are expected when llr = 0" (ldpc.py:214) -- the block
+    # fills with NaN, and dec_word = signbit(out_llrs) / the early-termination test read the sign of those NaNs
+    for cname, path in (("gallager96", "gallager/96.33.964.txt"), ("wimax960", "wimax/960.720.a.txt")):
+        p = get_ldpc_code_params(os.path.join(design_dir, path), True)
+        n = p["n_vnodes"]
+        for iters in (1, 2, 3, 4, 6):
+            B = 3
+            llr = 2.0 * (1.0 + 0.8 * rs.randn(n * B)) / 0.64
+            llr[0 * n + rs.randint(n)] = 0.0
+            llr[1 * n + rs.randint(n, size=3)] = 0.0              # block 2 stays clean
+            with np.errstate(all="ignore"):
+                dec, oll = ldpc_bp_decode(llr.copy(), p, "SPA", iters)
+            key = "spaz_%s_%d" % (cname, iters)
+            out[key + "__llr"], out[key + "__dec"], out[key + "__out"] = llr, np.asarray(dec).astype(np.int8), np.asarray(oll)
+            out[key + "__iters"] = np.array(iters)
+            names.append(key)
     # ---- MAP
     tr4 = Trellis(np.array([2]), np.array([[1, 7]]), feedback=5, code_type="rsc")
     tr8 = Trellis(np.array([3]), np.array([[1, 0o15]]), feedback=0o13, code_type="rsc")

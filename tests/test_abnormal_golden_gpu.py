@@ -68,3 +68,25 @@ def test_turbo_decode_regimes(gpu):
         dec = turbo_decode(g[key + "__sys"], g[key + "__p1"], g[key + "__p2"], tr, float(nv), int(iters),
                            Perm(g[key + "__perm"]), g[key + "__Lint"] if has_L else None)
         assert np.array_equal(dec, g[key + "__dec"]), key
+
+
+def test_sum_product_zero_llrs(gpu):
+    """An LLR of exactly 0 (ldpc.py:214 expects it): the block fills with NaN; dec_word = signbit(out_llrs) and the iteration count
+    depend on the NaNs' signs -- generated NaNs negative (x86), tanh / product NaNs positive (NumPy), DESIGN.md 2."""
+    from commpy_amd import _lib
+    from commpy_amd.channelcoding import ldpc_bp_decode
+    g, names = abnormal_cases("spaz_")
+    for key in names:
+        p = ldpc_params(key[5:key.rindex("_")])
+        ref = g[key + "__out"]
+        fin = np.isfinite(ref)
+        for path in ("resident", "tiled"):
+            _lib.ldpc_set_path(path)
+            try:
+                dec, out = ldpc_bp_decode(g[key + "__llr"].copy(), p, "SPA", int(g[key + "__iters"]))
+            finally:
+                _lib.ldpc_set_path(None)
+            assert np.array_equal(np.isnan(out), np.isnan(ref)), (key, path)
+            assert np.array_equal(np.signbit(out), np.signbit(ref)), (key, path)
+            assert np.all(np.abs(out[fin] - ref[fin]) <= TOL + 1e-6 * np.abs(ref[fin])), (key, path)
+            assert np.array_equal(dec, g[key + "__dec"]), (key, path)

@@ -239,3 +239,20 @@ def test_abnormal_turbo_decode_regimes():
             got = oracle.turbo_decode(g[key + "__sys"][b], g[key + "__p1"][b], g[key + "__p2"][b], tr, float(nv), int(iters),
                                       Perm(g[key + "__perm"]), g[key + "__Lint"][b] if has_L else None)
             assert np.array_equal(got, g[key + "__dec"][b]), (key, b)
+
+
+def test_abnormal_sum_product_zero_llrs():
+    """LLRs of exactly 0 in sum-product: NaN LLRs whose SIGNS decide dec_word and the early termination (ldpc.py:193, :205, :248)."""
+    from helpers import ldpc_params
+    g, names = abnormal_cases("spaz_")
+    assert len(names) == 10
+    for key in names:
+        p = ldpc_params(key[5:key.rindex("_")])
+        dec, out = oracle.ldpc_bp_decode(g[key + "__llr"].copy(), p, "SPA", int(g[key + "__iters"]))
+        ref = g[key + "__out"]
+        assert np.array_equal(np.isnan(out), np.isnan(ref)), key
+        assert np.array_equal(np.signbit(out), np.signbit(ref)), key
+        fin = np.isfinite(ref)
+        assert np.all(np.abs(out[fin] - ref[fin]) <= 1e-9 + 1e-9 * np.abs(ref[fin])), key
+        assert np.array_equal(dec, g[key + "__dec"]), key
+        assert np.isnan(ref).any()
