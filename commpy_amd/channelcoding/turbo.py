@@ -4,7 +4,7 @@ Same public names, arguments and return conventions as /root/reference/commpy/ch
 
 * ``turbo_encode`` (turbo.py:14-59)   host (input generator; keeps the reference's quirks B3/B4);
 * ``map_decode``   (turbo.py:163-251) DEVICE -> ``cpx_map_decode_batch``  (csrc/bcjr.hip);
-* ``turbo_decode`` (turbo.py:254-333) DEVICE -> ``cpx_turbo_decode_batch`` (whole iteration loop in one launch).
+* ``turbo_decode`` (turbo.py:254-333) DEVICE -> ``cpx_turbo_decode_batch`` (one launch per MAP pass + small interleaver launches; flagged codewords redone exactly).
 
 2-D inputs ``[B, N]`` decode a batch of independent codewords (extension).
 """

@@ -155,7 +155,11 @@ int cpx_viterbi_decode_batch_i64(const cpx_trellis *t, const double *coded, int6
  * cpx_turbo_decode_batch replaces turbo_decode(...) turbo.py:254-333: n_iter x (MAP1, interleave,
  *   MAP2, de-interleave); perm = interleaver.p_array (interleavers.py:13-47), shared by the batch;
  *   L_int may be NULL (zeros).  bits [B][N] uint8, already de-interleaved.
- * Limits: rate-1/2 component trellis (n == 2), I == 2, S <= 16.
+ * Limits: rate-1/2 component trellis (n == 2), I == 2, S <= 16; N < 2^24 (map), N < 2^21 (turbo).
+ * Inputs for which the reference's absolute-scale recursion underflows (turbo.py:62-76, :238-240: symbol amplitudes of 5 - 20 at
+ *   sigma^2 <= 0.1, priors of e^-200) or that are not finite give what the reference gives -- NaN / +-inf LLRs, their decisions --:
+ *   the fast kernels flag such codewords and a literal absolute-scale kernel decodes them again (blocks up to the scratch limit of
+ *   that path).
  */
 int cpx_map_decode_batch(const cpx_trellis *t, const double *sys, const double *par, const double *L_int,
                          int64_t B, int64_t N, double noise_variance, int want_bits, double *L_ext,
