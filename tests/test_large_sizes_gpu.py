@@ -121,3 +121,28 @@ def test_ldpc_whole_config4_batch_on_one_gpu(gpu, alg, name):
     for b in (d_msg, d_code, d_sym, d_llr, d_dec, d_out, d_it):
         b.free()
     lib.cpx_release_workspace()
+
+
+def test_map_and_turbo_long_blocks(gpu):
+    """Blocks of 2^20 and 2^22 + 5 steps (the pass addresses its arrays with 31-bit lane offsets into raw buffers, include/commpy_amd.h:
+    N < 2^24 for map_decode) and a turbo decode of N = 100 003 (odd length: partial chunk; interleaver through global memory, not LDS)."""
+    import oracle
+    from helpers import make_trellis
+    from commpy_amd.channelcoding import RandInterlv, map_decode, turbo_decode
+    tr = make_trellis("rsc_legacy_4")
+    rs = np.random.RandomState(1)
+    for B, N in ((18, 1 << 20), (3, (1 << 22) + 5)):
+        s_ = rs.choice([-1.0, 1.0], size=(B, N)) + rs.randn(B, N) * 0.8
+        p_ = rs.choice([-1.0, 1.0], size=(B, N)) + rs.randn(B, N) * 0.8
+        L = rs.randn(B, N)
+        Le, bits = map_decode(s_, p_, tr, 0.64, L, "decode")
+        for b in (0, B - 1):
+            Lo, bo = oracle.map_decode(s_[b], p_[b], tr, 0.64, L[b], "decode")
+            assert np.max(np.abs(Le[b] - Lo)) < 1e-5, (N, b)
+            assert not np.any((bits[b] != bo) & (np.abs(Lo) > 1e-5)), (N, b)
+    B, N = 17, 100003
+    il = RandInterlv(N, 5)
+    r = [rs.choice([-1.0, 1.0], size=(B, N)) + rs.randn(B, N) * 0.9 for _ in range(3)]
+    dec = turbo_decode(r[0], r[1], r[2], tr, 0.81, 2, il)
+    for b in (0, 16):
+        assert np.array_equal(dec[b], oracle.turbo_decode(r[0][b], r[1][b], r[2][b], tr, 0.81, 2, il)), b
