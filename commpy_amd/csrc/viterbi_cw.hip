@@ -95,6 +95,7 @@ struct CwParams {
     uint8_t *nanflags;            // 'soft': [B], 1 = the codeword received a NaN (re-decoded by viterbi.hip's redo launch)
     int64_t B, len, L, T, Lk, Tp;   // Tp: T rounded up to whole groups of log2(S) steps (row count of dec/best)
     int type, tb;
+    unsigned goff[32];            // table-driven kernel (G0 = G1 = 0): 1024 * (2-bit code of the branch 2j -> j, input 0) per butterfly j
 };
 
 // 'soft': the reference's clip lets a NaN through and the codeword's metrics are NaN from that step on (convcode.py:719,
@@ -146,11 +147,17 @@ struct NoHook {
 
 // `hook.at<P>()` is called at four fixed points of the step (after the branch metrics, after each half of the butterflies,
 // after the minimum tree): the fused kernel slots the traceback of the previous step in there.
+// G0 = G1 = 0: TABLE-DRIVEN codes -- any shift-register code whose two generators both tap the input bit and the oldest register bit
+// (every rate-1/2 code of full constraint length).  The four branches of butterfly j then carry the codes c_j, c_j ^ 3, c_j ^ 3, c_j,
+// so one 2-bit number per butterfly describes the code; it arrives as a byte offset goff[j] = 1024 c_j in scalar registers, the
+// step's branch metrics go to a table [4][64 lanes] of pairs (metric of c, metric of c ^ 3) in LDS (bml = this lane's column) and
+// every butterfly reads its pair from there: 32 16-byte LDS reads + 32 address adds per step more than the compiled-in codes.
 template <int LGS, unsigned G0, unsigned G1, int TYPE, int R, class Hook = NoHook>
 __device__ __forceinline__ void cw_step(double (&pm)[1 << LGS], double r0, double r1, unsigned long long &word, int &best,
-                                        const Hook &hook = Hook()) {
+                                        const Hook &hook = Hook(), unsigned char *bml = nullptr, const unsigned *goff = nullptr) {
     constexpr int type = TYPE;
     using C = SrCode<LGS, G0, G1>;
+    constexpr bool GEN = G0 == 0 && G1 == 0;
     constexpr int S = 1 << LGS, H = S / 2;
     if (type == CPX_VIT_SOFT) {                                    // coded_bits.clip(-500, 500) (:719)
         r0 = fmin(fmax(r0, -500.0), 500.0);
@@ -163,20 +170,53 @@ __device__ __forceinline__ void cw_step(double (&pm)[1 << LGS], double r0, doubl
     bmv[0] = (0.0 + m00) + m10; bmv[1] = (0.0 + m00) + m11;
     bmv[2] = (0.0 + m01) + m10; bmv[3] = (0.0 + m01) + m11;
     unsigned da = 0, db = 0;                                       // decisions of states 0..H-1 / H..S-1
-    hook.template at<0>();
+    if constexpr (GEN) {
 #pragma unroll
-    for (int j = 0; j < H; j++) {
-        if (j == H / 2) hook.template at<1>();
+        for (int cc = 0; cc < 4; cc++)                              // entry c = (metric of code c, metric of code c ^ 3): one 16-byte read per butterfly
+            *reinterpret_cast<double2 *>(bml + 1024 * cc) = make_double2(bmv[cc], bmv[cc ^ 3]);   // same wave: LDS executes in order
+    }
+    hook.template at<0>();
+    auto butterfly = [&](int j, double m_a0, double m_a1, double m_b0, double m_b1) {
         const int x = rotl<LGS>(2 * j, R), y = rotl<LGS>(2 * j + 1, R);
         const double a = pm[x], b = pm[y];                         // metrics of the predecessors 2j, 2j+1
-        const double a0 = a + bmv[C::code(j, 0)], a1 = b + bmv[C::code(j, 1)];          // into state j      (:629)
-        const double b0 = a + bmv[C::code(j + H, 0)], b1 = b + bmv[C::code(j + H, 1)];  // into state j + S/2
+        const double a0 = a + m_a0, a1 = b + m_a1;                 // into state j      (:629)
+        const double b0 = a + m_b0, b1 = b + m_b1;                 // into state j + S/2
         if (TYPE == CPX_VIT_UNQUANTIZED) {
             pm[x] = acs_select(da, a0, a1);                        // state j     now lives in register rotl(j, R+1) = x
             pm[y] = acs_select(db, b0, b1);                        // state j+S/2 now lives in register y
         } else {
             pm[x] = acs_min(da, a0, a1);
             pm[y] = acs_min(db, b0, b1);
+        }
+    };
+    if constexpr (GEN) {
+        // the two metrics of a butterfly come from LDS, four butterflies at a time and one group ahead of the arithmetic (left to
+        // itself the compiler issues all 64 reads of the step at once: 128 more live registers, 110 of them spilled to AGPRs)
+        constexpr int GB = 4, NG = H / GB;
+        double mc[2][GB], mx[2][GB];
+        auto fetch = [&](int g, int w) {
+#pragma unroll
+            for (int u = 0; u < GB; u++) {
+                const double2 v = *reinterpret_cast<const double2 *>(bml + goff[g * GB + u]);
+                mc[w][u] = v.x;                                    // code c_j
+                mx[w][u] = v.y;                                    // code c_j ^ 3
+            }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+            if (g * GB == H / 2) hook.template at<1>();
+            if (g + 1 < NG) fetch(g + 1, (g + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < GB; u++) butterfly(g * GB + u, mc[g & 1][u], mx[g & 1][u], mx[g & 1][u], mc[g & 1][u]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < H; j++) {
+            if (j == H / 2) hook.template at<1>();
+            butterfly(j, bmv[C::code(j, 0)], bmv[C::code(j, 1)], bmv[C::code(j + H, 0)], bmv[C::code(j + H, 1)]);
         }
     }
     hook.template at<2>();
@@ -274,7 +314,7 @@ __device__ __forceinline__ void bit_metrics_f32(int type, double r, float &m0, f
 
 template <int LGS, unsigned G0, unsigned G1, int TYPE, int R, class Hook = NoHook>
 __device__ __forceinline__ void cw_step(float (&pm)[1 << LGS], double r0, double r1, unsigned long long &word, int &best,
-                                        const Hook &hook = Hook()) {
+                                        const Hook &hook = Hook(), unsigned char * = nullptr, const unsigned * = nullptr) {
     using C = SrCode<LGS, G0, G1>;
     constexpr int S = 1 << LGS, H = S / 2;
     if (TYPE == CPX_VIT_SOFT) {                                    // coded_bits.clip(-500, 500) (:719)
@@ -423,9 +463,10 @@ constexpr int FR_RING_DEEP = 64;
 
 // slots of one wave: the ring (twice if mirrored) + one dummy slot per copy for steps > T
 template <int RING, bool MIR> constexpr int fused_slots() { return MIR ? 2 * RING + 2 : RING + 1; }
-template <int RING, bool MIR>
+template <int RING, bool MIR, bool GEN = false>
 constexpr size_t fused_wave_lds() {
-    return (size_t)fused_slots<RING, MIR>() * 64 * 8 + (size_t)64 * FR_OBPAD;   // ring + dummy slot(s), staging tile
+    // ring + dummy slot(s), staging tile, and for the table-driven codes the step's four branch metrics [4][64]
+    return (size_t)fused_slots<RING, MIR>() * 64 * 8 + (size_t)64 * FR_OBPAD + (GEN ? 4 * 64 * 16 : 0);
 }
 
 // The traceback walk of one step, cut into four batches of hops that cw_step's hook runs between the phases of the NEXT
@@ -489,8 +530,11 @@ __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_fused_kernel(CwPara
     if (grp * 64 >= p.B) return;                                                   // whole wave beyond the batch
     const bool valid = cw < p.B;
     const double *x = p.coded + (valid ? cw : 0) * p.len;
-    unsigned long long *ring = reinterpret_cast<unsigned long long *>(smem + (size_t)wv * fused_wave_lds<RING, MIR>());
+    constexpr bool GEN = G0 == 0 && G1 == 0;                                        // table-driven code (cw_step)
+    static_assert(!GEN || (!MIR && !RT && std::is_same<F, double>::value), "table-driven codes: unmirrored ring, default depth, float64");
+    unsigned long long *ring = reinterpret_cast<unsigned long long *>(smem + (size_t)wv * fused_wave_lds<RING, MIR, GEN>());
     unsigned char *obuf = reinterpret_cast<unsigned char *>(ring + fused_slots<RING, MIR>() * 64);
+    unsigned char *bml = obuf + 64 * FR_OBPAD + lane * 16;                         // GEN: this lane's column of the branch-metric table
     unsigned long long *mycol = ring + lane;                                       // slot s of this lane's codeword: mycol[s * 64]
     unsigned char *myrow = obuf + lane * FR_OBPAD;
 
@@ -564,7 +608,7 @@ __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_fused_kernel(CwPara
                 unsigned long long word;
                 int bst;
                 if constexpr (TYPE == CPX_VIT_SOFT) nan_or(nanmask, cur[R].x, cur[R].y);   // (steps > tmax re-read step tmax)
-                cw_step<LGS, G0, G1, TYPE, R>(pm, r0, r1, word, bst, walk);      // + hops 0 .. 3/4 H of the walk of step tt - 1
+                cw_step<LGS, G0, G1, TYPE, R>(pm, r0, r1, word, bst, walk, bml, p.goff);   // + hops 0 .. 3/4 H of the walk of step tt - 1
                 walk.finish();
                 myrow[g * LGS + R] = (unsigned char)((walk.st >> (LGS - 1)) & 1u);   // input bit of the branch into the state at step tt - 1 - H
                 // ring slot of step tt and (mirrored ring) its copy RING slots above; the (at most LGS - 1) steps > T of the last group
@@ -696,6 +740,56 @@ bool tables_match(const cpx_trellis *t) {
             if (t->pred_code[s * 2 + j] != C::code(s, j)) return false;
         }
     return true;
+}
+
+// Table-driven codes (cw_step, G0 = G1 = 0): a 2^LGS-state shift-register trellis of rate 1/2 whose butterflies have the form
+// (c, c ^ 3, c ^ 3, c) -- both generators tap the input and the oldest register bit.  Fills goff[j] = 512 c_j.
+template <int LGS>
+bool generic_match(const cpx_trellis *t, unsigned (&goff)[32]) {
+    static_assert((1 << LGS) / 2 <= 32, "goff holds 32 butterflies");
+    const int S = 1 << LGS, H = S / 2;
+    if (t->S != S || t->I != 2 || t->k != 1 || t->n != 2) return false;
+    for (int s = 0; s < S; s++)
+        for (int j = 0; j < 2; j++) {
+            if (t->pred_state[s * 2 + j] != (((s << 1) & (S - 1)) | j)) return false;
+            if (t->pred_input[s * 2 + j] != (s >> (LGS - 1))) return false;
+        }
+    for (int j = 0; j < H; j++) {
+        const int c = t->pred_code[j * 2 + 0];
+        if (c < 0 || c > 3) return false;
+        if (t->pred_code[j * 2 + 1] != (c ^ 3) || t->pred_code[(j + H) * 2 + 0] != (c ^ 3) || t->pred_code[(j + H) * 2 + 1] != c) return false;
+        goff[j] = 1024u * (unsigned)c;
+    }
+    for (int j = H; j < 32; j++) goff[j] = 0;
+    return true;
+}
+
+template <int LGS, int TYPE>
+int launch_fused_generic_typed(const CwParams &p, hipStream_t st) {
+    auto *fn = viterbi_cw_fused_kernel<LGS, 0u, 0u, TYPE, 5 * LGS - 2, false, double, FR_RING, false>;
+    const size_t lds = ACS_WAVES * fused_wave_lds<FR_RING, false, true>();
+    static bool raised[64] = {};
+    static std::mutex raised_mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    std::lock_guard<std::mutex> lk(raised_mu);
+    if (!raised[dev]) {
+        if (hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            (void)hipGetLastError();
+            return 0;
+        }
+        raised[dev] = true;
+    }
+    const unsigned groups = (unsigned)((p.B + 63) / 64), blocks = (groups + ACS_WAVES - 1) / ACS_WAVES;
+    hipLaunchKernelGGL(fn, dim3(blocks), dim3(64 * ACS_WAVES), lds, st, p);
+    return 1;
+}
+
+template <int LGS>
+int launch_fused_generic(const CwParams &p, hipStream_t st) {
+    if (p.type == CPX_VIT_HARD) return launch_fused_generic_typed<LGS, CPX_VIT_HARD>(p, st);
+    if (p.type == CPX_VIT_SOFT) return launch_fused_generic_typed<LGS, CPX_VIT_SOFT>(p, st);
+    return launch_fused_generic_typed<LGS, CPX_VIT_UNQUANTIZED>(p, st);
 }
 
 template <int LGS, unsigned G0, unsigned G1>
@@ -855,6 +949,13 @@ bool viterbi_codeword_path(const cpx_trellis *t, const double *d_coded, int64_t 
     //  but are not built: with 4 or 16 states the wave kernels already pack 16 / 4 codewords into a wavefront and the
     //  one-wave-per-SIMD structure of this path loses -- BASELINE config 1, 2^20 codewords: 0.77 ms here, 0.56 ms there.)
 #undef CPX_TRY
+    // any other 64-state rate-1/2 code of full constraint length, at the default traceback depth: the table-driven fused kernel
+    // (other depths, and the fp32-fast mode, go to the state-per-lane kernels)
+    if (tb == 30 && !two_kernels && !f32 && generic_match<6>(t, p.goff) && launch_fused_generic<6>(p, st)) {
+        if (hipGetLastError() != hipSuccess) { set_error("viterbi (table-driven codeword path): launch failed"); *rc = CPX_EHIP; }
+        note_kernel("viterbi_cw_fused_kernel<6,table-driven,%s,28>", type_name(type));
+        return true;
+    }
     return reject("no instantiation for this trellis");
 }
 
