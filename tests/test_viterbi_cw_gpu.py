@@ -173,6 +173,23 @@ def test_table_driven_codes(gpu, dtype):
         _decode(np.zeros((2, 60)), tr, None, "hard", "cw!")
 
 
+def test_table_driven_code_full_batch_default_dispatch(gpu):
+    """A 64-state code without a compiled-in instantiation, (135,147), as a batch that fills the chip: the default dispatch takes the
+    table-driven fused kernel; all 40 000 codewords equal the state-per-lane kernels, the first / last 700 the oracle."""
+    from commpy_amd import _lib
+    from commpy_amd.channelcoding import Trellis, conv_encode_batch, viterbi_decode
+    tr = Trellis(np.array([6]), np.array([[0o135, 0o147]]))
+    rs = np.random.RandomState(77)
+    B = 40000
+    coded = conv_encode_batch(rs.randint(0, 2, (B, 256)).astype(np.uint8), tr).astype(np.float64)
+    rx = 4.0 * coded - 2 + rs.standard_normal(coded.shape) * 1.6
+    got = viterbi_decode(rx, tr, None, "soft")
+    assert "table-driven" in _lib.last_kernel(), _lib.last_kernel()
+    assert np.array_equal(got, _decode(rx, tr, None, "soft", "wave"))
+    for lo in (0, B - 700):
+        assert np.array_equal(got[lo:lo + 700], oracle.viterbi_decode_mt(rx[lo:lo + 700], tr, None, "soft"))
+
+
 def test_continuous_termination_and_short_windows(gpu):
     """'cont' streams (no tail), tb_depth larger than the block, L smaller than the window."""
     from commpy_amd.channelcoding import conv_encode
