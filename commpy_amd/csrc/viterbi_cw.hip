@@ -28,6 +28,9 @@
 #include "cpx_internal.h"
 #include "cpx_math.h"
 #include "viterbi_cw_asm.h"
+#ifndef CPX_GEN_GB
+#define CPX_GEN_GB 2      // butterflies per LDS fetch group of the table-driven kernel (measured: 2: 2.14 ms, 4: 2.17, 8: 2.21)
+#endif
 
 #include <atomic>
 #include <cstdlib>
@@ -190,9 +193,9 @@ __device__ __forceinline__ void cw_step(double (&pm)[1 << LGS], double r0, doubl
         }
     };
     if constexpr (GEN) {
-        // the two metrics of a butterfly come from LDS, four butterflies at a time and one group ahead of the arithmetic (left to
+        // the two metrics of a butterfly come from LDS, a group of butterflies at a time (CPX_GEN_GB) and one group ahead of the arithmetic (left to
         // itself the compiler issues all 64 reads of the step at once: 128 more live registers, 110 of them spilled to AGPRs)
-        constexpr int GB = 4, NG = H / GB;
+        constexpr int GB = CPX_GEN_GB, NG = H / GB;
         double mc[2][GB], mx[2][GB];
         auto fetch = [&](int g, int w) {
 #pragma unroll
