@@ -113,10 +113,13 @@ int cpx_trellis_destroy(cpx_trellis *t);
  *   bits       [B][L] uint8 decoded bits, tail included (convcode.py:749)
  * Decision rule: the bit(s) of step s come from the survivor of the
  * first-minimum state at step min(s+tb_depth-2, n_steps), ties -> lowest index.
- * Kernel selection is internal and does not change a single output bit: batches of >= 3/4 * (SIMDs of the device) * 64
- * codewords of the K = 7 codes (133,171), (171,133) and (5,43) run one codeword per lane (csrc/viterbi_cw.hip: a single
- * fused kernel for tb_depth <= 5*m = 30, an add-compare-select + a traceback kernel with a 9 B per codeword-step device
- * workspace for 31 <= tb_depth <= 48); everything else runs one trellis state per lane (csrc/viterbi.hip).
+ * Kernel selection is internal and does not change a single output bit: batches of >= 0.45 * (SIMDs of the device) * 64
+ * codewords of a 64-state rate-1/2 shift-register code run one codeword per lane (csrc/viterbi_cw.hip): a single fused kernel
+ * for tb_depth <= 48 with the generators compiled in -- (133,171), (171,133) in both polynomial formats and Wifi80211's (5,43) --
+ * or, for any other pair whose generators both tap the input and the oldest register bit, with a run-time code table
+ * (default depth 30); an add-compare-select + a traceback kernel with a 9 B per codeword-step device workspace beyond that;
+ * everything else runs one trellis state per lane (csrc/viterbi.hip).  A NaN among 'soft' inputs is handled as the reference
+ * handles it (convcode.py:719 lets it through the clip): flagged codewords are decoded again by a NaN-exact instantiation.
  * cpx_viterbi_set_path (or the environment variable CPX_VITERBI_PATH = wave | cw | cw! | cw2 | cw2! at load time)
  * overrides the choice (tests, benchmarks); cpx_last_kernel reports which kernel ran.
  */
