@@ -204,7 +204,7 @@ struct RawChunk {
 
 // The arrays of a pass, seen from the pair of wavefronts that runs it: every pointer is wave-uniform and already points at
 // the pair's first codeword; a lane adds a 32-bit BYTE offset (codeword-in-pair * stride + step).  With 64-bit per-lane
-// addresses the pass kept ten address pairs in VGPRs and turbo_decode_kernel spilled them: every reload is a scratch load
+// addresses the pass kept ten address pairs in VGPRs and the (round-2, single-launch) turbo kernel spilled them: every reload is a scratch load
 // that retires through the same in-order counter as the prefetches, i.e. it waits for the HBM round trip issued just before
 // it (the "exposed memory time" of the round-2 ablations).
 struct PassIO {
