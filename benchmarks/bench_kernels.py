@@ -256,7 +256,7 @@ def bench_viterbi_small(lib, scale):
     d_in, d_out = dev.put(rx), dev.empty(B * 66)
     h = tr._device_handle()
     ms, _ = timeit(lib, lambda: _lib.check(lib.cpx_viterbi_decode_batch_dev(h, d_in, B, 132, 66, 67, 10, 0, d_out, None)))
-    emit("viterbi_wave_kernel<2,2,true,2>", "config 1: K=3 [[5,7]] 64-bit blocks, hard/BSC(0.05), B=%d" % B, B * 64,
+    emit(_lib.last_kernel(), "config 1: K=3 [[5,7]] 64-bit blocks, hard/BSC(0.05), B=%d" % B, B * 64,
          "info-bits", ms, B * (132 * 8 + 66), "valu")
     dev.free()
 

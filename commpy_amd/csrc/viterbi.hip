@@ -809,11 +809,13 @@ static int viterbi_dispatch(const cpx_trellis *t, const double *d_coded, const D
         if (viterbi_codeword_path(t, d_coded, Bcw, len, L, n_steps, tb_depth, decoding_type, d_bits, nanflags, st, &rc_cw)) {
             if (rc_cw != CPX_OK) return rc_cw;
             if (nanflags) {
-                // codeword path: one flag per codeword; the redo decodes a flagged codeword with one wavefront (64 states)
+                // codeword path: one flag per item of the redo kernel -- 64 / S consecutive codewords, the codewords of one
+                // wavefront of the state-per-lane kernel (one codeword for 64 states)
+                const int64_t items = (Bcw + (64 / t->S) - 1) / (64 / t->S);
                 VitParams q;
                 wave_params(q, d_coded, d_bits, Bcw, nanflags);
-                if (int rcr = launch_redo(t, q, Bcw, st)) return rcr;
-                nanflags += Bcw;
+                if (int rcr = launch_redo(t, q, items, st)) return rcr;
+                nanflags += items;
             }
             if (Bcw == B) return CPX_OK;
             d_coded += Bcw * len;

@@ -652,7 +652,12 @@ __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_fused_kernel(CwPara
         flush(tc0, n);
     }
     if constexpr (TYPE == CPX_VIT_SOFT)
-        if (valid) p.nanflags[cw] = (uint8_t)((nanmask >> lane) & 1ull);
+    {   // one flag per ITEM of the state-per-lane redo kernel (viterbi.hip): 64 / S consecutive codewords (one codeword for S = 64)
+            constexpr int CPI = 64 / S;
+            const int64_t item = grp * (64 / CPI) + lane;
+            if (lane < 64 / CPI && item * CPI < p.B)
+                p.nanflags[item] = (uint8_t)(((nanmask >> (lane * CPI)) & (CPI == 64 ? ~0ull : ((1ull << CPI) - 1ull))) != 0);
+        }
     // the last H output steps: one walk from best[T]; the state before hop h is the state of step T - h
     if (valid) {
         const int qT = T & (RING - 1);
@@ -834,6 +839,26 @@ int launch_fused_typed(const CwParams &p, hipStream_t st) {
     return 1;
 }
 
+// Small trellises (4 and 16 states) at their default depth: the same fused kernel on a 16- or 32-slot unmirrored ring -- 14.6 /
+// 22.8 KB of LDS per wave instead of 39, so that two workgroups fit a CU (the one-wave-per-SIMD structure of the 64-state kernel
+// leaves a 4-state step, ~60 instructions, waiting for its own latencies: 0.77 ms on BASELINE config 1 where the state-per-lane
+// kernel takes 0.56; with the small ring 0.42 ms).
+template <int LGS, unsigned G0, unsigned G1, int TYPE>
+int launch_fused_small_typed(const CwParams &p, hipStream_t st) {
+    constexpr int RING = fused_tb<LGS>() - 1 <= 16 ? 16 : 32;
+    auto *fn = viterbi_cw_fused_kernel<LGS, G0, G1, TYPE, fused_tb<LGS>() - 2, false, double, RING, false>;
+    const size_t lds = ACS_WAVES * fused_wave_lds<RING, false>();
+    const unsigned groups = (unsigned)((p.B + 63) / 64), blocks = (groups + ACS_WAVES - 1) / ACS_WAVES;
+    hipLaunchKernelGGL(fn, dim3(blocks), dim3(64 * ACS_WAVES), lds, st, p);
+    return 1;
+}
+template <int LGS, unsigned G0, unsigned G1>
+int launch_fused_small(const CwParams &p, hipStream_t st) {
+    if (p.type == CPX_VIT_HARD) return launch_fused_small_typed<LGS, G0, G1, CPX_VIT_HARD>(p, st);
+    if (p.type == CPX_VIT_SOFT) return launch_fused_small_typed<LGS, G0, G1, CPX_VIT_SOFT>(p, st);
+    return launch_fused_small_typed<LGS, G0, G1, CPX_VIT_UNQUANTIZED>(p, st);
+}
+
 // the default depth runs the compile-time walk; smaller depths the same kernel with a run-time hop count
 template <int LGS, unsigned G0, unsigned G1, class F>
 int launch_fused(const CwParams &p, hipStream_t st) {
@@ -948,10 +973,17 @@ bool viterbi_codeword_path(const cpx_trellis *t, const double *d_coded, int64_t 
     // (wifi80211.py:49, utilities.py:81-85) -- 0000101 / 0101011, bit-reversed 0120 / 0152.  The reference's
     // own link simulation (BASELINE config 5 with default arguments) decodes this 64-state code.
     CPX_TRY(6, 0120u, 0152u)
-    // (K = 3 (5,7) and K = 5 (23,35) instantiate and pass the same tests -- CPX_TRY(2, 05u, 07u), CPX_TRY(4, 031u, 027u) --
-    //  but are not built: with 4 or 16 states the wave kernels already pack 16 / 4 codewords into a wavefront and the
-    //  one-wave-per-SIMD structure of this path loses -- BASELINE config 1, 2^20 codewords: 0.77 ms here, 0.56 ms there.)
 #undef CPX_TRY
+    // K = 3 (5,7) -- BASELINE config 1 -- and K = 5 (23,35) at their default depths: the small-ring flavour of the fused kernel
+#define CPX_TRY_SMALL(LG, GA, GB)                                                                                       \
+    if (tb == fused_tb<LG>() && !two_kernels && !f32 && tables_match<LG, GA, GB>(t) && launch_fused_small<LG, GA, GB>(p, st)) { \
+        if (hipGetLastError() != hipSuccess) { set_error("viterbi (small fused codeword path): launch failed"); *rc = CPX_EHIP; } \
+        note_kernel("viterbi_cw_fused_kernel<%d,0%o,0%o,%s,%d,small ring>", LG, GA, GB, type_name(type), fused_tb<LG>() - 2);    \
+        return true;                                                                                                    \
+    }
+    CPX_TRY_SMALL(2, 05u, 07u)
+    CPX_TRY_SMALL(4, 031u, 027u)
+#undef CPX_TRY_SMALL
     // any other 64-state rate-1/2 code of full constraint length, at the default traceback depth: the table-driven fused kernel
     // (other depths, and the fp32-fast mode, go to the state-per-lane kernels)
     if (tb == 30 && !two_kernels && !f32 && generic_match<6>(t, p.goff) && launch_fused_generic<6>(p, st)) {

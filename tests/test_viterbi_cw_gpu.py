@@ -173,6 +173,33 @@ def test_table_driven_codes(gpu, dtype):
         _decode(np.zeros((2, 60)), tr, None, "hard", "cw!")
 
 
+@pytest.mark.parametrize("dtype", ["hard", "soft", "unquantized"])
+@pytest.mark.parametrize("name", ["t57", "k5_23_35"])
+def test_small_trellises_on_the_fused_kernel(gpu, name, dtype):
+    """K = 3 (5,7) -- BASELINE config 1 -- and K = 5 (23,35) at their default traceback depths: the fused kernel on its small ring;
+    ragged batches, block lengths around the flush period, a NaN codeword ('soft'); other depths fall back to the other paths."""
+    from commpy_amd import _lib
+    from commpy_amd.channelcoding import conv_encode_batch
+    tr = make_trellis(name)
+    rs = np.random.RandomState(len(name) + len(dtype))
+    for B, nbits in ((70, 64), (5, 200), (129, 97), (64, 1000)):
+        coded = conv_encode_batch(rs.randint(0, 2, (B, nbits)), tr).astype(float)
+        if dtype == "hard":
+            rx = np.where(rs.rand(*coded.shape) < 0.06, 1 - coded, coded)
+        elif dtype == "soft":
+            rx = 4.0 * coded - 2 + rs.randn(*coded.shape) * 1.5
+            rx[B // 2, rs.randint(rx.shape[1])] = np.nan
+        else:
+            rx = 2.0 * coded - 1 + rs.randn(*coded.shape) * 0.7
+        want = oracle.viterbi_decode(rx, tr, None, dtype)
+        got = _decode(rx, tr, None, dtype, "cw!")
+        assert "small ring" in _lib.last_kernel(), _lib.last_kernel()
+        assert np.array_equal(got, want), (name, dtype, B, nbits)
+        assert np.array_equal(_decode(rx, tr, None, dtype, "wave"), want)
+    with pytest.raises(ValueError):
+        _decode(np.zeros((2, 80)), tr, 7, "hard", "cw!")               # not the default depth: no instantiation
+
+
 def test_table_driven_code_full_batch_default_dispatch(gpu):
     """A 64-state code without a compiled-in instantiation, (135,147), as a batch that fills the chip: the default dispatch takes the
     table-driven fused kernel; all 40 000 codewords equal the state-per-lane kernels, the first / last 700 the oracle."""
