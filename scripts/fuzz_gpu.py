@@ -78,6 +78,41 @@ def main():
                 got = viterbi_decode(rx, tr, tb, dtype)
                 if not np.array_equal(got, want):
                     bad.append(("viterbi-other", name, dtype, B, steps, tb, int(np.sum(got != want))))
+                if name in ("t57", "k5_23_35"):                    # round 3: the small-ring fused kernel where it applies ("cw": fall back otherwise)
+                    _lib.viterbi_set_path("cw")
+                    got = viterbi_decode(rx, tr, tb, dtype)
+                    _lib.viterbi_set_path(None)
+                    if not np.array_equal(got, want):
+                        bad.append(("viterbi-small-cw", name, dtype, B, steps, tb, _lib.last_kernel(), int(np.sum(got != want))))
+            elif kind == "viterbi" and rs.rand() < 0.25:
+                # round 3: a random 64-state pair with both end taps through the table-driven fused kernel (default depth) or, at other
+                # depths, whatever the forced-but-not-strict codeword path falls back to
+                from commpy_amd.channelcoding import Trellis
+                g0, g1 = (int(0o101 | (rs.randint(0, 32) << 1)) for _ in range(2))
+                if g0 == g1:
+                    g1 ^= 0o24
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    trg = Trellis(np.array([6]), np.array([[g0, g1]]))
+                dtype = str(rs.choice(["hard", "soft", "unquantized"]))
+                B, nbits = int(rs.choice([1, 7, 64, 65, 130])), int(rs.randint(30, 300))
+                tb = None if rs.rand() < 0.7 else int(rs.randint(2, 49))
+                coded = conv_encode_batch(rs.randint(0, 2, (B, nbits)), trg).astype(float)
+                if dtype == "hard":
+                    rx = np.where(rs.rand(*coded.shape) < 0.1, 1 - coded, coded)
+                elif dtype == "soft":
+                    rx = 4.0 * coded - 2 + rs.randn(*coded.shape) * rs.choice([0.5, 2.0])
+                    if rs.rand() < 0.3:
+                        rx[rs.rand(*rx.shape) < 0.002] = np.nan
+                else:
+                    rx = 2.0 * coded - 1 + rs.randn(*coded.shape) * rs.choice([0.3, 0.8])
+                want = oracle.viterbi_decode(rx, trg, tb, dtype)
+                for path in ("cw", None):
+                    _lib.viterbi_set_path(path)
+                    got = viterbi_decode(rx, trg, tb, dtype)
+                    if not np.array_equal(got, want):
+                        bad.append(("viterbi-table", oct(g0), oct(g1), dtype, B, nbits, tb, path, _lib.last_kernel(), int(np.sum(got != want))))
+                _lib.viterbi_set_path(None)
             elif kind == "viterbi":
                 dtype = rs.choice(["hard", "soft", "unquantized"])
                 B, nbits = int(rs.choice([1, 2, 7, 63, 64, 65, 130, 300])), int(rs.randint(1, 400))
