@@ -208,7 +208,7 @@ __device__ __forceinline__ void cw_step(double (&pm)[1 << LGS], double r0, doubl
         fetch(0, 0);
 #pragma unroll
         for (int g = 0; g < NG; g++) {
-            if (g * GB == H / 2) hook.template at<1>();
+            if (g == (H / 2) / GB) hook.template at<1>();       // once per step, about half way
             if (g + 1 < NG) fetch(g + 1, (g + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -774,8 +774,9 @@ bool generic_match(const cpx_trellis *t, unsigned (&goff)[32]) {
 
 template <int LGS, int TYPE>
 int launch_fused_generic_typed(const CwParams &p, hipStream_t st) {
-    auto *fn = viterbi_cw_fused_kernel<LGS, 0u, 0u, TYPE, 5 * LGS - 2, false, double, FR_RING, false>;
-    const size_t lds = ACS_WAVES * fused_wave_lds<FR_RING, false, true>();
+    constexpr int RING = 5 * LGS - 1 <= 16 ? 16 : 32;              // a ring cut to the depth (see launch_fused_small_typed)
+    auto *fn = viterbi_cw_fused_kernel<LGS, 0u, 0u, TYPE, 5 * LGS - 2, false, double, RING, false>;
+    const size_t lds = ACS_WAVES * fused_wave_lds<RING, false, true>();
     static bool raised[64] = {};
     static std::mutex raised_mu;
     int dev = 0;
@@ -984,13 +985,16 @@ bool viterbi_codeword_path(const cpx_trellis *t, const double *d_coded, int64_t 
     CPX_TRY_SMALL(2, 05u, 07u)
     CPX_TRY_SMALL(4, 031u, 027u)
 #undef CPX_TRY_SMALL
-    // any other 64-state rate-1/2 code of full constraint length, at the default traceback depth: the table-driven fused kernel
-    // (other depths, and the fp32-fast mode, go to the state-per-lane kernels)
-    if (tb == 30 && !two_kernels && !f32 && generic_match<6>(t, p.goff) && launch_fused_generic<6>(p, st)) {
-        if (hipGetLastError() != hipSuccess) { set_error("viterbi (table-driven codeword path): launch failed"); *rc = CPX_EHIP; }
-        note_kernel("viterbi_cw_fused_kernel<6,table-driven,%s,28>", type_name(type));
-        return true;
+    // any other rate-1/2 shift-register code of full constraint length (4 .. 64 states), at its default traceback depth: the
+    // table-driven fused kernel (other depths, and the fp32-fast mode, go to the state-per-lane kernels)
+#define CPX_TRY_TABLE(LG)                                                                                               \
+    if (tb == fused_tb<LG>() && !two_kernels && !f32 && generic_match<LG>(t, p.goff) && launch_fused_generic<LG>(p, st)) { \
+        if (hipGetLastError() != hipSuccess) { set_error("viterbi (table-driven codeword path): launch failed"); *rc = CPX_EHIP; } \
+        note_kernel("viterbi_cw_fused_kernel<%d,table-driven,%s,%d>", LG, type_name(type), fused_tb<LG>() - 2);              \
+        return true;                                                                                                    \
     }
+    CPX_TRY_TABLE(6) CPX_TRY_TABLE(5) CPX_TRY_TABLE(4) CPX_TRY_TABLE(3) CPX_TRY_TABLE(2)
+#undef CPX_TRY_TABLE
     return reject("no instantiation for this trellis");
 }
 

@@ -114,10 +114,10 @@ int cpx_trellis_destroy(cpx_trellis *t);
  * Decision rule: the bit(s) of step s come from the survivor of the
  * first-minimum state at step min(s+tb_depth-2, n_steps), ties -> lowest index.
  * Kernel selection is internal and does not change a single output bit: batches of >= 0.45 * (SIMDs of the device) * 64
- * codewords of a 64-state rate-1/2 shift-register code run one codeword per lane (csrc/viterbi_cw.hip): a single fused kernel
- * for tb_depth <= 48 with the generators compiled in -- (133,171), (171,133) in both polynomial formats and Wifi80211's (5,43) --
- * or, for any other pair whose generators both tap the input and the oldest register bit, with a run-time code table
- * (default depth 30); an add-compare-select + a traceback kernel with a 9 B per codeword-step device workspace beyond that;
+ * codewords of a rate-1/2 shift-register code of 4 .. 64 states run one codeword per lane (csrc/viterbi_cw.hip): a single fused
+ * kernel with the generators compiled in -- K = 7 (133,171), (171,133) in both polynomial formats and Wifi80211's (5,43) for
+ * tb_depth <= 48; K = 3 (5,7) and K = 5 (23,35) at their default depth -- or, for any other pair whose generators both tap the
+ * input and the oldest register bit, with a run-time code table (default depth 5 * memory); an add-compare-select + a traceback kernel with a 9 B per codeword-step device workspace beyond that;
  * everything else runs one trellis state per lane (csrc/viterbi.hip).  A NaN among 'soft' inputs is handled as the reference
  * handles it (convcode.py:719 lets it through the clip): flagged codewords are decoded again by a NaN-exact instantiation.
  * cpx_viterbi_set_path (or the environment variable CPX_VITERBI_PATH = wave | cw | cw! | cw2 | cw2! at load time)

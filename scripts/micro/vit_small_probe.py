@@ -23,3 +23,19 @@ for mem, gm, B, nbits in ((2, [5, 7], 1 << 20, 64), (2, [5, 7], 1 << 17, 1024), 
         print(gm, B, nbits, path or "auto", round(ms, 3), "ms", _lib.last_kernel(), flush=True)
     _lib.viterbi_set_path(None)
     dev.free()
+
+# table-driven small codes: K = 4 (15,17), K = 6 (53,75)
+for mem, gm, B, nbits in ((3, [0o15, 0o17], 1 << 18, 256), (5, [0o53, 0o75], 1 << 16, 1024)):
+    tr = Trellis(np.array([mem]), np.array([gm]))
+    coded = conv_encode_batch(rs.randint(0, 2, (B, nbits)).astype(np.uint8), tr).astype(np.float64)
+    rx = np.where(rs.random_sample(coded.shape) < 0.05, 1 - coded, coded)
+    L = nbits + mem
+    dev = Dev(lib)
+    d_in, d_out = dev.put(rx), dev.empty(B * L)
+    h = tr._device_handle()
+    for path in (None, "wave"):
+        _lib.viterbi_set_path(path)
+        ms, _ = timeit(lib, lambda: _lib.check(lib.cpx_viterbi_decode_batch_dev(h, d_in, B, 2 * L, L, L, 5 * mem, 0, d_out, None)), steps=5)
+        print(gm, B, nbits, path or "auto", round(ms, 3), "ms", _lib.last_kernel(), flush=True)
+    _lib.viterbi_set_path(None)
+    dev.free()

@@ -142,18 +142,24 @@ def test_all_instantiated_generators(gpu, gm, fmt):
 
 
 @pytest.mark.parametrize("dtype", ["hard", "soft", "unquantized"])
-def test_table_driven_codes(gpu, dtype):
-    """Any 64-state rate-1/2 code whose generators both tap the input and the oldest register bit takes the fused kernel with a
-    run-time code table (csrc/viterbi_cw.hip, G0 = G1 = 0) at the default traceback depth: random generator pairs, ragged batches,
-    a NaN codeword ('soft'), against the oracle and the state-per-lane kernels; a code without both end taps is refused."""
+@pytest.mark.parametrize("mem", [2, 3, 4, 5, 6])
+def test_table_driven_codes(gpu, dtype, mem):
+    """Any rate-1/2 shift-register code of 4 .. 64 states whose generators both tap the input and the oldest register bit takes the
+    fused kernel with a run-time code table (csrc/viterbi_cw.hip, G0 = G1 = 0) at its default traceback depth: random generator
+    pairs, ragged batches, a NaN codeword ('soft'), against the oracle and the state-per-lane kernels; a code without both end
+    taps is refused."""
     from commpy_amd import _lib
     from commpy_amd.channelcoding import Trellis, conv_encode_batch
-    rs = np.random.RandomState(31)
-    for trial in range(5):
-        g0, g1 = (int(0o101 | (rs.randint(0, 32) << 1)) for _ in range(2))          # bits 6 and 0 set, middle taps random
-        if g0 == g1 or {g0, g1} == {0o133, 0o171}:
-            g1 ^= 0o24
-        tr = Trellis(np.array([6]), np.array([[g0, g1]]))
+    rs = np.random.RandomState(31 + mem)
+    ends = (1 << mem) | 1
+    seen = 0
+    for trial in range(5 if mem > 2 else 2):
+        g0, g1 = (int(ends | (rs.randint(0, 1 << (mem - 1)) << 1)) for _ in range(2))   # both end bits set, middle taps random
+        if g0 == g1:
+            g1 ^= 2 if mem > 1 else 0
+        if g0 == g1:
+            continue
+        tr = Trellis(np.array([mem]), np.array([[g0, g1]]))
         for B, nbits in ((70, 97), (5, 200), (129, 40)):
             coded = conv_encode_batch(rs.randint(0, 2, (B, nbits)), tr).astype(float)
             if dtype == "hard":
@@ -165,10 +171,13 @@ def test_table_driven_codes(gpu, dtype):
                 rx = 2.0 * coded - 1 + rs.randn(*coded.shape) * 0.8
             want = oracle.viterbi_decode(rx, tr, None, dtype)
             got = _decode(rx, tr, None, dtype, "cw!")
-            assert "table-driven" in _lib.last_kernel(), (_lib.last_kernel(), oct(g0), oct(g1))
-            assert np.array_equal(got, want), (dtype, oct(g0), oct(g1), B, nbits)
+            note = _lib.last_kernel()
+            assert "viterbi_cw_fused_kernel" in note, (note, oct(g0), oct(g1))
+            seen += "table-driven" in note
+            assert np.array_equal(got, want), (dtype, mem, oct(g0), oct(g1), B, nbits, note)
             assert np.array_equal(_decode(rx, tr, None, dtype, "wave"), want)
-    tr = Trellis(np.array([6]), np.array([[0o132, 0o171]]))                          # first generator does not tap the oldest bit
+    assert seen > 0 or mem == 2                                       # (memory 2 has one such pair, (5,7): compiled in)
+    tr = Trellis(np.array([mem]), np.array([[ends & ~1 | 2, ends]])) if mem > 1 else None   # first generator does not tap the oldest bit
     with pytest.raises(ValueError):
         _decode(np.zeros((2, 60)), tr, None, "hard", "cw!")
 
