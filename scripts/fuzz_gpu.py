@@ -88,15 +88,17 @@ def main():
                 # round 3: a random 64-state pair with both end taps through the table-driven fused kernel (default depth) or, at other
                 # depths, whatever the forced-but-not-strict codeword path falls back to
                 from commpy_amd.channelcoding import Trellis
-                g0, g1 = (int(0o101 | (rs.randint(0, 32) << 1)) for _ in range(2))
+                mem = int(rs.randint(2, 7))
+                ends = (1 << mem) | 1
+                g0, g1 = (int(ends | (rs.randint(0, 1 << (mem - 1)) << 1)) for _ in range(2))
                 if g0 == g1:
-                    g1 ^= 0o24
+                    g1 ^= 2
                 with warnings.catch_warnings():
                     warnings.simplefilter("ignore")
-                    trg = Trellis(np.array([6]), np.array([[g0, g1]]))
+                    trg = Trellis(np.array([mem]), np.array([[g0, g1]]))
                 dtype = str(rs.choice(["hard", "soft", "unquantized"]))
                 B, nbits = int(rs.choice([1, 7, 64, 65, 130])), int(rs.randint(30, 300))
-                tb = None if rs.rand() < 0.7 else int(rs.randint(2, 49))
+                tb = None if rs.rand() < 0.7 else int(rs.randint(2, min(49, nbits) + 1))
                 coded = conv_encode_batch(rs.randint(0, 2, (B, nbits)), trg).astype(float)
                 if dtype == "hard":
                     rx = np.where(rs.rand(*coded.shape) < 0.1, 1 - coded, coded)
