@@ -245,6 +245,30 @@ def bench_turbo(lib, scale, which):
     dev.free()
 
 
+def bench_viterbi_variants(lib, scale):
+    """The fused codeword-per-lane kernel away from the headline instantiation, on the config-2 geometry (65536 x 1024-bit, soft):
+    traceback depth 40 (64-slot ring), a pair without a compiled-in instantiation (table-driven), and the state-per-lane kernels."""
+    from commpy_amd.channelcoding import Trellis, conv_encode_batch
+    B = int(65536 * scale)
+    rs = np.random.RandomState(4)
+    for gm, tb, path, what in (([0o133, 0o171], 40, None, "tb_depth = 40"), ([0o135, 0o147], 30, None, "(135,147), no compiled-in instantiation"),
+                               ([0o133, 0o171], 30, "wave", "state-per-lane kernels")):
+        tr = Trellis(np.array([6]), np.array([gm]))
+        coded = conv_encode_batch(rs.randint(0, 2, (B, 1024)).astype(np.uint8), tr).astype(np.float64)
+        llr = np.ascontiguousarray(4.0 * coded - 2 + rs.standard_normal(coded.shape).astype(np.float32) * 1.4, dtype=np.float64)
+        dev = Dev(lib)
+        d_in, d_out = dev.put(llr), dev.empty(B * 1030)
+        h = tr._device_handle()
+        _lib.viterbi_set_path(path)
+        try:
+            ms, _ = timeit(lib, lambda: _lib.check(lib.cpx_viterbi_decode_batch_dev(h, d_in, B, 2060, 1030, 1030, tb, 1, d_out, None)), steps=10)
+            name = _lib.last_kernel()
+        finally:
+            _lib.viterbi_set_path(None)
+        emit(name, "config-2 geometry, %s, B=%d" % (what, B), B * 1024, "info-bits", ms, B * 17510, "valu")
+        dev.free()
+
+
 def bench_viterbi_small(lib, scale):
     from commpy_amd.channelcoding import Trellis, conv_encode_batch
     tr = Trellis(np.array([2]), np.array([[5, 7]]))
@@ -296,7 +320,7 @@ def bench_encoders(lib, scale):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--which", default="demod,ldpc,config4,turbo,map,viterbi_small,encoders")
+    ap.add_argument("--which", default="demod,ldpc,config4,turbo,map,viterbi_small,viterbi_variants,encoders")
     ap.add_argument("--scale", type=float, default=1.0)
     a = ap.parse_args()
     lib = _lib.load()
@@ -304,6 +328,8 @@ def main():
     which = a.which.split(",")
     if "demod" in which:
         bench_demod(lib, a.scale)
+    if "viterbi_variants" in which:
+        bench_viterbi_variants(lib, a.scale)
     if "viterbi_small" in which:
         bench_viterbi_small(lib, a.scale)
     if "turbo" in which or "map" in which:
