@@ -849,6 +849,20 @@ int launch_fused_small_typed(const CwParams &p, hipStream_t st) {
     constexpr int RING = fused_tb<LGS>() - 1 <= 16 ? 16 : 32;
     auto *fn = viterbi_cw_fused_kernel<LGS, G0, G1, TYPE, fused_tb<LGS>() - 2, false, double, RING, false>;
     const size_t lds = ACS_WAVES * fused_wave_lds<RING, false>();
+    if (lds > 64 * 1024) {                                        // (32-slot ring: 91 KB) dynamic LDS above 64 KiB is opt-in, once per kernel and device
+        static bool raised[64] = {};
+        static std::mutex raised_mu;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+        std::lock_guard<std::mutex> lk(raised_mu);
+        if (!raised[dev]) {
+            if (hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+                (void)hipGetLastError();
+                return 0;
+            }
+            raised[dev] = true;
+        }
+    }
     const unsigned groups = (unsigned)((p.B + 63) / 64), blocks = (groups + ACS_WAVES - 1) / ACS_WAVES;
     hipLaunchKernelGGL(fn, dim3(blocks), dim3(64 * ACS_WAVES), lds, st, p);
     return 1;
