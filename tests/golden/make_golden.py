@@ -788,6 +788,38 @@ def gen_abnormal():
 
 GENS["abnormal"] = gen_abnormal
 
+
+def gen_viterbi_pairs():
+    """Generator pairs beyond the fixture list -- the codes the table-driven and small-ring fused kernels of round 3 serve -- through
+    the LIVE reference: memory 2..6, both end taps set, hard / soft / unquantized, default traceback depth (and depth 40 for K = 7)."""
+    out, names = {}, []
+    rs = np.random.RandomState(606)
+    pairs = [(2, 7, 5), (3, 0o15, 0o17), (3, 0o13, 0o17), (4, 0o35, 0o23), (4, 0o27, 0o31), (5, 0o53, 0o75), (5, 0o61, 0o73),
+             (6, 0o135, 0o147), (6, 0o165, 0o127), (6, 0o133, 0o171)]
+    for mem, g0, g1 in pairs:
+        tr = Trellis(np.array([mem]), np.array([[g0, g1]]))
+        for dtype in ("hard", "soft", "unquantized"):
+            for tb in ((None, 40) if (mem, g0) == (6, 0o133) else (None,)):
+                B, nbits = 5, int(rs.randint(60, 140))
+                msg = rs.randint(0, 2, (B, nbits))
+                coded = np.stack([conv_encode(msg[b], tr) for b in range(B)]).astype(float)
+                if dtype == "hard":
+                    rx = np.where(rs.rand(*coded.shape) < 0.07, 1 - coded, coded)
+                elif dtype == "soft":
+                    rx = 4.0 * coded - 2 + rs.randn(*coded.shape) * 1.8
+                else:
+                    rx = 2.0 * coded - 1 + rs.randn(*coded.shape) * 0.8
+                dec = np.stack([viterbi_decode(rx[b].copy(), tr, tb, dtype) for b in range(B)]).astype(np.uint8)
+                key = "p%d_%o_%o_%s_%s" % (mem, g0, g1, dtype, tb)
+                out[key + "__rx"], out[key + "__dec"] = rx, dec
+                names.append(key)
+    out["names"] = np.array(names)
+    print("viterbi_pairs: %d cases" % len(names))
+    save("viterbi_pairs", **out)
+
+
+GENS["viterbi_pairs"] = gen_viterbi_pairs
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)

@@ -209,6 +209,24 @@ def test_small_trellises_on_the_fused_kernel(gpu, name, dtype):
         _decode(np.zeros((2, 80)), tr, 7, "hard", "cw!")               # not the default depth: no instantiation
 
 
+def test_generator_pairs_vs_live_reference(gpu):
+    """tests/golden/viterbi_pairs.npz: ten generator pairs of memory 2 .. 6 (table-driven, small-ring and compiled-in fused kernels,
+    the 64-slot ring at depth 40) decoded by the LIVE reference -- through the forced codeword path and the state-per-lane kernels."""
+    from commpy_amd import _lib
+    from commpy_amd.channelcoding import Trellis
+    from test_oracle_golden import pair_cases
+    g, cases = pair_cases()
+    seen = set()
+    for key, mem, g0, g1, dtype, tb in cases:
+        tr = Trellis(np.array([mem]), np.array([[g0, g1]]))
+        got = _decode(g[key + "__rx"], tr, tb, dtype, "cw!")
+        note = _lib.last_kernel()
+        seen.add("table" if "table-driven" in note else "small" if "small ring" in note else "deep" if "64-slot" in note else "compiled")
+        assert np.array_equal(got, g[key + "__dec"]), (key, note)
+        assert np.array_equal(_decode(g[key + "__rx"], tr, tb, dtype, "wave"), g[key + "__dec"]), key
+    assert seen >= {"table", "deep", "compiled"}, seen              # ((5,7) and (23,35) on the small ring: the t57 / k5_23_35 goldens)
+
+
 def test_table_driven_code_full_batch_default_dispatch(gpu):
     """A 64-state code without a compiled-in instantiation, (135,147), as a batch that fills the chip: the default dispatch takes the
     table-driven fused kernel; all 40 000 codewords equal the state-per-lane kernels, the first / last 700 the oracle."""
