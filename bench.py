@@ -204,6 +204,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=65536, help="codewords per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-path-check", action="store_true",
+                    help="skip the untimed full-batch comparison of the three Viterbi kernel families before the warm-up")
     ap.add_argument("--gather", action="store_true",
                     help="N > 1: all-gather the decoded bits of all ranks in every step (RCCL, on the decode stream)")
     ap.add_argument("--comm", choices=("rccl", "torch"), default="rccl",
@@ -316,6 +318,34 @@ def main():
         _lib.check(lib.cpx_timer_create(ctypes.byref(tmr)))
         timers.append(tmr)
     kernel_ms = []
+
+    # Untimed, before the warm-up: the three Viterbi kernel families on the WHOLE batch that is timed below -- the default dispatch
+    # (the fused kernel), the two-kernel codeword path and the state-per-lane kernels must return the same bits for all B codewords
+    # (the oracle comparison after the timed region covers 16 386 of them).  Said plainly: these ~7 ms of decoding also mean that the
+    # GPU is no longer at its idle clock when the W warm-up steps start (BENCH_DEBUG=1 prints the per-step times; --no-path-check
+    # leaves the check out).
+    path_check = None
+    if not args.no_path_check and args.precision == "fp64-parity":
+        d_alt, d_errs = ctypes.c_void_p(), ctypes.c_void_p()
+        _lib.check(lib.cpx_malloc(ctypes.byref(d_alt), B * L))
+        _lib.check(lib.cpx_malloc(ctypes.byref(d_errs), B * 4))
+        _lib.check(lib.cpx_viterbi_decode_batch_dev(h_tr, d_llr, B, LEN, L, T, TB, 1, d_bits, stream))
+        names, mism = [_lib.viterbi_last_path()], {}
+        errs = np.empty(B, dtype=np.int32)
+        for path in ("cw2", "wave"):
+            _lib.viterbi_set_path(path)
+            try:
+                _lib.check(lib.cpx_viterbi_decode_batch_dev(h_tr, d_llr, B, LEN, L, T, TB, 1, d_alt, stream))
+                names.append(_lib.viterbi_last_path())
+            finally:
+                _lib.viterbi_set_path(None)
+            _lib.check(lib.cpx_count_errors_dev(d_bits, L, d_alt, L, B, 1, L, d_errs, stream))
+            sync()
+            _lib.check(lib.cpx_memcpy_d2h(_lib.ptr(errs), d_errs, errs.nbytes))
+            mism[path] = int(errs.sum())
+        path_check = {"codewords": B, "kernel_paths": names, "mismatching_bits_vs_default_dispatch": mism}
+        for d in (d_alt, d_errs):
+            _lib.check(lib.cpx_free(d))
 
     def step(k):
         if k is not None:
@@ -448,7 +478,7 @@ def main():
                            else "no data-path collective"),
                        "collectives": ("engine RCCL binding (cpx_comm_*)" if comm is not None else
                                        "torch.distributed (nccl)" if dist is not None else "none (single process)")},
-            "ber": ber, "oracle_mismatched_bits": mism, "oracle_sample_codewords": checked, "build_id": build, "git_head": _git_head(),
+            "ber": ber, "oracle_mismatched_bits": mism, "oracle_sample_codewords": checked, "kernel_path_check": path_check, "build_id": build, "git_head": _git_head(),
             "demod_max_abs_err_vs_oracle": demod_err,
             # the kernel is bound by VALU issue, not by HBM: achieved / peak / frac are the HBM figures the
             # contract asks for, `valu` carries the ceiling that actually binds (from the PMC passes in profiles/)

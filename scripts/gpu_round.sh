@@ -18,7 +18,7 @@ if [[ $SEC == *s* ]]; then
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee $OUT/smoke.txt
 fi
 if [[ $SEC == *b* ]]; then
-  timeout 900 python bench.py --gpus 1 --steps 20 --warmup 3 2>&1 | tail -3 | tee $OUT/bench_n1.json
+  timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 2>&1 | tail -3 | tee $OUT/bench_n1.json
   timeout 600 python bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline --precision fp32-fast 2>&1 | tail -1 | tee $OUT/bench_fp32_fast.json | cut -c1-400
 fi
 if [[ $SEC == *d* ]]; then
