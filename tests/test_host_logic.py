@@ -153,3 +153,24 @@ def test_ldpc_design_files(tmp_path):
     assert not (w["parity_check_matrix"].dot(coded) % 2).any()
     with pytest.raises(ValueError):
         triang_ldpc_systematic_encode(np.array([0, 1]), w, False)
+
+
+@pytest.mark.timeout(240)
+def test_bench_cpu_baseline_legs():
+    """bench.py's cpu_baseline: the 'reference' leg (the unmodified CommPy decoder on a process pool) where the reference is present
+    -- the build container --, the C-port leg and the NumPy secondary everywhere; all on four codewords of the unquantised config-2
+    fixture, whose stored decodes are the live reference's."""
+    import bench                                                   # repo root is on sys.path (conftest); the pool's spawned workers import it by name
+    from helpers import golden
+    from test_oracle_golden import TableTrellis
+    g = golden("viterbi_c2u")
+    llr = np.ascontiguousarray(g["llr"][:4])
+    dec = np.unpackbits(g["dec"], axis=1)[:4, :1030].astype(np.int64)
+    res = bench.cpu_baseline(TableTrellis("k7_133_171"), llr, dec, budget_s=0.3)
+    port = res if res["kind"] == "port" else res["port"]
+    assert port["kind"] == "port" and port["value"] > 1e4
+    assert res["secondary"]["sample"].endswith("True")
+    if bench._find_reference():
+        assert res["kind"] == "reference" and res["cores"] == 4
+        assert "bits differing from the engine's on these codewords: 0" in res["sample"]
+        assert 100 < res["per_core"] < 1e5
