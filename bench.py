@@ -2,13 +2,17 @@
 """Headline benchmark: soft-decision Viterbi, K=7 rate-1/2 (0o133, 0o171), 1024-bit blocks,
 QPSK + AWGN at Eb/N0 = 3 dB, batch 65536 codewords per GPU (BASELINE.json configs[1]).
 
-    python bench.py --gpus N --steps K --warmup W [--gather] [--comm rccl|torch]
+    python bench.py --gpus N --steps K --warmup W [--comm rccl|torch]
 
 A "step" is one pass of the HIP Viterbi decoder over the whole per-GPU batch with the float64 LLRs
-already resident in HBM.  N > 1 (launched by torch.distributed.run, one process per GPU): weak
-scaling, every rank decodes its own 65536-codeword batch.  The path shards by codeword and has no exchange step, so
-by default the timed region contains no collective; ``--gather`` adds the one collective north_star names -- an
-RCCL all-gather of the decoded bits (uint8, 67.5 MB per rank and step) on the decode stream -- to every step.
+already resident in HBM.  N > 1 is weak scaling, one process per GPU, every rank decodes its own 65536-codeword batch.
+The ranks come from either launcher: ``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`` (RANK /
+WORLD_SIZE in the environment; WORLD_SIZE != N is an error), or plain ``python bench.py --gpus N``, which starts the N
+ranks ITSELF (subprocesses, no torch) after checking that N devices are visible -- it never silently runs one GPU.
+The path shards by codeword and has no exchange step, so `value` times the decode alone; the SAME K steps are then timed
+again with the one collective north_star names -- an RCCL all-gather of the decoded bits (uint8, 67.5 MB per rank and
+step) on the decode stream -- in every step and reported as `value_with_gather`; `comm_world` is what RCCL itself
+reports for the communicator (ncclCommCount).
 Collectives (closing barrier, max over ranks, error-count all-reduce, the optional all-gather) go through the
 engine's own RCCL binding (``cpx_comm_*``, commpy_amd.parallel.RankComm); torch is NOT imported.  ``--comm torch``
 uses torch.distributed instead (an explicit choice: if the RCCL communicator cannot be formed the run fails).  Rank 0 prints ONE JSON line with the contract fields plus `roofline`
@@ -197,6 +201,85 @@ def cpu_baseline(tr, llr_sample, gpu_bits=None, budget_s=8.0):
     return res
 
 
+def free_port():
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def launch_ranks(n, child_argv, env=None, timeout=None):
+    """Start the `n` ranks of a one-node job (one process per GPU) and wait for them: what `torch.distributed.run` does for
+    this script, without torch.  Every child gets RANK / LOCAL_RANK / WORLD_SIZE / LOCAL_WORLD_SIZE / MASTER_ADDR (127.0.0.1) /
+    MASTER_PORT and one CPX_COMM_NONCE per launch (the RCCL id exchange keys on it, commpy_amd/parallel.py).  stdout and
+    stderr are inherited: rank 0 prints the JSON line.  When a rank fails, the others -- who would wait for it in the next
+    collective -- are terminated (by pid) and the first non-zero exit code is returned."""
+    import subprocess
+    import uuid
+    base = dict(os.environ if env is None else env)
+    base.update({"WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1",
+                 "MASTER_PORT": str(free_port()), "CPX_COMM_NONCE": uuid.uuid4().hex})
+    procs = []
+    for r in range(n):
+        e = dict(base)
+        e.update({"RANK": str(r), "LOCAL_RANK": str(r)})
+        procs.append(subprocess.Popen(list(child_argv), env=e))
+    deadline = None if timeout is None else time.time() + timeout
+    rc = 0
+    live = list(procs)
+    while live:
+        for pr in list(live):
+            code = pr.poll()
+            if code is None:
+                continue
+            live.remove(pr)
+            if code != 0 and rc == 0:
+                rc = code
+        if live and (rc != 0 or (deadline is not None and time.time() > deadline)):
+            if rc == 0:
+                rc = 124
+            for pr in live:
+                pr.terminate()
+            for pr in live:
+                try:
+                    pr.wait(10)
+                except subprocess.TimeoutExpired:
+                    pr.kill()
+                    pr.wait()
+            live = []
+        if live:
+            time.sleep(0.05)
+    return rc
+
+
+def visible_devices():
+    """Number of HIP devices the engine sees (0 when there is none or the library cannot initialise one)."""
+    from commpy_amd import _lib
+    try:
+        return int(_lib.device_count())
+    except Exception:
+        return 0
+
+
+def resolve_world(args, environ=None, n_devices=None):
+    """Which of the three ways this invocation runs: ("single", 0, 1), ("rank", rank, world) or ("launch", 0, N).
+    Errors (SystemExit with a message) instead of EVER running fewer GPUs than --gpus asks for."""
+    env = os.environ if environ is None else environ
+    if "RANK" in env and "WORLD_SIZE" in env:
+        rank, world = int(env["RANK"]), int(env["WORLD_SIZE"])
+        if world != args.gpus:
+            raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks (rank %d): they must agree"
+                             % (args.gpus, world, rank))
+        return "rank", rank, world
+    if args.gpus <= 1:
+        return "single", 0, 1
+    have = visible_devices() if n_devices is None else n_devices
+    if have < args.gpus:
+        raise SystemExit("bench.py: --gpus %d needs %d visible MI355X devices, this box shows %d -- refusing to run a "
+                         "smaller job under that name" % (args.gpus, args.gpus, have))
+    return "launch", 0, args.gpus
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -207,7 +290,9 @@ def main():
     ap.add_argument("--no-path-check", action="store_true",
                     help="skip the untimed full-batch comparison of the three Viterbi kernel families before the warm-up")
     ap.add_argument("--gather", action="store_true",
-                    help="N > 1: all-gather the decoded bits of all ranks in every step (RCCL, on the decode stream)")
+                    help="accepted for older command lines; N > 1 always times both regions (decode alone -> value, decode + "
+                         "RCCL all-gather of the decoded bits on the decode stream -> value_with_gather)")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the second (decode + all-gather) timed region")
     ap.add_argument("--comm", choices=("rccl", "torch"), default="rccl",
                     help="collectives of the N > 1 run: the engine's own RCCL binding (default) or torch.distributed")
     ap.add_argument("--synth", choices=("device", "host"), default="device",
@@ -218,10 +303,13 @@ def main():
                          "headline: the line then carries dtype f32 and the measured mismatch count against the float64 oracle")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    mode, rank, world = resolve_world(args)
+    if mode == "launch":
+        # plain `python bench.py --gpus N`: this process only starts the N ranks (same script, same arguments) and waits
+        sys.exit(launch_ranks(world, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    distributed = mode == "rank"
+    args.gather = distributed and world > 1 and not args.no_gather
     torch = dist = comm = None
     if distributed and args.comm == "torch":
         # torch first: its bundled HIP runtime (same SONAME) is then shared by libcommpy_amd.so
@@ -312,12 +400,21 @@ def main():
     sync()
 
     # one HIP-event pair per timed step, recorded on the launch stream and read AFTER the timed region
-    timers = []
-    for _ in range(args.steps):
-        tmr = ctypes.c_void_p()
-        _lib.check(lib.cpx_timer_create(ctypes.byref(tmr)))
-        timers.append(tmr)
-    kernel_ms = []
+    def make_timers(n):
+        out = []
+        for _ in range(n):
+            tmr = ctypes.c_void_p()
+            _lib.check(lib.cpx_timer_create(ctypes.byref(tmr)))
+            out.append(tmr)
+        return out
+
+    def read_timers(tmrs):
+        out = []
+        for tmr in tmrs:
+            ms = ctypes.c_float()
+            _lib.check(lib.cpx_timer_elapsed_ms(tmr, ctypes.byref(ms)))
+            out.append(ms.value)
+        return out
 
     # Untimed, before the warm-up: the three Viterbi kernel families on the WHOLE batch that is timed below -- the default dispatch
     # (the fused kernel), the two-kernel codeword path and the state-per-lane kernels must return the same bits for all B codewords
@@ -347,78 +444,106 @@ def main():
         for d in (d_alt, d_errs):
             _lib.check(lib.cpx_free(d))
 
-    def step(k):
-        if k is not None:
-            _lib.check(lib.cpx_timer_start(timers[k], stream))
+    def step(tmr, gather):
+        if tmr is not None:
+            _lib.check(lib.cpx_timer_start(tmr, stream))
         _lib.check(lib.cpx_viterbi_decode_batch_dev(h_tr, d_llr, B, LEN, L, T, TB, 1, d_bits, stream))
-        if args.gather and world > 1:                               # the collective north_star names, on the decode stream
+        if gather:                                                  # the collective north_star names, on the decode stream
             if comm is not None:
                 comm.allgather_dev(d_bits, d_full, B * L, stream)
             else:
                 dist.all_gather_into_tensor(t_full.view(-1), t_bits.reshape(-1))
-        if k is not None:
-            _lib.check(lib.cpx_timer_stop(timers[k], stream))
+        if tmr is not None:
+            _lib.check(lib.cpx_timer_stop(tmr, stream))
 
-    # warm-up runs exactly what a timed step runs, event records included (the first hipEventRecord of a process
-    # that loaded torch's HIP runtime cost ~70 ms here, which must not land inside the K timed steps)
-    warm = ctypes.c_void_p()
-    _lib.check(lib.cpx_timer_create(ctypes.byref(warm)))
-    timers.append(warm)
-    for _ in range(max(args.warmup, 1)):
-        step(len(timers) - 1)
-    barrier(); sync()
-    kernel_name = _lib.last_kernel()                               # what the library really launched for this workload
-    if distributed:
-        # untimed rehearsal of the whole timed region (same K launches, same closing barrier + synchronize): one-time
-        # host-side costs of the collective path (seen sporadically as a ~70 ms stall in the first closing barrier of
-        # a process on a fresh box) land here, not in the measurement
-        for k in range(args.steps):
-            step(len(timers) - 1)
+    def timed_region(gather):
+        """W warm-up steps, (N > 1: an untimed rehearsal of the whole region,) then EXACTLY K steps between barrier +
+        synchronize on both sides; returns (elapsed seconds, MAX over ranks; per-step event times of this rank)."""
+        warm = make_timers(1)[0]
+        # warm-up runs exactly what a timed step runs, event records included (the first hipEventRecord of a process
+        # that loaded torch's HIP runtime cost ~70 ms here, which must not land inside the K timed steps)
+        for _ in range(max(args.warmup, 1)):
+            step(warm, gather)
         barrier(); sync()
-    timers.pop()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(k)
-    t1 = time.perf_counter()
-    barrier()
-    t2 = time.perf_counter()
-    sync()
-    elapsed = time.perf_counter() - t0
-    if os.environ.get("BENCH_DEBUG"):
-        print("debug: enqueue %.3f ms, barrier %.3f ms, sync %.3f ms" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3,
-                                                                           (t0 + elapsed - t2) * 1e3), file=sys.stderr)
-    for tmr in timers:
-        ms = ctypes.c_float()
-        _lib.check(lib.cpx_timer_elapsed_ms(tmr, ctypes.byref(ms)))
-        kernel_ms.append(ms.value)
-    if os.environ.get("BENCH_DEBUG"):
-        print("debug: per-step launch ms " + " ".join("%.3f" % v for v in kernel_ms), file=sys.stderr)
+        if distributed:
+            # untimed rehearsal of the whole timed region (same K launches, same closing barrier + synchronize): one-time
+            # host-side costs of the collective path (seen sporadically as a ~70 ms stall in the first closing barrier of
+            # a process on a fresh box) land here, not in the measurement
+            for k in range(args.steps):
+                step(warm, gather)
+            barrier(); sync()
+        tmrs = make_timers(args.steps)
+        barrier(); sync()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step(tmrs[k], gather)
+        t1 = time.perf_counter()
+        barrier()
+        t2 = time.perf_counter()
+        sync()
+        el = time.perf_counter() - t0
+        if os.environ.get("BENCH_DEBUG"):
+            print("debug[gather=%s]: enqueue %.3f ms, barrier %.3f ms, sync %.3f ms" % (
+                gather, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t0 + el - t2) * 1e3), file=sys.stderr)
+        ms = read_timers(tmrs)
+        if os.environ.get("BENCH_DEBUG"):
+            print("debug[gather=%s]: per-step launch ms " % gather + " ".join("%.3f" % v for v in ms), file=sys.stderr)
+        if comm is not None:
+            el = float(comm.allreduce(np.array([el]), "max")[0])                    # MAX over ranks
+        elif dist is not None:
+            tmax = torch.tensor([el], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el = float(tmax.item())
+        for tmr in tmrs + [warm]:
+            lib.cpx_timer_destroy(tmr)
+        return el, ms
+
+    elapsed, kernel_ms = timed_region(False)                       # `value`: the decode path alone (no data-path collective)
+    kernel_name = _lib.last_kernel()                               # what the library really launched for this workload
+    elapsed_g = gather_ms = None
+    if args.gather:
+        elapsed_g, gather_ms = timed_region(True)                  # `value_with_gather`: the same K steps + the all-gather
+    comm_world = None
     if comm is not None:
-        elapsed = float(comm.allreduce(np.array([elapsed]), "max")[0])          # MAX over ranks
+        nr, nl, fr = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _lib.check(lib.cpx_comm_info(comm.h, ctypes.byref(nr), ctypes.byref(nl), ctypes.byref(fr)))
+        comm_world = {"nranks": nr.value, "this_rank": fr.value, "source": "ncclCommCount / ncclCommUserRank"}
     elif dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        comm_world = {"nranks": dist.get_world_size(), "this_rank": dist.get_rank(), "source": "torch.distributed"}
 
     # ---- correctness of what was timed: BER vs the messages, parity vs the oracle on a sample ----
     bits = np.empty((B, L), dtype=np.uint8)
     _lib.check(lib.cpx_memcpy_d2h(_lib.ptr(bits), d_bits, bits.nbytes))
     nerr = int(np.sum(bits[:, :MSG_BITS] != msgs))
     gather_ok = None
-    if args.gather and world > 1:
-        # every rank holds every rank's bits: this rank's own slot must equal what it decoded, and the error count over the
-        # gathered array (against the all-reduced total below) shows the other slots carry the other ranks' results
-        full = np.empty((world, B, L), dtype=np.uint8)
-        _lib.check(lib.cpx_memcpy_d2h(_lib.ptr(full), d_full, full.nbytes))
-        gather_ok = bool(np.array_equal(full[rank], bits))
+
+    def allreduce_i64(v):
+        v = np.ascontiguousarray(v, dtype=np.int64)
+        if comm is not None:
+            return comm.allreduce(v)
+        t = torch.tensor(v, dtype=torch.int64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t.cpu().numpy()
+
     if world > 1:
         # error counts of all shards: an RCCL all-reduce of int64 counters (links.py:252-260), outside the timed region
-        if comm is not None:
-            nerr = int(comm.allreduce(np.array([nerr], np.int64))[0])
-        else:
-            terr = torch.tensor([nerr], dtype=torch.int64, device="cuda")
-            dist.all_reduce(terr, op=dist.ReduceOp.SUM)
-            nerr = int(terr.item())
+        nerr = int(allreduce_i64([nerr])[0])
+    if args.gather:
+        # every rank holds every rank's bits: this rank's own slot must equal what it decoded, and every OTHER slot must carry
+        # the checksums (ones count, position-weighted sum) its owner computed from its own decode and published by all-reduce
+        full = np.empty((world, B, L), dtype=np.uint8)
+        _lib.check(lib.cpx_memcpy_d2h(_lib.ptr(full), d_full, full.nbytes))
+        w = (np.arange(L, dtype=np.int64) % 251) + 1
+
+        def cks(a):
+            return [int(a.sum(dtype=np.int64)), int((a.sum(axis=0, dtype=np.int64) * w).sum())]
+
+        mine = np.zeros((world, 2), np.int64)
+        mine[rank] = cks(bits)
+        published = allreduce_i64(mine.reshape(-1)).reshape(world, 2)
+        gather_ok = bool(np.array_equal(full[rank], bits) and
+                         all(cks(full[r]) == list(published[r]) for r in range(world)))
+        gather_ok = bool(allreduce_i64([0 if gather_ok else 1])[0] == 0)         # true only if it held on EVERY rank
     ber = nerr / float(world * B * MSG_BITS)
     out = None
     if rank == 0:
@@ -442,6 +567,7 @@ def main():
         kavg = float(np.mean(kernel_ms))
         achieved = ALG_BYTES_PER_CW * B / (kavg * 1e-3) / 1e9
         value = world * B * MSG_BITS * args.steps / elapsed
+        value_g = None if elapsed_g is None else world * B * MSG_BITS * args.steps / elapsed_g
         # HBM traffic and VALU occupancy of this kernel from the committed rocprofv3 PMC passes (scripts/collect_pmc.py).  They
         # cannot be measured inside this run (counters need the profiler), so they are quoted ONLY when the file was recorded
         # by a library built from the same Viterbi sources as the one loaded now (cpx_build_id, "viterbi" digest), for the same
@@ -473,9 +599,9 @@ def main():
             "config": {"workload": "configs[1]: K=7 (0o133,0o171) r=1/2, 1024-bit blocks, soft Viterbi over "
                                    "AWGN+QPSK at Eb/N0=3 dB, batch=%d codewords per GPU, tb_depth=30" % B,
                        "batch_per_gpu": B, "block_bits": MSG_BITS, "ebn0_db": EBN0_DB,
-                       "parallelism": "codewords sharded x%d, %s" % (
-                           world, "RCCL all-gather of the decoded bits in every step" if (args.gather and world > 1)
-                           else "no data-path collective"),
+                       "parallelism": "codewords sharded x%d, no data-path collective in `value`%s" % (
+                           world, "; `value_with_gather`: + one RCCL all-gather of the decoded bits (%d B per rank) per step"
+                           % (B * L) if args.gather else ""),
                        "collectives": ("engine RCCL binding (cpx_comm_*)" if comm is not None else
                                        "torch.distributed (nccl)" if dist is not None else "none (single process)")},
             "ber": ber, "oracle_mismatched_bits": mism, "oracle_sample_codewords": checked, "kernel_path_check": path_check, "build_id": build, "git_head": _git_head(),
@@ -500,8 +626,17 @@ def main():
                          "note": "serial float64 add-compare-select recursion: VALU-issue bound (valu.busy_frac), the HBM "
                                  "fraction is reported because the metric asks for it"},
         }
-        if gather_ok is not None:
-            out["gather_own_slot_ok"] = gather_ok
+        if distributed:
+            # N > 1: the same K steps with north_star's one collective (all-gather of the decoded bits) on the decode stream in
+            # every step; comm_world = what the communicator itself reports, so "did RCCL see N ranks" is answerable from here
+            out["value_with_gather"] = value_g
+            out["ms_per_step_with_gather"] = None if elapsed_g is None else elapsed_g / args.steps * 1e3
+            out["gather"] = None if gather_ms is None else {
+                "bytes_per_rank_per_step": B * L, "step_ms_avg_rank0": float(np.mean(gather_ms)),
+                "all_slots_ok_on_all_ranks": gather_ok,
+                "note": "HIP events on rank 0 around decode + ncclAllGather (in place, [world][B][L] uint8 on every GPU)"}
+            out["comm_world"] = comm_world
+            out["launcher"] = "bench.py (subprocess per rank)" if os.environ.get("CPX_COMM_NONCE") else "external (RANK/WORLD_SIZE set)"
         if not args.no_cpu_baseline and world == 1:                # reported at N = 1 only; the other ranks would idle
             out["cpu_baseline"] = cpu_baseline(tr, llr_s, bits[:ns, :].astype(np.int64))
         else:

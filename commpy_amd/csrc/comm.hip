@@ -41,6 +41,8 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
@@ -68,6 +70,8 @@ int load_rccl() {
     SYM(CommInitRank, "ncclCommInitRank");
     SYM(CommInitAll, "ncclCommInitAll");
     SYM(CommDestroy, "ncclCommDestroy");
+    SYM(CommCount, "ncclCommCount");
+    SYM(CommUserRank, "ncclCommUserRank");
     SYM(AllGather, "ncclAllGather");
     SYM(AllReduce, "ncclAllReduce");
     SYM(GroupStart, "ncclGroupStart");
@@ -177,11 +181,19 @@ int cpx_comm_init_all(const int *devices, int ndev, cpx_comm **out) {
     return CPX_OK;
 }
 
+/* What RCCL itself reports for the communicator (ncclCommCount / ncclCommUserRank of the first local rank), not the numbers
+ * the caller passed in: bench.py prints them as `comm_world`, so "did RCCL see N ranks" is answerable from its line. */
 int cpx_comm_info(const cpx_comm *c, int *nranks, int *nlocal, int *first_rank) {
-    CPX_REQUIRE(c, CPX_EINVAL, "cpx_comm_info: null communicator");
-    if (nranks) *nranks = c->nranks;
+    CPX_REQUIRE(c && c->nlocal >= 1 && c->comms[0], CPX_EINVAL, "cpx_comm_info: null communicator");
+    int count = -1, urank = -1;
+    CPX_NCCL(g_rccl.CommCount(c->comms[0], &count));
+    CPX_NCCL(g_rccl.CommUserRank(c->comms[0], &urank));
+    CPX_REQUIRE(count == c->nranks && urank == c->rank0, CPX_EHIP,
+                "cpx_comm_info: RCCL reports rank %d of %d, the communicator was formed as rank %d of %d", urank, count,
+                c->rank0, c->nranks);
+    if (nranks) *nranks = count;
     if (nlocal) *nlocal = c->nlocal;
-    if (first_rank) *first_rank = c->rank0;
+    if (first_rank) *first_rank = urank;
     return CPX_OK;
 }
 

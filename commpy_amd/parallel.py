@@ -14,8 +14,8 @@ Two ways to span several GPUs:
     ``DeviceGroup().viterbi_decode(llr, trellis, None, 'soft')`` instead of ``viterbi_decode(...)``.  One host thread
     per device enqueues that device's work (ctypes drops the GIL, ``hipSetDevice`` is per thread).
 ``RankComm(rank, world)``  one process per GPU (``bench.py`` under ``torch.distributed.run``): rank 0 creates the
-    128-byte RCCL id and hands it to the other ranks through a file in ``/tmp`` named after the launcher's pid and
-    ``MASTER_PORT`` (one node, as the bench contract says).
+    128-byte RCCL id and hands it to the other ranks through a file in ``/tmp`` that carries a per-launch nonce
+    (one node, as the bench contract says).
 
 ``sharded_decode`` / ``reduce_counters`` take any object with the small ``Collective`` protocol (``rank``, ``world``,
 ``allgather_rows``, ``allreduce``): ``RankComm`` on GPUs; the CPU tests (tests/test_parallel_gloo.py) plug a gloo-backed
@@ -33,7 +33,7 @@ import numpy as np
 from commpy_amd import _lib
 
 __all__ = ['shard_bounds', 'shard_counts', 'pad_shard', 'unpad_gathered', 'sharded_decode', 'reduce_counters',
-           'exchange_unique_id', 'RankComm', 'DeviceGroup']
+           'exchange_unique_id', 'launch_nonce', 'RankComm', 'DeviceGroup']
 
 
 # ---- shard arithmetic (pure host code) --------------------------------------------------------------------------------
@@ -106,56 +106,76 @@ def reduce_counters(counters, comm=None):
 _comm_seq = 0                      # communicators formed by this process so far: all ranks create them in the same order
 
 
-def _launcher_start_time():
-    """Start time of the parent process (the launcher all ranks of one torch.distributed.run share), 0.0 if unknown."""
+def _launcher_start_ticks():
+    """Start time of the parent process -- the launcher all ranks of one job share -- in clock ticks since boot (field 22
+    of /proc/<pid>/stat: what the kernel recorded at fork, the same number for every reader and never the same for a later
+    process that reuses the pid).  '0' if /proc is not there."""
     try:
-        return os.stat('/proc/%d' % os.getppid()).st_ctime
-    except OSError:
-        return 0.0
+        with open('/proc/%d/stat' % os.getppid(), 'rb') as f:
+            stat = f.read().decode('ascii', 'replace')
+        return stat[stat.rindex(')') + 2:].split()[19]          # fields after "pid (comm) ": state is field 3 -> index 19 = 22
+    except (OSError, ValueError, IndexError):
+        return '0'
+
+
+def launch_nonce(seq=0):
+    """What identifies ONE communicator of ONE launch, computed identically by all its ranks: ``$CPX_COMM_NONCE`` when the
+    launcher set one (bench.py's own launcher does: random per launch), else launcher pid + its start ticks; plus
+    ``MASTER_PORT``, the elastic run id / restart count and ``seq`` (communicators this process has formed before)."""
+    env = os.environ
+    base = env.get('CPX_COMM_NONCE') or 'pid%d.%s' % (os.getppid(), _launcher_start_ticks())
+    return '%s.%s.%s.%s.%d' % (base, env.get('MASTER_PORT', '0'), env.get('TORCHELASTIC_RUN_ID', 'none'),
+                               env.get('TORCHELASTIC_RESTART_COUNT', '0'), seq)
 
 
 def _default_id_path(seq):
-    return os.path.join(tempfile.gettempdir(), 'cpx_comm_%d_%s_%s_%d.id' % (
-        os.getppid(), os.environ.get('MASTER_PORT', '0'), os.environ.get('TORCHELASTIC_RUN_ID', 'none'), seq))
+    import hashlib
+    return os.path.join(tempfile.gettempdir(), 'cpx_comm_%s.id' % hashlib.sha256(launch_nonce(seq).encode()).hexdigest()[:24])
 
 
-def exchange_unique_id(rank, world, make_id, path=None, timeout=180.0, seq=0):
+_ID_MAGIC = b'CPXID1\n'
+
+
+def exchange_unique_id(rank, world, make_id, path=None, timeout=180.0, seq=0, nonce=None):
     """Rank 0 calls ``make_id() -> bytes`` and publishes the result; every rank returns the same bytes.
 
-    Single-node launches only (the bench contract): the id travels through a file.  Its default name holds the
-    launcher's pid (all ranks of one ``torch.distributed.run`` share their parent), ``MASTER_PORT``, the elastic run id
-    and ``seq`` -- the number of communicators this job has formed before -- so every communicator of every launch has
-    its own file.  A file left behind by a crashed earlier launch that happens to have the same name is not trusted:
-    rank 0 removes it before it creates the id, and the other ranks only accept a file written after their launcher
-    started.  The write is atomic (temporary file + rename)."""
+    Single-node launches only (the bench contract): the id travels through a file.  Its default name is a hash of
+    ``launch_nonce(seq)``, and the file CONTENT starts with that nonce: a reader accepts a file only if it carries the nonce
+    of its own launch, so a file left behind by another (crashed) job is never taken for this communicator's whatever its
+    age -- no clock or mtime is consulted.  Rank 0 removes a leftover of the same name before it creates the id; the write
+    is atomic (temporary file + rename)."""
     if world == 1:
         return make_id()
+    if nonce is None:
+        nonce = launch_nonce(seq)
     if path is None:
         path = _default_id_path(seq)
+    head = _ID_MAGIC + nonce.encode() + b'\n'
     if rank == 0:
         try:
-            os.remove(path)                                   # a stale id must never be read as this communicator's
+            os.remove(path)
         except OSError:
             pass
         blob = make_id()
-        fd, tmp = tempfile.mkstemp(dir=os.path.dirname(path))
+        fd, tmp = tempfile.mkstemp(dir=os.path.dirname(path) or '.')
         with os.fdopen(fd, 'wb') as f:
-            f.write(blob)
+            f.write(head + blob)
         os.replace(tmp, path)
         return blob
-    fresh_after = _launcher_start_time() - 2.0
     deadline = time.time() + timeout
+    seen_foreign = False
     while True:
         try:
-            if os.stat(path).st_mtime >= fresh_after:
-                with open(path, 'rb') as f:
-                    blob = f.read()
-                if blob:
-                    return blob
+            with open(path, 'rb') as f:
+                data = f.read()
+            if data.startswith(head) and len(data) > len(head):
+                return data[len(head):]
+            seen_foreign = seen_foreign or bool(data)
         except OSError:
             pass
         if time.time() > deadline:
-            raise TimeoutError('rank %d: no communicator id at %s after %.0f s' % (rank, path, timeout))
+            raise TimeoutError('rank %d: no communicator id for launch %r at %s after %.0f s%s' % (
+                rank, nonce, path, timeout, ' (a file of another launch is there)' if seen_foreign else ''))
         time.sleep(0.01)
 
 

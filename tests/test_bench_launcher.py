@@ -1,0 +1,123 @@
+"""bench.py's own rank launcher and the RCCL id rendezvous, on CPU (no GPU, no torch): `python bench.py --gpus N` must
+start N ranks or fail -- never print a one-GPU line under an N-GPU name (round-3 review, row e)."""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import textwrap
+import time
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import bench  # noqa: E402
+
+
+def _args(gpus):
+    return argparse.Namespace(gpus=gpus)
+
+
+def test_resolve_world_modes():
+    assert bench.resolve_world(_args(1), environ={}) == ("single", 0, 1)
+    assert bench.resolve_world(_args(4), environ={}, n_devices=8) == ("launch", 0, 4)
+    assert bench.resolve_world(_args(4), environ={"RANK": "3", "WORLD_SIZE": "4"}) == ("rank", 3, 4)
+    assert bench.resolve_world(_args(1), environ={"RANK": "0", "WORLD_SIZE": "1"}) == ("rank", 0, 1)
+    with pytest.raises(SystemExit) as e:                               # fewer devices than asked for: refuse
+        bench.resolve_world(_args(8), environ={}, n_devices=1)
+    assert "needs 8 visible" in str(e.value) and "shows 1" in str(e.value)
+    with pytest.raises(SystemExit) as e:                               # launcher and flag disagree: refuse
+        bench.resolve_world(_args(2), environ={"RANK": "0", "WORLD_SIZE": "8"})
+    assert "WORLD_SIZE=8" in str(e.value)
+    with pytest.raises(SystemExit):                                    # the old silent case: --gpus 8 in a 1-rank environment
+        bench.resolve_world(_args(8), environ={"RANK": "0", "WORLD_SIZE": "1"})
+
+
+def test_gpus_2_without_devices_fails_with_a_clear_message():
+    """The shape of the driver's command line on a box that cannot satisfy it (this container has no GPU at all)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "needs 2 visible MI355X devices" in r.stderr
+    assert "n_gpus" not in r.stdout                                    # no JSON line of a smaller job
+
+
+STUB = textwrap.dedent('''
+    import json, os, sys, time
+    sys.path.insert(0, %(root)r)
+    from commpy_amd.parallel import exchange_unique_id, shard_bounds
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    assert os.environ["LOCAL_RANK"] == os.environ["RANK"] and os.environ["MASTER_ADDR"] == "127.0.0.1"
+    assert int(os.environ["MASTER_PORT"]) > 0 and len(os.environ["CPX_COMM_NONCE"]) == 32
+    if rank == 1:
+        time.sleep(%(late)f)                     # a rank that reaches the rendezvous long after rank 0 published the id
+    blob = exchange_unique_id(rank, world, lambda: bytes([7]) * 128, timeout=60)      # default path: keyed by the nonce
+    assert blob == bytes([7]) * 128
+    lo, hi = shard_bounds(1000, rank, world)     # the stub "decode": every rank reports its shard
+    open(os.path.join(%(out)r, "rank%%d.json" %% rank), "w").write(json.dumps({"rank": rank, "rows": [lo, hi],
+                                                                               "nonce": os.environ["CPX_COMM_NONCE"]}))
+    if rank == %(fail)d:
+        sys.exit(3)
+    if %(hang)d and rank != 0:
+        time.sleep(600)                          # would wait for the failed rank in a collective
+    if rank == 0:
+        print(json.dumps({"n_gpus": world}), flush=True)
+''')
+
+
+def _stub(tmp_path, late=0.0, fail=-1, hang=0):
+    path = tmp_path / "stub.py"
+    path.write_text(STUB % {"root": ROOT, "out": str(tmp_path), "late": late, "fail": fail, "hang": hang})
+    return [sys.executable, str(path)]
+
+
+def test_launch_ranks_starts_n_ranks_with_a_per_launch_nonce(tmp_path, capfd):
+    rc = bench.launch_ranks(4, _stub(tmp_path, late=3.0), timeout=120)
+    assert rc == 0
+    got = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(4)]
+    assert [g["rows"] for g in got] == [[0, 250], [250, 500], [500, 750], [750, 1000]]
+    assert len({g["nonce"] for g in got}) == 1
+    assert json.loads(capfd.readouterr().out.strip().splitlines()[-1]) == {"n_gpus": 4}    # rank 0's line passes through
+    # a second launch gets another nonce (and so another id file)
+    assert bench.launch_ranks(2, _stub(tmp_path), timeout=120) == 0
+    assert json.load(open(tmp_path / "rank0.json"))["nonce"] != got[0]["nonce"]
+
+
+def test_launch_ranks_propagates_a_failing_rank_and_stops_the_others(tmp_path):
+    t0 = time.time()
+    rc = bench.launch_ranks(3, _stub(tmp_path, fail=0, hang=1), timeout=120)
+    assert rc == 3
+    assert time.time() - t0 < 60                                       # the sleeping ranks were terminated, not waited for
+
+
+def test_id_exchange_rejects_a_file_of_another_launch(tmp_path):
+    """the freshness test compared an mtime with a procfs ctime.  Now a reader only accepts a file that carries
+    its own launch's nonce -- whatever the clocks say."""
+    from commpy_amd import parallel
+    path = str(tmp_path / "id")
+    # a leftover with the right magic but another launch's nonce, freshly written
+    with open(path, "wb") as f:
+        f.write(parallel._ID_MAGIC + b"other-launch\n" + b"\xee" * 128)
+    with pytest.raises(TimeoutError) as e:
+        parallel.exchange_unique_id(1, 2, None, path=path, timeout=0.3, nonce="this-launch")
+    assert "another launch" in str(e.value)
+    # rank 0 of this launch replaces it; a reader that arrives later (any delay) gets this launch's id
+    assert parallel.exchange_unique_id(0, 2, lambda: b"\x11" * 128, path=path, nonce="this-launch") == b"\x11" * 128
+    os.utime(path, (1.0e9, 1.0e9))                                     # an "old" mtime must not matter any more
+    assert parallel.exchange_unique_id(1, 2, None, path=path, timeout=5, nonce="this-launch") == b"\x11" * 128
+    # the nonce distinguishes launchers, ports, restarts and communicators of one job
+    n0 = parallel.launch_nonce(0)
+    assert parallel.launch_nonce(1) != n0
+    old = os.environ.get("CPX_COMM_NONCE")
+    try:
+        os.environ["CPX_COMM_NONCE"] = "abc"
+        assert parallel.launch_nonce(0).startswith("abc.") and parallel.launch_nonce(0) != n0
+    finally:
+        if old is None:
+            del os.environ["CPX_COMM_NONCE"]
+        else:
+            os.environ["CPX_COMM_NONCE"] = old
+    assert parallel._launcher_start_ticks().isdigit() and int(parallel._launcher_start_ticks()) > 0
