@@ -312,16 +312,26 @@ def write_ldpc_params(parity_check_matrix, file_path):
 
 
 def triang_ldpc_systematic_encode(message_bits, ldpc_code_params, pad=True):
-    """Systematic encoder for (approximately) triangular LDPC codes (host) -- ldpc.py:302-354."""
-    if ldpc_code_params.get('generator_matrix') is None or ldpc_code_params.get('parity_check_matrix') is None:
+    """Systematic encoder for (approximately) lower-triangular LDPC codes (host input generator) -- what ldpc.py:302-354
+    returns: int8 ``(n, n_blocks)`` with block b in COLUMN b, message part on top (squeezed to 1-D for one block).
+    ``generator_matrix`` / ``parity_check_matrix`` are added to the dictionary when missing (``build_matrix``).  A message
+    that does not fill its last block is zero-padded, or refused with ``ValueError`` when ``pad`` is false."""
+    if any(ldpc_code_params.get(key) is None for key in ('generator_matrix', 'parity_check_matrix')):
         build_matrix(ldpc_code_params)
-    block_length = ldpc_code_params['generator_matrix'].shape[1]
-    modulo = len(message_bits) % block_length
-    if modulo:
-        if pad:
-            message_bits = np.concatenate((message_bits, np.zeros(block_length - modulo, message_bits.dtype)))
-        else:
-            raise ValueError('Padding is disable but message length is not a multiple of block length.')
-    message_bits = message_bits.reshape(block_length, -1, order='F')
-    parity_part = ldpc_code_params['generator_matrix'].dot(message_bits) % 2
-    return np.vstack((message_bits, parity_part)).squeeze().astype(np.int8)
+    gen = ldpc_code_params['generator_matrix']
+    k = gen.shape[1]
+    msg = np.asarray(message_bits)
+    n_blocks, rest = divmod(len(msg), k)
+    if rest:
+        if not pad:
+            raise ValueError('message of %d bits is not a whole number of %d-bit blocks and pad=False' % (len(msg), k))
+        n_blocks += 1
+        grown = np.zeros(n_blocks * k, dtype=msg.dtype)
+        grown[:len(msg)] = msg
+        msg = grown
+    blocks = msg.reshape(n_blocks, k)                     # consecutive message bits fill one block (= one output column)
+    parity = gen.dot(blocks.T) % 2                        # generator over the reals, reduced mod 2 like ldpc.py:353
+    code = np.empty((k + parity.shape[0], n_blocks), dtype=np.int8)
+    code[:k] = blocks.T
+    code[k:] = parity
+    return code.squeeze()

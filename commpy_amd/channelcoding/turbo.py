@@ -11,31 +11,45 @@ Same public names, arguments and return conventions as /root/reference/commpy/ch
 import numpy as np
 
 from commpy_amd import _lib
-from commpy_amd.channelcoding.convcode import conv_encode
+from commpy_amd.channelcoding.convcode import conv_encode_batch
 
 __all__ = ['turbo_encode', 'map_decode', 'turbo_decode']
 
 
 def turbo_encode(msg_bits, trellis1, trellis2, interleaver):
-    """Parallel-concatenated rate-1/3 turbo encoder (host) -- turbo.py:14-59.
+    """Parallel-concatenated rate-1/3 turbo encoder (host input generator) -- what turbo.py:14-59 returns, also for a
+    batch ``[B, N]`` of messages (extension; lists of ``[B, ...]`` arrays then).
 
-    Returns ``[sys_stream, non_sys_stream_1, non_sys_stream_2]`` exactly like the reference,
-    including: ``'rsc'`` passed as the *termination* argument (turbo.py:47: ``conv_encode`` then reserves room
-    for a tail -- anything but 'cont' does, convcode.py:509-512 -- but clocks none, which only 'term' would,
-    :538, so the reserved tail stays zero), the tailed systematic stream being interleaved, and the second parity stream
-    keeping ``conv_encode``'s unpunctured length with a zero tail (quirks B3/B4) -- use
-    ``non_sys_stream_2[:N]``.
+    Returns ``[systematic, parity_1, parity_2]``.  Two properties of the reference's result are kept on purpose:
+
+    * no component encoder is terminated.  The reference passes ``'rsc'`` where ``conv_encode`` expects the termination mode
+      (turbo.py:47,53): room for a tail is reserved (anything but 'cont' does that, convcode.py:509-512) but never clocked
+      (only 'term' would, :538), and the reserved part is cut off again -- so ``systematic`` is the message and ``parity_1``
+      the parity of the plain walk from state 0;
+    * ``parity_2`` has ``2 (N + m2) - m2`` entries: the N parity bits of the permuted message first, zeros behind them
+      (the punctured stream keeps the unpunctured length, convcode.py:552-556) -- use ``parity_2[:N]``.
+
+    The interleaver sees the systematic stream with its all-zero reserved tail, like in the reference; one that exposes
+    ``p_array`` (all of commpy's do, interleavers.py:13-47) is applied as one gather for the whole batch.
     """
-    stream = conv_encode(msg_bits, trellis1, 'rsc')
-    sys_stream = stream[::2]
-    non_sys_stream_1 = stream[1::2]
-    interlv_msg_bits = interleaver.interlv(sys_stream)
-    puncture_matrix = np.array([[0, 1]])
-    non_sys_stream_2 = conv_encode(interlv_msg_bits, trellis2, 'rsc', puncture_matrix)
-    sys_stream = sys_stream[0:-trellis1.total_memory]
-    non_sys_stream_1 = non_sys_stream_1[0:-trellis1.total_memory]
-    non_sys_stream_2 = non_sys_stream_2[0:-trellis2.total_memory]
-    return [sys_stream, non_sys_stream_1, non_sys_stream_2]
+    msgs = np.asarray(msg_bits)
+    single = msgs.ndim == 1
+    rows = msgs.reshape(1, -1) if single else msgs
+    B, N = rows.shape
+    m1, m2 = int(trellis1.total_memory), int(trellis2.total_memory)
+    pairs1 = conv_encode_batch(rows, trellis1, 'rsc')                    # [B, 2 (N + m1)]: (systematic, parity), zero tail
+    tailed = pairs1[:, 0::2]                                             # [B, N + m1]
+    perm = getattr(interleaver, 'p_array', None)
+    if perm is not None:
+        permuted = tailed[:, np.asarray(perm)]
+    else:                                                                # duck-typed interleaver: only .interlv
+        permuted = np.stack([np.asarray(interleaver.interlv(r)) for r in tailed])
+    pairs2 = conv_encode_batch(permuted, trellis2, 'rsc')
+    n2 = pairs2.shape[1] // 2                                            # len(permuted) + m2 parity positions, tail zero
+    parity_2 = np.zeros((B, 2 * n2 - m2), dtype=pairs2.dtype)
+    parity_2[:, :n2] = pairs2[:, 1::2]
+    out = [tailed[:, :tailed.shape[1] - m1], pairs1[:, 1::2][:, :tailed.shape[1] - m1], parity_2]
+    return [o[0] for o in out] if single else out
 
 
 def _batch(a):

@@ -43,11 +43,13 @@ class SISOFlatChannel:
         return self._fading_param
 
     @fading_param.setter
-    def fading_param(self, fading_param):
-        if fading_param[1] + absolute(fading_param[0]) ** 2 != 1:
-            raise ValueError("With this parameters, the channel would add or remove energy.")
-        self._fading_param = fading_param
-        self._isComplex = isinstance(fading_param[0], complex)
+    def fading_param(self, value):
+        mean, variance = value[0], value[1]
+        if variance + absolute(mean) ** 2 != 1:                      # energy conservation test of channels.py:205-206
+            raise ValueError('fading_param = (mean, variance) must satisfy variance + |mean|^2 == 1: this channel would '
+                             'add or remove energy')
+        self._isComplex = isinstance(mean, complex)
+        self._fading_param = value
 
     @property
     def k_factor(self):

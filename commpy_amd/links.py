@@ -38,16 +38,11 @@ class LinkModel:
 
     def __init__(self, modulate, channel, receive, num_bits_symbol, constellation, Es=1, decoder=None,
                  rate=Fraction(1, 1)):
-        self.modulate = modulate
-        self.channel = channel
-        self.receive = receive
-        self.num_bits_symbol = num_bits_symbol
-        self.constellation = constellation
-        self.Es = Es
-        if type(rate) is float:
-            rate = Fraction(rate).limit_denominator(100)
-        self.rate = rate
+        # the attribute set of links.py:137-153; a float rate becomes the nearest fraction with denominator <= 100
+        self.rate = Fraction(rate).limit_denominator(100) if type(rate) is float else rate
         self.decoder = (lambda msg: msg) if decoder is None else decoder
+        self.modulate, self.channel, self.receive = modulate, channel, receive
+        self.num_bits_symbol, self.constellation, self.Es = num_bits_symbol, constellation, Es
         self.full_simulation_results = None
         self.tx_batch = 64            # transmissions generated / decoded per GPU batch
 
