@@ -63,11 +63,16 @@ class SISOFlatChannel:
         self.noise_std = sqrt((self.isComplex + 1) * self.nb_tx * Es / (code_rate * SNR_lin))
 
     def generate_noises(self, dims):
-        assert self.noise_std is not None, "Noise standard deviation must be set before propagation."
+        """Noise samples for one propagation (channels.py:37-55).  Draw order and scaling are the reference's: real part
+        first, and HALF of noise_std per component on the complex branch (:53) -- the receiver is told noise_std**2."""
+        if self.noise_std is None:
+            raise AssertionError('Noise standard deviation must be set before propagation.')
+        noises = standard_normal(dims)
         if self.isComplex:
-            self.noises = (standard_normal(dims) + 1j * standard_normal(dims)) * self.noise_std * 0.5
+            noises = (noises + 1j * standard_normal(dims)) * self.noise_std * 0.5
         else:
-            self.noises = standard_normal(dims) * self.noise_std
+            noises = noises * self.noise_std
+        self.noises = noises
 
     def propagate(self, msg):
         """Fading + noise (channels.py:181-221); ``msg`` may be 1-D or ``[batch, nsym]``."""
@@ -95,10 +100,8 @@ def bec(input_bits, p_e):
 
 def bsc(input_bits, p_t):
     """Binary symmetric channel (channels.py:652-673)."""
-    output_bits = asarray(input_bits).copy()
-    flip_locs = (random(len(output_bits)) <= p_t)
-    output_bits[flip_locs] = 1 ^ output_bits[flip_locs]
-    return output_bits
+    bits = asarray(input_bits)
+    return where(random(len(bits)) <= p_t, 1 ^ bits, bits)          # one uniform draw per bit, flipped where it is <= p_t
 
 
 def awgn(input_signal, snr_dB, rate=1.0):

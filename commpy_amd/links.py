@@ -84,13 +84,11 @@ class LinkModel:
         return np.stack(msgs), np.stack(decs)
 
     def _prepare(self, send_chunk, err_min, code_rate):
-        if send_chunk is None:
-            send_chunk = err_min
-        if type(code_rate) is float:
-            code_rate = Fraction(code_rate).limit_denominator(100)
-        self.rate = code_rate
-        divider = (Fraction(1, self.num_bits_symbol * self.channel.nb_tx) * 1 / code_rate).denominator
-        return max(divider, send_chunk // divider * divider), code_rate
+        """Chunk size rounded down to a whole number of channel uses (at least one), code rate as a fraction (links.py:203-214)."""
+        self.rate = code_rate = Fraction(code_rate).limit_denominator(100) if type(code_rate) is float else code_rate
+        chunk = err_min if send_chunk is None else send_chunk
+        divider = (Fraction(1, self.num_bits_symbol * self.channel.nb_tx) / code_rate).denominator
+        return max(divider, chunk // divider * divider), code_rate
 
     def link_performance_full_metrics(self, SNRs, tx_max, err_min, send_chunk=None, code_rate=Fraction(1, 1),
                                       number_chunks_per_send=1, stop_on_surpass_error=True):
@@ -101,10 +99,9 @@ class LinkModel:
         stops after the first SNR whose total errors stay below ``err_min``.  The BER denominator is
         ``total_tx_send * send_chunk`` -- it ignores ``number_chunks_per_send`` (quirk B11).
         """
+        n_snr = len(SNRs)
         BERs = np.zeros_like(SNRs, dtype=float)
-        BEs = np.zeros((len(SNRs), tx_max), dtype=int)
-        CEs = np.zeros((len(SNRs), tx_max), dtype=int)
-        NCs = np.zeros((len(SNRs), tx_max), dtype=int)
+        BEs, CEs, NCs = (np.zeros((n_snr, tx_max), dtype=int) for _ in range(3))      # bit errors, chunk errors, chunk counts
         send_chunk, code_rate = self._prepare(send_chunk, err_min, code_rate)
         n_bits = send_chunk * number_chunks_per_send
         for id_SNR in range(len(SNRs)):
@@ -128,23 +125,22 @@ class LinkModel:
                     chunk_count[id_tx] = number_chunks_per_send
                     total_tx_send += 1
                     id_tx += 1
-            BERs[id_SNR] = bit_err.sum() / (total_tx_send * send_chunk)
-            BEs[id_SNR] = bit_err
-            CEs[id_SNR] = np.where(bit_err > 0, 1, 0)
-            NCs[id_SNR] = chunk_count
-            if BEs[id_SNR].sum() < err_min:
+            n_err = int(bit_err.sum())
+            BEs[id_SNR], NCs[id_SNR] = bit_err, chunk_count
+            CEs[id_SNR] = bit_err > 0                        # a transmission is one chunk here: in error or not (:257)
+            BERs[id_SNR] = n_err / (total_tx_send * send_chunk)              # quirk B11: ignores number_chunks_per_send
+            if n_err < err_min:                              # this point never collected err_min errors: the sweep ends (:262)
                 break
-        self.full_simulation_results = BERs, BEs, CEs, NCs
-        return BERs, BEs, CEs, NCs
+        self.full_simulation_results = results = (BERs, BEs, CEs, NCs)
+        return results
 
     def link_performance(self, SNRs, send_max, err_min, send_chunk=None, code_rate=1):
         """BER per SNR: send chunks until ``send_max`` bits or ``err_min`` errors (links.py:269-343)."""
         BERs = np.zeros_like(SNRs, dtype=float)
         send_chunk, code_rate = self._prepare(send_chunk, err_min, code_rate)
-        for id_SNR in range(len(SNRs)):
-            self.channel.set_SNR_dB(SNRs[id_SNR], float(code_rate), self.Es)
-            bit_send = 0
-            bit_err = 0
+        for id_SNR, snr_db in enumerate(SNRs):
+            self.channel.set_SNR_dB(snr_db, float(code_rate), self.Es)
+            bit_send = bit_err = 0
             while bit_send < send_max and bit_err < err_min:
                 remaining = int(np.ceil((send_max - bit_send) / send_chunk))
                 n_blk = self._block_size(remaining)
