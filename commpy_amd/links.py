@@ -149,9 +149,9 @@ class LinkModel:
                 for j in range(n_blk):                      # sequential stop rule of the reference
                     if not (bit_send < send_max and bit_err < err_min):
                         break
-                    bit_err += int(errs[j])
                     bit_send += send_chunk
+                    bit_err += int(errs[j])
             BERs[id_SNR] = bit_err / bit_send
-            if bit_err < err_min:
-                break
+            if not bit_err >= err_min:                       # send_max reached before err_min errors: higher SNRs stay 0 (:341)
+                return BERs
         return BERs
