@@ -55,6 +55,10 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f), errors="replace").read()
                 assert not re.search(r"^\s*(import|from)\s+oracle\b", src, flags=re.M), f
                 assert "cpx_oracle" not in src and "libcpx_oracle" not in src, f
+                # oracle/_ref (the reference's own files, shipped for bench.py's cpu_baseline) and the reference checkout
+                # are just as far out of the product's reach: no import of `commpy` proper, no path into either
+                assert not re.search(r"^\s*(import|from)\s+commpy(\.|\s)", src, flags=re.M), f
+                assert "oracle/_ref" not in src and "make_ref" not in src and "CPX_REFERENCE_PATH" not in src, f
 
 
 def test_new_entry_points_fail_loudly_without_device():

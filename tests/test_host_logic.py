@@ -174,3 +174,29 @@ def test_bench_cpu_baseline_legs():
         assert res["kind"] == "reference" and res["cores"] == 4
         assert "bits differing from the engine's on these codewords: 0" in res["sample"]
         assert 100 < res["per_core"] < 1e5
+
+
+@pytest.mark.timeout(240)
+def test_bench_times_the_reference_from_oracle_ref(monkeypatch):
+    """The copy of the reference's six hot-path files that travels to the GPU box (oracle/_ref, placed by build() through
+    oracle/make_ref.py) is complete enough to run the reference's own viterbi_decode in a worker process, is byte-identical
+    to the checkout where both exist, and gives the stored live-reference decodes."""
+    import bench
+    from oracle import make_ref
+    from helpers import golden
+    from test_oracle_golden import TableTrellis
+    ref = make_ref.make()
+    if ref is None:
+        pytest.skip("oracle/_ref not populated (build() runs make_ref where /root/reference exists)")
+    if os.path.isdir(make_ref.DEFAULT_SRC):
+        assert make_ref.check()
+    prov = open(os.path.join(ref, "PROVENANCE.txt")).read()
+    assert all(f in prov for f in make_ref.FILES) and os.path.isfile(os.path.join(ref, "LICENSE.txt"))
+    monkeypatch.setenv("CPX_REFERENCE_PATH", ref)
+    assert bench._find_reference() == ref
+    g = golden("viterbi_c2u")
+    llr = np.ascontiguousarray(g["llr"][:2])
+    dec = np.unpackbits(g["dec"], axis=1)[:2, :1030].astype(np.int64)
+    res = bench.cpu_baseline(TableTrellis("k7_133_171"), llr, dec, budget_s=0.2)
+    assert res["kind"] == "reference" and res["cores"] == 2 and ref in res["sample"]
+    assert "bits differing from the engine's on these codewords: 0" in res["sample"]
