@@ -214,7 +214,7 @@ def get_precision():
 
 
 def viterbi_last_path():
-    """'fused' | 'cw2' | 'wave' | 'wide' | 'fused+wave' ...: the Viterbi kernel path of the last call, from cpx_last_kernel."""
+    """'fused' | 'cw2' | 'wave' | 'wide' | 'general' | 'fused+wave' ...: the Viterbi kernel path of the last call, from cpx_last_kernel."""
     k = last_kernel()
     parts = []
     if "viterbi_cw_fused_kernel" in k:
@@ -225,11 +225,13 @@ def viterbi_last_path():
         parts.append("wave")
     if "viterbi_wide_kernel" in k:
         parts.append("wide")
+    if "viterbi_generic_kernel" in k:
+        parts.append("general")
     return "+".join(parts)
 
 
 def viterbi_set_path(mode):
-    """Force a Viterbi kernel path: None/'auto', 'wave', 'cw', 'cw!', 'cw2', 'cw2!' (tests and benchmarks)."""
+    """Force a Viterbi kernel path: None/'auto', 'wave', 'cw', 'cw!', 'cw2', 'cw2!', 'general' (tests and benchmarks)."""
     check(load().cpx_viterbi_set_path(None if mode is None else mode.encode()))
 
 

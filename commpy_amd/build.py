@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(CSRC, "libcommpy_amd.so")
-SOURCES = ["runtime.hip", "viterbi.hip", "viterbi_cw.hip", "bcjr.hip", "bcjr_exact.hip", "ldpc.hip", "ldpc_resident.hip", "demod.hip", "linksim.hip", "encoders.hip",
+SOURCES = ["runtime.hip", "viterbi.hip", "viterbi_cw.hip", "viterbi_generic.hip", "bcjr.hip", "bcjr_exact.hip", "ldpc.hip", "ldpc_resident.hip", "demod.hip", "linksim.hip", "encoders.hip",
            "comm.hip"]
 
 
@@ -45,7 +45,7 @@ def _digest(names):
 
 # what the Viterbi kernels are compiled from: bench.py only trusts committed rocprofv3 counters of the headline kernel when
 # they were recorded with a library built from exactly these sources (cpx_build_id() of the .so == the id in the PMC file)
-VITERBI_SOURCES = ["viterbi.hip", "viterbi_cw.hip", "viterbi_cw_asm.h", "cpx_math.h", "cpx_internal.h", "demod_dev.h"]
+VITERBI_SOURCES = ["viterbi.hip", "viterbi_cw.hip", "viterbi_generic.hip", "viterbi_cw_asm.h", "cpx_math.h", "cpx_internal.h", "demod_dev.h"]
 
 
 def source_build_id():

@@ -139,6 +139,21 @@ class Trellis:
                 self.output_table[state][inp] = bitarray2dec(outbits)
                 self.next_state_table[state][inp] = bitarray2dec(sr)
 
+    # -- any trellis-like object ------------------------------------------------------------------
+    @classmethod
+    def from_tables(cls, k, n, total_memory, next_state_table, output_table, code_type='default'):
+        """A Trellis from ready-made tables (extension): what the decoders read is ``k, n, total_memory, number_states,
+        number_inputs, next_state_table, output_table`` (convcode.py:590-749, turbo.py:78-158), so any code that can be
+        written as such tables decodes -- also one the reference's constructor cannot build."""
+        self = cls.__new__(cls)
+        self.k, self.n, self.total_memory, self.code_type = int(k), int(n), int(total_memory), code_type
+        self.next_state_table = np.array(next_state_table, dtype=int)
+        self.output_table = np.array(output_table, dtype=int)
+        self.number_states, self.number_inputs = self.next_state_table.shape
+        if self.number_inputs != 2 ** self.k or self.output_table.shape != self.next_state_table.shape:
+            raise ValueError('tables must be [number_states, 2 ** k]')
+        return self
+
     # -- device handle ---------------------------------------------------------------------------
     def _device_handle(self):
         """Opaque cpx_trellis* carrying the tables to the current GPU (created on first use, one per device)."""
@@ -156,6 +171,24 @@ class Trellis:
                 return h
             hs = self.__dict__['_cpx_handles'] = _lib.DeviceHandles(create, 'cpx_trellis_destroy')
         return hs.get()
+
+
+def device_trellis(trellis):
+    """cpx_trellis* for ``trellis``: a commpy_amd Trellis, or ANY object with the reference's trellis attributes (the
+    reference's decoders are duck-typed, convcode.py:590-749) -- its tables are uploaded once and cached on the object."""
+    own = getattr(trellis, '_device_handle', None)
+    if own is not None:
+        return own()
+    cached = getattr(trellis, '_cpx_shadow', None)
+    if cached is None or cached[0] is not trellis.next_state_table or cached[1] is not trellis.output_table:
+        shadow = Trellis.from_tables(trellis.k, trellis.n, trellis.total_memory, trellis.next_state_table,
+                                     trellis.output_table, getattr(trellis, 'code_type', 'default'))
+        cached = (trellis.next_state_table, trellis.output_table, shadow)
+        try:
+            trellis._cpx_shadow = cached
+        except AttributeError:
+            pass
+    return cached[2]._device_handle()
 
 
 def conv_encode(message_bits, trellis, termination='term', puncture_matrix=None):
@@ -336,6 +369,6 @@ def viterbi_decode(coded_bits, trellis, tb_depth=None, decoding_type='hard'):
     if B and L:
         if tb < 2:
             raise ValueError('tb_depth must be >= 2')
-        _lib.check(lib.cpx_viterbi_decode_batch_i64(trellis._device_handle(), _lib.ptr(x), B, length, L, n_steps, tb,
+        _lib.check(lib.cpx_viterbi_decode_batch_i64(device_trellis(trellis), _lib.ptr(x), B, length, L, n_steps, tb,
                                                     _VIT_TYPES[decoding_type], _lib.ptr(res)))
     return res[0] if single else res

@@ -11,7 +11,7 @@ Same public names, arguments and return conventions as /root/reference/commpy/ch
 import numpy as np
 
 from commpy_amd import _lib
-from commpy_amd.channelcoding.convcode import conv_encode_batch
+from commpy_amd.channelcoding.convcode import conv_encode_batch, device_trellis
 
 __all__ = ['turbo_encode', 'map_decode', 'turbo_decode']
 
@@ -74,7 +74,7 @@ def map_decode(sys_symbols, non_sys_symbols, trellis, noise_variance, L_int, mod
     L_ext = np.zeros((B, N))
     bits = np.zeros((B, N), dtype=np.uint8)
     if B and N:
-        _lib.check(lib.cpx_map_decode_batch(trellis._device_handle(), _lib.ptr(s), _lib.ptr(p), _lib.ptr(li), B, N,
+        _lib.check(lib.cpx_map_decode_batch(device_trellis(trellis), _lib.ptr(s), _lib.ptr(p), _lib.ptr(li), B, N,
                                             float(noise_variance), 1 if mode == 'decode' else 0, _lib.ptr(L_ext),
                                             _lib.ptr(bits)))
     bits = bits.astype(np.int64)
@@ -105,7 +105,7 @@ def turbo_decode(sys_symbols, non_sys_symbols_1, non_sys_symbols_2, trellis, noi
             raise ValueError('L_int must have the shape of sys_symbols')
     bits = np.zeros((B, N), dtype=np.uint8)
     if B and N:
-        _lib.check(lib.cpx_turbo_decode_batch(trellis._device_handle(), _lib.ptr(s), _lib.ptr(p1), _lib.ptr(p2),
+        _lib.check(lib.cpx_turbo_decode_batch(device_trellis(trellis), _lib.ptr(s), _lib.ptr(p1), _lib.ptr(p2),
                                               None if li is None else _lib.ptr(li), _lib.ptr(perm), B, N,
                                               float(noise_variance), int(number_iterations), _lib.ptr(bits)))
     bits = bits.astype(np.int64)

@@ -34,8 +34,9 @@
 // reciprocal: a common positive factor per time step cancels in app1/app0 and in every later normalisation, so LLRs
 // differ from the reference's only by rounding (measured <= 1e-13; tolerance 1e-5).
 // Waves of a workgroup only meet at the phase boundary and between the stages of turbo_decode (__syncthreads +
-// agent-scope fences: the partner's checkpoints / LLRs are read through L2).  turbo_decode runs its whole iteration loop
-// inside ONE launch; the interleaver is a gather/scatter through per-codeword L arrays in a slab.
+// workgroup-scope fences: the partner's checkpoints are read through the CU's L1 / L2).  turbo_decode is a SEQUENCE of launches
+// (since round 3): one turbo_pass_kernel per MAP pass and one turbo_stage_kernel between passes -- slab initialisation,
+// interleaver / deinterleaver through LDS, final decisions -- see turbo_pass_kernel below.
 #include "cpx_internal.h"
 #include "cpx_math.h"
 
@@ -769,7 +770,7 @@ int fill_tables(const cpx_trellis *t, MapTables &tb) {
     if (int rcd = check_handle_device(t->device, "map_decode")) return rcd;
     CPX_REQUIRE(t->I == 2 && t->k == 1, CPX_ELIMIT, "map_decode: only k = 1 (two inputs per step) trellises are supported, like the reference's priors[2]");
     CPX_REQUIRE(t->n >= 2, CPX_EINVAL, "map_decode: needs a rate-1/2 trellis (n >= 2)");
-    CPX_REQUIRE(t->S >= 2 && t->S <= 16, CPX_ELIMIT, "map_decode: 2..16 states supported (got %d)", t->S);
+    CPX_REQUIRE(t->S >= 2, CPX_ELIMIT, "map_decode: needs at least 2 states (got %d)", t->S);
     tb.next_state = t->d_next; tb.output = t->d_out;
     tb.pred_state = t->d_pred_state; tb.pred_input = t->d_pred_input; tb.pred_code = t->d_pred_code;
     tb.n = t->n;
@@ -801,6 +802,11 @@ int cpx_map_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const do
     CPX_REQUIRE(N < (1ll << 24), CPX_ELIMIT, "map_decode: blocks of 2^24 steps or more are not supported (31-bit lane offsets over 16 codewords)");
     if (B == 0 || N == 0) return CPX_OK;
     hipStream_t st = pick_stream(stream);
+    if (t->S > 16) {                                              // beyond the wave-pair kernels: the literal absolute-scale kernel alone
+        rc = bcjr_exact_map(t, d_sys, d_par, d_L_int, B, N, 2 * noise_variance, want_bits, d_L_ext, d_bits, nullptr, st);
+        if (rc == CPX_OK) note_kernel("map_exact_kernel<true> (%d states, one codeword per lane)", t->S);
+        return rc;
+    }
     const int GW = pick_gw(t->S, B);
     const int64_t npairs = (B + GW - 1) / GW;
     const int np = pick_npair(npairs);
@@ -846,6 +852,11 @@ int cpx_turbo_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const 
     CPX_REQUIRE(N < (1ll << 21), CPX_ELIMIT, "turbo_decode: blocks of 2^21 steps or more are not supported (31-bit lane offsets into a 16-codeword slab)");
     if (B == 0 || N == 0) return CPX_OK;
     hipStream_t st = pick_stream(stream);
+    if (t->S > 16) {                                              // see cpx_map_decode_batch_dev
+        rc = bcjr_exact_turbo(t, d_sys, d_p1, d_p2, d_L_int_or_null, d_perm, B, N, 2 * noise_variance, n_iter, d_bits, nullptr, st);
+        if (rc == CPX_OK) note_kernel("turbo_exact_kernel<true> (%d states, one codeword per lane)", t->S);
+        return rc;
+    }
     const int GW = pick_gw(t->S, B);
     const int64_t npairs = (B + GW - 1) / GW;
     const int np = pick_npair(npairs);

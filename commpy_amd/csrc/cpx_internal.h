@@ -103,7 +103,10 @@ bool trace_enabled();
 bool precision_fast();
 
 void viterbi_prefer_cw(bool on);   // thread-local: the next dispatches of this thread take the codeword path whatever the batch size
-int viterbi_path_flags();   // bit 0 wave only, bit 1 codeword path forced, bit 2 strict, bit 3 two-kernel form
+int viterbi_path_flags();   // bit 0 wave only, bit 1 codeword path forced, bit 2 strict, bit 3 two-kernel form, bit 4 general kernel
+// the general Viterbi kernel (viterbi_generic.hip): any trellis cpx_trellis_create accepts, any traceback depth
+int viterbi_generic(const ::cpx_trellis *t, const double *d_coded, int64_t B, int64_t len, int64_t L, int64_t T, int tb, int type,
+                    uint8_t *d_bits, hipStream_t st);
 
 inline hipStream_t pick_stream(void *s) { return s ? reinterpret_cast<hipStream_t>(s) : lib_stream(); }
 
@@ -129,7 +132,7 @@ struct ArenaBuf {
 }  // namespace cpx
 
 // ---- handles -----------------------------------------------------------------------------------
-#define CPX_MAX_STATES 128
+#define CPX_MAX_STATES 65536   // the specialised kernels stop at 128; viterbi_generic.hip / bcjr_exact.hip serve the rest
 #define CPX_MAX_INPUTS 4
 #define CPX_MAX_N 6
 

@@ -4,7 +4,7 @@
 //                    written at index i*nb + nb-1-b, sums in increasing constellation index m;
 //   hard (:121-123): first-minimum nearest point |y-c_m| -> MSB-first nb bits (int8).
 // Element-wise map: one received symbol per lane, tables (<= 256 points, 4 KiB) staged in LDS and read
-// as wave-uniform broadcasts.  float64 like the reference.  Each symbol is read once (16 B) and nb
+// as wave-uniform broadcasts (larger constellations, up to 65536 points: the same formulas with the table read from HBM).  float64 like the reference.  Each symbol is read once (16 B) and nb
 // outputs written once: HBM traffic equals the algorithmic bytes (16 + 8*nb per symbol).
 //
 // Two code paths, chosen when the modem handle is created:
@@ -153,6 +153,43 @@ __global__ __launch_bounds__(DEMOD_BLOCK) void demod_hard_sep_kernel(const doubl
     }
 }
 
+// ---- constellations of more than MAX_M points (the reference takes any power of two, modulation.py:159-166) -------------------
+// The same formulas with the table read from HBM (wave-uniform addresses: scalar loads) and up to 16 bits per symbol.
+// (nb is a run-time value; the accumulators of bits nb .. 15 collect sums nobody reads.)
+template <bool RCP>
+__global__ __launch_bounds__(DEMOD_BLOCK) void demod_soft_any_kernel(const double2 *__restrict__ y, int64_t Ns,
+                                                                     const double2 *__restrict__ cst, int M, int nb,
+                                                                     double noise_var, double scale, double *__restrict__ llr) {
+    const double ninv = -1.0 / noise_var;
+    for (int64_t i = (int64_t)blockIdx.x * DEMOD_BLOCK + threadIdx.x; i < Ns; i += (int64_t)gridDim.x * DEMOD_BLOCK) {
+        const double2 cur = y[i];
+        double num[16], den[16];
+#pragma unroll
+        for (int b = 0; b < 16; b++) { num[b] = 0.0; den[b] = 0.0; }
+        for (int m = 0; m < M; m++) {
+            const double2 c = cst[m];
+            const double a = hypot(cur.x - c.x, cur.y - c.y);       // abs(current_symbol - symbol)
+            const double e = exp(RCP ? (a * a) * ninv : (-(a * a)) / noise_var);   // (:134,136)
+#pragma unroll
+            for (int b = 0; b < 16; b++) {
+                if ((m >> b) & 1) num[b] += e; else den[b] += e;
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 16; b++)
+            if (b < nb) llr[i * nb + nb - 1 - b] = fast_log(num[b] / den[b]) * scale;   // (:137)
+    }
+}
+
+__global__ __launch_bounds__(DEMOD_BLOCK) void demod_hard_any_kernel(const double2 *__restrict__ y, int64_t Ns,
+                                                                     const double2 *__restrict__ cst, int M, int nb,
+                                                                     int8_t *__restrict__ bits) {
+    for (int64_t i = (int64_t)blockIdx.x * DEMOD_BLOCK + threadIdx.x; i < Ns; i += (int64_t)gridDim.x * DEMOD_BLOCK) {
+        const int best = hard_scan(cst, M, y[i]);
+        for (int b = 0; b < nb; b++) bits[i * nb + b] = (int8_t)((best >> (nb - 1 - b)) & 1);   // dec2bitarray (:123)
+    }
+}
+
 unsigned grid_for(int64_t Ns) {
     int64_t blocks = (Ns + DEMOD_BLOCK - 1) / DEMOD_BLOCK;
     const int64_t cap = 256 * 16;   // 256 CUs x 16 resident blocks; grid-stride beyond that
@@ -168,7 +205,7 @@ extern "C" {
 int cpx_modem_create(const double *constellation_re_im, int M, cpx_modem **out) {
     CPX_REQUIRE(constellation_re_im && out, CPX_EINVAL, "cpx_modem_create: null pointer");
     CPX_REQUIRE(M >= 2 && (M & (M - 1)) == 0, CPX_EINVAL, "Constellation length must be a power of 2.");
-    CPX_REQUIRE(M <= MAX_M, CPX_ELIMIT, "cpx_modem_create: constellations above %d points are not supported", MAX_M);
+    CPX_REQUIRE(M <= 65536, CPX_ELIMIT, "cpx_modem_create: constellations above 65536 points (16 bits per symbol) are not supported");
     int rc = ensure_device();
     if (rc) return rc;
     cpx_modem *m = new cpx_modem;
@@ -225,6 +262,13 @@ int cpx_demod_soft_scaled_dev(const cpx_modem *m, const double *d_y, int64_t Ns,
     const double2 *c = reinterpret_cast<const double2 *>(m->d_const);
     dim3 grid(grid_for(Ns)), block(DEMOD_BLOCK);
     const bool rcp = noise_var > 1e-290 && noise_var < 1e290;     // 1 / noise_var is a normal number
+    if (m->M > MAX_M) {                                           // table too large for the LDS kernels
+        if (rcp) hipLaunchKernelGGL(demod_soft_any_kernel<true>, grid, block, 0, st, y, Ns, c, m->M, m->nbits, noise_var, scale, d_llr);
+        else hipLaunchKernelGGL(demod_soft_any_kernel<false>, grid, block, 0, st, y, Ns, c, m->M, m->nbits, noise_var, scale, d_llr);
+        CPX_HIP(hipGetLastError());
+        note_kernel("demod_soft_any_kernel<%s> (%d points)", rcp ? "rcp" : "div", m->M);
+        return CPX_OK;
+    }
     if (m->separable) {
         switch (m->nbits / 2) {
 #define CASE(NH) case NH:                                                                                                \
@@ -262,6 +306,12 @@ int cpx_demod_hard_dev(const cpx_modem *m, const double *d_y, int64_t Ns, int8_t
     dim3 grid(grid_for(Ns)), block(DEMOD_BLOCK);
     const double2 *y = reinterpret_cast<const double2 *>(d_y);
     const double2 *c = reinterpret_cast<const double2 *>(m->d_const);
+    if (m->M > MAX_M) {
+        hipLaunchKernelGGL(demod_hard_any_kernel, grid, block, 0, st, y, Ns, c, m->M, m->nbits, d_bits);
+        CPX_HIP(hipGetLastError());
+        note_kernel("demod_hard_any_kernel (%d points)", m->M);
+        return CPX_OK;
+    }
     if (m->separable) {
         switch (m->nbits / 2) {
 #define CASE(NH) case NH: hipLaunchKernelGGL(demod_hard_sep_kernel<NH>, grid, block, 0, st, y, Ns, c, m->d_axes, d_bits); break;

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(LB) void ldpc_init_kernel(double *__restrict__ llr,
                     llr[b * n_v + v] = x;
                     if (clipped) *clipped = 1;                    // lets the host-buffer entry point skip the copy back
                 } else if (nanflags) {
-                    nanflags[b] = 1;                              // min-sum: the block is decoded again, NaN-exact (ldpc_msa_exact_kernel)
+                    nanflags[b] = 1;                              // min-sum: the block is decoded again, NaN-exact (ldpc_exact_kernel<false>)
                 }
             }
         }
@@ -589,30 +589,37 @@ __global__ __launch_bounds__(LB) void ldpc_final_kernel(Bufs bf, int n_v, int64_
 // NaN signs: every NaN here is a propagated copy of an input NaN (the clip bounds the values, no operation of the loop creates
 // one), and neither x86 nor gfx950 changes the sign of a NaN it propagates; with inputs of ONE NaN sign (np.nan) results are
 // the reference's bit for bit; with mixed signs, which NaN an operation of two NaNs returns is unspecified on both sides.
-struct MsaExactParams {
+// The same literal kernel is also the GENERAL path: a Tanner graph with a check of more than MAXDEG = 32 edges (the reference
+// has no limit, ldpc.py:144-254; the tiled and resident kernels keep a row in registers / 5-bit positions) is decoded by it
+// alone, min-sum or sum-product, every block (flags == null).  Sum-product rows use the exact-order sequence of ldpc_dev.h
+// (tanh as (1 - e) / (1 + e), sequential product, reciprocal, clip, 2 atanh, clip -- :209-227), the one the fast kernels
+// fall back to near saturation.
+struct ExactParams {
     const double *llr;        // [B][n_v], already clipped in place
-    const uint8_t *flags;     // [B]
+    const uint8_t *flags;     // [B], or null: every block
     double *out;              // element (v, b) at v * sv + b * sb: [n_v][B] or block-major [B][n_v]
     int8_t *dec;
     int64_t sv, sb;
     int32_t *iters;           // [B] or null
-    double *scratch;          // per workgroup: M[E], tot[n_v]
+    double *scratch;          // per workgroup: M[E] (variable -> check), R[E] (check -> variable), tot[n_v]
     const int32_t *edge_var, *row_ptr, *col_ptr, *col_edge;
     int64_t B, E;
     int n_v, n_c, n_iters;
 };
 
-__global__ __launch_bounds__(256) void ldpc_msa_exact_kernel(MsaExactParams p) {
+template <bool SPA>
+__global__ __launch_bounds__(256) void ldpc_exact_kernel(ExactParams p) {
     __shared__ int any;
     __shared__ unsigned char flagged[256];
     const int tid = threadIdx.x;
-    double *M = p.scratch + (int64_t)blockIdx.x * (p.E + p.n_v);
-    double *tot = M + p.E;
+    double *M = p.scratch + (int64_t)blockIdx.x * (2 * p.E + p.n_v);
+    double *R = M + p.E;
+    double *tot = R + p.E;
     const int64_t per = (p.B + gridDim.x - 1) / gridDim.x;        // contiguous share of the blocks
     const int64_t lo = (int64_t)blockIdx.x * per, hi = (lo + per < p.B) ? lo + per : p.B;
     for (int64_t base = lo; base < hi; base += 256) {
         __syncthreads();
-        flagged[tid] = (base + tid < hi) ? p.flags[base + tid] : 0;
+        flagged[tid] = (base + tid < hi) ? (p.flags ? p.flags[base + tid] : 1) : 0;
         __syncthreads();
         for (int i = 0; i < 256 && base + i < hi; i++) {
             if (!__builtin_amdgcn_readfirstlane((int)flagged[i])) continue;   // workgroup-uniform: a SCALAR branch around the barriers below
@@ -632,32 +639,44 @@ __global__ __launch_bounds__(256) void ldpc_msa_exact_kernel(MsaExactParams p) {
                 }
                 __syncthreads();
                 if (!__builtin_amdgcn_readfirstlane(any)) break;     // uniform (scalar) exit
-                for (int c = tid; c < p.n_c; c += 256) {          // (:231-238)
+                for (int c = tid; c < p.n_c; c += 256) {
                     const int b0 = p.row_ptr[c], deg = p.row_ptr[c + 1] - b0;
-                    double row[MAXDEG];
-                    for (int j = 0; j < deg; j++) row[j] = M[b0 + j];
-                    for (int j = 0; j < deg; j++) {
-                        double sp = 1.0, mn = __builtin_huge_val();
-                        for (int q = 0; q < deg; q++) {
-                            if (q == j) continue;
-                            const double v = row[q];
-                            double sg = (double)((v > 0.0) - (v < 0.0));          // np.sign; sign(NaN) = that NaN
-                            if (v != v) sg = v;
-                            sp *= sg;                                             // .prod()
-                            const double av = fabs(v);
-                            if (av < mn || av != av) mn = av;                     // .min() propagates NaN
+                    if (SPA) {                                    // (:209-227), exact-order row
+                        double prod = 1.0;
+                        for (int j = 0; j < deg; j++) {
+                            double se, u, w;
+                            spa_in(M[b0 + j], se, u, w);
+                            prod *= spa_exact_t(se);
                         }
-                        M[b0 + j] = sp * mn;
+                        for (int j = 0; j < deg; j++) {
+                            double se, u, w;
+                            spa_in(M[b0 + j], se, u, w);
+                            R[b0 + j] = spa_out_exact(spa_exact_t(se), prod);
+                        }
+                    } else {                                      // (:231-238)
+                        for (int j = 0; j < deg; j++) {
+                            double sp = 1.0, mn = __builtin_huge_val();
+                            for (int q = 0; q < deg; q++) {
+                                if (q == j) continue;
+                                const double v = M[b0 + q];
+                                double sg = (double)((v > 0.0) - (v < 0.0));          // np.sign; sign(NaN) = that NaN
+                                if (v != v) sg = v;
+                                sp *= sg;                                             // .prod()
+                                const double av = fabs(v);
+                                if (av < mn || av != av) mn = av;                     // .min() propagates NaN
+                            }
+                            R[b0 + j] = sp * mn;
+                        }
                     }
                 }
                 __syncthreads();
                 for (int v = tid; v < p.n_v; v += 256) {          // (:243-248)
                     double msum = 0.0;
-                    for (int q = p.col_ptr[v]; q < p.col_ptr[v + 1]; q++) msum += M[p.col_edge[q]];   // sum(0): increasing check
+                    for (int q = p.col_ptr[v]; q < p.col_ptr[v + 1]; q++) msum += R[p.col_edge[q]];   // sum(0): increasing check
                     const double t = msum + l[v];
                     for (int q = p.col_ptr[v]; q < p.col_ptr[v + 1]; q++) {
                         const int e = p.col_edge[q];
-                        double m = M[e] * -1.0;                   // data *= -1 (:244)
+                        double m = R[e] * -1.0;                   // data *= -1 (:244)
                         m += 1.0 * t;                             // data += H.multiply(msg_sum + llr).data (:245)
                         M[e] = m;
                     }
@@ -674,6 +693,17 @@ __global__ __launch_bounds__(256) void ldpc_msa_exact_kernel(MsaExactParams p) {
             __syncthreads();
         }
     }
+}
+
+// in-place clip of the LLRs (ldpc.py:186) for the general path (the other paths clip while loading a block); *clipped = 1
+// when a value changed (may be null)
+__global__ __launch_bounds__(256) void ldpc_clip_kernel(double *llr, int64_t n, int *clipped) {
+    bool ch = false;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double v = llr[i], c = clip_nan(v, -500.0, 500.0);
+        if (c != v && v == v) { llr[i] = c; ch = true; }
+    }
+    if (clipped && __ballot(ch) != 0 && (threadIdx.x & 63) == 0) *clipped = 1;
 }
 
 }  // namespace
@@ -723,7 +753,7 @@ static int blob_view(const void *blob, size_t nbytes, LdpcBlobView &v) {
     CPX_REQUIRE(memcmp(h->magic, LDPC_BLOB_MAGIC, 8) == 0 && h->version == 1, CPX_EINVAL, "ldpc blob: bad magic / version");
     CPX_REQUIRE(h->n_v > 0 && h->n_c > 0 && h->n_edges > 0 && h->n_edges < (1ll << 30) && h->n_v < (1 << 24) && h->n_c < (1 << 24),
                 CPX_EINVAL, "ldpc blob: bad dimensions");
-    CPX_REQUIRE(h->max_cdeg >= 1 && h->max_cdeg <= MAXDEG && h->max_vdeg >= 1 && h->cpad == ((h->max_cdeg + 3) & ~3) &&
+    CPX_REQUIRE(h->max_cdeg >= 1 && h->max_vdeg >= 1 && h->cpad == ((h->max_cdeg + 3) & ~3) &&
                 h->vpad == ((h->max_vdeg + 3) & ~3), CPX_EINVAL, "ldpc blob: bad degrees");
     const size_t words = blob_payload_words(h->n_edges, h->n_v, h->n_c, h->cpad, h->vpad);
     CPX_REQUIRE(h->payload_words == words && nbytes == sizeof(LdpcBlobHeader) + 4 * words, CPX_EINVAL, "ldpc blob: size mismatch");
@@ -756,7 +786,7 @@ static int blob_view(const void *blob, size_t nbytes, LdpcBlobView &v) {
     for (int64_t e = 0; e < E; e++) {
         CPX_REQUIRE(v.edge_check[e] >= 0 && v.edge_check[e] < h->n_c && v.edge_var[e] >= 0 && v.edge_var[e] < h->n_v &&
                     v.col_edge[e] >= 0 && v.col_edge[e] < E && (v.col_cj[e] >> 5) >= 0 && (v.col_cj[e] >> 5) < h->n_c &&
-                    (v.col_cj[e] & 31) < h->max_cdeg, CPX_EINVAL, "ldpc blob: index out of range");
+                    (v.col_cj[e] & 31) < std::max(h->max_cdeg, 1), CPX_EINVAL, "ldpc blob: index out of range");
     }
     for (size_t i = 0; i < v.n_row_pad; i++)
         CPX_REQUIRE(v.row_pad[i] >= 0 && v.row_pad[i] < h->n_v, CPX_EINVAL, "ldpc blob: padded row entry out of range");
@@ -777,7 +807,7 @@ static int blob_view(const void *blob, size_t nbytes, LdpcBlobView &v) {
     for (int q = 0; q < h->n_v; q++)
         for (int i = v.col_ptr[q]; i < v.col_ptr[q + 1]; i++) {
             const int e = v.col_edge[i], cj = v.col_cj[i], c = cj >> 5, pos = cj & 31;
-            CPX_REQUIRE(v.edge_var[e] == q && v.edge_check[e] == c && pos == e - v.row_ptr[c], CPX_EINVAL,
+            CPX_REQUIRE(v.edge_var[e] == q && v.edge_check[e] == c && pos == ((e - v.row_ptr[c]) & 31), CPX_EINVAL,
                         "ldpc blob: column view and edge list disagree");
             const size_t k = (size_t)q * h->vpad + (size_t)(i - v.col_ptr[q]);
             CPX_REQUIRE(v.col_pad_edge[k] == e && v.col_pad_cj[k] == cj, CPX_EINVAL, "ldpc blob: padded columns and column view disagree");
@@ -807,7 +837,8 @@ int cpx_ldpc_blob_build(int n_vnodes, int n_cnodes, int64_t n_edges, const int32
     int max_cdeg = 0, max_vdeg = 0;
     for (int c = 0; c < n_cnodes; c++) { max_cdeg = std::max(max_cdeg, row_ptr[c + 1]); row_ptr[c + 1] += row_ptr[c]; }
     for (int v = 0; v < n_vnodes; v++) { max_vdeg = std::max(max_vdeg, col_ptr[v + 1]); col_ptr[v + 1] += col_ptr[v]; }
-    CPX_REQUIRE(max_cdeg <= MAXDEG, CPX_ELIMIT, "cpx_ldpc_create: check degree %d > %d not supported", max_cdeg, MAXDEG);
+    // a check of more than MAXDEG edges: the 5-bit position field below wraps -- such a code is only ever decoded by
+    // ldpc_exact_kernel, which does not read it
     const int cpad = (max_cdeg + 3) & ~3, vpad = (max_vdeg + 3) & ~3;
     const size_t words = blob_payload_words(E, n_vnodes, n_cnodes, cpad, vpad);
     *need = sizeof(LdpcBlobHeader) + 4 * words;
@@ -838,7 +869,7 @@ int cpx_ldpc_blob_build(int n_vnodes, int n_cnodes, int64_t n_edges, const int32
     for (int64_t e = 0; e < E; e++) {                                            // increasing e == increasing check
         const int32_t q = fill[edge_var[e]]++;
         b_ce[q] = (int32_t)e;
-        b_cj[q] = (edge_check[e] << 5) | (int32_t)(e - row_ptr[edge_check[e]]);
+        b_cj[q] = (edge_check[e] << 5) | ((int32_t)(e - row_ptr[edge_check[e]]) & 31);
     }
     for (int k = 0; k < n_cnodes; k++)
         for (int j = 0; j < row_ptr[k + 1] - row_ptr[k]; j++) b_rpad[(size_t)k * cpad + j] = edge_var[row_ptr[k] + j];
@@ -950,20 +981,35 @@ static int ldpc_decode_impl(const cpx_ldpc *c, double *d_llr, int64_t B, int alg
     hipStream_t st = pick_stream(stream);
     const int64_t sv = block_major ? 1 : B, sb = block_major ? (int64_t)c->n_v : 1;    // strides of d_out / d_dec (variable, block)
     // min-sum: one flag byte per block, set by the kernels that load the LLRs when they meet a NaN; flagged blocks are
-    // decoded again by ldpc_msa_exact_kernel (scratch-arena slots 4 / 5)
+    // decoded again by ldpc_exact_kernel<false> (scratch-arena slots 4 / 5)
     uint8_t *nanflags = nullptr;
-    const unsigned g_ex = (unsigned)std::min<int64_t>(B, 2 * device_cus());
-    auto msa_redo = [&]() -> int {
-        if (!nanflags) return CPX_OK;
-        MsaExactParams q;
+    // literal kernel: `flags` selects the blocks (null = all), `wgs` workgroups, each with (2 E + n_v) doubles of scratch
+    auto exact = [&](const uint8_t *flags, unsigned wgs, int algo) -> int {
+        ExactParams q;
         void *sc = nullptr;
-        if (int rcs = workspace(st, 5, sizeof(double) * (size_t)g_ex * (size_t)(c->n_edges + c->n_v), &sc)) return rcs;
-        q.llr = d_llr; q.flags = nanflags; q.out = d_out; q.dec = d_dec; q.iters = d_iters; q.scratch = static_cast<double *>(sc);
+        if (int rcs = workspace(st, 5, sizeof(double) * (size_t)wgs * (size_t)(2 * c->n_edges + c->n_v), &sc)) return rcs;
+        q.llr = d_llr; q.flags = flags; q.out = d_out; q.dec = d_dec; q.iters = d_iters; q.scratch = static_cast<double *>(sc);
         q.edge_var = c->d_edge_var; q.row_ptr = c->d_row_ptr; q.col_ptr = c->d_col_ptr; q.col_edge = c->d_col_edge;
         q.B = B; q.E = c->n_edges; q.n_v = c->n_v; q.n_c = c->n_c; q.n_iters = n_iters; q.sv = sv; q.sb = sb;
-        hipLaunchKernelGGL(ldpc_msa_exact_kernel, dim3(g_ex), dim3(256), 0, st, q);
+        if (algo == CPX_LDPC_SPA) hipLaunchKernelGGL(ldpc_exact_kernel<true>, dim3(wgs), dim3(256), 0, st, q);
+        else hipLaunchKernelGGL(ldpc_exact_kernel<false>, dim3(wgs), dim3(256), 0, st, q);
         CPX_HIP(hipGetLastError());
         return CPX_OK;
+    };
+    if (c->max_cdeg > MAXDEG) {                                   // the general path: every block through the literal kernel
+        if (d_clipped) CPX_HIP(hipMemsetAsync(d_clipped, 0, sizeof(int), st));
+        const int64_t n = B * (int64_t)c->n_v;
+        hipLaunchKernelGGL(ldpc_clip_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, st, d_llr, n, d_clipped);
+        CPX_HIP(hipGetLastError());
+        if (int rce = exact(nullptr, (unsigned)std::min<int64_t>(B, 4 * device_cus()), alg)) return rce;
+        note_kernel("ldpc_exact_kernel<%s> (check degree %d > %d)", alg == CPX_LDPC_SPA ? "SPA" : "MSA", c->max_cdeg, MAXDEG);
+        return CPX_OK;
+    }
+    // the redo launch behind a min-sum decode: with no NaN in the batch its workgroups read their share of the flag bytes and
+    // exit, so it gets a SMALL grid (64 workgroups: 8 MB of scratch for the (1944,1296) code, was 2 per CU = 37 MB)
+    auto msa_redo = [&]() -> int {
+        if (!nanflags) return CPX_OK;
+        return exact(nanflags, (unsigned)std::min<int64_t>(B, 64), CPX_LDPC_MSA);
     };
     if (alg == CPX_LDPC_MSA) {
         void *w = nullptr;

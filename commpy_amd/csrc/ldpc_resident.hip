@@ -51,7 +51,7 @@ struct ResParams {
     int32_t *iters;          // [B] executed iterations, may be null
     int *queue;              // next block to hand out
     int *clipped;            // set to 1 when the in-place clip changed a value (may be null)
-    uint8_t *nanflags;       // min-sum: [B], 1 = a NaN among the block's LLRs (decoded again by ldpc_msa_exact_kernel); else null
+    uint8_t *nanflags;       // min-sum: [B], 1 = a NaN among the block's LLRs (decoded again by ldpc_exact_kernel<false>); else null
     const int32_t *row_deg;  // [n_c] check degree
     const int32_t *row_q;    // [n_c][cpad] LDS byte offset of Q[variable of the j-th edge]; padding -> the +inf slot
     const int32_t *col_r;    // [n_v][vpad] LDS byte offset of R[q-th edge of the variable], increasing check; padding -> the 0.0 slot
@@ -573,6 +573,7 @@ bool ldpc_spa_exact() {
 int ldpc_resident_tables(cpx_ldpc *c, const int32_t *row_ptr, const int32_t *row_pad, const int32_t *col_ptr,
                          const int32_t *col_pad_cj) {
     if (res_lds_bytes(c) > LDS_BYTES) return CPX_OK;              // does not fit: the handle only serves the tiled path
+    if (c->max_cdeg > 32) return CPX_OK;                          // 5-bit row positions: such a code takes ldpc_exact_kernel (ldpc.hip)
     const int n_v = c->n_v, n_c = c->n_c, cpad = c->cpad, vpad = c->vpad;
     const int roff = res_roff(n_v), rs = res_rstride(c);
     std::vector<int32_t> dg((size_t)n_c), rq((size_t)n_c * cpad + 16, 8 * n_v),

@@ -172,12 +172,13 @@ __global__ __launch_bounds__(LS_BLOCK) void modulate_kernel(const uint8_t *__res
                                                             const double2 *__restrict__ cst, int M,
                                                             double2 *__restrict__ sym) {
     __shared__ double2 c_s[256];
-    for (int m = threadIdx.x; m < M; m += LS_BLOCK) c_s[m] = cst[m];
+    const bool staged = M <= 256;                                 // larger tables (up to 65536 points) are gathered from HBM / L2
+    if (staged) for (int m = threadIdx.x; m < M; m += LS_BLOCK) c_s[m] = cst[m];
     __syncthreads();
     for (int64_t i = (int64_t)blockIdx.x * LS_BLOCK + threadIdx.x; i < nsym; i += (int64_t)gridDim.x * LS_BLOCK) {
         int label = 0;
         for (int q = 0; q < nb; q++) label = (label << 1) | (bits[i * nb + q] & 1);
-        sym[i] = c_s[label];
+        sym[i] = staged ? c_s[label] : cst[label];
     }
 }
 

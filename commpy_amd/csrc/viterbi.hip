@@ -709,7 +709,7 @@ static bool shift_register(const cpx_trellis *t) {
 }
 
 // ring size and dynamic LDS of the state-per-lane kernels for this trellis and p.tb (sets p.RS)
-static int wave_lds(const cpx_trellis *t, VitParams &p, size_t *lds) {
+static size_t wave_lds_bytes(const cpx_trellis *t, VitParams &p, size_t *lds) {
     const int PL = (t->I == 2) ? 1 : 2;
     if (t->S > 64) {
         const int SPL = t->S / 64;
@@ -722,7 +722,10 @@ static int wave_lds(const cpx_trellis *t, VitParams &p, size_t *lds) {
         *lds = sizeof(double) * 64 * p.NC + sizeof(double) * (64 + 8) + sizeof(unsigned long long) * p.RS * PL +
                sizeof(unsigned short) * S * t->I + (size_t)p.RS * G;
     }
-    CPX_REQUIRE(*lds <= 64 * 1024, CPX_ELIMIT, "viterbi: tb_depth %d needs %zu B of LDS (> 64 KiB)", p.tb, *lds);
+    return *lds;
+}
+static int wave_lds(const cpx_trellis *t, VitParams &p, size_t *lds) {
+    CPX_REQUIRE(wave_lds_bytes(t, p, lds) <= 64 * 1024, CPX_ELIMIT, "viterbi: tb_depth %d needs %zu B of LDS (> 64 KiB)", p.tb, *lds);
     return CPX_OK;
 }
 
@@ -770,14 +773,24 @@ static int viterbi_dispatch(const cpx_trellis *t, const double *d_coded, const D
     CPX_REQUIRE(B >= 0 && len >= 0 && L >= 0, CPX_EINVAL, "viterbi: negative size");
     CPX_REQUIRE(tb_depth >= 2, CPX_EINVAL, "viterbi: tb_depth must be >= 2");
     CPX_REQUIRE((L / t->k) * (int64_t)t->n <= len, CPX_EINVAL, "viterbi: L inconsistent with len");
-    CPX_REQUIRE(t->I == 2 || t->I == 4, CPX_ELIMIT, "viterbi: trellis with %d inputs per step not supported (k <= 2)", t->I);
-    CPX_REQUIRE(t->n <= CPX_MAX_N, CPX_ELIMIT, "viterbi: n = %d > %d not supported", t->n, CPX_MAX_N);
-    CPX_REQUIRE(t->S >= 2 && t->S <= 128, CPX_ELIMIT, "viterbi: %d states not supported (2..128)", t->S);
+    // what the specialised kernels below are instantiated for; every other trellis / window takes viterbi_generic.hip
+    bool general = !(t->I == 2 || t->I == 4) || t->n > CPX_MAX_N || t->S < 2 || t->S > 128;
+    if (!general) {
+        VitParams q;
+        q.tb = tb_depth; q.NC = 1 << t->n;
+        size_t need = 0;
+        general = wave_lds_bytes(t, q, &need) > 64 * 1024;       // the traceback ring of the state-per-lane kernels lives in LDS
+    }
+    if (dm) {
+        CPX_REQUIRE(!general, CPX_ELIMIT, "demod_hard_viterbi: this trellis / traceback depth takes the two-call path (demodulate, then viterbi_decode)");
+    }
     if (B == 0 || L == 0) return CPX_OK;
     hipStream_t st = pick_stream(stream);
     if (n_steps <= 0 || n_steps * t->k < L) CPX_HIP(hipMemsetAsync(d_bits, 0, (size_t)(B * L), st));
     if (n_steps <= 0) return CPX_OK;
     note_kernel("");
+    if (general || (viterbi_path_flags() & 16))
+        return viterbi_generic(t, d_coded, B, len, L, n_steps, tb_depth, decoding_type, d_bits, st);
     // 'soft': one flag byte per work item of the launches below (see "NaN among 'soft' inputs"); scratch-arena slot 3
     uint8_t *nanflags = nullptr;
     if (decoding_type == CPX_VIT_SOFT && !dm) {

@@ -893,13 +893,15 @@ int launch_fused(const CwParams &p, hipStream_t st) {
 namespace cpx {
 
 // Kernel-path override (tests, benchmarks): bit 0 = "wave" (state-per-lane kernels only), bit 1 = forced codeword path,
-// bit 2 = strict ("!": fail instead of falling back), bit 3 = two-kernel form even where the fused kernel applies.
+// bit 2 = strict ("!": fail instead of falling back), bit 3 = two-kernel form even where the fused kernel applies,
+// bit 4 = "general" (the slow-but-complete kernel of viterbi_generic.hip whatever the trellis).
 // Initialised once from the environment variable CPX_VITERBI_PATH, changed at run time through cpx_viterbi_set_path().
 static std::atomic<int> g_vit_path{-1};
 
 static int parse_path(const char *e) {
     if (!e || !e[0]) return 0;
     if (e[0] == 'w') return 1;
+    if (e[0] == 'g') return 16;                      // "general": viterbi_generic.hip for every trellis
     if (e[0] != 'c') return 0;
     return 2 | (strchr(e, '!') ? 4 : 0) | (strchr(e, '2') ? 8 : 0);
 }
@@ -1015,8 +1017,8 @@ bool viterbi_codeword_path(const cpx_trellis *t, const double *d_coded, int64_t 
 }  // namespace cpx
 
 extern "C" int cpx_viterbi_set_path(const char *mode) {
-    if (mode && mode[0] && mode[0] != 'w' && mode[0] != 'c' && strcmp(mode, "auto") != 0) {
-        cpx::set_error("cpx_viterbi_set_path: unknown mode '%s' (auto | wave | cw | cw! | cw2 | cw2!)", mode);
+    if (mode && mode[0] && mode[0] != 'w' && mode[0] != 'c' && mode[0] != 'g' && strcmp(mode, "auto") != 0) {
+        cpx::set_error("cpx_viterbi_set_path: unknown mode '%s' (auto | wave | cw | cw! | cw2 | cw2! | general)", mode);
         return CPX_EINVAL;
     }
     cpx::g_vit_path.store((mode && strcmp(mode, "auto") != 0) ? cpx::parse_path(mode) : 0, std::memory_order_relaxed);

@@ -118,9 +118,11 @@ int cpx_trellis_destroy(cpx_trellis *t);
  * kernel with the generators compiled in -- K = 7 (133,171), (171,133) in both polynomial formats and Wifi80211's (5,43) for
  * tb_depth <= 48; K = 3 (5,7) and K = 5 (23,35) at their default depth -- or, for any other pair whose generators both tap the
  * input and the oldest register bit, with a run-time code table (default depth 5 * memory); an add-compare-select + a traceback kernel with a 9 B per codeword-step device workspace beyond that;
- * everything else runs one trellis state per lane (csrc/viterbi.hip).  A NaN among 'soft' inputs is handled as the reference
+ * every other trellis of up to 128 states, k <= 2, n <= 6 runs one trellis state per lane (csrc/viterbi.hip); the rest of the
+ * reference's argument domain (up to 65536 states, k <= 8, n <= 16, any traceback depth) one workgroup per codeword
+ * (csrc/viterbi_generic.hip: slow, complete).  A NaN among 'soft' inputs is handled as the reference
  * handles it (convcode.py:719 lets it through the clip): flagged codewords are decoded again by a NaN-exact instantiation.
- * cpx_viterbi_set_path (or the environment variable CPX_VITERBI_PATH = wave | cw | cw! | cw2 | cw2! at load time)
+ * cpx_viterbi_set_path (or the environment variable CPX_VITERBI_PATH = wave | cw | cw! | cw2 | cw2! | general at load time)
  * overrides the choice (tests, benchmarks); cpx_last_kernel reports which kernel ran.
  */
 int cpx_viterbi_decode_batch(const cpx_trellis *t, const double *coded, int64_t B, int64_t len,
@@ -129,7 +131,7 @@ int cpx_viterbi_decode_batch_dev(const cpx_trellis *t, const double *d_coded, in
                                  int64_t L, int64_t n_steps, int tb_depth, int decoding_type,
                                  uint8_t *d_bits, void *stream);
 /* Kernel-path override for tests and benchmarks (initial value: environment variable CPX_VITERBI_PATH):
- * NULL / "" / "auto" = automatic, "wave", "cw", "cw!", "cw2", "cw2!" as described above. */
+ * NULL / "" / "auto" = automatic, "wave", "cw", "cw!", "cw2", "cw2!" as described above, "general" = the general kernel. */
 int cpx_viterbi_set_path(const char *mode);
 /* Fused hard demodulation + hard-decision Viterbi: replaces the pair
  *   bits = modem.demodulate(y, 'hard')            commpy/modulation.py:121-123

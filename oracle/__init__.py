@@ -151,6 +151,11 @@ def turbo_decode(sys_symbols, non_sys_symbols_1, non_sys_symbols_2, trellis, noi
 def ldpc_edges(ldpc_code_params):
     """Edge list sorted by (check, variable) from the reference's adjacency arrays (ldpc.py:39-41)."""
     n_c = int(ldpc_code_params['n_cnodes'])
+    if 'cnode_adj_list' not in ldpc_code_params:                  # a dict that only carries the matrix (ldpc.py:189-195 reads just that)
+        H = np.asarray(ldpc_code_params['parity_check_matrix'].todense()
+                       if hasattr(ldpc_code_params['parity_check_matrix'], 'todense') else ldpc_code_params['parity_check_matrix'])
+        ec, ev = np.nonzero(H)                                    # row-major: sorted by (check, variable)
+        return ec.astype(np.int32), ev.astype(np.int32)
     mcd = int(ldpc_code_params['max_cnode_deg'])
     adj = np.asarray(ldpc_code_params['cnode_adj_list']).reshape(n_c, mcd)
     deg = np.asarray(ldpc_code_params['cnode_deg_list'])

@@ -820,6 +820,158 @@ def gen_viterbi_pairs():
 
 GENS["viterbi_pairs"] = gen_viterbi_pairs
 
+
+def gen_general():
+    """The reference's argument domain BEYOND what the specialised kernels serve (round 4): trellises of 256 and 512 states,
+    k = 3, n = 8 / 10 outputs per step (NumPy's eight-accumulator add.reduce order in the branch metrics), traceback windows
+    of hundreds of steps; map_decode / turbo_decode on 32- and 64-state RSC trellises; belief propagation on a Tanner graph
+    with checks of 40 edges; 1024-point constellations.  All through the LIVE reference.
+
+    K = 9 / n >= 8: the reference's own Trellis raises OverflowError for total memory >= 8 and for n >= 8 under NumPy 2 (an
+    int8 overflow in bitarray2dec during its table construction), so those tables come from commpy_amd's host Trellis (pure
+    Python, checked here against a plain shift-register model) and are handed to the reference's viterbi_decode /
+    conv_encode as a duck-typed trellis object.  Every decode below is the reference's own."""
+    sys.path.insert(0, REPO)
+    from commpy_amd.channelcoding.convcode import Trellis as OurTrellis
+    out, names = {}, []
+    rs = np.random.RandomState(4040)
+
+    class Duck:
+        pass
+
+    def duck(gs, mem):
+        """feed-forward k = 1 code with generators `gs`: commpy_amd's tables, checked against a plain shift-register model"""
+        t = OurTrellis(np.array([mem]), np.array([list(gs)]))
+        # state = the last `mem` inputs, most recent first; 'MSB' polynomial format: bit w of g is the tap on D^w
+        # (convcode.py:196-197), i.e. on bit mem - w of the register word (input, state)
+        S, n = 1 << mem, len(gs)
+        rev = [int(format(int(g), "0%db" % (mem + 1))[::-1], 2) for g in gs]
+        for st in range(S):
+            for u in (0, 1):
+                reg = (u << mem) | st
+                o = 0
+                for gr in rev:
+                    o = 2 * o + (bin(reg & gr).count("1") & 1)
+                assert t.output_table[st, u] == o and t.next_state_table[st, u] == reg >> 1
+        d = Duck()
+        for a in ("k", "n", "total_memory", "number_states", "number_inputs", "code_type"):
+            setattr(d, a, getattr(t, a))
+        d.next_state_table = np.array(t.next_state_table)
+        d.output_table = np.array(t.output_table)
+        return d
+
+    def viterbi_cases(tag, tr, nbits_list, tbs, B=3, types=("hard", "soft", "unquantized"), noise=1.0):
+        out[tag + "__next"] = np.asarray(tr.next_state_table, dtype=np.int64)
+        out[tag + "__outp"] = np.asarray(tr.output_table, dtype=np.int64)
+        out[tag + "__kn"] = np.array([tr.k, tr.n, tr.total_memory])
+        for dtype in types:
+            for nbits, tb in zip(nbits_list, tbs):
+                msg = rs.randint(0, 2, (B, nbits))
+                coded = np.stack([conv_encode(msg[b], tr) for b in range(B)]).astype(float)
+                if dtype == "hard":
+                    rx = np.where(rs.rand(*coded.shape) < 0.06 * noise, 1 - coded, coded)
+                elif dtype == "soft":
+                    rx = 4.0 * coded - 2 + rs.randn(*coded.shape) * 1.7 * noise
+                else:
+                    rx = 2.0 * coded - 1 + rs.randn(*coded.shape) * 0.8 * noise
+                t0 = time.time()
+                dec = np.stack([viterbi_decode(rx[b].copy(), tr, tb, dtype) for b in range(B)]).astype(np.uint8)
+                key = "%s|%s|%s|%d" % (tag, dtype, tb, nbits)
+                out[key + "__rx"], out[key + "__dec"] = rx, dec
+                names.append(key)
+                print("  %s: %.1fs, residual errors %d" % (key, time.time() - t0, int(np.sum(dec[:, :nbits] != msg))))
+
+    viterbi_cases("k9_561_753", duck((0o561, 0o753), 8), (96, 70), (None, 25))
+    viterbi_cases("k10_1167_1545", duck((0o1167, 0o1545), 9), (60,), (None,), B=2, types=("soft",))
+    viterbi_cases("k3n4", Trellis(np.array([1, 1, 1]), np.array([[1, 0, 0, 3], [0, 1, 0, 3], [0, 0, 1, 3]])), (120, 90), (None, 9))
+    viterbi_cases("k3n5m2", Trellis(np.array([2, 1, 1]), np.array([[7, 0, 0, 5, 3], [0, 3, 0, 1, 2], [0, 0, 3, 2, 1]])), (90,), (None,))
+    viterbi_cases("r1_8", duck((0o17, 0o15, 0o13, 0o11, 0o7, 0o5, 0o16, 0o12), 3), (80, 50), (None, 6), noise=3.0)
+    viterbi_cases("r1_10", duck((7, 5, 6, 3, 7, 5, 4, 1, 2, 7), 2), (64,), (None,), noise=3.5)
+    # a traceback window far beyond what the state-per-lane kernels hold in LDS (K = 7, depth 600 and depth > block)
+    viterbi_cases("k7_tb", Trellis(np.array([6]), np.array([[0o133, 0o171]])), (700, 100), (600, 80), B=2, types=("soft", "hard"))
+    out["vit_names"] = np.array(names)
+
+    # ---- map_decode / turbo_decode beyond 16 states ----
+    mnames, tnames = [], []
+    for tag, mem, g, fb in (("rsc32", 5, 0o67, 0o45), ("rsc64", 6, 0o171, 0o133)):
+        tr = Trellis(np.array([mem]), np.array([[1, g]]), fb, "rsc")
+        out[tag + "__next"] = np.asarray(tr.next_state_table, dtype=np.int64)
+        out[tag + "__outp"] = np.asarray(tr.output_table, dtype=np.int64)
+        out[tag + "__kn"] = np.array([tr.k, tr.n, tr.total_memory])
+        for N, ebn0 in ((48, 1.0), (100, 3.0)):
+            msg = rs.randint(0, 2, N)
+            coded = conv_encode(msg, tr, "cont")
+            nv = 1 / (2 * 0.5 * 10 ** (ebn0 / 10.0))
+            sys_r = 2.0 * coded[0::2] - 1 + np.sqrt(nv) * rs.randn(N)
+            par_r = 2.0 * coded[1::2] - 1 + np.sqrt(nv) * rs.randn(N)
+            for kind in (0, 1):
+                L_int = np.zeros(N) if kind == 0 else rs.randn(N) * 2.0
+                L, bits = map_decode(sys_r.copy(), par_r.copy(), tr, nv, L_int.copy(), "decode")
+                key = "%s|%d|%d" % (tag, N, kind)
+                out[key + "__sys"], out[key + "__par"], out[key + "__lint"] = sys_r, par_r, L_int
+                out[key + "__nv"] = np.array(nv)
+                out[key + "__L"], out[key + "__bits"] = np.asarray(L), np.asarray(bits, dtype=np.int64)
+                mnames.append(key)
+        N, iters = 64, 2
+        il = RandInterlv(N, 99)
+        msg = rs.randint(0, 2, N)
+        s, p1, p2 = turbo_encode(msg, tr, tr, il)
+        p2 = p2[:N]
+        nv = 1 / (2 * (1.0 / 3) * 10 ** (2.0 / 10.0))
+        sr, p1r, p2r = (2.0 * v[:N] - 1 + np.sqrt(nv) * rs.randn(N) for v in (s, p1, p2))
+        dec = turbo_decode(sr.copy(), p1r.copy(), p2r.copy(), tr, nv, iters, il)
+        key = "%s|turbo" % tag
+        out[key + "__sys"], out[key + "__p1"], out[key + "__p2"] = sr, p1r, p2r
+        out[key + "__nv"], out[key + "__iters"] = np.array(nv), np.array(iters)
+        out[key + "__perm"] = np.asarray(il.p_array, dtype=np.int64)
+        out[key + "__dec"] = np.asarray(dec, dtype=np.int64)
+        tnames.append(key)
+        print("  %s: turbo errors %d" % (key, int(np.sum(dec != msg))))
+    out["map_names"], out["turbo_names"] = np.array(mnames), np.array(tnames)
+
+    # ---- LDPC: checks of 40 edges (n = 400, 40 checks, column weight 4) ----
+    import scipy.sparse as sp
+    n_v, n_c, wc = 400, 40, 4
+    H = np.zeros((n_c, n_v), np.int8)
+    for v in range(n_v):
+        H[(np.arange(wc) * 10 + v * 7 + v // 40) % n_c, v] = 1
+    assert H.sum(1).min() == 40 and H.sum(1).max() == 40 and H.sum(0).min() == wc
+    out["ldpc_H"] = H
+    lnames = []
+    for alg in ("MSA", "SPA"):
+        for sigma, nblk, its in ((0.45, 2, 12), (0.7, 3, 8)):
+            params = {"n_vnodes": n_v, "n_cnodes": n_c, "parity_check_matrix": sp.csc_matrix(H)}
+            tx = np.ones(n_v * nblk)                         # all-zero codeword, BPSK +1, LLR = 2 y / sigma^2 (positive = bit 0)
+            llr = 2 * (tx + sigma * rs.randn(n_v * nblk)) / sigma ** 2
+            dec, ol = ldpc_bp_decode(llr.copy(), params, alg, its)
+            key = "ldpc|%s|%g|%d" % (alg, sigma, its)
+            out[key + "__llr"], out[key + "__dec"], out[key + "__out"] = llr, np.asarray(dec), np.asarray(ol)
+            lnames.append(key)
+            print("  %s: bit errors %d" % (key, int(np.asarray(dec).sum())))
+    out["ldpc_names"] = np.array(lnames)
+
+    # ---- 1024-QAM (separable but above the LDS tables) and a 512-point custom constellation ----
+    dnames = []
+    for tag, modem in (("qam1024", QAMModem(1024)), ("custom512", None)):
+        if modem is None:
+            pts = (rs.randn(512) + 1j * rs.randn(512)) * 3
+            modem = Modem(pts)
+        cst = np.asarray(modem.constellation)
+        nsym = 6
+        tx = cst[rs.randint(0, len(cst), nsym)]
+        nvar = 0.5 if tag == "qam1024" else 0.05
+        y = tx + np.sqrt(nvar / 2) * (rs.randn(nsym) + 1j * rs.randn(nsym))
+        out[tag + "__cst"], out[tag + "__y"], out[tag + "__nv"] = cst, y, np.array(nvar)
+        out[tag + "__soft"] = modem.demodulate(y, "soft", nvar)
+        out[tag + "__hard"] = modem.demodulate(y, "hard")
+        dnames.append(tag)
+    out["demod_names"] = np.array(dnames)
+    print("general: %d viterbi, %d map, %d turbo, %d ldpc, %d demod cases" % (len(names), len(mnames), len(tnames), len(lnames), len(dnames)))
+    save("general", **out)
+
+
+GENS["general"] = gen_general
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)

@@ -69,3 +69,22 @@ def ldpc_params(prefix):
               "vnode_deg_list"):
         d[k] = g[prefix + "__" + k]
     return d
+
+
+class GeneralTrellis:
+    """Trellis-like object from the tables stored in general.npz (round 4: the reference's wider argument domain)."""
+
+    def __init__(self, tag):
+        g = golden("general")
+        self.next_state_table = g[tag + "__next"]
+        self.output_table = g[tag + "__outp"]
+        self.k, self.n, self.total_memory = [int(v) for v in g[tag + "__kn"]]
+        self.number_states, self.number_inputs = self.next_state_table.shape
+
+
+def viterbi_valid_bits(length, trellis):
+    """Decoded positions the reference really writes: k * (number of trellis steps), at most L.  Behind them
+    ``decoded_bits`` is uninitialised ``np.empty`` memory (convcode.py:711, :721), e.g. 1 of 94 bits of a k = 3 code whose
+    padded message is not a multiple of k."""
+    L = int(length * (trellis.k / trellis.n))
+    return min(L, (int((L + trellis.total_memory) / trellis.k) - 1) * trellis.k)

@@ -278,3 +278,61 @@ def test_viterbi_generator_pairs_vs_reference():
         tr = Trellis(np.array([mem]), np.array([[g0, g1]]))
         got = oracle.viterbi_decode(g[key + "__rx"], tr, tb, dtype)
         assert np.array_equal(got, g[key + "__dec"]), key
+
+
+# ---- round 4: the reference's argument domain beyond the specialised kernels (tests/golden/general.npz) ------------------------
+def _general_cases(kind):
+    return [str(k) for k in golden("general")[kind]]
+
+
+def test_general_viterbi_vs_reference():
+    """256 / 512 states, k = 3, n = 8 and 10 (NumPy's eight-accumulator sum in the branch metric), traceback depth 600."""
+    from helpers import GeneralTrellis, viterbi_valid_bits
+    g = golden("general")
+    for key in _general_cases("vit_names"):
+        tag, dtype, tb, _ = key.split("|")
+        tr = GeneralTrellis(tag)
+        dec = oracle.viterbi_decode(g[key + "__rx"], tr, None if tb == "None" else int(tb), dtype)
+        nv = viterbi_valid_bits(g[key + "__rx"].shape[1], tr)
+        assert np.array_equal(dec[:, :nv], g[key + "__dec"][:, :nv]), key
+
+
+def test_general_map_turbo_vs_reference():
+    from helpers import GeneralTrellis
+    g = golden("general")
+    for key in _general_cases("map_names"):
+        tr = GeneralTrellis(key.split("|")[0])
+        L, bits = oracle.map_decode(g[key + "__sys"], g[key + "__par"], tr, float(g[key + "__nv"]), g[key + "__lint"], "decode")
+        assert np.max(np.abs(L - g[key + "__L"])) < 1e-9, key
+        assert np.array_equal(bits, g[key + "__bits"]), key
+    for key in _general_cases("turbo_names"):
+        tr = GeneralTrellis(key.split("|")[0])
+        dec = oracle.turbo_decode(g[key + "__sys"], g[key + "__p1"], g[key + "__p2"], tr, float(g[key + "__nv"]),
+                                  int(g[key + "__iters"]), Perm(g[key + "__perm"]))
+        assert np.array_equal(dec, g[key + "__dec"]), key
+
+
+def test_general_ldpc_degree_40_vs_reference():
+    import scipy.sparse as sp
+    g = golden("general")
+    H = g["ldpc_H"]
+    params = {"n_vnodes": H.shape[1], "n_cnodes": H.shape[0], "parity_check_matrix": sp.csc_matrix(H)}
+    for key in _general_cases("ldpc_names"):
+        alg = key.split("|")[1]
+        dec, out = oracle.ldpc_bp_decode(g[key + "__llr"].copy(), params, alg, int(key.split("|")[3]))
+        if alg == "MSA":
+            assert np.array_equal(out, g[key + "__out"]), key
+        else:
+            assert np.max(np.abs(out - g[key + "__out"])) < 1e-6, (key, np.max(np.abs(out - g[key + "__out"])))
+        assert np.array_equal(dec, g[key + "__dec"]), key
+
+
+def test_general_demod_large_constellations_vs_reference():
+    g = golden("general")
+    for tag in _general_cases("demod_names"):
+        soft = oracle.demodulate(g[tag + "__cst"], g[tag + "__y"], "soft", float(g[tag + "__nv"]))
+        ref = g[tag + "__soft"]
+        fin = np.isfinite(ref)
+        assert np.array_equal(fin, np.isfinite(soft)) and np.array_equal(soft[~fin], ref[~fin], equal_nan=True), tag
+        assert np.max(np.abs(soft[fin] - ref[fin])) < 1e-9, tag
+        assert np.array_equal(oracle.demodulate(g[tag + "__cst"], g[tag + "__y"], "hard"), g[tag + "__hard"]), tag

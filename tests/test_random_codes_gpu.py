@@ -159,10 +159,17 @@ def test_ldpc_random_structures(gpu, seed, n_v, n_c, lo, hi):
             assert np.mean(close) > 0.999, np.max(np.abs(out[fin] - oo[fin]))
 
 
-def test_ldpc_check_degree_limit(gpu):
-    """Engine limit: a check row is kept in registers / a 32-bit sign mask, degree <= 32 (documented in include/commpy_amd.h)."""
+def test_ldpc_check_degree_above_32_takes_the_general_kernel(gpu):
+    """Round 4: a check of more than 32 edges (rows are kept in registers / a 32-bit sign mask by the fast kernels) no longer
+    raises: the literal kernel decodes the whole code, min-sum bit-identical to the oracle, sum-product within 1e-5."""
+    from commpy_amd import _lib
     from commpy_amd.channelcoding import ldpc_bp_decode
     rs = np.random.RandomState(9)
     p = _random_ldpc(rs, 80, 4, np.array([40, 33, 10, 12]))
-    with pytest.raises(ValueError):
-        ldpc_bp_decode(rs.randn(80), p, "MSA", 3)
+    for alg in ("MSA", "SPA"):
+        llr = rs.randn(80 * 3) * 2.0 + 1.5
+        dec, out, its = ldpc_bp_decode(llr.copy(), p, alg, 6, return_iterations=True)
+        assert "ldpc_exact_kernel" in _lib.last_kernel()
+        do, oo, io = oracle.ldpc_bp_decode(llr.copy(), p, alg, 6, return_iters=True)
+        assert np.array_equal(its, io) and np.array_equal(dec, do)
+        assert np.array_equal(out, oo) if alg == "MSA" else np.max(np.abs(out - oo)) <= 1e-5
