@@ -48,8 +48,18 @@ namespace {
 
 constexpr int CH = 8;          // steps per chunk
 constexpr int KNORM = 4;       // renormalise alpha / beta every KNORM steps
-constexpr int XS_ROW = 64 * 2 + 4;   // doubles per step row of the parked branch products: 128 + 4 pad (the time-parallel
-                                    // epilogue reads one step per lane: a 1024-byte row stride puts its eight steps on the same banks)
+// ---- LDS layout (round 4: re-laid for zero bank conflicts; scripts/micro/lds_bank_sim.py is the model it was chosen with) ----
+// rocprofv3 had SQ_LDS_BANK_CONFLICT at 2.0 cycles per LDS instruction in rounds 2 and 3.  The model, with the lane groups and
+// bank functions of the CDNA4 LDS (ds_read_b64: 2 x 32 lanes over 64 dword banks, ds_read_b128: 4 x 16 interleaved lanes,
+// ds_write_b64: 4 x 16 lanes over 32 banks), found three sources in the round-3 layout ([step][codeword][gamma x 4, prior x 2],
+// products [step][lane][2], rows of 132 doubles): the 6-double item stride puts the gamma of codewords g and g + 5 on one bank
+// (2 extra cycles per gamma read), a lane's two products are adjacent so lanes l and l + 8 of a 16-lane store group collide
+// (4 per store), and the epilogue's 16-lane b128 groups mix steps 0-3 of two codewords with steps 4-7 of two others (12 per read).
+// Now: gamma [step][codeword][4] (row = 4 GW + 2 doubles) and priors [step][codeword][2] (row = 2 GW + 2) are separate tables --
+// 32 consecutive lanes read 32 different 8-byte slots --, the products are slot-major [step][input][lane] (row = 130), and the
+// (codeword, step) item of a lane is permuted so that every b128 lane group holds ONE half (steps 0-3 or 4-7) of four codewords
+// of equal parity (item_of).  Model: 0 conflict cycles on all 94 LDS instructions of a phase-2 chunk (round 3: 224).
+constexpr int XS_ROW = 2 * 64 + 2;   // doubles per step row of the parked branch products: [input 0 | input 1][64 lanes] + 2 pad
 constexpr int NPAIR = 4;       // (forward, reverse) wave pairs per full-size workgroup: 8 waves = 2 per SIMD of a CU
 
 // ---- outside the reference's representable range: detect and redo --------------------------------------------------------
@@ -97,7 +107,7 @@ template <int LGS>
 struct Ctx {
     static constexpr int S = 1 << LGS;
     static constexpr int NI = 2;                                       // (codeword, step) items per lane: CH*GW <= 128
-    int lane, g, s, GW, P;                                             // P: doubles per step row of `tab`
+    int lane, g, s, GW, GS, PS;                                        // GS / PS: doubles per step row of `gam` / `pri`
     bool fwd;                                                          // forward (alpha) wave of the pair
     int sb[2];                                                         // sr4: MSB of next_state[s][i] (which successor input i leads to)
     bool active;                                                       // lane belongs to one of the GW decoded slots
@@ -108,8 +118,9 @@ struct Ctx {
     int ilo;
     int o_glo, o_ghi;                 // offsets of gamma(code of the branch to lo / hi) inside an item of `tab`
     // LDS of this wave
-    double *tab;    // [CH][GW][6] (+2 pad per step): gamma[4], priors p0, p1 of every (step, codeword) item
-    double *xs;     // [CH][64][2]  per-lane branch products alpha*gamma*beta of the chunk (phase 2)
+    double *gam;    // [CH][GW][4] (+2 pad per step): gamma[4] of every (step, codeword) item
+    double *pri;    // [CH][GW][2] (+2 pad per step): priors p0, p1
+    double *xs;     // [CH][2][64] (+2 pad per step): per-lane branch products alpha*gamma*beta of the chunk, by input (phase 2)
     double *rw;     // [CH][64]     alpha rows of a partial (last) chunk: the rolled code path keeps them here
     double *xch;    // [64]         exchange buffer (trellises without the DPP fast path)
     // "detect and redo": lanes that raised a flag (one mask for the whole pass: three masks that resolve the codeword cost six
@@ -122,7 +133,17 @@ struct Ctx {
 __device__ __forceinline__ void flag_or(unsigned long long &mask, bool cond) { mask |= __ballot(cond); }
 
 template <int LGS>
-__host__ __device__ constexpr size_t wave_lds_doubles(int GW) { return (size_t)CH * (GW * 6 + 2) + (size_t)CH * (XS_ROW + 64) + 64; }
+__host__ __device__ constexpr size_t wave_lds_doubles(int GW) { return (size_t)CH * (GW * 6 + 4) + (size_t)CH * (XS_ROW + 64) + 64; }
+
+// The (codeword slot, step) item a lane stages, loads and finishes (two per lane, q = 0 / 1: CH * GW <= 128 items per chunk).
+// Eight consecutive lanes hold the eight steps of ONE codeword (64-byte segments of the pass's arrays); which codeword and in
+// which order is chosen for the epilogue's ds_read_b128 lane groups {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} (+32): blocks
+// 1, 2, 5, 6 hold their steps with the halves swapped, blocks 0-3 serve the even codewords and blocks 4-7 the odd ones.
+__device__ __forceinline__ void item_of(int lane, int q, int &gg, int &tl) {
+    const int bk = lane >> 3;
+    gg = (((bk & 3) << 1) | (bk >> 2)) + 8 * q;
+    tl = (lane & 7) ^ ((((bk + 1) >> 1) & 1) << 2);
+}
 
 template <int LGS>
 __device__ __forceinline__ void init_ctx(Ctx<LGS> &c, const MapTables &tb, unsigned char *smem, int GW) {
@@ -131,7 +152,8 @@ __device__ __forceinline__ void init_ctx(Ctx<LGS> &c, const MapTables &tb, unsig
     c.lane = threadIdx.x & 63;
     c.fwd = (wave & 1) == 0;
     c.GW = GW;
-    c.P = GW * 6 + 2;
+    c.GS = GW * 4 + 2;
+    c.PS = GW * 2 + 2;
     c.active = (c.lane >> LGS) < GW;
     c.g = c.active ? (c.lane >> LGS) : 0;                         // idle lanes shadow slot 0 (reads only)
     c.s = c.lane & (S - 1);
@@ -148,7 +170,8 @@ __device__ __forceinline__ void init_ctx(Ctx<LGS> &c, const MapTables &tb, unsig
     c.o_glo = c.sb[0] ? c.code[1] : c.code[0];
     c.o_ghi = c.sb[0] ? c.code[0] : c.code[1];
     double *p = reinterpret_cast<double *>(smem) + (size_t)wave * wave_lds_doubles<LGS>(GW);
-    c.tab = p; p += CH * c.P;
+    c.gam = p; p += CH * c.GS;
+    c.pri = p; p += CH * c.PS;
     c.xs = p;  p += CH * XS_ROW;
     c.rw = p;  p += CH * 64;
     c.xch = p;
@@ -197,8 +220,8 @@ __device__ __forceinline__ void exchange_pred(const Ctx<LGS> &c, double v, doubl
 }
 
 // ---- time-parallel stage of a chunk --------------------------------------------------------------------------
-// A chunk has CH*GW (codeword, step) items, at most 2 per lane: item p = lane + 64*q -> codeword slot p / CH,
-// step p % CH (consecutive lanes -> consecutive steps of one codeword: coalesced 64-byte segments).
+// A chunk has CH*GW (codeword, step) items, at most 2 per lane: item_of(lane, q) -> (codeword slot, step); eight consecutive
+// lanes hold the eight steps of one codeword: 64-byte segments of the pass's arrays.
 struct RawChunk {
     double r0[2], r1[2], li[2];
 };
@@ -255,7 +278,8 @@ template <int LGS>
 __device__ __forceinline__ void load_raw(const Ctx<LGS> &c, const PassIO &io, RawChunk &rc, int t0, int len) {
 #pragma unroll
     for (int q = 0; q < 2; q++) {
-        const int p = c.lane + 64 * q, gg = p / CH, tl = p % CH;
+        int gg, tl;
+        item_of(c.lane, q, gg, tl);
         const unsigned t = (unsigned)(t0 + tl);                   // 0-based step index
         const unsigned m = item_mask(gg, io.ncw, tl, len);        // no such item: zeros
         rc.r0[q] = buf_ld(io.rsys, item_off(m, ((unsigned)(gg * io.sstride) + t) * 8u), io.osys);
@@ -264,7 +288,7 @@ __device__ __forceinline__ void load_raw(const Ctx<LGS> &c, const PassIO &io, Ra
     }
 }
 
-// tab[tl][g] = gamma'[0..3], q0, q1 into LDS -- the branch probabilities (_compute_branch_prob :62-76) and the priors
+// gam[tl][g] = gamma'[0..3], pri[tl][g] = q0, q1 into LDS -- the branch probabilities (_compute_branch_prob :62-76) and the priors
 // (:239-240) of every item, each up to a factor that is COMMON to the step and therefore cancels in the normalised
 // recursions and in app1/app0:
 //   gamma[c] = exp(-((r0-c0)^2 + (r1-c1)^2)/nv2) = E * (c0 matches sign(r0) ? 1 : Qa) * (c1 matches sign(r1) ? 1 : Qb),
@@ -273,10 +297,10 @@ __device__ __forceinline__ void load_raw(const Ctx<LGS> &c, const PassIO &io, Ra
 //   (p0, p1) = (1 / (1 + e^L), 1 - p0): the reference's own two operations (round 2 used the scale-free weights (1, e^L) /
 //     (e^-L, 1); they are more accurate than the reference where 1 - p0 cancels -- L < -30 -- and non-zero where its p1 is
 //     exactly 0 -- L < -36.7 --, which is a difference as soon as the channel contradicts such a prior).
-// The row stride P = 6 GW + 2 doubles makes the eight lanes that hold consecutive steps of a codeword hit eight
-// different 16-byte bank groups.  (An entry-major row [6][GW], which makes the recursions' reads conflict-free, was measured:
-// six 8-byte staging stores per item instead of three 16-byte ones and the extra address arithmetic cost more than the
-// conflicts -- MAP pass 0.329 instead of 0.320 ms, config 3 5.37 instead of 5.14 ms.)
+// Row strides of 4 GW + 2 / 2 GW + 2 doubles: the eight lanes that hold the steps of a codeword store to eight different
+// 16-byte bank groups, and the recursions' 8-byte reads of 32 consecutive lanes are conflict-free (see "LDS layout" above).
+// (An entry-major row [6][GW] was measured in round 2: six 8-byte staging stores per item instead of three 16-byte ones cost
+// more than the conflicts they removed; the two-table form keeps the 16-byte stores.)
 // PRE (turbo_decode): the channel factors do not change between the passes of a decode, so they are evaluated ONCE per
 // launch (signed_q below) and a pass reads copysign(Qa, r0), copysign(Qb, r1) where it would read r0, r1: one exp per item
 // and pass -- the prior -- instead of three.
@@ -291,7 +315,8 @@ __device__ __forceinline__ void stage_chunk(const Ctx<LGS> &c, const RawChunk &r
     const double lim = T_A * nv2;
 #pragma unroll
     for (int q = 0; q < 2; q++) {
-        const int p = c.lane + 64 * q, gg = p / CH, tl = p % CH;
+        int gg, tl;
+        item_of(c.lane, q, gg, tl);
         if (gg < GW) {
             const double r0 = rc.r0[q], r1 = rc.r1[q], li = rc.li[q];
             const double qa = PRE ? fabs(r0) : exp(k4 * fabs(r0)), qb = PRE ? fabs(r1) : exp(k4 * fabs(r1));
@@ -309,10 +334,10 @@ __device__ __forceinline__ void stage_chunk(const Ctx<LGS> &c, const RawChunk &r
             const bool n0 = PRE ? __double2hiint(r0) < 0 : r0 < 0.0, n1 = PRE ? __double2hiint(r1) < 0 : r1 < 0.0;
             const double a0 = n0 ? 1.0 : qa, a1 = n0 ? qa : 1.0;  // systematic bit 0 (c0 = -1) / 1 (c0 = +1)
             const double b0 = n1 ? 1.0 : qb, b1 = n1 ? qb : 1.0;  // parity bit
-            double2 *row = reinterpret_cast<double2 *>(c.tab + tl * c.P + gg * 6);
+            double2 *row = reinterpret_cast<double2 *>(c.gam + tl * c.GS + gg * 4);
             row[0] = make_double2(a0 * b0, a0 * b1);              // code = 2*sys_bit + parity_bit
             row[1] = make_double2(a1 * b0, a1 * b1);
-            row[2] = make_double2(p0, p1);
+            *reinterpret_cast<double2 *>(c.pri + tl * c.PS + gg * 2) = make_double2(p0, p1);
         }
     }
     asm volatile("" ::: "memory");
@@ -330,22 +355,22 @@ __device__ __forceinline__ void stage_chunk(const Ctx<LGS> &c, const RawChunk &r
 // 2|(s>>1) on the shift-register fast path, the branches of input 0 / 1 otherwise
 template <int LGS, bool SR>
 __device__ __forceinline__ void beta_w(const Ctx<LGS> &c, int tl, double &g_lo, double &g_hi, double &w_lo, double &w_hi) {
-    const double *it = c.tab + tl * c.P + c.g * 6;
+    const double *it = c.gam + tl * c.GS + c.g * 4, *pr = c.pri + tl * c.PS + c.g * 2;
     if (LGS == 2 && SR) {
         g_lo = it[c.o_glo]; g_hi = it[c.o_ghi];
-        w_lo = g_lo * it[4 + c.ilo]; w_hi = g_hi * it[5 - c.ilo];
+        w_lo = g_lo * pr[c.ilo]; w_hi = g_hi * pr[1 - c.ilo];
     } else {
         g_lo = it[c.code[0]]; g_hi = it[c.code[1]];
-        w_lo = g_lo * it[4]; w_hi = g_hi * it[5];
+        w_lo = g_lo * pr[0]; w_hi = g_hi * pr[1];
     }
 }
 
 // weights of the two incoming branches of this lane's state, in np.where order (:136-138)
 template <int LGS>
 __device__ __forceinline__ void alpha_w(const Ctx<LGS> &c, int tl, double &w0, double &w1) {
-    const double *it = c.tab + tl * c.P + c.g * 6;
-    w0 = it[c.pcode[0]] * it[4 + c.pin[0]];
-    w1 = it[c.pcode[1]] * it[4 + c.pin[1]];
+    const double *it = c.gam + tl * c.GS + c.g * 4, *pr = c.pri + tl * c.PS + c.g * 2;
+    w0 = it[c.pcode[0]] * pr[c.pin[0]];
+    w1 = it[c.pcode[1]] * pr[c.pin[1]];
 }
 
 // beta of this lane's two successors (see beta_w for the order)
@@ -368,10 +393,10 @@ __device__ __forceinline__ void beta_step(const Ctx<LGS> &c, int tl, double &b, 
     double lo, hi;
     beta_nbrs<LGS, SR>(c, b, lo, hi);
     if (X) {
-        double *xo = c.xs + tl * XS_ROW + c.lane * 2;             // idle lanes own a slot too
-        const int s_lo = (LGS == 2 && SR) ? c.ilo : 0;
-        xo[s_lo] = (a_own * g_lo) * lo;
-        xo[1 - s_lo] = (a_own * g_hi) * hi;
+        double *xo = c.xs + tl * XS_ROW + c.lane;                 // idle lanes own a slot too
+        const int s_lo = (LGS == 2 && SR) ? c.ilo : 0;            // the input of the "lo" branch: its product goes to that input's row
+        xo[s_lo * 64] = (a_own * g_lo) * lo;
+        xo[(1 - s_lo) * 64] = (a_own * g_hi) * hi;
     }
     b = __builtin_fma(hi, w_hi, lo * w_lo);
     if ((tl & (KNORM - 1)) == 0) {
@@ -447,13 +472,19 @@ __device__ __forceinline__ void epilogue(const Ctx<LGS> &c, const PassIO &io, co
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int q = 0; q < 2; q++) {
-        const int p = c.lane + 64 * q, gg = p / CH, tl = p % CH;
+        int gg, tl;
+        item_of(c.lane, q, gg, tl);
         const unsigned m = item_mask(gg, io.ncw, tl, len);        // no such item: computes on whatever LDS holds, stores nowhere
         const bool ok = m != 0;
-        const double2 *x = reinterpret_cast<const double2 *>(c.xs + tl * XS_ROW + (gg < c.GW ? gg : 0) * S * 2);
+        // the S products of input 0 and of input 1 of this item: the lanes of codeword slot gg are gg * S .. gg * S + S - 1
+        const double2 *x0 = reinterpret_cast<const double2 *>(c.xs + tl * XS_ROW + (gg < c.GW ? gg : 0) * S), *x1 = x0 + 32;
         double app0 = 0.0, app1 = 0.0;
 #pragma unroll
-        for (int st = 0; st < S; st++) { const double2 v = x[st]; app0 += v.x; app1 += v.y; }
+        for (int st = 0; st < S / 2; st++) {                      // sums in state order (:141-143)
+            const double2 v0 = x0[st], v1 = x1[st];
+            app0 += v0.x; app0 += v0.y;
+            app1 += v1.x; app1 += v1.y;
+        }
         const double lr = fast_log(app1 / app0);
         flag_or(c.bad, ok && (!(fabs(lr) < __builtin_huge_val()) || !(fmax(app0, app1) >= T_SMALL)));   // (D), (E)
         const double L = io.ext ? lr : li[q] + lr;
