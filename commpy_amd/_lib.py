@@ -60,6 +60,7 @@ SYMBOLS = {
                                      c_void_p]),
     "cpx_viterbi_set_path": (c_int, [c_char_p]),
     "cpx_ldpc_set_path": (c_int, [c_char_p]),
+    "cpx_demod_set_path": (c_int, [c_char_p]),
     "cpx_demod_hard_viterbi_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int,
                                              c_void_p]),
     "cpx_demod_hard_viterbi_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int,
@@ -233,6 +234,11 @@ def viterbi_last_path():
 def viterbi_set_path(mode):
     """Force a Viterbi kernel path: None/'auto', 'wave', 'cw', 'cw!', 'cw2', 'cw2!', 'general' (tests and benchmarks)."""
     check(load().cpx_viterbi_set_path(None if mode is None else mode.encode()))
+
+
+def demod_set_path(mode):
+    """Soft-demodulator form: None/'auto' (four exponentials per axis for square QAM of 64 points and more) or 'plain'."""
+    check(load().cpx_demod_set_path(None if mode is None else mode.encode()))
 
 
 def ldpc_set_path(mode):

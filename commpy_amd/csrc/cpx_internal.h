@@ -182,4 +182,8 @@ struct cpx_modem {
     // axis-separable square constellations (QAMModem): label = (a << nbits/2) | b, point = xs[a] + 1j*ys[b]
     bool separable = false;
     double *d_axes = nullptr;   // [2][sqrt(M)]: xs then ys
+    // ... whose levels are equally spaced and labelled in reflected Gray order (QAMModem): level j = axes[0] + j * gp_step has
+    // label j ^ (j >> 1) -- the soft demodulator then needs four exp per axis (demod.hip, GP)
+    bool gp = false;
+    double gp_step[2] = {0.0, 0.0};
 };

@@ -23,7 +23,10 @@
 #include "cpx_math.h"
 #include "demod_dev.h"
 
+#include <atomic>
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
 
 using namespace cpx;
 
@@ -64,25 +67,68 @@ __global__ __launch_bounds__(DEMOD_BLOCK) void demod_soft_kernel(const double2 *
 // RCP: the exponent -d^2 / noise_var is formed as d^2 * (-1 / noise_var) -- one multiplication instead of a 12-instruction
 // division per exponential (16 of them per 64-QAM symbol, a sixth of the kernel); the two agree to an ulp of the exponent,
 // i.e. ~1e-14 on an LLR (the bar is 1e-5).  The host selects it when 1 / noise_var is a normal number.
+// GP (round 4): the R levels of an axis are EQUALLY SPACED and labelled in reflected Gray order -- every constellation QAMModem
+// builds (modulation.py:258-261 + the Gray re-indexing of :72-75): level j = p0 + j d carries label j ^ (j >> 1).  Then the
+// exponentials of an axis form a geometric progression of geometric progressions,
+//     e[j+1] = e[j] rho[j],  rho[j] = exp((2 d (x - p[j]) - d^2) / N0),  rho[j+1] = rho[j] Q,  Q = exp(-2 d^2 / N0)
+// (and the mirror image downwards), so FOUR exp per axis -- the two middle levels and their two first ratios -- give all R values,
+// the rest by two multiplications per level: 64-QAM 8 instead of 16 exp per symbol, 256-QAM 8 instead of 32.  Starting in the
+// middle keeps every factor that matters a normal number: the results carry a few more roundings than exp itself (~1e-15 on an
+// LLR).  Where they could not -- a middle-level exponential below 1e-290, an axis whose sum is below 1e-30, or anything non-finite --
+// the symbol joins the point-by-point redo below (which the +-600 rule already sends the deep-underflow cases to); with both
+// guards passed and every |LLR| < 600, every term that contributes to a sum at the 1e-7 level is above 1e-300.
 template <int NH, bool RCP>
+__device__ __forceinline__ bool axis_gp(double v, const double *ax, double d, double noise_var, double ninv, double c1, double c2,
+                                        double Q, double (&e)[1 << NH], double &sum) {
+    constexpr int R = 1 << NH, JL = R / 2 - 1, JH = R / 2;
+    constexpr int GL = JL ^ (JL >> 1), GH = JH ^ (JH >> 1);       // labels of the two middle levels
+    const double dl = v - ax[GL], dh = v - ax[GH];
+    const double el = exp(RCP ? (dl * dl) * ninv : (-(dl * dl)) / noise_var);
+    const double eh = exp(RCP ? (dh * dh) * ninv : (-(dh * dh)) / noise_var);
+    e[GL] = el;
+    e[GH] = eh;
+    double cur = eh, r = exp(c1 * dh - c2);
+#pragma unroll
+    for (int j = JH + 1; j < R; j++) { cur *= r; e[j ^ (j >> 1)] = cur; r *= Q; }
+    cur = el;
+    r = exp(-c1 * dl - c2);
+#pragma unroll
+    for (int j = JL - 1; j >= 0; j--) { cur *= r; e[j ^ (j >> 1)] = cur; r *= Q; }
+    sum = 0.0;
+#pragma unroll
+    for (int a = 0; a < R; a++) sum += e[a];                      // label order, like the plain path
+    return !(fmin(el, eh) >= 1e-290) || !(sum >= 1e-30);
+}
+
+template <int NH, bool RCP, bool GP>
 __global__ __launch_bounds__(DEMOD_BLOCK) void demod_soft_sep_kernel(const double2 *__restrict__ y, int64_t Ns,
                                                                      const double *__restrict__ axes, double noise_var,
-                                                                     double scale, double *__restrict__ llr) {
+                                                                     double scale, double step_x, double step_y,
+                                                                     double *__restrict__ llr) {
     const double ninv = -1.0 / noise_var;
     constexpr int R = 1 << NH, NB = 2 * NH;
     __shared__ double ax_s[2 * R];
     for (int m = threadIdx.x; m < 2 * R; m += DEMOD_BLOCK) ax_s[m] = axes[m];
     __syncthreads();
+    // GP: per-call constants of the two axes (2 d / N0, d^2 / N0, Q)
+    const double c1x = GP ? 2.0 * step_x / noise_var : 0.0, c2x = GP ? step_x * step_x / noise_var : 0.0, Qx = GP ? exp(-2.0 * c2x) : 0.0;
+    const double c1y = GP ? 2.0 * step_y / noise_var : 0.0, c2y = GP ? step_y * step_y / noise_var : 0.0, Qy = GP ? exp(-2.0 * c2y) : 0.0;
     for (int64_t i = (int64_t)blockIdx.x * DEMOD_BLOCK + threadIdx.x; i < Ns; i += (int64_t)gridDim.x * DEMOD_BLOCK) {
         const double2 cur = y[i];
         double ex[R], ey[R], sx = 0.0, sy = 0.0;
+        bool redo = false;
+        if (GP) {
+            redo |= axis_gp<NH, RCP>(cur.x, ax_s, step_x, noise_var, ninv, c1x, c2x, Qx, ex, sx);
+            redo |= axis_gp<NH, RCP>(cur.y, ax_s + R, step_y, noise_var, ninv, c1y, c2y, Qy, ey, sy);
+        } else {
 #pragma unroll
-        for (int a = 0; a < R; a++) {
-            const double dx = cur.x - ax_s[a], dy = cur.y - ax_s[R + a];
-            ex[a] = exp(RCP ? (dx * dx) * ninv : (-(dx * dx)) / noise_var);
-            ey[a] = exp(RCP ? (dy * dy) * ninv : (-(dy * dy)) / noise_var);
-            sx += ex[a];
-            sy += ey[a];
+            for (int a = 0; a < R; a++) {
+                const double dx = cur.x - ax_s[a], dy = cur.y - ax_s[R + a];
+                ex[a] = exp(RCP ? (dx * dx) * ninv : (-(dx * dx)) / noise_var);
+                ey[a] = exp(RCP ? (dy * dy) * ninv : (-(dy * dy)) / noise_var);
+                sx += ex[a];
+                sy += ey[a];
+            }
         }
         double out[NB];
 #pragma unroll
@@ -100,7 +146,6 @@ __global__ __launch_bounds__(DEMOD_BLOCK) void demod_soft_sep_kernel(const doubl
         // sum-of-products and product-of-sums round differently (measured at 29 dB: 0.9 apart at |LLR| = 740, a handful of
         // inf / finite flips).  Such a symbol is redone the reference's way -- every point, hypot, division, increasing label --
         // so that its rounding and its +-inf / NaN pattern are the reference's (modulation.py:125-137).
-        bool redo = false;
 #pragma unroll
         for (int b = 0; b < NB; b++) redo |= !(fabs(out[b]) < 600.0);
         if (redo) {
@@ -190,6 +235,19 @@ __global__ __launch_bounds__(DEMOD_BLOCK) void demod_hard_any_kernel(const doubl
     }
 }
 
+// "plain": the R-exponentials-per-axis form of the separable kernel also where the progression applies (A/B runs, tests);
+// initial value from the environment variable CPX_DEMOD, changed through cpx_demod_set_path()
+std::atomic<int> g_demod_plain{-1};
+bool demod_plain() {
+    int v = g_demod_plain.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char *e = getenv("CPX_DEMOD");
+        v = (e && strcmp(e, "plain") == 0) ? 1 : 0;
+        g_demod_plain.store(v, std::memory_order_relaxed);
+    }
+    return v != 0;
+}
+
 unsigned grid_for(int64_t Ns) {
     int64_t blocks = (Ns + DEMOD_BLOCK - 1) / DEMOD_BLOCK;
     const int64_t cap = 256 * 16;   // 256 CUs x 16 resident blocks; grid-stride beyond that
@@ -232,9 +290,33 @@ int cpx_modem_create(const double *constellation_re_im, int M, cpx_modem **out) 
             CPX_HIP(hipMalloc((void **)&m->d_axes, sizeof(double) * 2 * R));
             CPX_HIP(hipMemcpy(m->d_axes, axes.data(), sizeof(double) * 2 * R, hipMemcpyHostToDevice));
             m->separable = true;
+            // equally spaced levels in reflected Gray order (what QAMModem builds)?  level j = p0 + j d has label j ^ (j >> 1)
+            bool gp = R >= 2;
+            for (int ax = 0; ax < 2 && gp; ax++) {
+                const double *a = axes.data() + ax * R;
+                // (a scaled table, levels * 1/sqrt(Es), sits within a few ulp of the ideal grid: the progression then evaluates
+                //  e^{-(x - p)^2 / N0} for a level some 1e-15 |p| off its stored value -- far inside the kernel's own rounding)
+                const int top = (R - 1) ^ ((R - 1) >> 1);
+                const double p0 = a[0], d = (a[top] - a[0]) / (R - 1);
+                double big = 0.0;
+                for (int j = 0; j < R; j++) big = std::max(big, std::fabs(a[j]));
+                for (int j = 0; j < R && gp; j++) gp = std::fabs(a[j ^ (j >> 1)] - (p0 + j * d)) <= 16.0 * 2.2e-16 * big;
+                gp = gp && d != 0.0 && std::isfinite(d);
+                m->gp_step[ax] = d;
+            }
+            m->gp = gp;
         }
     }
     *out = m;
+    return CPX_OK;
+}
+
+int cpx_demod_set_path(const char *mode) {
+    if (mode && mode[0] && strcmp(mode, "auto") != 0 && strcmp(mode, "plain") != 0) {
+        set_error("cpx_demod_set_path: unknown mode '%s' (auto | plain)", mode);
+        return CPX_EINVAL;
+    }
+    g_demod_plain.store((mode && strcmp(mode, "plain") == 0) ? 1 : 0, std::memory_order_relaxed);
     return CPX_OK;
 }
 
@@ -269,14 +351,22 @@ int cpx_demod_soft_scaled_dev(const cpx_modem *m, const double *d_y, int64_t Ns,
         note_kernel("demod_soft_any_kernel<%s> (%d points)", rcp ? "rcp" : "div", m->M);
         return CPX_OK;
     }
+    const bool gp = m->gp && m->nbits >= 6 && !demod_plain();
     if (m->separable) {
         switch (m->nbits / 2) {
-#define CASE(NH) case NH:                                                                                                \
-        if (rcp) hipLaunchKernelGGL((demod_soft_sep_kernel<NH, true>), grid, block, 0, st, y, Ns, m->d_axes, noise_var, scale, d_llr);   \
-        else hipLaunchKernelGGL((demod_soft_sep_kernel<NH, false>), grid, block, 0, st, y, Ns, m->d_axes, noise_var, scale, d_llr);   \
+#define LAUNCH(NH, RC, GPV) hipLaunchKernelGGL((demod_soft_sep_kernel<NH, RC, GPV>), grid, block, 0, st, y, Ns, m->d_axes, noise_var, \
+                                               scale, m->gp_step[0], m->gp_step[1], d_llr)
+#define CASE(NH) case NH:                                         \
+        if (rcp) LAUNCH(NH, true, false); else LAUNCH(NH, false, false);  \
         break;
-            CASE(1) CASE(2) CASE(3) CASE(4)
+#define CASE_GP(NH) case NH:                                      \
+        if (gp) { if (rcp) LAUNCH(NH, true, true); else LAUNCH(NH, false, true); }       \
+        else { if (rcp) LAUNCH(NH, true, false); else LAUNCH(NH, false, false); }        \
+        break;
+            CASE(1) CASE(2) CASE_GP(3) CASE_GP(4)                 // the progression pays from 8 levels per axis on (4 exp instead of R)
 #undef CASE
+#undef CASE_GP
+#undef LAUNCH
             default: set_error("demod: unsupported bits per symbol %d", m->nbits); return CPX_ELIMIT;
         }
     } else {
@@ -291,7 +381,7 @@ int cpx_demod_soft_scaled_dev(const cpx_modem *m, const double *d_y, int64_t Ns,
         }
     }
     CPX_HIP(hipGetLastError());
-    if (m->separable) note_kernel("demod_soft_sep_kernel<%d,%s>", m->nbits / 2, rcp ? "rcp" : "div");
+    if (m->separable) note_kernel("demod_soft_sep_kernel<%d,%s%s>", m->nbits / 2, rcp ? "rcp" : "div", gp ? ",gp" : "");
     else note_kernel("demod_soft_kernel<%d,%s>", m->nbits, rcp ? "rcp" : "div");
     return CPX_OK;
 }

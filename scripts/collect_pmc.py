@@ -9,9 +9,11 @@ FETCH_SIZE and WRITE_SIZE in separate passes -- they do not fit one pass, MI355X
 Writes <out>/<name>_pmc.json: for every kernel whose name contains --match, the mean value per dispatch of every
 counter, the mean duration, and derived figures:
 
-  traffic_bytes_per_launch   FETCH_SIZE (KiB) x 1024 x fetch_scale + WRITE_SIZE (KiB) x 1024; --fetch-scale 2 applies the
-                             guide's gfx950 correction for wide (16 B/lane) coalesced streaming reads, which FETCH_SIZE
-                             reports at half their size
+  traffic_bytes_per_launch   FETCH_SIZE (KiB) x 1024 x fetch_scale + WRITE_SIZE (KiB) x 1024; --fetch-scale 2 (the default) is
+                             the calibrated gfx950 correction: FETCH_SIZE reports HALF the bytes of every read pattern the
+                             decoders use -- 16 / 8 / 4 / 1 byte per lane and 64-byte buffer-load segments, factors 1.98 - 2.00
+                             on a known 1 GiB (scripts/micro/fetch_calib.py -> profiles/r04_fetch_calibration.json) --, WRITE_SIZE
+                             is exact for 8- and 16-byte stores (1.00) and 4 % high for byte stores
   valu.busy_frac             SQ_ACTIVE_INST_VALU (quad-cycles, summed over waves) x 4 / (SIMDs in use x kernel cycles),
                              kernel cycles = GRBM_GUI_ACTIVE / 8 (the counter is summed over the XCDs)
   valu.insts_per_launch      SQ_INSTS_VALU

@@ -24,11 +24,11 @@ from helpers import make_trellis  # noqa: E402
 from test_random_codes_gpu import _random_ldpc  # noqa: E402
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=0)
-    a = ap.parse_args()
+    a = ap.parse_args(argv)
     from commpy_amd import _lib
     from commpy_amd.channelcoding import RandInterlv, conv_encode_batch, ldpc_bp_decode, map_decode, turbo_decode, viterbi_decode
     from commpy_amd.modulation import PSKModem, QAMModem
@@ -78,6 +78,11 @@ def main():
                 got = viterbi_decode(rx, tr, tb, dtype)
                 if not np.array_equal(got, want):
                     bad.append(("viterbi-other", name, dtype, B, steps, tb, int(np.sum(got != want))))
+                _lib.viterbi_set_path("general")                   # round 4: the general kernel on the same case
+                got = viterbi_decode(rx, tr, tb, dtype)
+                _lib.viterbi_set_path(None)
+                if not np.array_equal(got, want):
+                    bad.append(("viterbi-other-general", name, dtype, B, steps, tb, int(np.sum(got != want))))
                 if name in ("t57", "k5_23_35"):                    # round 3: the small-ring fused kernel where it applies ("cw": fall back otherwise)
                     _lib.viterbi_set_path("cw")
                     got = viterbi_decode(rx, tr, tb, dtype)
@@ -133,7 +138,7 @@ def main():
                 else:
                     rx = 2.0 * coded - 1 + rs.randn(*coded.shape) * rs.choice([0.3, 0.8, 2.0])
                 want = oracle.viterbi_decode(rx, tr7, tb, dtype)
-                for path in ("cw!", "cw2!", "wave", None):
+                for path in ("cw!", "cw2!", "wave", "general", None):      # round 4: + the general kernel (viterbi_generic.hip)
                     _lib.viterbi_set_path(path)
                     got = viterbi_decode(rx, tr7, tb, dtype)
                     if not np.array_equal(got, want):

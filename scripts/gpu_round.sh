@@ -4,7 +4,9 @@
 #   sections: t(ests) s(moke) b(ench.py) d(ist: torchrun N=1 over the engine's RCCL binding) k(ernel benches)
 #             l(ink + host-api + multi-GPU benches) v(iterbi PMC passes) u(turbo/map PMC passes) m(demod PMC passes)
 #             x(ldpc PMC passes) r(octx marker trace of the host-API benchmark, CPX_TRACE=1)
-TAG=${1:-r03}
+#             c(alibration of FETCH_SIZE / WRITE_SIZE on known byte counts, scripts/micro/fetch_calib.py)
+#             f(uzz: scripts/fuzz_gpu.py for 90 s) L(ong run: bench.py --steps 500)
+TAG=${1:-r04}
 SEC=${2:-tsbdklvu}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
@@ -41,7 +43,7 @@ if [[ $SEC == *v* ]]; then
       python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | tail -40
 fi
 if [[ $SEC == *u* ]]; then
-  timeout 1500 python scripts/collect_pmc.py --out $OUT --name turbo_c3 --match _kernel --fetch-scale 1 -- \
+  timeout 1500 python scripts/collect_pmc.py --out $OUT --name turbo_c3 --match _kernel --fetch-scale 2 -- \
       python $R/benchmarks/bench_kernels.py --which turbo,map 2>&1 | tail -60
 fi
 if [[ $SEC == *m* ]]; then
@@ -49,10 +51,19 @@ if [[ $SEC == *m* ]]; then
       python $R/benchmarks/bench_kernels.py --which demod 2>&1 | tail -60
 fi
 if [[ $SEC == *x* ]]; then
-  timeout 1500 python scripts/collect_pmc.py --out $OUT --name ldpc_c4 --match ldpc_ --fetch-scale 1 -- \
+  timeout 1500 python scripts/collect_pmc.py --out $OUT --name ldpc_c4 --match ldpc_ --fetch-scale 2 -- \
       python $R/benchmarks/bench_kernels.py --which ldpc 2>&1 | tail -80
-  timeout 900 python scripts/collect_pmc.py --out $OUT --name ldpc_resident_fixed20 --match ldpc_resident --fetch-scale 1 -- \
+  timeout 900 python scripts/collect_pmc.py --out $OUT --name ldpc_resident_fixed20 --match ldpc_resident --fetch-scale 2 -- \
       python $R/scripts/micro/ldpc_fixed_iters.py 2>&1 | tail -5
+fi
+if [[ $SEC == *c* ]]; then
+  timeout 600 python scripts/micro/fetch_calib.py --out $OUT 2>&1 | tail -3
+fi
+if [[ $SEC == *f* ]]; then
+  timeout 300 python scripts/fuzz_gpu.py --seconds 90 2>&1 | tail -4 | tee $OUT/fuzz.txt
+fi
+if [[ $SEC == *L* ]]; then
+  timeout 600 python bench.py --gpus 1 --steps 500 --warmup 5 --no-cpu-baseline 2>&1 | tail -1 | tee $OUT/bench_n1_steps500.json | cut -c1-300
 fi
 if [[ $SEC == *r* ]]; then
   # roctx ranges of the entry points (CPX_TRACE=1) next to the kernels: rocprofv3 marker trace of the host-API benchmark

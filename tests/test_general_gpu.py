@@ -197,3 +197,59 @@ def test_demod_large_constellations_vs_live_reference(gpu, tag):
     sym = modulate_gpu(md, bits)
     assert np.array_equal(sym, md.modulate(bits))
     assert np.array_equal(md.demodulate(sym, "hard"), bits)
+
+
+# ---- soft demodulator: four exponentials per axis (geometric progression) vs one per level vs the oracle ------------------------
+@pytest.mark.parametrize("m", [64, 256])
+def test_soft_demod_progression_form_equals_plain_form_and_oracle(gpu, m):
+    """Square QAM of 64 points and more takes the progression form (demod.hip, GP).  From -5 dB to 40 dB Es/N0, with outliers
+    far outside the constellation, scaled and shifted constellations: same non-finite pattern as the oracle, values within 1e-9
+    of it (the contract is 1e-5) and within 1e-9 of the plain form."""
+    from commpy_amd import _lib
+    from commpy_amd.modulation import Modem, QAMModem
+    base = QAMModem(m)
+    rs = np.random.RandomState(m)
+    worst = 0.0
+    for scale, shift in ((1.0, 0.0), (1.0 / np.sqrt(base.Es), 0.0), (0.37, 0.11 - 0.07j)):
+        md = Modem(base.constellation * scale + shift, reorder_as_gray=False)
+        es = np.mean(np.abs(md.constellation - shift) ** 2)
+        for snr_db in (-5.0, 8.0, 18.0, 27.0, 33.0, 40.0):
+            N0 = es / 10 ** (snr_db / 10)
+            ns = 3000
+            y = md.constellation[rs.randint(0, md.m, ns)] + np.sqrt(N0 / 2) * (rs.randn(ns) + 1j * rs.randn(ns))
+            y[::97] *= 6.0                                         # far outside the constellation
+            y[5] = complex(np.inf, 0.0)
+            y[6] = complex(np.nan, 1.0)
+            soft = md.demodulate(y, "soft", N0)
+            assert ",gp" in _lib.last_kernel(), _lib.last_kernel()
+            try:
+                _lib.demod_set_path("plain")
+                plain = md.demodulate(y, "soft", N0)
+                assert ",gp" not in _lib.last_kernel()
+            finally:
+                _lib.demod_set_path(None)
+            want = oracle.demodulate(md.constellation, y, "soft", N0)
+            for got in (soft, plain):
+                assert np.array_equal(np.isfinite(got), np.isfinite(want)), (scale, snr_db)
+                assert np.array_equal(np.isnan(got), np.isnan(want)), (scale, snr_db)
+                inf = np.isinf(want)
+                assert np.array_equal(got[inf], want[inf])
+            fin = np.isfinite(want)
+            worst = max(worst, float(np.max(np.abs(soft[fin] - want[fin]))))
+            assert np.max(np.abs(soft[fin] - want[fin])) < 1e-9, (scale, snr_db, np.max(np.abs(soft[fin] - want[fin])))
+            assert np.max(np.abs(soft[fin] - plain[fin])) < 1e-9
+    print("soft demod progression form, QAM-%d: max |LLR - oracle| = %.3g" % (m, worst))
+
+
+def test_soft_demod_progression_needs_gray_equally_spaced_axes(gpu):
+    """A separable constellation whose levels are NOT equally spaced keeps the plain form."""
+    from commpy_amd import _lib
+    from commpy_amd.modulation import Modem, QAMModem
+    c = QAMModem(64).constellation.copy()
+    c = np.sign(c.real) * np.abs(c.real) ** 1.2 + 1j * c.imag     # warped real axis: still label = (a << 3) | b
+    md = Modem(c, reorder_as_gray=False)
+    rs = np.random.RandomState(1)
+    y = c[rs.randint(0, 64, 500)] + 0.3 * (rs.randn(500) + 1j * rs.randn(500))
+    soft = md.demodulate(y, "soft", 0.2)
+    assert "demod_soft_sep_kernel" in _lib.last_kernel() and ",gp" not in _lib.last_kernel()
+    assert np.max(np.abs(soft - oracle.demodulate(c, y, "soft", 0.2))) < 1e-9
