@@ -13,7 +13,23 @@ namespace cpx {
 // the LDPC passes exactly as it does through libm); denormals are handled by v_frexp.
 // SPECIAL = false drops the four special-value selects: for arguments known to be finite and >= 1 (the Viterbi branch
 // metrics take log(exp(r) + 1) with |r| <= 500) the result is bit-identical and 4 compares + 8 selects shorter.
-template <bool SPECIAL = true>
+// x / y for NORMAL, well-scaled operands (no denormals, no overflow of the quotient, y != 0): hardware reciprocal, two Newton
+// steps, one residual correction -- 8 instructions against the 12 of the IEEE division sequence (v_div_scale x 2, v_rcp, five
+// v_fma, v_div_fmas, v_div_fixup); the result is within 1 ulp (not always correctly rounded).  Only where a caller's contract
+// allows that and its operands are known to be in range: the sum-product fast row (ldpc_dev.h, 4e-6 budget).
+__device__ __forceinline__ double div_nr(double x, double y) {
+    double r = __builtin_amdgcn_rcp(y);
+    double e = __builtin_fma(-y, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-y, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    const double q = x * r;
+    return __builtin_fma(__builtin_fma(-y, q, x), r, q);
+}
+
+// NR = true: the division of the argument reduction by div_nr (its operands are in [-0.3, 0.42] / [1.7, 2.42]): < 2 ulp instead of
+// < 1 ulp -- NOT for the Viterbi branch metrics or anything else that is compared bit for bit.
+template <bool SPECIAL = true, bool NR = false>
 __device__ __forceinline__ double fast_log(double x) {
     constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
     constexpr double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
@@ -25,7 +41,7 @@ __device__ __forceinline__ double fast_log(double x) {
     m = lo ? m + m : m;                                           // [sqrt(1/2), sqrt(2))
     e = lo ? e - 1 : e;
     const double f = m - 1.0;
-    const double s = f / (2.0 + f);
+    const double s = NR ? div_nr(f, 2.0 + f) : f / (2.0 + f);
     const double z = s * s, w = z * z;
     const double t1 = w * __builtin_fma(w, __builtin_fma(w, Lg6, Lg4), Lg2);
     const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, Lg7, Lg5), Lg3), Lg1);

@@ -62,7 +62,15 @@ __device__ __forceinline__ bool spa_row_near(double U, double W, double emax) {
 __device__ __forceinline__ double spa_out_fast(double U, double W, double se) {
     const double e = fabs(se);
     const double n1 = W * __builtin_copysign(1.0 - e, se), n2 = U * (1.0 + e);
-    return fast_log((n1 + n2) / (n1 - n2));                       // 2 atanh(x), |x| < 1 - 2^-32: no clip binds
+    // 2 atanh(x), |x| < 1 - 2^-32: no clip binds.  Round 4: a row that is not "near" has |n1 - n2| >= 2^-32 |n1| with n1 = W u_j a
+    // product of normal numbers (|u_j| >= 2^-53, W in [1, 2^deg]) and a quotient in (2^-33, 2^33): both divisions -- this one and
+    // the one inside the logarithm -- run as reciprocal + two Newton steps + residual (cpx_math.h div_nr: 8 instead of 12
+    // instructions, < 2 ulp) and the logarithm drops its special-value selects; the row stays inside its 4e-6 budget.
+#ifdef CPX_SPA_IEEE_DIV                                           /* A/B builds (scripts/build_variant.sh): the round-3 row */
+    return fast_log((n1 + n2) / (n1 - n2));
+#else
+    return fast_log<false, true>(div_nr(n1 + n2, n1 - n2));
+#endif
 }
 // NaN signs.  An LLR of exactly 0 is a case the reference expects (ldpc.py:214: "Runtime Warnings are expected when llr = 0"):
 // tanh(0) = 0, 1 / 0 = inf, inf * 0 = NaN, and from there the block fills with NaN -- but dec_word = signbit(out_llrs) (:193,

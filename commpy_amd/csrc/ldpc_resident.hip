@@ -465,16 +465,19 @@ __global__ __launch_bounds__(1024, 8) void ldpc_resident_f32_kernel(ResParams p)
         // Retire: the a-posteriori LLRs (and, for block-major outputs, their sign bits) as one contiguous row -- the layout the
         // reference's own results have in memory (ldpc.py:251-253 reshapes with order='F': one block per column of an F-ordered
         // array IS one block per contiguous row).  Not waited for: the next block's loads queue behind these stores.
+        // A block that was a codeword on arrival (k == 0: no variable pass ran) returns its clipped input LLRs UNCHANGED like the
+        // reference (out_llrs = llr_vec.copy(), ldpc.py:194) -- the float64 input, not its float32 image in LDS.
         double *__restrict__ orow = p.out + (int64_t)b * p.n_v;
+        const bool untouched = k == 0;
         if (p.dec) {
             int8_t *__restrict__ drow = p.dec + (int64_t)b * p.n_v;
             for (int v = tid; v < p.n_v; v += nt) {
-                const double x = (double)ldsf(4 * v);                            // the same thread reloads these entries for the next block
+                const double x = untouched ? in[v] : (double)ldsf(4 * v);       // the same thread reloads these entries for the next block
                 orow[v] = x;                                     // (:247)
                 drow[v] = (int8_t)(__builtin_signbit(x) ? 1 : 0);    // (:248)
             }
         } else {
-            for (int v = tid; v < p.n_v; v += nt) orow[v] = (double)ldsf(4 * v);
+            for (int v = tid; v < p.n_v; v += nt) orow[v] = untouched ? in[v] : (double)ldsf(4 * v);
         }
         if (tid == 0) {
             if (p.iters) p.iters[b] = k;

@@ -95,7 +95,8 @@ struct CwParams {
     unsigned long long *dec;      // [groups][T][64]  decision word of step t of the lane's codeword
     unsigned char *best;          // [groups][T][64]  first-argmin state
     uint8_t *bits;                // [B][L]
-    uint8_t *nanflags;            // 'soft': [B], 1 = the codeword received a NaN (re-decoded by viterbi.hip's redo launch)
+    uint8_t *nanflags;            // 'soft': one byte per item of the redo launch (64 / S consecutive codewords; one codeword for 64 states),
+                                  // 1 = an item's codeword received a NaN (viterbi.hip decodes the item again, NaN-exact)
     int64_t B, len, L, T, Lk, Tp;   // Tp: T rounded up to whole groups of log2(S) steps (row count of dec/best)
     int type, tb;
     unsigned goff[32];            // table-driven kernel (G0 = G1 = 0): 1024 * (2-bit code of the branch 2j -> j, input 0) per butterfly j
@@ -443,6 +444,9 @@ __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_acs_kernel(CwParams
 #pragma unroll
         for (int u = 0; u < LGS; u++) cur[u] = nxt[u];
     }
+    // One flag per ITEM of the redo kernel = 64 / S consecutive codewords (viterbi_dispatch reads them that way); the two-kernel form
+    // is only instantiated for 64 states, where an item is one codeword and this per-codeword store IS the per-item one.
+    static_assert(LGS == 6, "viterbi_cw_acs_kernel writes per-codeword NaN flags: valid for 64-state trellises only (items of one codeword)");
     if constexpr (TYPE == CPX_VIT_SOFT)
         if (valid) p.nanflags[cw] = (uint8_t)((nanmask >> lane) & 1ull);
 }
@@ -534,7 +538,7 @@ __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_fused_kernel(CwPara
     const bool valid = cw < p.B;
     const double *x = p.coded + (valid ? cw : 0) * p.len;
     constexpr bool GEN = G0 == 0 && G1 == 0;                                        // table-driven code (cw_step)
-    static_assert(!GEN || (!MIR && !RT && std::is_same<F, double>::value), "table-driven codes: unmirrored ring, default depth, float64");
+    static_assert(!GEN || (!MIR && std::is_same<F, double>::value), "table-driven codes: unmirrored ring, float64");
     unsigned long long *ring = reinterpret_cast<unsigned long long *>(smem + (size_t)wv * fused_wave_lds<RING, MIR, GEN>());
     unsigned char *obuf = reinterpret_cast<unsigned char *>(ring + fused_slots<RING, MIR>() * 64);
     unsigned char *bml = obuf + 64 * FR_OBPAD + lane * 16;                         // GEN: this lane's column of the branch-metric table
@@ -772,10 +776,10 @@ bool generic_match(const cpx_trellis *t, unsigned (&goff)[32]) {
     return true;
 }
 
-template <int LGS, int TYPE>
+template <int LGS, int TYPE, bool RT>
 int launch_fused_generic_typed(const CwParams &p, hipStream_t st) {
     constexpr int RING = 5 * LGS - 1 <= 16 ? 16 : 32;              // a ring cut to the depth (see launch_fused_small_typed)
-    auto *fn = viterbi_cw_fused_kernel<LGS, 0u, 0u, TYPE, 5 * LGS - 2, false, double, RING, false>;
+    auto *fn = viterbi_cw_fused_kernel<LGS, 0u, 0u, TYPE, 5 * LGS - 2, RT, double, RING, false>;
     const size_t lds = ACS_WAVES * fused_wave_lds<RING, false, true>();
     static bool raised[64] = {};
     static std::mutex raised_mu;
@@ -794,11 +798,13 @@ int launch_fused_generic_typed(const CwParams &p, hipStream_t st) {
     return 1;
 }
 
+// the default depth runs the compile-time walk; smaller depths the same kernel with a run-time hop count (round 4)
 template <int LGS>
 int launch_fused_generic(const CwParams &p, hipStream_t st) {
-    if (p.type == CPX_VIT_HARD) return launch_fused_generic_typed<LGS, CPX_VIT_HARD>(p, st);
-    if (p.type == CPX_VIT_SOFT) return launch_fused_generic_typed<LGS, CPX_VIT_SOFT>(p, st);
-    return launch_fused_generic_typed<LGS, CPX_VIT_UNQUANTIZED>(p, st);
+    const bool rt = p.tb != 5 * LGS;
+    if (p.type == CPX_VIT_HARD) return rt ? launch_fused_generic_typed<LGS, CPX_VIT_HARD, true>(p, st) : launch_fused_generic_typed<LGS, CPX_VIT_HARD, false>(p, st);
+    if (p.type == CPX_VIT_SOFT) return rt ? launch_fused_generic_typed<LGS, CPX_VIT_SOFT, true>(p, st) : launch_fused_generic_typed<LGS, CPX_VIT_SOFT, false>(p, st);
+    return rt ? launch_fused_generic_typed<LGS, CPX_VIT_UNQUANTIZED, true>(p, st) : launch_fused_generic_typed<LGS, CPX_VIT_UNQUANTIZED, false>(p, st);
 }
 
 template <int LGS, unsigned G0, unsigned G1>
@@ -844,10 +850,10 @@ int launch_fused_typed(const CwParams &p, hipStream_t st) {
 // 22.8 KB of LDS per wave instead of 39, so that two workgroups fit a CU (the one-wave-per-SIMD structure of the 64-state kernel
 // leaves a 4-state step, ~60 instructions, waiting for its own latencies: 0.77 ms on BASELINE config 1 where the state-per-lane
 // kernel takes 0.56; with the small ring 0.42 ms).
-template <int LGS, unsigned G0, unsigned G1, int TYPE>
+template <int LGS, unsigned G0, unsigned G1, int TYPE, bool RT>
 int launch_fused_small_typed(const CwParams &p, hipStream_t st) {
     constexpr int RING = fused_tb<LGS>() - 1 <= 16 ? 16 : 32;
-    auto *fn = viterbi_cw_fused_kernel<LGS, G0, G1, TYPE, fused_tb<LGS>() - 2, false, double, RING, false>;
+    auto *fn = viterbi_cw_fused_kernel<LGS, G0, G1, TYPE, fused_tb<LGS>() - 2, RT, double, RING, false>;
     const size_t lds = ACS_WAVES * fused_wave_lds<RING, false>();
     if (lds > 64 * 1024) {                                        // (32-slot ring: 91 KB) dynamic LDS above 64 KiB is opt-in, once per kernel and device
         static bool raised[64] = {};
@@ -869,9 +875,10 @@ int launch_fused_small_typed(const CwParams &p, hipStream_t st) {
 }
 template <int LGS, unsigned G0, unsigned G1>
 int launch_fused_small(const CwParams &p, hipStream_t st) {
-    if (p.type == CPX_VIT_HARD) return launch_fused_small_typed<LGS, G0, G1, CPX_VIT_HARD>(p, st);
-    if (p.type == CPX_VIT_SOFT) return launch_fused_small_typed<LGS, G0, G1, CPX_VIT_SOFT>(p, st);
-    return launch_fused_small_typed<LGS, G0, G1, CPX_VIT_UNQUANTIZED>(p, st);
+    const bool rt = p.tb != fused_tb<LGS>();                       // below the default depth: run-time hop count (round 4)
+    if (p.type == CPX_VIT_HARD) return rt ? launch_fused_small_typed<LGS, G0, G1, CPX_VIT_HARD, true>(p, st) : launch_fused_small_typed<LGS, G0, G1, CPX_VIT_HARD, false>(p, st);
+    if (p.type == CPX_VIT_SOFT) return rt ? launch_fused_small_typed<LGS, G0, G1, CPX_VIT_SOFT, true>(p, st) : launch_fused_small_typed<LGS, G0, G1, CPX_VIT_SOFT, false>(p, st);
+    return rt ? launch_fused_small_typed<LGS, G0, G1, CPX_VIT_UNQUANTIZED, true>(p, st) : launch_fused_small_typed<LGS, G0, G1, CPX_VIT_UNQUANTIZED, false>(p, st);
 }
 
 // the default depth runs the compile-time walk; smaller depths the same kernel with a run-time hop count
@@ -991,22 +998,24 @@ bool viterbi_codeword_path(const cpx_trellis *t, const double *d_coded, int64_t 
     // own link simulation (BASELINE config 5 with default arguments) decodes this 64-state code.
     CPX_TRY(6, 0120u, 0152u)
 #undef CPX_TRY
-    // K = 3 (5,7) -- BASELINE config 1 -- and K = 5 (23,35) at their default depths: the small-ring flavour of the fused kernel
+    // K = 3 (5,7) -- BASELINE config 1 -- and K = 5 (23,35) up to their default depths: the small-ring flavour of the fused kernel
 #define CPX_TRY_SMALL(LG, GA, GB)                                                                                       \
-    if (tb == fused_tb<LG>() && !two_kernels && !f32 && tables_match<LG, GA, GB>(t) && launch_fused_small<LG, GA, GB>(p, st)) { \
+    if (tb >= 2 && tb <= fused_tb<LG>() && !two_kernels && !f32 && tables_match<LG, GA, GB>(t) && launch_fused_small<LG, GA, GB>(p, st)) { \
         if (hipGetLastError() != hipSuccess) { set_error("viterbi (small fused codeword path): launch failed"); *rc = CPX_EHIP; } \
-        note_kernel("viterbi_cw_fused_kernel<%d,0%o,0%o,%s,%d,small ring>", LG, GA, GB, type_name(type), fused_tb<LG>() - 2);    \
+        note_kernel("viterbi_cw_fused_kernel<%d,0%o,0%o,%s,%d,small ring%s>", LG, GA, GB, type_name(type), fused_tb<LG>() - 2,   \
+                    tb == fused_tb<LG>() ? "" : ",runtime hops");                                                       \
         return true;                                                                                                    \
     }
     CPX_TRY_SMALL(2, 05u, 07u)
     CPX_TRY_SMALL(4, 031u, 027u)
 #undef CPX_TRY_SMALL
-    // any other rate-1/2 shift-register code of full constraint length (4 .. 64 states), at its default traceback depth: the
-    // table-driven fused kernel (other depths, and the fp32-fast mode, go to the state-per-lane kernels)
+    // any other rate-1/2 shift-register code of full constraint length (4 .. 64 states), up to its default traceback depth: the
+    // table-driven fused kernel (deeper windows, and the fp32-fast mode, go to the state-per-lane kernels)
 #define CPX_TRY_TABLE(LG)                                                                                               \
-    if (tb == fused_tb<LG>() && !two_kernels && !f32 && generic_match<LG>(t, p.goff) && launch_fused_generic<LG>(p, st)) { \
+    if (tb >= 2 && tb <= fused_tb<LG>() && !two_kernels && !f32 && generic_match<LG>(t, p.goff) && launch_fused_generic<LG>(p, st)) { \
         if (hipGetLastError() != hipSuccess) { set_error("viterbi (table-driven codeword path): launch failed"); *rc = CPX_EHIP; } \
-        note_kernel("viterbi_cw_fused_kernel<%d,table-driven,%s,%d>", LG, type_name(type), fused_tb<LG>() - 2);              \
+        note_kernel("viterbi_cw_fused_kernel<%d,table-driven,%s,%d%s>", LG, type_name(type), fused_tb<LG>() - 2,              \
+                    tb == fused_tb<LG>() ? "" : ",runtime hops");                                                       \
         return true;                                                                                                    \
     }
     CPX_TRY_TABLE(6) CPX_TRY_TABLE(5) CPX_TRY_TABLE(4) CPX_TRY_TABLE(3) CPX_TRY_TABLE(2)

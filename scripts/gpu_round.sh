@@ -5,7 +5,7 @@
 #             l(ink + host-api + multi-GPU benches) v(iterbi PMC passes) u(turbo/map PMC passes) m(demod PMC passes)
 #             x(ldpc PMC passes) r(octx marker trace of the host-API benchmark, CPX_TRACE=1)
 #             c(alibration of FETCH_SIZE / WRITE_SIZE on known byte counts, scripts/micro/fetch_calib.py)
-#             f(uzz: scripts/fuzz_gpu.py for 90 s) L(ong run: bench.py --steps 500)
+#             f(uzz: scripts/fuzz_gpu.py for 90 s) L(ong run: bench.py --steps 500) T(olerance table of the sum-product decoder)
 TAG=${1:-r04}
 SEC=${2:-tsbdklvu}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -55,6 +55,9 @@ if [[ $SEC == *x* ]]; then
       python $R/benchmarks/bench_kernels.py --which ldpc 2>&1 | tail -80
   timeout 900 python scripts/collect_pmc.py --out $OUT --name ldpc_resident_fixed20 --match ldpc_resident --fetch-scale 2 -- \
       python $R/scripts/micro/ldpc_fixed_iters.py 2>&1 | tail -5
+fi
+if [[ $SEC == *T* ]]; then
+  timeout 600 python scripts/spa_tolerance_table.py --out $OUT 2>&1 | tail -3
 fi
 if [[ $SEC == *c* ]]; then
   timeout 600 python scripts/micro/fetch_calib.py --out $OUT 2>&1 | tail -3

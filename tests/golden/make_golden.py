@@ -972,6 +972,50 @@ def gen_general():
 
 GENS["general"] = gen_general
 
+
+def gen_ldpc_c4y():
+    """Round 4, for the sum-product tolerance table (profiles/r04_spa_tolerance.*): the BASELINE config-4 chain at Eb/N0 = 8,
+    9 and 10 dB, 24 blocks each, sum-product only, 50 iterations, through the reference.  Stored: the reference demodulator's
+    LLRs (the decoder input), the reference's out_llrs / dec_word, the sent codewords."""
+    import multiprocessing as mp
+    sys.path.insert(0, REPO)
+    from commpy_amd.devicelink import gf2_generator
+    own = os.path.join(REPO, "commpy_amd/channelcoding/designs/ldpc/ieee80211n/1944.1296.txt")
+    p = get_ldpc_code_params(own, True)
+    P = gf2_generator({k: v for k, v in p.items() if k not in ("generator_matrix",)})
+    md = QAMModem(64)
+    rs = np.random.RandomState(4131)
+    nblk, iters = 24, 50
+    out, jobs = {}, []
+    for ebn0 in (8.0, 9.0, 10.0):
+        msg = rs.randint(0, 2, (nblk, 1296)).astype(np.uint8)
+        code = np.concatenate([msg, (msg.astype(np.int64) @ P.T.astype(np.int64) % 2).astype(np.uint8)], axis=1)
+        N0 = md.Es / ((2.0 / 3) * 6 * 10 ** (ebn0 / 10.0))
+        s = md.modulate(code.reshape(-1))
+        y = s + np.sqrt(N0 / 2) * (rs.randn(len(s)) + 1j * rs.randn(len(s)))
+        with np.errstate(all="ignore"):
+            llr = -md.demodulate(y, "soft", N0)
+        tag = "e%d" % int(ebn0)
+        out[tag + "__code"] = code
+        out[tag + "__llr"] = llr.reshape(nblk, 1944)
+        for b in range(nblk):
+            jobs.append((tag, b, (llr[b * 1944:(b + 1) * 1944].copy(), "SPA", iters, own)))
+    t0 = time.time()
+    with mp.Pool(os.cpu_count()) as pool:
+        res = pool.map(_c4x_one, [j[2] for j in jobs], chunksize=1)
+    for (tag, b, _), (dec, oll) in zip(jobs, res):
+        out.setdefault(tag + "__dec", np.zeros((nblk, 1944), np.int8))[b] = dec
+        out.setdefault(tag + "__out", np.zeros((nblk, 1944)))[b] = oll
+    for tag in ("e8", "e9", "e10"):
+        ok = [int(np.array_equal(out[tag + "__dec"][b], out[tag + "__code"][b].astype(np.int8))) for b in range(nblk)]
+        print("c4y %s: decoded==sent per block %s, max |out| %.1f" % (tag, ok, np.abs(out[tag + "__out"]).max()))
+    print("c4y: %d reference decodes in %.1fs" % (len(jobs), time.time() - t0))
+    out["iters"] = np.array(iters)
+    save("ldpc_c4y", **out)
+
+
+GENS["ldpc_c4y"] = gen_ldpc_c4y
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)

@@ -336,3 +336,15 @@ def test_general_demod_large_constellations_vs_reference():
         assert np.array_equal(fin, np.isfinite(soft)) and np.array_equal(soft[~fin], ref[~fin], equal_nan=True), tag
         assert np.max(np.abs(soft[fin] - ref[fin])) < 1e-9, tag
         assert np.array_equal(oracle.demodulate(g[tag + "__cst"], g[tag + "__y"], "hard"), g[tag + "__hard"]), tag
+
+
+def test_spa_tolerance_contract_oracle_vs_reference():
+    """72 live-reference blocks of the config-4 chain at 8 / 9 / 10 dB (ldpc_c4y.npz): dec_word exact, out_llrs inside the
+    banded contract of helpers.spa_contract (profiles/r04_spa_tolerance.md is the measured table)."""
+    from helpers import spa_contract
+    g = golden("ldpc_c4y")
+    p = ldpc_params("n1944")
+    for t in ("e8", "e9", "e10"):
+        dec, out = oracle.ldpc_bp_decode(g[t + "__llr"].reshape(-1).copy(), p, "SPA", int(g["iters"]))
+        assert np.array_equal(dec.T, g[t + "__dec"]), t
+        spa_contract(out.T, g[t + "__out"], "oracle " + t)

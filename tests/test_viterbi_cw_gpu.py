@@ -177,6 +177,18 @@ def test_table_driven_codes(gpu, dtype, mem):
             assert np.array_equal(got, want), (dtype, mem, oct(g0), oct(g1), B, nbits, note)
             assert np.array_equal(_decode(rx, tr, None, dtype, "wave"), want)
     assert seen > 0 or mem == 2                                       # (memory 2 has one such pair, (5,7): compiled in)
+    # round 4: traceback depths below the default stay on the table-driven kernel (run-time hop count)
+    if mem > 2:
+        for tb in (2, 5 * mem // 2, 5 * mem - 1):
+            B, nbits = 66, 120
+            coded = conv_encode_batch(rs.randint(0, 2, (B, nbits)), tr).astype(float)
+            rx = {"hard": lambda: np.where(rs.rand(*coded.shape) < 0.08, 1 - coded, coded),
+                  "soft": lambda: 4.0 * coded - 2 + rs.randn(*coded.shape) * 2.0,
+                  "unquantized": lambda: 2.0 * coded - 1 + rs.randn(*coded.shape) * 0.8}[dtype]()
+            got = _decode(rx, tr, tb, dtype, "cw!")
+            note = _lib.last_kernel()
+            assert "viterbi_cw_fused_kernel" in note and ("runtime hops" in note), note
+            assert np.array_equal(got, oracle.viterbi_decode(rx, tr, tb, dtype)), (dtype, mem, tb, note)
     tr = Trellis(np.array([mem]), np.array([[ends & ~1 | 2, ends]])) if mem > 1 else None   # first generator does not tap the oldest bit
     with pytest.raises(ValueError):
         _decode(np.zeros((2, 60)), tr, None, "hard", "cw!")
@@ -186,7 +198,8 @@ def test_table_driven_codes(gpu, dtype, mem):
 @pytest.mark.parametrize("name", ["t57", "k5_23_35"])
 def test_small_trellises_on_the_fused_kernel(gpu, name, dtype):
     """K = 3 (5,7) -- BASELINE config 1 -- and K = 5 (23,35) at their default traceback depths: the fused kernel on its small ring;
-    ragged batches, block lengths around the flush period, a NaN codeword ('soft'); other depths fall back to the other paths."""
+    ragged batches, block lengths around the flush period, a NaN codeword ('soft'); shallower depths run the same kernel with a
+    run-time hop count (round 4), deeper ones fall back to the other paths."""
     from commpy_amd import _lib
     from commpy_amd.channelcoding import conv_encode_batch
     tr = make_trellis(name)
@@ -205,8 +218,20 @@ def test_small_trellises_on_the_fused_kernel(gpu, name, dtype):
         assert "small ring" in _lib.last_kernel(), _lib.last_kernel()
         assert np.array_equal(got, want), (name, dtype, B, nbits)
         assert np.array_equal(_decode(rx, tr, None, dtype, "wave"), want)
+    # round 4: depths BELOW the default stay on the small-ring kernel (run-time hop count); deeper windows have no instantiation
+    default_tb = 5 * tr.total_memory
+    for tb in (2, 3, default_tb // 2, default_tb - 1):
+        B, nbits = 67, 150
+        coded = conv_encode_batch(rs.randint(0, 2, (B, nbits)), tr).astype(float)
+        rx = {"hard": lambda: np.where(rs.rand(*coded.shape) < 0.06, 1 - coded, coded),
+              "soft": lambda: 4.0 * coded - 2 + rs.randn(*coded.shape) * 1.5,
+              "unquantized": lambda: 2.0 * coded - 1 + rs.randn(*coded.shape) * 0.7}[dtype]()
+        got = _decode(rx, tr, tb, dtype, "cw!")
+        note = _lib.last_kernel()
+        assert "small ring" in note and "runtime hops" in note, note
+        assert np.array_equal(got, oracle.viterbi_decode(rx, tr, tb, dtype)), (name, dtype, tb)
     with pytest.raises(ValueError):
-        _decode(np.zeros((2, 80)), tr, 7, "hard", "cw!")               # not the default depth: no instantiation
+        _decode(np.zeros((2, 80)), tr, default_tb + 1, "hard", "cw!")
 
 
 def test_generator_pairs_vs_live_reference(gpu):
