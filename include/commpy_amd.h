@@ -91,7 +91,9 @@ int cpx_timer_destroy(void *timer);
  *   Replaces nothing by itself; it carries Trellis.next_state_table / output_table
  *   (reference commpy/channelcoding/convcode.py:117-255) to the device.  Tables are [S][I]
  *   row-major int32.  Predecessor lists are derived in np.where order (convcode.py:561-572), which
- *   defines the ACS tie-break.  Limits: S = 2^m <= 128, I = 2^k <= 4 for Viterbi, n <= 6.
+ *   defines the ACS tie-break.  Limits: S = 2^m <= 65536, I = 2^k <= 256, n <= 16; every state needs exactly I incoming branches
+ *   (the reference indexes pmetrics[number_inputs], convcode.py:604-629).  The specialised kernels serve S <= 128, k <= 2, n <= 6;
+ *   the general kernels (viterbi_generic.hip, bcjr_exact.hip) the rest.
  */
 int cpx_trellis_create(int k, int n, int n_states, int n_inputs, const int32_t *next_state_table,
                        const int32_t *output_table, cpx_trellis **out);
@@ -160,7 +162,9 @@ int cpx_viterbi_decode_batch_i64(const cpx_trellis *t, const double *coded, int6
  * cpx_turbo_decode_batch replaces turbo_decode(...) turbo.py:254-333: n_iter x (MAP1, interleave,
  *   MAP2, de-interleave); perm = interleaver.p_array (interleavers.py:13-47), shared by the batch;
  *   L_int may be NULL (zeros).  bits [B][N] uint8, already de-interleaved.
- * Limits: rate-1/2 component trellis (n == 2), I == 2, S <= 16; N < 2^24 (map), N < 2^21 (turbo).
+ * Limits: k = 1 (I == 2, like the reference's priors[2]), n >= 2; N < 2^24 (map), N < 2^21 (turbo).  2 .. 16 states run the
+ *   wave-pair kernels of bcjr.hip; larger trellises the literal kernel of bcjr_exact.hip alone (one codeword per lane, scratch
+ *   (N + 1) * S doubles per lane: CPX_ELIMIT only beyond 4 GB for 64 lanes).
  * Inputs for which the reference's absolute-scale recursion underflows (turbo.py:62-76, :238-240: symbol amplitudes of 5 - 20 at
  *   sigma^2 <= 0.1, priors of e^-200) or that are not finite give what the reference gives -- NaN / +-inf LLRs, their decisions --:
  *   the fast kernels flag such codewords and a literal absolute-scale kernel decodes them again (blocks up to the scratch limit of
@@ -191,7 +195,8 @@ int cpx_turbo_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const 
  *   dec_word  [n_v][B] int8 and out_llrs [n_v][B] float64: one block per COLUMN, the reference's
  *             output layout (ldpc.py:251-253)
  *   iters_done[B] int32 executed iterations per block (early exit ldpc.py:205-206), may be NULL
- * Limits (CPX_ELIMIT): check degree <= 32 (a row lives in registers / one 32-bit sign mask), n_v, n_c < 2^24.
+ * Limits (CPX_ELIMIT): n_v, n_c < 2^24.  Checks of up to 32 edges run the LDS-resident / tiled kernels (a row lives in registers
+ * / one 32-bit sign mask); a code with a larger check is decoded by the literal kernel (ldpc_exact_kernel) alone.
  */
 #define CPX_LDPC_SPA 0
 #define CPX_LDPC_MSA 1

@@ -93,28 +93,28 @@ def viterbi_valid_bits(length, trellis):
 # ---- the sum-product tolerance CONTRACT (round 4; measured table: profiles/r04_spa_tolerance.md) ---------------------------------
 # `2 atanh(x)` turns a one-ulp difference of `tanh` into eps / (1 - |x|) on the message, and at |x| = 1 the reference's own
 # clip decides between a message of 37 and one of 500 (ldpc.py:224-227): above |LLR| ~ 26 NO implementation with another
-# libm -- the C oracle (glibc) included -- reproduces NumPy's values one by one.  Against the LIVE reference on 72 blocks of the
-# config-4 chain (8 / 9 / 10 dB) the oracle, the engine's fast row and its exact row all measure:
+# libm -- the C oracle (glibc) included -- reproduces NumPy's values one by one, and where a clip flips, a whole block's
+# large LLRs move with it (4 of 24 blocks at 9 dB carry 95 % of all deviations).  Against the LIVE reference on 72 blocks of
+# the config-4 chain (8 / 9 / 10 dB) the oracle, the engine's fast row and its exact row all measure:
 #   dec_word and iteration counts exact;  |LLR| < 10: <= 1e-9;  [10, 26): 99.99 % within 1e-5, max 3e-5 .. 9e-5;
-#   [26, 50): 99.85 % within 1e-5;  [50, 100): 98.3 %;  >= 100: 86 % (single values up to 463 off -- 37 vs 500).
-# The contract below is that table with a margin (it is checked per Eb/N0 point: 24 blocks); tests and documents
-# (README) quote THIS function:
-#   |LLR| < 10: every value within 1e-5;  [10, 26): >= 99.95 % within 1e-5 and never beyond 2e-4;
-#   [26, 50): >= 99.5 %;  [50, 100): >= 95 %;  >= 100: >= 75 % within 1e-5.
-SPA_BANDS = ((0.0, 10.0, 1.0, 1e-5), (10.0, 26.0, 0.9995, 2e-4), (26.0, 50.0, 0.995, None), (50.0, 100.0, 0.95, None),
-             (100.0, 1e9, 0.75, None))
+#   [26, 50): 99.85 % within 1e-5;  [50, 100): 98.3 %;  >= 100: 86 % pooled, 62 - 82 % at 9 dB (single values 463 off).
+# The CONTRACT -- what tests assert and INTEGRATION.md / README / DESIGN.md state -- is the part of that table that is a bound:
+#   |LLR| < 10: every value within 1e-5;   10 <= |LLR| < 26: >= 99.95 % within 1e-5 and none beyond 2e-4;
+#   |LLR| >= 26: the SIGN (dec_word) and finiteness only -- the fractions above are measurements, not promises.
+SPA_BANDS = ((0.0, 10.0, 1.0, 1e-5), (10.0, 26.0, 0.9995, 2e-4))
 
 
 def spa_contract(out, want, what=""):
-    """Assert the sum-product `out_llrs` contract of `out` against reference values `want` (same shape): per |want| band
-    (lo, hi, minimum fraction within 1e-5, hard maximum or None)."""
-    dev, mag = np.abs(np.asarray(out) - np.asarray(want)).ravel(), np.abs(np.asarray(want)).ravel()
-    assert np.all(np.isfinite(dev)), what
+    """Assert the sum-product `out_llrs` contract of `out` against reference values `want` (same shape)."""
+    out, want = np.asarray(out), np.asarray(want)
+    dev, mag = np.abs(out - want).ravel(), np.abs(want).ravel()
+    assert np.all(np.isfinite(out)), what
     for lo, hi, frac, hard in SPA_BANDS:
         m = (mag >= lo) & (mag < hi)
         if not m.any():
             continue
         got = float(np.mean(dev[m] <= 1e-5))
         assert got >= frac or (1 - got) * m.sum() <= 1, (what, lo, hi, got, float(dev[m].max()))   # (one stray value in a small band is not a rate)
-        if hard is not None:
-            assert float(dev[m].max()) <= hard, (what, lo, hi, float(dev[m].max()))
+        assert float(dev[m].max()) <= hard, (what, lo, hi, float(dev[m].max()))
+    big = np.abs(want) >= 26.0
+    assert np.array_equal(np.signbit(out[big]), np.signbit(want[big])), what
