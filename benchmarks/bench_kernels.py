@@ -2,7 +2,7 @@
 """Secondary benchmarks: the other kernels of the hot path on their BASELINE.json configurations
 (device-resident inputs, HIP-event timing on the launch stream).  One JSON line per kernel.
 
-    python benchmarks/bench_kernels.py [--which demod,ldpc,turbo,map,viterbi_small] [--scale 1.0]
+    python benchmarks/bench_kernels.py [--which demod,ldpc,turbo,map,viterbi_small,viterbi_variants,viterbi_k9,config4,encoders] [--scale 1.0]
 
   demod   64-QAM soft LLR, 324 symbols x 32768 codewords (config 4's per-GPU share)   -> HBM roofline
   ldpc    (1944,1296) BP, 50 iterations max, B = 32768 (config 4 per-GPU share), SPA and MSA
@@ -269,6 +269,28 @@ def bench_viterbi_variants(lib, scale):
         dev.free()
 
 
+def bench_viterbi_k9(lib, scale):
+    """K = 9 (561,753), 256 states (round 4): four states per lane on the wide kernel, and the general kernel on a smaller batch."""
+    from commpy_amd.channelcoding import Trellis, conv_encode_batch
+    tr = Trellis(np.array([8]), np.array([[0o561, 0o753]]))
+    rs = np.random.RandomState(9)
+    for path, B in ((None, int(16384 * scale)), ("general", int(2048 * scale))):
+        coded = conv_encode_batch(rs.randint(0, 2, (B, 1024)).astype(np.uint8), tr).astype(np.float64)      # 2064 values, 1032 bits
+        llr = np.ascontiguousarray(4.0 * coded - 2 + rs.standard_normal(coded.shape).astype(np.float32) * 1.4, dtype=np.float64)
+        L, T = coded.shape[1] // 2, coded.shape[1] // 2 + 8 - 1
+        dev = Dev(lib)
+        d_in, d_out = dev.put(llr), dev.empty(B * L)
+        h = tr._device_handle()
+        _lib.viterbi_set_path(path)
+        try:
+            ms, _ = timeit(lib, lambda: _lib.check(lib.cpx_viterbi_decode_batch_dev(h, d_in, B, coded.shape[1], L, T, 40, 1, d_out, None)), steps=3)
+            name = _lib.last_kernel()
+        finally:
+            _lib.viterbi_set_path(None)
+        emit(name, "K=9 (561,753) r=1/2, 1024-bit blocks, soft, tb_depth 40, B=%d" % B, B * 1024, "info-bits", ms, B * (coded.shape[1] * 8 + L), "valu")
+        dev.free()
+
+
 def bench_viterbi_small(lib, scale):
     from commpy_amd.channelcoding import Trellis, conv_encode_batch
     tr = Trellis(np.array([2]), np.array([[5, 7]]))
@@ -320,7 +342,7 @@ def bench_encoders(lib, scale):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--which", default="demod,ldpc,config4,turbo,map,viterbi_small,viterbi_variants,encoders")
+    ap.add_argument("--which", default="demod,ldpc,config4,turbo,map,viterbi_small,viterbi_variants,viterbi_k9,encoders")
     ap.add_argument("--scale", type=float, default=1.0)
     a = ap.parse_args()
     lib = _lib.load()
@@ -330,6 +352,8 @@ def main():
         bench_demod(lib, a.scale)
     if "viterbi_variants" in which:
         bench_viterbi_variants(lib, a.scale)
+    if "viterbi_k9" in which:
+        bench_viterbi_k9(lib, a.scale)
     if "viterbi_small" in which:
         bench_viterbi_small(lib, a.scale)
     if "turbo" in which or "map" in which:

@@ -467,7 +467,7 @@ __global__ __launch_bounds__(64) void viterbi_wave_redo_kernel(VitParams p, int6
     }
 }
 
-// ---- S > 64 (total_memory 7: 128 states): SPL = S/64 states per lane, one codeword per wavefront ----
+// ---- S > 64 (total_memory 7: 128 states; total_memory 8, k = 1: 256 states): SPL = S/64 states per lane, one codeword per wavefront ----
 // State q*64 + lane lives in register q of that lane.  Predecessor metrics go through a small LDS
 // buffer (write all S metrics, read the I predecessors by address) instead of shuffles; everything
 // else (branch-metric table, decision ring, sliding traceback, first-argmin rule) is as above.
@@ -738,7 +738,8 @@ static int launch_redo(const cpx_trellis *t, VitParams p, int64_t nitems, hipStr
     CPX_REQUIRE(nw < (1ll << 31), CPX_ELIMIT, "viterbi: batch too large");
     const dim3 grid((unsigned)nw), block(64);
     if (t->S > 64) {
-        if (t->I == 2) hipLaunchKernelGGL((viterbi_wide_redo_kernel<2, 2>), grid, block, lds, st, p, nitems);
+        if (t->S == 256) hipLaunchKernelGGL((viterbi_wide_redo_kernel<4, 2>), grid, block, lds, st, p, nitems);
+        else if (t->I == 2) hipLaunchKernelGGL((viterbi_wide_redo_kernel<2, 2>), grid, block, lds, st, p, nitems);
         else hipLaunchKernelGGL((viterbi_wide_redo_kernel<2, 4>), grid, block, lds, st, p, nitems);
     } else {
         const bool sr = shift_register(t);
@@ -774,7 +775,8 @@ static int viterbi_dispatch(const cpx_trellis *t, const double *d_coded, const D
     CPX_REQUIRE(tb_depth >= 2, CPX_EINVAL, "viterbi: tb_depth must be >= 2");
     CPX_REQUIRE((L / t->k) * (int64_t)t->n <= len, CPX_EINVAL, "viterbi: L inconsistent with len");
     // what the specialised kernels below are instantiated for; every other trellis / window takes viterbi_generic.hip
-    bool general = !(t->I == 2 || t->I == 4) || t->n > CPX_MAX_N || t->S < 2 || t->S > 128;
+    // (256 states with k = 1 -- K = 9, round 4 -- run four states per lane on the wide kernel: its tables hold 8-bit state numbers)
+    bool general = !(t->I == 2 || t->I == 4) || t->n > CPX_MAX_N || t->S < 2 || (t->S > 128 && !(t->S == 256 && t->I == 2));
     if (!general) {
         VitParams q;
         q.tb = tb_depth; q.NC = 1 << t->n;
@@ -851,11 +853,12 @@ static int viterbi_dispatch(const cpx_trellis *t, const double *d_coded, const D
     if (int rcl = wave_lds(t, p, &lds)) return rcl;
     if (t->S > 64) {                                             // 128 states: two states per lane
         CPX_REQUIRE(B < (1ll << 31), CPX_ELIMIT, "viterbi: batch too large");
-        if (t->I == 2) hipLaunchKernelGGL((viterbi_wide_kernel<2, 2>), dim3((unsigned)B), dim3(64), lds, st, p);
+        if (t->S == 256) hipLaunchKernelGGL((viterbi_wide_kernel<4, 2>), dim3((unsigned)B), dim3(64), lds, st, p);
+        else if (t->I == 2) hipLaunchKernelGGL((viterbi_wide_kernel<2, 2>), dim3((unsigned)B), dim3(64), lds, st, p);
         else hipLaunchKernelGGL((viterbi_wide_kernel<2, 4>), dim3((unsigned)B), dim3(64), lds, st, p);
         CPX_HIP(hipGetLastError());
         if (p.nanflags) if (int rcr = launch_redo(t, p, B, st)) return rcr;
-        note_kernel("viterbi_wide_kernel<2,%d>", t->I);
+        note_kernel("viterbi_wide_kernel<%d,%d>", t->S / 64, t->I);
         return CPX_OK;
     }
     const int S = t->S, G = 64 / S;

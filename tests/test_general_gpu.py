@@ -35,7 +35,9 @@ def test_viterbi_general_vs_live_reference(gpu, key):
     dec = viterbi_decode(rx, tr, tbd, dtype)
     # (K = 7 with a window of 600 steps still fits the LDS ring of the state-per-lane kernel: that case checks the general
     #  kernel by forcing it below)
-    assert tag == "k7_tb" or "general" in _lib.viterbi_last_path(), _lib.last_kernel()
+    # K = 9 (256 states, k = 1) runs four states per lane on the wide kernel; everything else here is the general kernel's
+    want_path = {"k7_tb": None, "k9_561_753": "wide"}.get(tag, "general")
+    assert want_path is None or want_path in _lib.viterbi_last_path(), _lib.last_kernel()
     nv = viterbi_valid_bits(rx.shape[1], tr)
     assert dec.dtype == np.int64 and np.array_equal(dec[:, :nv], g[key + "__dec"][:, :nv])
     one = viterbi_decode(rx[0], tr, tbd, dtype)                    # 1-D call, the reference's own shape
@@ -81,6 +83,37 @@ def test_general_kernel_equals_specialised_kernels(gpu, name, dtype):
         want = oracle.viterbi_decode(rx, tr, tb, dtype)
         if tb is None or tb - 1 <= int((want.shape[1] + tr.total_memory) / tr.k) - 1:   # else the reference returns np.empty memory
             assert np.array_equal(dec, want), (name, dtype, B, nbits, tb)
+
+
+def test_k9_batch_on_the_wide_kernel_vs_oracle_and_general_kernel(gpu):
+    """K = 9 (561,753), the standard 256-state code: 300 codewords of 200 bits, soft with +-inf and one NaN codeword, through
+    the four-states-per-lane kernel (and its NaN redo) = the general kernel = the oracle."""
+    from commpy_amd import _lib
+    from commpy_amd.channelcoding import Trellis, conv_encode_batch, viterbi_decode
+    tr = Trellis(np.array([8]), np.array([[0o561, 0o753]]))
+    rs = np.random.RandomState(9)
+    B, nbits = 300, 200
+    coded = conv_encode_batch(rs.randint(0, 2, (B, nbits)), tr).astype(float)
+    for dtype in ("soft", "hard", "unquantized"):
+        if dtype == "soft":
+            rx = 4.0 * coded - 2 + rs.randn(*coded.shape) * 2.2
+            rx[rs.rand(*rx.shape) < 0.003] = np.inf
+            rx[7, 130] = np.nan
+        elif dtype == "hard":
+            rx = np.where(rs.rand(*coded.shape) < 0.07, 1 - coded, coded)
+        else:
+            rx = 2.0 * coded - 1 + rs.randn(*coded.shape) * 0.9
+        for tb in (None, 17):
+            dec = viterbi_decode(rx, tr, tb, dtype)
+            assert _lib.viterbi_last_path() == "wide", _lib.last_kernel()
+            want = oracle.viterbi_decode(rx[:40], tr, tb, dtype)
+            assert np.array_equal(dec[:40], want), (dtype, tb)
+            try:
+                _lib.viterbi_set_path("general")
+                gen = viterbi_decode(rx, tr, tb, dtype)
+            finally:
+                _lib.viterbi_set_path(None)
+            assert np.array_equal(dec, gen), (dtype, tb)
 
 
 def test_viterbi_general_random_large_codes_vs_oracle(gpu):
