@@ -117,6 +117,35 @@ __global__ __launch_bounds__(DEMOD_BLOCK) void demod_soft_sep_kernel(const doubl
         const double2 cur = y[i];
         double ex[R], ey[R], sx = 0.0, sy = 0.0;
         bool redo = false;
+        if constexpr (GP && NH == 1) {
+            // Two levels per axis (QPSK / 4-QAM): LLR(bit of the real axis) = log(e[1] sy / (e[0] sy)) = (dx0^2 - dx1^2) / N0 -- no
+            // exp, no log, no division; the kernel is then bound by its 32 bytes per symbol.  Valid while every one of the four
+            // point probabilities exp(-(dx^2 + dy^2) / N0) the reference adds up is a normal number with room to spare: all four
+            // exponents below 650 (e^-650 = 1e-282).  Beyond that -- far outliers, Es/N0 above ~22 dB -- the reference's sums
+            // underflow in its own pattern (-inf, NaN) and the symbol is decided point by point below, as before.
+            const double dx0 = cur.x - ax_s[0], dx1 = cur.x - ax_s[1], dy0 = cur.y - ax_s[R], dy1 = cur.y - ax_s[R + 1];
+            const double qx0 = dx0 * dx0, qx1 = dx1 * dx1, qy0 = dy0 * dy0, qy1 = dy1 * dy1;
+            const double worst = RCP ? (fmax(qx0, qx1) + fmax(qy0, qy1)) * -ninv : (fmax(qx0, qx1) + fmax(qy0, qy1)) / noise_var;
+            double out[NB];
+            out[1] = RCP ? (qx1 - qx0) * ninv : (qx0 - qx1) / noise_var;           // label bit 1 = real-axis index
+            out[0] = RCP ? (qy1 - qy0) * ninv : (qy0 - qy1) / noise_var;           // label bit 0 = imag-axis index
+            if (!(worst < 650.0)) {
+                double num[NB] = {0.0, 0.0}, den[NB] = {0.0, 0.0};
+                for (int m = 0; m < R * R; m++) {
+                    const double h = hypot(cur.x - ax_s[m >> NH], cur.y - ax_s[R + (m & (R - 1))]);
+                    const double e = exp((-(h * h)) / noise_var);
+#pragma unroll
+                    for (int b = 0; b < NB; b++) {
+                        if ((m >> b) & 1) num[b] += e; else den[b] += e;
+                    }
+                }
+#pragma unroll
+                for (int b = 0; b < NB; b++) out[b] = fast_log(num[b] / den[b]);
+            }
+#pragma unroll
+            for (int b = 0; b < NB; b++) llr[i * NB + NB - 1 - b] = out[b] * scale;   // (:137)
+            continue;
+        }
         if (GP) {
             redo |= axis_gp<NH, RCP>(cur.x, ax_s, step_x, noise_var, ninv, c1x, c2x, Qx, ex, sx);
             redo |= axis_gp<NH, RCP>(cur.y, ax_s + R, step_y, noise_var, ninv, c1y, c2y, Qy, ey, sy);
@@ -351,7 +380,7 @@ int cpx_demod_soft_scaled_dev(const cpx_modem *m, const double *d_y, int64_t Ns,
         note_kernel("demod_soft_any_kernel<%s> (%d points)", rcp ? "rcp" : "div", m->M);
         return CPX_OK;
     }
-    const bool gp = m->gp && m->nbits >= 6 && !demod_plain();
+    const bool gp = m->gp && (m->nbits >= 6 || m->nbits == 2) && !demod_plain();
     if (m->separable) {
         switch (m->nbits / 2) {
 #define LAUNCH(NH, RC, GPV) hipLaunchKernelGGL((demod_soft_sep_kernel<NH, RC, GPV>), grid, block, 0, st, y, Ns, m->d_axes, noise_var, \
@@ -363,7 +392,7 @@ int cpx_demod_soft_scaled_dev(const cpx_modem *m, const double *d_y, int64_t Ns,
         if (gp) { if (rcp) LAUNCH(NH, true, true); else LAUNCH(NH, false, true); }       \
         else { if (rcp) LAUNCH(NH, true, false); else LAUNCH(NH, false, false); }        \
         break;
-            CASE(1) CASE(2) CASE_GP(3) CASE_GP(4)                 // the progression pays from 8 levels per axis on (4 exp instead of R)
+            CASE_GP(1) CASE(2) CASE_GP(3) CASE_GP(4)              // two levels: closed form; 8 and 16 levels: progression (4 exp instead of R)
 #undef CASE
 #undef CASE_GP
 #undef LAUNCH
