@@ -85,12 +85,23 @@ def _git_head():
 
 def _find_reference():
     """Directory that holds the UNMODIFIED reference package `commpy` (veeresht/CommPy), or None.  Looked for in
-    $CPX_REFERENCE_PATH, then /root/reference (the build container; absent on the GPU box), then oracle/_ref -- the six
-    hot-path files of the reference that __graft_entry__.build() places there, byte for byte and with their licence, so that
-    they travel to the GPU box with the working tree (oracle/make_ref.py; git-ignored, test infrastructure) --, then sys.path."""
-    for cand in (os.environ.get("CPX_REFERENCE_PATH"), "/root/reference", os.path.join(ROOT, "oracle", "_ref")):
-        if cand and os.path.isfile(os.path.join(cand, "commpy", "channelcoding", "convcode.py")):
+    $CPX_REFERENCE_PATH, then /root/reference (the build container; absent on the GPU box), then
+    oracle/_ref/commpy_reference.zip -- the six hot-path files of the reference that __graft_entry__.build() packs there, byte
+    for byte and with their licence, so that they travel to the GPU box with the working tree (oracle/make_ref.py; git-ignored,
+    test infrastructure; a zip archive is a valid sys.path entry) --, then sys.path."""
+    for cand in (os.environ.get("CPX_REFERENCE_PATH"), "/root/reference", os.path.join(ROOT, "oracle", "_ref", "commpy_reference.zip")):
+        if not cand:
+            continue
+        if os.path.isfile(os.path.join(cand, "commpy", "channelcoding", "convcode.py")):
             return cand
+        if os.path.isfile(cand) and cand.endswith(".zip"):          # the packed copy: a sys.path entry (zipimport)
+            import zipfile
+            try:
+                with zipfile.ZipFile(cand) as z:
+                    if "commpy/channelcoding/convcode.py" in z.namelist():
+                        return cand
+            except (OSError, zipfile.BadZipFile):
+                pass
     try:
         import importlib.util
         spec = importlib.util.find_spec("commpy")

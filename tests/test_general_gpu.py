@@ -153,6 +153,24 @@ def test_viterbi_general_random_large_codes_vs_oracle(gpu):
         assert np.array_equal(dec[:, :nv], oracle.viterbi_decode(rx, tr, tbd, dtype)[:, :nv]), (it, dtype)
 
 
+@pytest.mark.parametrize("mem", [11, 12, 13])
+def test_viterbi_thousands_of_states_vs_oracle(gpu, mem):
+    """2048 states (path metrics still in LDS), 4096 and 8192 (metrics in the HBM scratch; 128 ballot words per decision plane)."""
+    from commpy_amd import _lib
+    from commpy_amd.channelcoding import Trellis, conv_encode_batch, viterbi_decode
+    rs = np.random.RandomState(mem)
+    gm = rs.randint(1, 2 ** (mem + 1), (1, 2))
+    gm[0] |= 1 | (1 << mem)
+    tr = Trellis(np.array([mem]), gm)
+    B, nbits = 3, 70
+    coded = conv_encode_batch(rs.randint(0, 2, (B, nbits)), tr).astype(float)
+    rx = 4.0 * coded - 2 + rs.randn(*coded.shape) * 2.5
+    for tb in (None, 20):
+        dec = viterbi_decode(rx, tr, tb, "soft")
+        assert "general" in _lib.viterbi_last_path()
+        assert np.array_equal(dec, oracle.viterbi_decode(rx, tr, tb, "soft")), (mem, tb)
+
+
 @pytest.mark.parametrize("key", _names("map_names"))
 def test_map_decode_32_and_64_states_vs_live_reference(gpu, key):
     from commpy_amd import _lib

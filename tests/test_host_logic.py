@@ -190,8 +190,9 @@ def test_bench_times_the_reference_from_oracle_ref(monkeypatch):
         pytest.skip("oracle/_ref not populated (build() runs make_ref where /root/reference exists)")
     if os.path.isdir(make_ref.DEFAULT_SRC):
         assert make_ref.check()
-    prov = open(os.path.join(ref, "PROVENANCE.txt")).read()
-    assert all(f in prov for f in make_ref.FILES) and os.path.isfile(os.path.join(ref, "LICENSE.txt"))
+    assert ref.endswith(".zip")                                    # one archive, a sys.path entry (zipimport)
+    prov = open(os.path.join(os.path.dirname(ref), "PROVENANCE.txt")).read()
+    assert all(f in prov for f in make_ref.FILES) and os.path.isfile(os.path.join(os.path.dirname(ref), "LICENSE.txt"))
     monkeypatch.setenv("CPX_REFERENCE_PATH", ref)
     assert bench._find_reference() == ref
     g = golden("viterbi_c2u")
