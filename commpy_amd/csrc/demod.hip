@@ -222,8 +222,26 @@ __global__ __launch_bounds__(DEMOD_BLOCK) void demod_hard_sep_kernel(const doubl
     __syncthreads();
     for (int64_t i = (int64_t)blockIdx.x * DEMOD_BLOCK + threadIdx.x; i < Ns; i += (int64_t)gridDim.x * DEMOD_BLOCK) {
         const int best = hard_sep<NH>(c_s, ax_s, y[i]);
+        // dec2bitarray (:123): NB bytes of 0 / 1, MSB first, as ONE store per lane where the alignment allows it (round 4: six
+        // byte stores per 64-QAM symbol left the kernel at 43 % of HBM peak); byte k of the little-endian word = bit NB-1-k
+        unsigned long long w = 0;
 #pragma unroll
-        for (int b = 0; b < NB; b++) bits[i * NB + b] = (int8_t)((best >> (NB - 1 - b)) & 1);   // dec2bitarray (:123)
+        for (int b = 0; b < NB; b++) w |= (unsigned long long)((best >> (NB - 1 - b)) & 1) << (8 * b);
+        int8_t *o = bits + i * NB;
+        if (((uintptr_t)bits & 7) != 0) {                         // a caller's odd output pointer: byte stores
+#pragma unroll
+            for (int b = 0; b < NB; b++) o[b] = (int8_t)(w >> (8 * b));
+        } else if constexpr (NB == 2) {
+            *reinterpret_cast<unsigned short *>(o) = (unsigned short)w;                      // 2 i: 2-byte aligned
+        } else if constexpr (NB == 4) {
+            *reinterpret_cast<unsigned *>(o) = (unsigned)w;                                  // 4 i
+        } else if constexpr (NB == 8) {
+            *reinterpret_cast<unsigned long long *>(o) = w;                                  // 8 i
+        } else {                                                                             // 6 i: 2-byte aligned
+            *reinterpret_cast<unsigned short *>(o) = (unsigned short)w;
+            *reinterpret_cast<unsigned short *>(o + 2) = (unsigned short)(w >> 16);
+            *reinterpret_cast<unsigned short *>(o + 4) = (unsigned short)(w >> 32);
+        }
     }
 }
 
