@@ -618,9 +618,10 @@ __global__ __launch_bounds__(256) void ldpc_exact_kernel(ExactParams p) {
     const int64_t per = (p.B + gridDim.x - 1) / gridDim.x;        // contiguous share of the blocks
     const int64_t lo = (int64_t)blockIdx.x * per, hi = (lo + per < p.B) ? lo + per : p.B;
     for (int64_t base = lo; base < hi; base += 256) {
-        __syncthreads();
-        flagged[tid] = (base + tid < hi) ? (p.flags ? p.flags[base + tid] : 1) : 0;
-        __syncthreads();
+        const int mine = (base + tid < hi) ? (p.flags ? p.flags[base + tid] : 1) : 0;
+        __syncthreads();                                          // the previous round's readers of `flagged` are done
+        flagged[tid] = (unsigned char)mine;
+        if (!__syncthreads_or(mine)) continue;                    // nothing flagged among these 256 blocks (the usual case): one barrier
         for (int i = 0; i < 256 && base + i < hi; i++) {
             if (!__builtin_amdgcn_readfirstlane((int)flagged[i])) continue;   // workgroup-uniform: a SCALAR branch around the barriers below
             const int64_t b = base + i;
