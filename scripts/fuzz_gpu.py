@@ -39,11 +39,11 @@ def main(argv=None):
         rsc = [make_trellis("rsc_legacy_4"), make_trellis("rsc_legacy_8")]
     others = {}
     t_end = time.time() + a.seconds
-    n = {"viterbi": 0, "ldpc": 0, "map": 0, "turbo": 0, "demod": 0}
+    n = {"viterbi": 0, "ldpc": 0, "map": 0, "turbo": 0, "demod": 0, "general": 0}
     modems = [QAMModem(4), QAMModem(16), QAMModem(64), QAMModem(256), PSKModem(2), PSKModem(4), PSKModem(8), PSKModem(16)]
     bad = []
     while time.time() < t_end:
-        kind = rs.choice(["viterbi", "viterbi", "ldpc", "map", "turbo", "demod"])
+        kind = rs.choice(["viterbi", "viterbi", "ldpc", "map", "turbo", "demod", "general"])
         n[kind] += 1
         try:
             if kind == "viterbi" and rs.rand() < 0.35:
@@ -144,6 +144,109 @@ def main(argv=None):
                     if not np.array_equal(got, want):
                         bad.append(("viterbi", dtype, B, nbits, tb, path, int(np.sum(got != want))))
                 _lib.viterbi_set_path(None)
+            elif kind == "general":
+                # round 4: the argument domain beyond the specialised kernels -- random trellises with many states / k = 3 / n up to 12
+                # (general Viterbi kernel; K = 9: the wide kernel), MAP above 16 states, checks of more than 32 edges, constellations
+                # above 256 points
+                from commpy_amd.channelcoding import Trellis
+                from commpy_amd.modulation import Modem
+                sub = int(rs.randint(5))
+                if sub <= 1:
+                    with warnings.catch_warnings():
+                        warnings.simplefilter("ignore")
+                        if sub == 0:
+                            m = int(rs.choice([7, 8, 8, 9, 10]))
+                            nn = int(rs.randint(2, 4))
+                            gm = rs.randint(1, 2 ** (m + 1), (1, nn))
+                            gm[0, 0] |= 1 | (1 << m)
+                            trg = Trellis(np.array([m]), gm)
+                        else:
+                            mem = rs.randint(1, 3, 3)
+                            nn = int(rs.randint(4, 13))
+                            gm = rs.randint(0, 2 ** (int(mem.max()) + 1), (3, nn))
+                            for i3 in range(3):
+                                gm[i3, i3] |= 1
+                            trg = Trellis(mem, gm)
+                    try:
+                        trg._device_handle()
+                    except ValueError:
+                        n[kind] -= 1
+                        continue
+                    dtype = str(rs.choice(["hard", "soft", "unquantized"]))
+                    B, nbits = int(rs.choice([1, 2, 9, 65])), int(rs.randint(20, 160))
+                    nbits -= nbits % trg.k
+                    nbits = max(nbits, 6 * trg.k)
+                    coded = conv_encode_batch(rs.randint(0, 2, (B, nbits)), trg).astype(float)
+                    L = int(coded.shape[1] * trg.k / trg.n)
+                    T = int((L + trg.total_memory) / trg.k) - 1
+                    tb = None if rs.rand() < 0.5 else int(rs.randint(2, max(3, min(T, 70)) + 1))
+                    if (tb if tb is not None else min(5 * trg.total_memory, L)) - 1 > T:
+                        tb = max(2, T // 2)
+                    if dtype == "hard":
+                        rx = np.where(rs.rand(*coded.shape) < 0.1, 1 - coded, coded)
+                    elif dtype == "soft":
+                        rx = 4.0 * coded - 2 + rs.randn(*coded.shape) * rs.choice([1.0, 3.0])
+                        rx[rs.rand(*rx.shape) < 0.004] = np.inf
+                        if rs.rand() < 0.3:
+                            rx[rs.rand(*rx.shape) < 0.003] = np.nan
+                    else:
+                        rx = 2.0 * coded - 1 + rs.randn(*coded.shape) * rs.choice([0.5, 1.2])
+                    want = oracle.viterbi_decode(rx, trg, tb, dtype)
+                    nvld = min(L, T * trg.k)
+                    for path in (None, "general"):
+                        _lib.viterbi_set_path(path)
+                        got = viterbi_decode(rx, trg, tb, dtype)
+                        if not np.array_equal(got[:, :nvld], want[:, :nvld]):
+                            bad.append(("general-viterbi", trg.number_states, trg.k, trg.n, dtype, B, nbits, tb, path, _lib.last_kernel(),
+                                        int(np.sum(got[:, :nvld] != want[:, :nvld]))))
+                    _lib.viterbi_set_path(None)
+                elif sub == 2:
+                    m = int(rs.choice([5, 6, 7]))
+                    with warnings.catch_warnings():
+                        warnings.simplefilter("ignore")
+                        trg = Trellis(np.array([m]), np.array([[1, int(rs.randint(1, 2 ** (m + 1))) | 1]]),
+                                      np.array([[int(rs.randint(1, 2 ** (m + 1))) | 1 | (1 << m)]]), 'rsc')
+                    B, N = int(rs.choice([1, 5, 70])), int(rs.randint(4, 60))
+                    nv = float(rs.choice([0.4, 1.0]))
+                    s_, p_, L_ = rs.randn(B, N) * 1.3, rs.randn(B, N) * 1.3, rs.randn(B, N) * rs.choice([0.0, 2.0])
+                    Lx, bits = map_decode(s_, p_, trg, nv, L_, "decode")
+                    for b in (0, B - 1):
+                        Lo, bo = oracle.map_decode(s_[b], p_[b], trg, nv, L_[b], "decode")
+                        if not (np.max(np.abs(Lx[b] - Lo)) < 1e-5) or np.any((bits[b] != bo) & (np.abs(Lo) > 1e-5)):
+                            bad.append(("general-map", trg.number_states, B, N, nv))
+                elif sub == 3:
+                    n_c = int(rs.randint(3, 12))
+                    n_v = int(rs.randint(60, 160))
+                    deg = rs.randint(33, min(n_v - 1, 60) + 1, size=n_c)
+                    p = _random_ldpc(rs, n_v, n_c, deg)
+                    B, iters = int(rs.choice([1, 4, 33])), int(rs.randint(1, 6))
+                    llr = rs.randn(B * n_v) * rs.choice([1.0, 3.0]) + rs.choice([0.5, 2.0])
+                    for alg in ("MSA", "SPA"):
+                        if alg == "SPA" and (np.max(np.abs(llr)) > 12.0 or iters > 3):
+                            continue
+                        do, oo, io = oracle.ldpc_bp_decode(llr.copy(), dict(p), alg, iters, True)
+                        d, o, it = ldpc_bp_decode(llr.copy(), dict(p), alg, iters, return_iterations=True)
+                        ok = np.array_equal(it, io) and "ldpc_exact_kernel" in _lib.last_kernel()
+                        if alg == "MSA":
+                            ok = ok and np.array_equal(o, oo) and np.array_equal(d, do)
+                        else:
+                            ok = ok and np.mean(np.abs(o - oo) <= 1e-5 + 1e-6 * np.abs(oo)) > 0.999
+                        if not ok:
+                            bad.append(("general-ldpc", alg, n_v, n_c, B, iters, _lib.last_kernel()))
+                else:
+                    nb = int(rs.choice([9, 10]))
+                    M = 1 << nb
+                    md = Modem((rs.randn(M) + 1j * rs.randn(M)) * 2.0) if sub == 3 or rs.rand() < 0.5 else QAMModem(1024)
+                    ns = int(rs.choice([1, 5, 40]))
+                    N0 = float(rs.choice([0.01, 0.3, 2.0]))
+                    y = md.constellation[rs.randint(0, md.m, ns)] + np.sqrt(N0 / 2) * (rs.randn(ns) + 1j * rs.randn(ns))
+                    hard, soft = md.demodulate(y, "hard"), md.demodulate(y, "soft", N0)
+                    ho, so = oracle.demodulate(md.constellation, y, "hard"), oracle.demodulate(md.constellation, y, "soft", N0)
+                    fin = np.isfinite(so)
+                    if not np.array_equal(hard, ho) or not np.array_equal(np.isfinite(soft), fin) or \
+                            not np.array_equal(soft[~fin], so[~fin], equal_nan=True) or \
+                            (fin.any() and np.max(np.abs(soft[fin] - so[fin])) > 1e-5):
+                        bad.append(("general-demod", md.m, ns, N0))
             elif kind == "ldpc":
                 n_c = int(rs.randint(8, 120))
                 n_v = int(n_c + rs.randint(8, 200))
@@ -201,12 +304,15 @@ def main(argv=None):
             elif kind == "demod":
                 md = modems[int(rs.randint(len(modems)))]
                 ns = int(rs.choice([1, 7, 256, 1000]))
-                N0 = float(rs.choice([0.05, 0.5, 2.0]))
+                N0 = float(rs.choice([0.002, 0.05, 0.5, 2.0, 30.0]))    # round 4: + very high / very low SNR (closed-form and progression guards)
                 y = md.constellation[rs.randint(0, md.m, ns)] + np.sqrt(N0 / 2) * (rs.randn(ns) + 1j * rs.randn(ns))
+                if rs.rand() < 0.3:
+                    y[rs.randint(0, ns)] *= 8.0                        # an outlier far outside the constellation
                 hard, soft = md.demodulate(y, "hard"), md.demodulate(y, "soft", N0)
                 ho, so = oracle.demodulate(md.constellation, y, "hard"), oracle.demodulate(md.constellation, y, "soft", N0)
                 fin = np.isfinite(so)
                 if not np.array_equal(hard, ho) or not np.array_equal(np.isfinite(soft), fin) or \
+                        not np.array_equal(soft[~fin], so[~fin], equal_nan=True) or \
                         (fin.any() and np.max(np.abs(soft[fin] - so[fin])) > 1e-5):
                     bad.append(("demod", md.m, ns, N0))
             else:
