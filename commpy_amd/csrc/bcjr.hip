@@ -244,6 +244,7 @@ struct PassIO {
     int want_bits;
     int sstride, pstride;         // per-codeword strides (elements)
     bool ext;                     // turbo: write L - L_int, the quantity the next half-iteration interleaves (:318, :328)
+    bool pout;                    // turbo, all passes but the last two: write prior0(L - L_int) = app0 / (app0 + app1) instead (see epilogue)
     int lstride, ncw, N;          // ncw: codewords of the batch this pair really has (<= GW, may be <= 0)
     double nv2;
     double *ckpt;                 // this pair's checkpoint rows [nchunks + 1][64]
@@ -485,9 +486,28 @@ __device__ __forceinline__ void epilogue(const Ctx<LGS> &c, const PassIO &io, co
             app0 += v0.x; app0 += v0.y;
             app1 += v1.x; app1 += v1.y;
         }
-        const double lr = fast_log(app1 / app0);
-        flag_or(c.bad, ok && (!(fabs(lr) < __builtin_huge_val()) || !(fmax(app0, app1) >= T_SMALL)));   // (D), (E)
-        const double L = io.ext ? lr : li[q] + lr;
+        // turbo_decode, every pass whose output only ever becomes the NEXT pass's prior (all but the last two, round 4): the stage
+        // kernel would turn E = log(app1 / app0) into prior0(E) = 1 / (1 + e^E) = app0 / (app0 + app1) -- the logarithm here and the
+        // exponential there cancel, so the pass writes that quotient itself and the stage kernel only permutes.  A second division
+        // instead of the log (45 instructions per item: ablation 4.53 -> 4.23 ms per config-3 decode with all twelve logs gone); the
+        // priors differ from the reference's log -> exp round trip by its own rounding (~|E| 1e-16 relative).
+        double L;
+        if (io.pout) {
+            // ... as 1 / (1 + r), r = app1 / app0 -- the reference's own last two operations with r in the place of e^{log r}: the exact
+            // zeros of its priors (1 + e rounds to 1 below e = 2^-53: p1 = 0; e = inf: p0 = 0) fall where the reference has them, which
+            // app0 / (app0 + app1) does not guarantee (caught by the extreme-regime fixtures)
+            const double r = app1 / app0;
+            L = 1.0 / (1.0 + r);
+            flag_or(c.bad, ok && (!(r > 0.0 && r < __builtin_huge_val()) || !(fmax(app0, app1) >= T_SMALL)));   // (D): log r not finite; (E)
+        } else {
+#ifdef CPX_AB_NO_EPILOG_LOG                                        /* ablation builds only (experiments/README.md): what the logarithm costs */
+            const double lr = app1 / app0 - 1.0;
+#else
+            const double lr = fast_log(app1 / app0);
+#endif
+            flag_or(c.bad, ok && (!(fabs(lr) < __builtin_huge_val()) || !(fmax(app0, app1) >= T_SMALL)));   // (D), (E)
+            L = io.ext ? lr : li[q] + lr;
+        }
         const unsigned t = (unsigned)(t_lo + tl);
         buf_st(io.rout, item_off(m, ((unsigned)(gg * io.lstride) + t) * 8u), io.oout, L);
         if (BITS) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)((io.want_bits && L > 0) ? 1 : 0), io.rbits,
@@ -627,7 +647,7 @@ __global__ __launch_bounds__(128 * NPAIR) void map_decode_kernel(MapParams p) {
     const int64_t cw0 = pair * p.GW, o0 = cw0 * p.N;
     const int64_t left = p.B - cw0;
     PassIO io;
-    io.N = (int)p.N; io.sstride = io.pstride = io.lstride = io.N; io.ext = false;
+    io.N = (int)p.N; io.sstride = io.pstride = io.lstride = io.N; io.ext = false; io.pout = false;
     io.ncw = (int)(left < p.GW ? left : p.GW); io.nv2 = p.nv2;
     const unsigned span = io.ncw > 0 ? OOB : 0u;                  // a pair past the end of the batch: everything out of range
     io.rsys = pass_buffer(p.sys + o0, span); io.rpar = pass_buffer(p.par + o0, span);
@@ -672,7 +692,7 @@ __device__ __forceinline__ int64_t slab_off(const TurboParams &p, int a, int64_t
 // VGPRs, no scratch); a kernel boundary costs ~2 us, 25 of them per decode.  Measured, same box: 5.24 ms (persistent) -> 4.82 ms
 // (launch per pass, row slab) -> chunked slab: see DESIGN.md 4.2.
 template <int LGS, bool SR>
-__global__ __launch_bounds__(128 * NPAIR) void turbo_pass_kernel(TurboParams p, int second) {
+__global__ __launch_bounds__(128 * NPAIR) void turbo_pass_kernel(TurboParams p, int second, int pout) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Ctx<LGS> c;
     init_ctx<LGS>(c, p.tb, smem, p.GW);
@@ -686,7 +706,8 @@ __global__ __launch_bounds__(128 * NPAIR) void turbo_pass_kernel(TurboParams p, 
     io.ncw = (int)(left < p.GW ? left : p.GW);
     io.ckpt = p.ckpt + pair * (K + 1) * 64;
     io.flags = p.flags ? p.flags + cw0 : nullptr;
-    io.ext = true;                                                // the pass writes E = L - L_int (:318, :328)
+    io.ext = true;                                                // the pass writes E = L - L_int (:318, :328) ...
+    io.pout = pout != 0;                                          // ... or prior0(E) directly (epilogue)
     double *base = p.larr + cw0 * ls;                              // the pair's first codeword
     //   first  half-iteration: [L_ext_1, _] = map_decode(sys,   non_sys_1, trellis, nv, L_int_1, 'compute')   (:315)
     //   second half-iteration: [L_2, bits]  = map_decode(sys_i, non_sys_2, trellis, nv, L_int_2, mode)        (:326)
@@ -705,7 +726,7 @@ __global__ __launch_bounds__(128 * NPAIR) void turbo_pass_kernel(TurboParams p, 
 // (:148-152, :331).  One wavefront per codeword, four per workgroup; `lds_n`
 // doubles of LDS per wavefront when a codeword's array fits -- the permutations then go THROUGH LDS: coalesced read, LDS
 // scatter / gather, coalesced write (round 1 gathered from HBM: a 64-byte line per 8-byte element) -- else 0.
-__global__ __launch_bounds__(256) void turbo_stage_kernel(TurboParams p, int mode, int lds_n, int keep_l) {
+__global__ __launch_bounds__(256) void turbo_stage_kernel(TurboParams p, int mode, int lds_n, int keep_l, int pin) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t cwg = (int64_t)blockIdx.x * 4 + wv;
@@ -749,14 +770,14 @@ __global__ __launch_bounds__(256) void turbo_stage_kernel(TurboParams p, int mod
 #pragma unroll 4
             for (int64_t t = lane; t < N; t += 64) {
                 const double L = buf[p.perm[t]];
-                at(2, t) = prior0(L);
+                at(2, t) = pin ? L : prior0(L);                     // pin: the pass already wrote prior0(E) (turbo_pass_kernel, pout)
                 if (keep_l) at(0, t) = L;                           // the last L_int_2 itself, for the final decision (mode 3)
             }
         } else {
 #pragma unroll 4
             for (int64_t t = lane; t < N; t += 64) {
                 const double L = at(1, p.perm[t]);
-                at(2, t) = prior0(L);
+                at(2, t) = pin ? L : prior0(L);
                 if (keep_l) at(0, t) = L;
             }
         }
@@ -766,10 +787,10 @@ __global__ __launch_bounds__(256) void turbo_stage_kernel(TurboParams p, int mod
             for (int64_t t = lane; t < N; t += 64) buf[p.perm[t]] = at(1, t);
             asm volatile("" ::: "memory");
 #pragma unroll 4
-            for (int64_t t = lane; t < N; t += 64) at(0, t) = prior0(buf[t]);
+            for (int64_t t = lane; t < N; t += 64) at(0, t) = pin ? buf[t] : prior0(buf[t]);
         } else {
 #pragma unroll 4
-            for (int64_t t = lane; t < N; t += 64) at(0, p.perm[t]) = prior0(at(1, t));
+            for (int64_t t = lane; t < N; t += 64) at(0, p.perm[t]) = pin ? at(1, t) : prior0(at(1, t));
         }
     } else {
 #pragma unroll 4
@@ -909,13 +930,13 @@ int cpx_turbo_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const 
     CPX_REQUIRE((B + 3) / 4 < (1ll << 31), CPX_ELIMIT, "turbo_decode: batch too large");
     const dim3 sgrid((unsigned)((B + 3) / 4)), sblock(256);
     const size_t slds = (size_t)lds_n * 8 * 4;
-    auto stage = [&](int mode, int keep_l = 0) { hipLaunchKernelGGL(turbo_stage_kernel, sgrid, sblock, slds, st, p, mode, lds_n, keep_l); };
-    auto pass = [&](int second) -> int {
+    auto stage = [&](int mode, int keep_l = 0, int pin = 0) { hipLaunchKernelGGL(turbo_stage_kernel, sgrid, sblock, slds, st, p, mode, lds_n, keep_l, pin); };
+    auto pass = [&](int second, int pout) -> int {
         switch (p.tb.lgS) {
-#define CASE(LG) case LG: hipLaunchKernelGGL((turbo_pass_kernel<LG, false>), grid, block, sizeof(double) * 2 * np * wave_lds_doubles<LG>(GW), st, p, second); break;
+#define CASE(LG) case LG: hipLaunchKernelGGL((turbo_pass_kernel<LG, false>), grid, block, sizeof(double) * 2 * np * wave_lds_doubles<LG>(GW), st, p, second, pout); break;
             case 2:
-                if (p.tb.sr4) hipLaunchKernelGGL((turbo_pass_kernel<2, true>), grid, block, sizeof(double) * 2 * np * wave_lds_doubles<2>(GW), st, p, second);
-                else hipLaunchKernelGGL((turbo_pass_kernel<2, false>), grid, block, sizeof(double) * 2 * np * wave_lds_doubles<2>(GW), st, p, second);
+                if (p.tb.sr4) hipLaunchKernelGGL((turbo_pass_kernel<2, true>), grid, block, sizeof(double) * 2 * np * wave_lds_doubles<2>(GW), st, p, second, pout);
+                else hipLaunchKernelGGL((turbo_pass_kernel<2, false>), grid, block, sizeof(double) * 2 * np * wave_lds_doubles<2>(GW), st, p, second, pout);
                 break;
             CASE(1) CASE(3) CASE(4)
 #undef CASE
@@ -924,9 +945,13 @@ int cpx_turbo_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const 
         return CPX_OK;
     };
     stage(0);
+    static const bool no_pout = [] { const char *e = getenv("CPX_TURBO_POUT"); return e && e[0] == '0'; }();   // A/B runs
     for (int h = 0; h < 2 * n_iter; h++) {
-        if ((rc = pass(h & 1))) return rc;
-        if (h < 2 * n_iter - 1) stage(1 + (h & 1), h == 2 * n_iter - 2);   // the last interleave also keeps L_int_2 itself
+        // every pass but the last two hands prior0(E) to the next one directly (epilogue): the last MAP 2 needs L_int_2 and E_2 as
+        // LLRs for the decision L_2 = L_int_2 + E_2 > 0 (:148-152, :326-331)
+        const int pout = (h <= 2 * n_iter - 3 && !no_pout) ? 1 : 0;
+        if ((rc = pass(h & 1, pout))) return rc;
+        if (h < 2 * n_iter - 1) stage(1 + (h & 1), h == 2 * n_iter - 2, pout);   // the last interleave also keeps L_int_2 itself
     }
     stage(3);
     CPX_HIP(hipGetLastError());
