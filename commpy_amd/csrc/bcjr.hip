@@ -30,7 +30,7 @@
 //       states of a codeword are DPP butterflies (no LDS).  A full chunk is unrolled (compile-time LDS offsets);
 //   (3) phase 2 only: the per-lane branch products alpha*gamma*beta are parked in LDS and a time-parallel epilogue adds
 //       them in state order, divides, takes the log and writes the LLRs as coalesced segments.
-// The sum-normalisation of the reference (turbo.py:110-111, :155-158) is applied every KNORM = 4 steps with the hardware
+// The sum-normalisation of the reference (turbo.py:110-111, :155-158) is applied every KNORM = 8 steps with the hardware
 // reciprocal: a common positive factor per time step cancels in app1/app0 and in every later normalisation, so LLRs
 // differ from the reference's only by rounding (measured <= 1e-13; tolerance 1e-5).
 // Waves of a workgroup only meet at the phase boundary and between the stages of turbo_decode (__syncthreads +
@@ -47,7 +47,12 @@ using namespace cpx;
 namespace {
 
 constexpr int CH = 8;          // steps per chunk
-constexpr int KNORM = 4;       // renormalise alpha / beta every KNORM steps
+#ifndef CPX_KNORM
+#define CPX_KNORM 8
+#endif
+constexpr int KNORM = CPX_KNORM;   // renormalise alpha / beta every KNORM steps (a power of two <= CH).  Round 4: 8 = once per chunk (4: +1 % on a
+                                   // turbo decode, +2.4 % on a MAP pass; 2: +3 % / +8 %).  Every step multiplies by gamma' p <= 1, so the sums only
+                                   // shrink between two normalisations and flag (C) -- a sum below 1e-150 -- bounds all of them whatever the interval.
 // ---- LDS layout (round 4: re-laid for zero bank conflicts; scripts/micro/lds_bank_sim.py is the model it was chosen with) ----
 // rocprofv3 had SQ_LDS_BANK_CONFLICT at 2.0 cycles per LDS instruction in rounds 2 and 3.  The model, with the lane groups and
 // bank functions of the CDNA4 LDS (ds_read_b64: 2 x 32 lanes over 64 dword banks, ds_read_b128: 4 x 16 interleaved lanes,
