@@ -167,8 +167,14 @@ __global__ __launch_bounds__(DEMOD_BLOCK) void demod_soft_sep_kernel(const doubl
             for (int a = 0; a < R; a++) {
                 if ((a >> b) & 1) { nx += ex[a]; ny += ey[a]; } else { qx += ex[a]; qy += ey[a]; }
             }
-            out[NH + b] = fast_log((nx * sy) / (qx * sy));    // label bit NH+b = bit b of the real-axis index a
-            out[b] = fast_log((ny * sx) / (qy * sx));         // label bit b    = bit b of the imag-axis index b
+            // label bit NH+b = bit b of the real-axis index a, label bit b = bit b of the imag-axis index.  Round 4: the quotient by
+            // reciprocal + Newton and the logarithm without its special-value selects (cpx_math.h: -20 instructions per LLR) -- the
+            // symbols those would be needed for (a quotient outside (e^-600, e^600), zero, inf or NaN: exactly the |LLR| >= 600 /
+            // non-finite rule below, tested on the quotient) are decided point by point anyway
+            const double qa = div_nr(nx * sy, qx * sy), qb = div_nr(ny * sx, qy * sx);
+            redo |= !(qa > 2.7e-261 && qa < 3.7e260) || !(qb > 2.7e-261 && qb < 3.7e260);
+            out[NH + b] = fast_log<false, true>(qa);
+            out[b] = fast_log<false, true>(qb);
         }
         // The factorised sums are only as good as the reference's point-by-point ones while nothing is near the underflow
         // threshold: an LLR beyond +-600 (or non-finite) means some sum of e^{-d^2/N0} terms is down among the denormals, where
