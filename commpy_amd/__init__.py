@@ -27,4 +27,25 @@ def set_precision(mode):
     _lib.set_precision(mode)
 
 
-__all__ = ["channelcoding", "modulation", "utilities", "parallel", "set_precision"]
+class precision:
+    """``with commpy_amd.precision('fp32-fast'): ...`` -- the precision mode for the calls inside the block only; the previous mode is
+    restored on the way out, exceptions included (round-4 answer to the process-global switch: enable it exactly around the decoder
+    that should use it)."""
+
+    def __init__(self, mode):
+        self.mode = mode
+        self._previous = None
+
+    def __enter__(self):
+        from commpy_amd import _lib
+        self._previous = _lib.get_precision()
+        _lib.set_precision(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        from commpy_amd import _lib
+        _lib.set_precision(self._previous)
+        return False
+
+
+__all__ = ["channelcoding", "modulation", "utilities", "parallel", "set_precision", "precision"]

@@ -131,3 +131,19 @@ def test_ldpc_fast_mode_decodes_like_the_parity_mode(gpu, lib, alg):
     assert same_word > 0.999
     assert abs(fer1 - fer0) <= 0.01 + 0.2 * fer0
     assert abs(i1.mean() - i0.mean()) < 0.5
+
+
+def test_precision_context_manager_restores_the_mode(gpu, lib):
+    """``with commpy_amd.precision('fp32-fast')`` switches the mode for the block only -- also when the block raises."""
+    import commpy_amd
+    assert lib.get_precision() == "fp64-parity"
+    with commpy_amd.precision("fp32-fast"):
+        assert lib.get_precision() == "fp32-fast"
+        with commpy_amd.precision("fp64-parity"):
+            assert lib.get_precision() == "fp64-parity"
+        assert lib.get_precision() == "fp32-fast"
+    assert lib.get_precision() == "fp64-parity"
+    with pytest.raises(RuntimeError):
+        with commpy_amd.precision("fp32-fast"):
+            raise RuntimeError("boom")
+    assert lib.get_precision() == "fp64-parity"
