@@ -128,10 +128,11 @@ struct Ctx {
     double *xs;     // [CH][2][64] (+2 pad per step): per-lane branch products alpha*gamma*beta of the chunk, by input (phase 2)
     double *rw;     // [CH][64]     alpha rows of a partial (last) chunk: the rolled code path keeps them here
     double *xch;    // [64]         exchange buffer (trellises without the DPP fast path)
-    // "detect and redo": lanes that raised a flag (one mask for the whole pass: three masks that resolve the codeword cost six
-    // more SGPRs in kernels that already spill them; a flag therefore sends all GW codewords of the pair to the redo path);
-    // mutable: the helpers take the context by const reference
-    mutable unsigned long long bad;
+    // "detect and redo": lanes that raised a flag, one mask per lane -> codeword mapping so that a flag sends ITS codeword to the
+    // redo path and not all GW of the pair (round 4): bad_s -- flags of the recursions, lane = (codeword slot, state);
+    // bad_i[q] -- flags of the time-parallel stage / epilogue, lane = item q of item_of.  mutable: the helpers take the context by
+    // const reference
+    mutable unsigned long long bad_s, bad_i0, bad_i1;
 };
 
 // v is wave-level: OR the lanes for which `cond` holds into a mask on the scalar unit
@@ -180,14 +181,22 @@ __device__ __forceinline__ void init_ctx(Ctx<LGS> &c, const MapTables &tb, unsig
     c.xs = p;  p += CH * XS_ROW;
     c.rw = p;  p += CH * 64;
     c.xch = p;
-    c.bad = 0;
+    c.bad_s = 0; c.bad_i0 = 0; c.bad_i1 = 0;
 }
 
-// a flag was raised during the pass: flag bytes of all codewords of the pair (both waves of a pair may store the same 1)
+// flags raised during the pass -> flag bytes of the codewords they belong to (both waves of a pair may store the same 1): lane cw
+// looks up the lanes of its own codeword slot in the three masks
 template <int LGS>
 __device__ __forceinline__ void publish_flags(const Ctx<LGS> &c, uint8_t *flags, int ncw) {
-    if (flags && c.bad != 0 && c.lane < ncw) flags[c.lane] = 1;
-    c.bad = 0;
+    constexpr int S = Ctx<LGS>::S;
+    if (flags && (c.bad_s | c.bad_i0 | c.bad_i1) != 0 && c.lane < ncw) {
+        const int cw = c.lane;
+        const unsigned long long st = (c.bad_s >> (cw * S)) & ((S == 64) ? ~0ull : ((1ull << S) - 1ull));
+        const int gg = cw & 7, bk = ((gg & 1) << 2) | (gg >> 1);      // item_of: block bk of eight lanes serves codeword slot gg (+ 8 q)
+        const unsigned long long it = (((cw >> 3) ? c.bad_i1 : c.bad_i0) >> (8 * bk)) & 0xffull;
+        if ((st | it) != 0) flags[cw] = 1;
+    }
+    c.bad_s = 0; c.bad_i0 = 0; c.bad_i1 = 0;
 }
 
 // value of `v` in lane (quad base + idx), idx in 0..3 per lane: 4 quad broadcasts + selects (no LDS)
@@ -328,7 +337,7 @@ __device__ __forceinline__ void stage_chunk(const Ctx<LGS> &c, const RawChunk &r
             const double qa = PRE ? fabs(r0) : exp(k4 * fabs(r0)), qb = PRE ? fabs(r1) : exp(k4 * fabs(r1));
             if (!PRE) {                                           // (A); turbo_decode checks the received values once, at its start
                 const double u0 = fabs(r0) + 1.0, u1 = fabs(r1) + 1.0;
-                flag_or(c.bad, !(u0 * u0 + u1 * u1 <= lim));
+                flag_or(q ? c.bad_i1 : c.bad_i0, !(u0 * u0 + u1 * u1 <= lim));
             }
             // priors exactly as the reference forms them (:239-240): e^L may overflow (p0 = 0), 1 - p0 may cancel to 0.
             // PRE (turbo_decode): the stage kernel that produced L_int has already evaluated prior0(L_int) -- the same two operations,
@@ -407,7 +416,7 @@ __device__ __forceinline__ void beta_step(const Ctx<LGS> &c, int tl, double &b, 
     b = __builtin_fma(hi, w_hi, lo * w_lo);
     if ((tl & (KNORM - 1)) == 0) {
         const double sum = group_sum<LGS>(b);
-        flag_or(c.bad, !(sum >= T_SMALL));                        // (C)
+        flag_or(c.bad_s, c.active && !(sum >= T_SMALL));          // (C)
         b = b * __builtin_amdgcn_rcp(sum);
     }
 }
@@ -419,7 +428,7 @@ __device__ __forceinline__ void alpha_step(const Ctx<LGS> &c, int tl, double &a,
     a = __builtin_fma(ap1, w1, ap0 * w0);
     if ((tl & (KNORM - 1)) == KNORM - 1) {
         const double sum = group_sum<LGS>(a);
-        flag_or(c.bad, !(sum >= T_SMALL));                        // (C)
+        flag_or(c.bad_s, c.active && !(sum >= T_SMALL));          // (C)
         a = a * __builtin_amdgcn_rcp(sum);
     }
 }
@@ -503,14 +512,14 @@ __device__ __forceinline__ void epilogue(const Ctx<LGS> &c, const PassIO &io, co
             // app0 / (app0 + app1) does not guarantee (caught by the extreme-regime fixtures)
             const double r = app1 / app0;
             L = 1.0 / (1.0 + r);
-            flag_or(c.bad, ok && (!(r > 0.0 && r < __builtin_huge_val()) || !(fmax(app0, app1) >= T_SMALL)));   // (D): log r not finite; (E)
+            flag_or(q ? c.bad_i1 : c.bad_i0, ok && (!(r > 0.0 && r < __builtin_huge_val()) || !(fmax(app0, app1) >= T_SMALL)));   // (D): log r not finite; (E)
         } else {
 #ifdef CPX_AB_NO_EPILOG_LOG                                        /* ablation builds only (experiments/README.md): what the logarithm costs */
             const double lr = app1 / app0 - 1.0;
 #else
             const double lr = fast_log(app1 / app0);
 #endif
-            flag_or(c.bad, ok && (!(fabs(lr) < __builtin_huge_val()) || !(fmax(app0, app1) >= T_SMALL)));   // (D), (E)
+            flag_or(q ? c.bad_i1 : c.bad_i0, ok && (!(fabs(lr) < __builtin_huge_val()) || !(fmax(app0, app1) >= T_SMALL)));   // (D), (E)
             L = io.ext ? lr : li[q] + lr;
         }
         const unsigned t = (unsigned)(t_lo + tl);

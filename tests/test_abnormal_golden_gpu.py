@@ -5,6 +5,8 @@ The fast kernels only detect these inputs; flagged codewords / blocks are decode
 import numpy as np
 import pytest
 
+import oracle
+
 from helpers import Perm, ldpc_params, make_trellis
 from test_oracle_golden import abnormal_cases, same_nonfinite_pattern
 
@@ -90,3 +92,36 @@ def test_sum_product_zero_llrs(gpu):
             assert np.array_equal(np.signbit(out), np.signbit(ref)), (key, path)
             assert np.all(np.abs(out[fin] - ref[fin]) <= TOL + 1e-6 * np.abs(ref[fin])), (key, path)
             assert np.array_equal(dec, g[key + "__dec"]), (key, path)
+
+
+def test_flags_resolve_the_codeword_inside_a_full_pair(gpu):
+    """Round 4: a flag of the BCJR pass belongs to ONE codeword of the 16 a wave pair decodes (three lane masks: recursion lanes,
+    stage / epilogue items).  A batch large enough for full pairs (16 384 codewords) with abnormal codewords planted at every
+    position class of a pair -- slot 0, an odd slot, slot 8 (second item set), slot 15, the last codeword of the batch -- and in
+    every flag class (a far received pair: stage flag; a contradicting prior of 200: recursion / epilogue flags): the planted
+    codewords AND their neighbours equal the oracle (same NaN / inf pattern, 1e-5)."""
+    from commpy_amd.channelcoding import map_decode
+    tr = make_trellis("rsc_legacy_4")
+    rs = np.random.RandomState(99)
+    B, N, nv = 16384, 48, 0.1
+    sy = rs.randn(B, N) * 0.4 + rs.choice([-1.0, 1.0], size=(B, N))
+    pa = rs.randn(B, N) * 0.4 + rs.choice([-1.0, 1.0], size=(B, N))
+    li = rs.randn(B, N)
+    planted = [0, 3, 16 + 8, 32 + 15, 1000 * 16 + 5, B - 1]
+    for i, cw in enumerate(planted):
+        if i % 2 == 0:
+            sy[cw, 7] = 14.0                                       # worst branch probability below e^-345: flag (A)
+            pa[cw, 9] = -17.0
+        else:
+            li[cw, 11] = 200.0 * np.sign(-sy[cw, 11])              # a prior of e^-200 against the channel: flags (C) - (E)
+            sy[cw, 11] *= 6.0
+    L, bits = map_decode(sy, pa, tr, nv, li, "decode")
+    check = sorted(set(c + d for c in planted for d in (-1, 0, 1) if 0 <= c + d < B))
+    for cw in check:
+        Lo, bo = oracle.map_decode(sy[cw], pa[cw], tr, nv, li[cw], "decode")
+        assert np.array_equal(np.isnan(L[cw]), np.isnan(Lo)) and np.array_equal(np.isposinf(L[cw]), np.isposinf(Lo)) and \
+            np.array_equal(np.isneginf(L[cw]), np.isneginf(Lo)), cw
+        fin = np.isfinite(Lo)
+        assert np.max(np.abs(L[cw][fin] - Lo[fin]), initial=0.0) < 1e-5, (cw, np.max(np.abs(L[cw][fin] - Lo[fin])))
+        sure = fin & (np.abs(Lo) > 1e-5)
+        assert np.array_equal(bits[cw][sure], bo[sure]), cw
