@@ -209,13 +209,14 @@ def bench_config4(lib, scale):
     dev.free()
 
 
-def bench_turbo(lib, scale, which):
+def bench_turbo(lib, scale, which, states=4):
     import warnings
     from commpy_amd.channelcoding import RandInterlv, Trellis
     from commpy_amd.devicelink import turbo_encode_gpu
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        tr = Trellis(np.array([2]), np.array([[1, 7]]), 5, "rsc")
+        # 4 states: BASELINE config 3;  8 states: the LTE / UMTS constituent code (1, 15/13) (SURVEY 8d "optional 8-state")
+        tr = Trellis(np.array([2]), np.array([[1, 7]]), 5, "rsc") if states == 4 else Trellis(np.array([3]), np.array([[1, 0o15]]), 0o13, "rsc")
     N, B = 1024, int(16384 * scale)
     il = RandInterlv(N, 1234)
     rs = np.random.RandomState(20)
@@ -235,12 +236,12 @@ def bench_turbo(lib, scale, which):
         ms, _ = timeit(lib, lambda: _lib.check(lib.cpx_turbo_decode_batch_dev(h, d_s, d_p1, d_p2, None, d_perm, B, N, nv, 6,
                                                                              d_bits, None)), steps=3)
         bits = dev.get(d_bits, (B, N), np.uint8)
-        emit("turbo_decode (turbo_pass_kernel x 12 + turbo_stage_kernel)", "rate-1/3 4-state RSC, N=1024, 6 iterations, Eb/N0=1.5 dB, B=%d" % B, B * N,
+        emit("turbo_decode (turbo_pass_kernel x 12 + turbo_stage_kernel)", "rate-1/3 %d-state RSC, N=1024, 6 iterations, Eb/N0=1.5 dB, B=%d" % (states, B), B * N,
              "info-bits", ms, B * 25600, "latency/valu", {"ber": float(np.mean(bits != msgs))})
     if "map" in which:
         ms, _ = timeit(lib, lambda: _lib.check(lib.cpx_map_decode_batch_dev(h, d_s, d_p1, d_zero, B, N, nv, 1, d_L, d_bits,
                                                                            None)), steps=3)
-        emit("map_decode_kernel", "one MAP pass, 4-state RSC, N=1024, B=%d" % B, B * N, "info-bits", ms, B * 33792,
+        emit("map_decode_kernel", "one MAP pass, %d-state RSC, N=1024, B=%d" % (states, B), B * N, "info-bits", ms, B * 33792,
              "latency/valu")
     dev.free()
 
@@ -342,7 +343,7 @@ def bench_encoders(lib, scale):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--which", default="demod,ldpc,config4,turbo,map,viterbi_small,viterbi_variants,viterbi_k9,encoders")
+    ap.add_argument("--which", default="demod,ldpc,config4,turbo,map,turbo8,viterbi_small,viterbi_variants,viterbi_k9,encoders")
     ap.add_argument("--scale", type=float, default=1.0)
     a = ap.parse_args()
     lib = _lib.load()
@@ -358,6 +359,8 @@ def main():
         bench_viterbi_small(lib, a.scale)
     if "turbo" in which or "map" in which:
         bench_turbo(lib, a.scale, which)
+    if "turbo8" in which:
+        bench_turbo(lib, a.scale, ["turbo", "map"], states=8)
     if "ldpc" in which:
         bench_ldpc(lib, a.scale)
     if "config4" in which:
