@@ -23,6 +23,7 @@
 #include "cpx_math.h"
 #include "demod_dev.h"
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
@@ -200,6 +201,156 @@ __global__ __launch_bounds__(DEMOD_BLOCK) void demod_soft_sep_kernel(const doubl
         }
 #pragma unroll
         for (int b = 0; b < NB; b++) llr[i * NB + NB - 1 - b] = out[b] * scale;   // (:137)
+    }
+}
+
+// ---- "fp32-fast" soft decisions (cpx_set_precision) ---------------------------------------------------------------------
+// Not the parity mode: float32 arithmetic with the hardware exp2 / log2, in log-sum-exp form -- every exponent is taken relative to
+// the largest of its sum, so nothing underflows where float64 would not either and the result is FINITE wherever the exponents are
+// (the reference's -inf / NaN pattern of modulation.py:134-137 at extreme Es/N0 is deliberately not reproduced; it yields the LLR the
+// formula defines).  Contract (tests/test_fp32_fast_gpu.py): |LLR_fast - LLR_fp64| <= 2e-5 + 4e-6 |LLR_fp64| (measured: a quarter of
+// that at worst, PSK-2..16 / QAM-4..256, Es/N0 0..28 dB), identical hard decisions sign(LLR) wherever |LLR_fp64| > 1e-3.  Inputs and outputs stay float64 arrays (the API does not
+// change); the kernel is then bound by its 16 + 8 nb bytes per symbol, so the LLRs of a wave go through LDS and leave as full 512-byte
+// rows (a lane's own nb doubles are 8 nb bytes apart from its neighbour's).
+constexpr float LN2_F = 0.6931471805599453f;
+// a sum below this is re-formed relative to its own largest term (v_exp_f32 / v_log_f32 lose their accuracy among the denormals)
+constexpr float F32_TINY = 1e-30f;
+
+// log2( sum_{a in sel} 2^t[a] ) for the members of `t` whose label has bit b set (WANT = 1) or clear (WANT = 0)
+template <int R, int WANT>
+__device__ __forceinline__ float lse2_subset(const float (&t)[R], int b) {
+    float m = -INFINITY;
+#pragma unroll
+    for (int a = 0; a < R; a++) if (((a >> b) & 1) == WANT) m = fmaxf(m, t[a]);
+    float s = 0.0f;
+#pragma unroll
+    for (int a = 0; a < R; a++) if (((a >> b) & 1) == WANT) s += __builtin_amdgcn_exp2f(t[a] - m);
+    return m + __builtin_amdgcn_logf(s);                          // v_log_f32 is log2
+}
+
+template <int NB>
+__device__ __forceinline__ void store_rows_f32(const float (&out)[NB], float scale, int64_t i0, int64_t Ns, double *__restrict__ llr,
+                                               float *stage) {
+    // stage: [64 * NB] floats of this wave; lane l holds symbol i0 + l; out[b] goes to llr[(i0 + l) * NB + NB - 1 - b]
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int b = 0; b < NB; b++) stage[lane * NB + NB - 1 - b] = out[b] * scale;
+    __builtin_amdgcn_wave_barrier();
+    const int64_t base = i0 * NB, end = Ns * NB;
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+        const int64_t o = base + k * 64 + lane;
+        if (o < end) llr[o] = (double)stage[k * 64 + lane];
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int NH>
+__global__ __launch_bounds__(DEMOD_BLOCK) void demod_soft_sep_f32_kernel(const double2 *__restrict__ y, int64_t Ns,
+                                                                         const double *__restrict__ axes, double noise_var,
+                                                                         double scale, double *__restrict__ llr) {
+    constexpr int R = 1 << NH, NB = 2 * NH;
+    __shared__ float ax_s[2 * R];
+    __shared__ float stage_s[DEMOD_BLOCK * NB];
+    for (int m = threadIdx.x; m < 2 * R; m += DEMOD_BLOCK) ax_s[m] = (float)axes[m];
+    __syncthreads();
+    const float c = (float)(-1.4426950408889634 / noise_var);     // exponents in base 2
+    const float sc = (float)scale * LN2_F;
+    float *stage = stage_s + (threadIdx.x >> 6) * 64 * NB;
+    // whole waves walk the array together (the row stores need all 64 lanes of a wave at the same trip count)
+    const int64_t n_rows = (Ns + 63) >> 6, wave0 = (int64_t)blockIdx.x * (DEMOD_BLOCK / 64) + (threadIdx.x >> 6);
+    for (int64_t row = wave0; row < n_rows; row += (int64_t)gridDim.x * (DEMOD_BLOCK / 64)) {
+        const int64_t i0 = row << 6, i = i0 + (threadIdx.x & 63);
+        const double2 cur = y[i < Ns ? i : Ns - 1];
+        const float x = (float)cur.x, yy = (float)cur.y;
+        float tx[R], ty[R];
+#pragma unroll
+        for (int a = 0; a < R; a++) {
+            const float dx = x - ax_s[a], dy = yy - ax_s[R + a];
+            tx[a] = dx * dx * c;
+            ty[a] = dy * dy * c;
+        }
+        // R exponentials per axis relative to the axis' nearest level; a bit subset whose members all flush to zero against that
+        // maximum (|LLR| beyond ~69) is summed again relative to its own maximum
+        float mx = tx[0], my = ty[0];
+#pragma unroll
+        for (int a = 1; a < R; a++) { mx = fmaxf(mx, tx[a]); my = fmaxf(my, ty[a]); }
+        float ex[R], ey[R];
+#pragma unroll
+        for (int a = 0; a < R; a++) { ex[a] = __builtin_amdgcn_exp2f(tx[a] - mx); ey[a] = __builtin_amdgcn_exp2f(ty[a] - my); }
+        float out[NB];
+#pragma unroll
+        for (int b = 0; b < NH; b++) {
+            // label bit NH+b = bit b of the real-axis index, label bit b = bit b of the imag-axis index; the other axis cancels
+            float nx = 0.0f, qx = 0.0f, ny = 0.0f, qy = 0.0f;
+#pragma unroll
+            for (int a = 0; a < R; a++) {
+                if ((a >> b) & 1) { nx += ex[a]; ny += ey[a]; } else { qx += ex[a]; qy += ey[a]; }
+            }
+            out[NH + b] = __builtin_amdgcn_logf(nx) - __builtin_amdgcn_logf(qx);
+            out[b] = __builtin_amdgcn_logf(ny) - __builtin_amdgcn_logf(qy);
+            if (!(nx >= F32_TINY) || !(qx >= F32_TINY)) out[NH + b] = lse2_subset<R, 1>(tx, b) - lse2_subset<R, 0>(tx, b);
+            if (!(ny >= F32_TINY) || !(qy >= F32_TINY)) out[b] = lse2_subset<R, 1>(ty, b) - lse2_subset<R, 0>(ty, b);
+        }
+        store_rows_f32<NB>(out, sc, i0, Ns, llr, stage);
+    }
+}
+
+// generic constellation (PSK, custom tables), <= MAX_M points in LDS: two scans per bit subset would cost 2 M nb exponentials, so one
+// scan finds the nearest point overall, a second adds 2^(t - t_max) into the per-bit sums; a subset whose every member is 2^-126
+// below the overall maximum (its sum flushes to zero) is evaluated again relative to its own maximum
+template <int NB>
+__global__ __launch_bounds__(DEMOD_BLOCK) void demod_soft_f32_kernel(const double2 *__restrict__ y, int64_t Ns,
+                                                                     const double2 *__restrict__ cst, int M, double noise_var,
+                                                                     double scale, double *__restrict__ llr) {
+    __shared__ float2 c_s[MAX_M];
+    __shared__ float stage_s[DEMOD_BLOCK * NB];
+    for (int m = threadIdx.x; m < M; m += DEMOD_BLOCK) c_s[m] = make_float2((float)cst[m].x, (float)cst[m].y);
+    __syncthreads();
+    const float c = (float)(-1.4426950408889634 / noise_var);
+    const float sc = (float)scale * LN2_F;
+    float *stage = stage_s + (threadIdx.x >> 6) * 64 * NB;
+    const int64_t n_rows = (Ns + 63) >> 6, wave0 = (int64_t)blockIdx.x * (DEMOD_BLOCK / 64) + (threadIdx.x >> 6);
+    for (int64_t row = wave0; row < n_rows; row += (int64_t)gridDim.x * (DEMOD_BLOCK / 64)) {
+        const int64_t i0 = row << 6, i = i0 + (threadIdx.x & 63);
+        const double2 cur = y[i < Ns ? i : Ns - 1];
+        const float x = (float)cur.x, yy = (float)cur.y;
+        float tmax = -INFINITY;
+        for (int m = 0; m < M; m++) {
+            const float dx = x - c_s[m].x, dy = yy - c_s[m].y;
+            tmax = fmaxf(tmax, (dx * dx + dy * dy) * c);
+        }
+        float num[NB], den[NB];
+#pragma unroll
+        for (int b = 0; b < NB; b++) { num[b] = 0.0f; den[b] = 0.0f; }
+        for (int m = 0; m < M; m++) {
+            const float dx = x - c_s[m].x, dy = yy - c_s[m].y;
+            const float e = __builtin_amdgcn_exp2f((dx * dx + dy * dy) * c - tmax);
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+                if ((m >> b) & 1) num[b] += e; else den[b] += e;
+            }
+        }
+        float out[NB];
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            out[b] = __builtin_amdgcn_logf(num[b]) - __builtin_amdgcn_logf(den[b]);
+            if (!(num[b] >= F32_TINY) || !(den[b] >= F32_TINY)) {   // a subset far below the nearest point: relative to its own maximum
+                float mx[2] = {-INFINITY, -INFINITY}, s[2] = {0.0f, 0.0f};
+                for (int m = 0; m < M; m++) {
+                    const float dx = x - c_s[m].x, dy = yy - c_s[m].y;
+                    const int w = (m >> b) & 1;
+                    mx[w] = fmaxf(mx[w], (dx * dx + dy * dy) * c);
+                }
+                for (int m = 0; m < M; m++) {
+                    const float dx = x - c_s[m].x, dy = yy - c_s[m].y;
+                    const int w = (m >> b) & 1;
+                    s[w] += __builtin_amdgcn_exp2f((dx * dx + dy * dy) * c - mx[w]);
+                }
+                out[b] = (mx[1] + __builtin_amdgcn_logf(s[1])) - (mx[0] + __builtin_amdgcn_logf(s[0]));
+            }
+        }
+        store_rows_f32<NB>(out, sc, i0, Ns, llr, stage);
     }
 }
 
@@ -402,6 +553,30 @@ int cpx_demod_soft_scaled_dev(const cpx_modem *m, const double *d_y, int64_t Ns,
         else hipLaunchKernelGGL(demod_soft_any_kernel<false>, grid, block, 0, st, y, Ns, c, m->M, m->nbits, noise_var, scale, d_llr);
         CPX_HIP(hipGetLastError());
         note_kernel("demod_soft_any_kernel<%s> (%d points)", rcp ? "rcp" : "div", m->M);
+        return CPX_OK;
+    }
+    if (precision_fast() && noise_var > 1e-30 && noise_var < 1e30 && std::isfinite(scale)) {   // float32 log-sum-exp variants
+        const unsigned rows = (unsigned)std::min<int64_t>((Ns + 63) / 64, (int64_t)256 * 16 * (DEMOD_BLOCK / 64));
+        dim3 gridf((rows + DEMOD_BLOCK / 64 - 1) / (DEMOD_BLOCK / 64));
+        if (m->separable) {
+            switch (m->nbits / 2) {
+#define CASE(NH) case NH: hipLaunchKernelGGL(demod_soft_sep_f32_kernel<NH>, gridf, block, 0, st, y, Ns, m->d_axes, noise_var, scale, d_llr); break;
+                CASE(1) CASE(2) CASE(3) CASE(4)
+#undef CASE
+                default: set_error("demod: unsupported bits per symbol %d", m->nbits); return CPX_ELIMIT;
+            }
+            CPX_HIP(hipGetLastError());
+            note_kernel("demod_soft_sep_f32_kernel<%d>", m->nbits / 2);
+        } else {
+            switch (m->nbits) {
+#define CASE(NB) case NB: hipLaunchKernelGGL(demod_soft_f32_kernel<NB>, gridf, block, 0, st, y, Ns, c, m->M, noise_var, scale, d_llr); break;
+                CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+#undef CASE
+                default: set_error("demod: unsupported bits per symbol %d", m->nbits); return CPX_ELIMIT;
+            }
+            CPX_HIP(hipGetLastError());
+            note_kernel("demod_soft_f32_kernel<%d>", m->nbits);
+        }
         return CPX_OK;
     }
     const bool gp = m->gp && (m->nbits >= 6 || m->nbits == 2) && !demod_plain();

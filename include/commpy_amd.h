@@ -59,7 +59,8 @@ int cpx_last_kernel(char *name, int cap);
  * parity claims are made in.  "fp32-fast": kernels that have a float32 variant use it -- the fused codeword-per-lane Viterbi
  * kernel (float32 path metrics, correlation branch metric; measured mismatch rate in DESIGN.md 4.1) and the LDS-resident LDPC
  * kernels (float32 messages, hardware exp2 / log2 / reciprocal for sum-product; same decoded words and frame error rate on the
- * measured workloads) -- NOT bit-exact and NOT under the 1e-5 LLR criterion; every other kernel is unaffected.
+ * measured workloads) and soft demodulation (float32 log-sum-exp, |dLLR| <= 2e-5 + 4e-6 |LLR|, finite where the
+ * reference's sums underflow) -- NOT bit-exact and NOT under the 1e-5 LLR criterion; every other kernel is unaffected.
  * cpx_last_kernel shows "f32" in the name when a variant ran. */
 int cpx_set_precision(const char *mode);
 int cpx_get_precision(void);   /* 0 fp64-parity, 1 fp32-fast */

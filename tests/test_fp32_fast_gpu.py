@@ -70,8 +70,8 @@ def test_hard_is_identical_and_unquantized_close(gpu, lib, dtype):
 
 
 def test_fast_mode_leaves_every_other_kernel_alone(gpu, lib):
-    """Small Viterbi batches (state-per-lane kernels), the tiled LDPC path, BCJR and the demodulators have no float32 variant:
-    same results, bit for bit."""
+    """Small Viterbi batches (state-per-lane kernels), the tiled LDPC path, BCJR and the hard-decision demodulator have no float32
+    variant: same results, bit for bit."""
     from commpy_amd.channelcoding import ldpc_bp_decode, map_decode, viterbi_decode
     from commpy_amd.modulation import QAMModem
     from helpers import ldpc_params
@@ -91,7 +91,7 @@ def test_fast_mode_leaves_every_other_kernel_alone(gpu, lib):
             d, o = ldpc_bp_decode(l.copy(), p, "SPA", 5)
         finally:
             lib.ldpc_set_path(None)
-        return (viterbi_decode(x, tr, None, "soft"), d, o, md.demodulate(y, "soft", 0.1),
+        return (viterbi_decode(x, tr, None, "soft"), d, o, md.demodulate(y, "hard"),
                 map_decode(s_, p_, tr4, 0.7, np.zeros(50), "compute")[0])
 
     a = run()
@@ -147,3 +147,87 @@ def test_precision_context_manager_restores_the_mode(gpu, lib):
         with commpy_amd.precision("fp32-fast"):
             raise RuntimeError("boom")
     assert lib.get_precision() == "fp64-parity"
+
+
+# ---- fp32-fast soft demodulation (round 4): float32 log-sum-exp kernels, float64 arrays in and out -------------------------------------
+def _modem(kind, M):
+    from commpy_amd.modulation import PSKModem, QAMModem
+    return QAMModem(M) if kind == "qam" else PSKModem(M)
+
+
+@pytest.mark.parametrize("kind,M", [("qam", 4), ("qam", 16), ("qam", 64), ("qam", 256), ("psk", 2), ("psk", 4), ("psk", 8), ("psk", 16)])
+def test_soft_demod_fast_mode_tolerance(gpu, lib, kind, M):
+    """Contract of the float32 demodulator: |LLR_fast - LLR_fp64| <= 2e-5 + 4e-6 |LLR_fp64| (modulation.py:125-137 in float64 is the
+    reference), same hard decisions wherever the float64 LLR is not within 1e-3 of zero; ragged sizes keep their layout."""
+    md = _modem(kind, M)
+    rs = np.random.RandomState(M + len(kind))
+    Es = float(np.mean(np.abs(md.constellation) ** 2))
+    worst_abs, worst_rel = 0.0, 0.0
+    for snr_db, Ns in ((0.0, 4099), (10.0, 65), (20.0, 40000), (28.0, 1), (14.0, 63), (27.0, 3000)):
+        N0 = Es / 10 ** (snr_db / 10)
+        y = md.constellation[rs.randint(0, M, Ns)] + np.sqrt(N0 / 2) * (rs.randn(Ns) + 1j * rs.randn(Ns))
+        lib.set_precision(None)
+        ref = md.demodulate(y, "soft", N0)
+        assert "f32" not in lib.last_kernel()
+        lib.set_precision("fp32-fast")
+        fast = md.demodulate(y, "soft", N0)
+        assert "_f32_kernel" in lib.last_kernel(), lib.last_kernel()
+        assert fast.shape == ref.shape and fast.dtype == np.float64
+        fin = np.isfinite(ref) & (np.abs(ref) < 600)                # beyond: the float64 sums are among the denormals themselves
+        assert np.all(np.isfinite(fast))
+        err = np.abs(fast - ref)[fin]
+        worst_abs = max(worst_abs, float(err.max(initial=0.0)))
+        worst_rel = max(worst_rel, float((err / (2e-5 + 4e-6 * np.abs(ref[fin]))).max(initial=0.0)))
+        assert np.all(err <= 2e-5 + 4e-6 * np.abs(ref[fin])), (snr_db, float(err.max()))
+        sure = fin & (np.abs(ref) > 1e-3)
+        assert np.array_equal(fast[sure] > 0, ref[sure] > 0)
+    print("fp32-fast demod %s-%d: worst |dLLR| %.2e, worst fraction of the allowance %.2f" % (kind, M, worst_abs, worst_rel))
+
+
+def test_soft_demod_fast_mode_is_finite_where_float64_underflows(gpu, lib):
+    """At Es/N0 far beyond any operating point the reference's sums underflow (-inf / NaN, modulation.py:134-137) and fp64-parity
+    reproduces that; the log-sum-exp form does not underflow: finite LLRs with the sign of the nearest point's bits."""
+    from commpy_amd.modulation import QAMModem
+    md = QAMModem(64)
+    rs = np.random.RandomState(5)
+    idx = rs.randint(0, 64, 5000)
+    y = md.constellation[idx] + 0.01 * (rs.randn(5000) + 1j * rs.randn(5000))
+    N0 = 1e-3
+    ref = md.demodulate(y, "soft", N0)
+    assert not np.all(np.isfinite(ref))
+    with __import__("commpy_amd").precision("fp32-fast"):
+        fast = md.demodulate(y, "soft", N0)
+        hard = md.demodulate(y, "hard")
+    assert np.all(np.isfinite(fast))
+    assert np.array_equal((fast > 0).astype(np.int8), hard.astype(np.int8))
+    fin = np.isfinite(ref) & (np.abs(ref) < 600)
+    assert np.all(np.abs(fast - ref)[fin] <= 2e-5 + 4e-6 * np.abs(ref[fin]))
+
+
+def test_soft_demod_fast_mode_scaled_and_device_entry(gpu, lib):
+    """cpx_demod_soft_scaled_dev (the LDPC sign convention, scale = -1) in fp32-fast: exactly the negated LLRs, same layout; a noise
+    variance outside the float32 range keeps the float64 kernel."""
+    from commpy_amd.devicelink import DeviceBuf
+    from commpy_amd.modulation import PSKModem, QAMModem
+    so = lib.load()
+    rs = np.random.RandomState(8)
+    for md in (QAMModem(16), PSKModem(8)):
+        ns, nb = 777, md.num_bits_symbol
+        y = md.constellation[rs.randint(0, md.m, ns)] + 0.3 * (rs.randn(ns) + 1j * rs.randn(ns))
+        ref = md.demodulate(y, "soft", 0.4)
+        lib.set_precision("fp32-fast")
+        d_y = DeviceBuf(y.nbytes)
+        lib.check(so.cpx_memcpy_h2d(d_y.ptr, lib.ptr(y), y.nbytes))
+        outs = []
+        for scale in (1.0, -1.0):
+            d_l = DeviceBuf(ns * nb * 8)
+            lib.check(so.cpx_demod_soft_scaled_dev(md._device_handle(), d_y.ptr, ns, 0.4, scale, d_l.ptr, None))
+            assert "_f32_kernel" in lib.last_kernel()
+            o = np.empty(ns * nb)
+            lib.check(so.cpx_memcpy_d2h(lib.ptr(o), d_l.ptr, o.nbytes))
+            outs.append(o)
+        assert np.array_equal(outs[1], -outs[0])
+        assert np.all(np.abs(outs[0] - ref) <= 2e-5 + 4e-6 * np.abs(ref))
+        md.demodulate(y, "soft", 1e-40)
+        assert "f32" not in lib.last_kernel()
+        lib.set_precision(None)
