@@ -242,7 +242,8 @@ def demod_set_path(mode):
 
 
 def ldpc_set_path(mode):
-    """Force an LDPC decoder path: None/'auto', 'tiled' (HBM-resident tiles), 'resident' (LDS-resident, strict)."""
+    """Force an LDPC decoder path: None/'auto', 'tiled' (HBM-resident tiles), 'resident' (LDS-resident, strict), 'resident-log' (the same with
+    the log-domain sum-product row instead of the ratio-domain kernel)."""
     check(load().cpx_ldpc_set_path(None if mode is None else mode.encode()))
 
 

@@ -16,6 +16,11 @@ __device__ __forceinline__ double min_f64(double a, double b) {     // one v_min
     asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+__device__ __forceinline__ double max_f64(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ double ntload(const double *p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ void ntstore(double v, double *p) { __builtin_nontemporal_store(v, p); }
 

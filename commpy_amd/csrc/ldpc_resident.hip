@@ -61,6 +61,12 @@ struct ResParams {
     int rstride;             // doubles per row of R: max check degree, made odd (an even stride of 8-byte words is an LDS bank conflict)
     int n_v, n_c, cpad, vpad, max_iter;
     int roff, ctl_off;       // LDS byte offsets of R and of the control words
+    // ratio-domain sum-product (ldpc_resident_ratio_kernel) and the redo launch behind it
+    double *e0;              // [workgroups][n_v] exp(llr) of the block a workgroup is decoding (L2-resident scratch)
+    int *redo_count;         // blocks the ratio kernel hands back (a NaN, a saturated iteration): count ...
+    int *redo_list;          // ... and block indices [B]
+    const int *blist;        // ldpc_resident_kernel: decode blocks blist[0 .. *bcount) instead of 0 .. B-1 (null: all)
+    const int *bcount;
 };
 
 // LDS accesses by absolute byte address: the kernel declares no static LDS, so its dynamic segment starts at address 0
@@ -218,7 +224,8 @@ __global__ __launch_bounds__(1024, 6) void ldpc_resident_kernel(ResParams p) {
     // next s_barrier while lane 0 was still retiring): wave 0 met the barrier twice per block and the kernel hung.
     auto pop = [&]() {                                           // thread 0 only
         const int t = atomicAdd(p.queue, 1);
-        ctl[2] = t < p.B ? t : -1;
+        if (p.blist) ctl[2] = t < *p.bcount ? p.blist[t] : -1;   // the redo launch behind the ratio kernel: listed blocks only
+        else ctl[2] = t < p.B ? t : -1;
     };
     if (tid == 0) {
         stsd(8 * p.n_v, __builtin_huge_val());                   // dummy Q (row padding)
@@ -319,6 +326,187 @@ __global__ __launch_bounds__(1024, 6) void ldpc_resident_kernel(ResParams p) {
             if (p.nanflags) p.nanflags[b] = (uint8_t)ctl[3];
             ctl[3] = 0;
             ctl[0] = 0; ctl[1] = 0;                              // (a thread that has yet to read a flag of this block reads the 0 that sent the others here)
+            pop();
+        }
+        __syncthreads();
+        b = __builtin_amdgcn_readfirstlane(ctl[2]);
+    }
+}
+
+// ---- sum-product in the RATIO domain (round 4) ---------------------------------------------------------------------------------------
+// The log-domain row above spends most of its instructions on one exp (e = exp(-|m|)) and one log (2 atanh) per edge and iteration.
+// Kept as likelihood ratios -- X_v = exp(out_llr_v) per variable, rho_cj = exp(R_cj) per edge -- the same iteration needs neither:
+//     exp(m_j) = X[v_j] / rho_j,    e_j = exp(-|m_j|) = min(X, rho) / max(X, rho)  (ONE division),    sign(m_j) = (X >= rho)
+//     rho_j  <-  (W u_j + U w_j) / (W u_j - U w_j)        (the one-division row of ldpc_dev.h without its logarithm)
+//     X_v    <-  exp(llr_v) prod_j rho_j                   (exp(llr) once per block, kept in an L2-resident scratch row)
+// and out_llrs = log X is formed ONCE, when the block retires.  The sign of out_llr_v (dec_word, the syndrome test) is X_v < 1: it is
+// kept in the sign bit of the stored X.  The arithmetic differs from the log-domain row by roundings of ~1e-16 relative to the
+// ratios, i.e. ~1e-15 absolute on the messages: the same class as the one-division row (scripts/micro/spa_ratio_emul.py decodes the 72
+// live-reference blocks of ldpc_c4y.npz with it in NumPy: dec_word, iteration counts, banded contract all met; near rows 0.03 - 0.7 %).
+// Range: the product of a variable is taken over its factors above and below 1 separately; if either leaves the normal range, or the
+// ratio leaves (2^-990, 2^990), the variable is summed through logarithms and, beyond +-680, stored as the LLR itself (ratio_encode).
+// What the ratio domain cannot carry is handed back (redo_list) and decoded again by ldpc_resident_kernel, from the untouched LLRs:
+//   * a NaN (an LLR of exactly zero makes one with a SIGN the reference's dec_word reads, see ldpc_dev.h; a NaN input);
+//   * an iteration in which more than half of the rows are near saturation: there the result is decided by how the reference's own
+//     operation sequence rounds (+-500 against 37.4), which the exact-order row reproduces only from log-domain inputs.  Correctly
+//     scaled channel LLRs do this to about one block in a hundred (their last iteration); LLRs scaled up several times do it always.
+__device__ __forceinline__ double spa_ratio_fast(double U, double W, double se) {
+    const double e = fabs(se);
+    const double n1 = W * __builtin_copysign(1.0 - e, se), n2 = U * (1.0 + e);
+    return div_nr(n1 + n2, n1 - n2);                             // exp(2 atanh(x)) = (1 + x) / (1 - x), |x| < 1 - 2^-32: positive, normal
+}
+
+__device__ __forceinline__ void check_spa_ratio(const ResParams &p, int c, int *ctl, int *flag) {
+    const int deg = p.row_deg[c];
+    const int4 *__restrict__ qv = reinterpret_cast<const int4 *>(p.row_q + (int64_t)c * p.cpad);
+    const int rb = p.roff + 8 * c * p.rstride;
+    int sx = 0;
+    double U = 1.0, W = 1.0, emax = 0.0;
+    for (int j0 = 0; __builtin_amdgcn_ballot_w64(j0 < deg) != 0; j0 += 4) {
+        const int4 a = qv[j0 >> 2];
+        const double q[4] = {ldsd(a.x), ldsd(a.y), ldsd(a.z), ldsd(a.w)};
+#pragma unroll
+        for (int u4 = 0; u4 < 4; u4++) {
+            const int j = j0 + u4;
+            if (j < deg) {
+                sx ^= __double2hiint(q[u4]);                     // sign bit of the stored X = (out_llr < 0) (:193, :248)
+                const double X = fabs(q[u4]), r = ldsd(rb + 8 * j);
+                const double e = div_nr(min_f64(X, r), max_f64(X, r));      // exp(-|m|), m = out_llr - R (:244-245)
+                const double se = X >= r ? e : -e;               // ... with the sign of m
+                U *= __builtin_copysign(1.0 - e, se);
+                W *= 1.0 + e;
+                emax = max_f64(emax, e);
+                stsd(rb + 8 * j, se);
+            }
+        }
+    }
+    if (sx < 0) *flag = 1;
+    const bool near = spa_row_near(U, W, emax);
+    if (__builtin_amdgcn_ballot_w64(!near) != 0) {
+        for (int j = 0; __builtin_amdgcn_ballot_w64(j < deg) != 0; j++)
+            if (j < deg && !near) stsd(rb + 8 * j, spa_ratio_fast(U, W, ldsd(rb + 8 * j)));
+    }
+    if (__builtin_amdgcn_ballot_w64(near) != 0) {
+        if (near) atomicAdd(&ctl[4], 1);
+        double prod = 1.0;
+        for (int j = 0; __builtin_amdgcn_ballot_w64(j < deg) != 0; j++)
+            if (j < deg && near) prod *= spa_exact_t(ldsd(rb + 8 * j));
+        for (int j = 0; __builtin_amdgcn_ballot_w64(j < deg) != 0; j++)
+            if (j < deg && near) {
+                const double R = spa_out_exact(spa_exact_t(ldsd(rb + 8 * j)), prod);
+                if (R != R) ctl[3] = 1;                          // the block goes back to the log-domain kernel
+                stsd(rb + 8 * j, exp(R));                        // |R| <= 500
+            }
+    }
+}
+
+// X beyond 2^+-990 is past every use as a ratio (tanh(m / 2) is 1.0 in float64 from |m| ~ 37 on): such a slot carries out_llr ITSELF,
+// Q 2^1000 above and 2^-1000 / |Q| below, so that a retiring block still has the reference's msg_sum + llr (:245-247) for it
+constexpr double RATIO_TOP = 0x1p990, RATIO_BOT = 0x1p-990, RATIO_ENC = 0x1p1000, RATIO_DEC = 0x1p-1000;
+
+__device__ __forceinline__ double ratio_encode(double Q) {       // |Q| >= 680
+    return Q > 0.0 ? Q * RATIO_ENC : RATIO_DEC / -Q;
+}
+__device__ __forceinline__ double ratio_llr(double a) {          // a = |stored X|
+    if (a >= RATIO_TOP) return a * RATIO_DEC;
+    if (a <= RATIO_BOT) return -(RATIO_DEC / a);
+    return fast_log(a);
+}
+
+__device__ __forceinline__ void var_node_ratio(const ResParams &p, int v, double e0, const double *__restrict__ in) {
+    const int trips = p.vgrp[__builtin_amdgcn_readfirstlane(v) >> 6];
+    const int4 *__restrict__ rf = reinterpret_cast<const int4 *>(p.col_r + (int64_t)v * p.vpad);
+    double big = max_f64(e0, 1.0), small = min_f64(e0, 1.0);
+    for (int t = 0; t < trips; t++) {
+        const int4 a = rf[t];
+        const double r0 = ldsd(a.x), r1 = ldsd(a.y), r2 = ldsd(a.z), r3 = ldsd(a.w);      // padding: 1.0
+        big *= max_f64(r0, 1.0); small *= min_f64(r0, 1.0);
+        big *= max_f64(r1, 1.0); small *= min_f64(r1, 1.0);
+        big *= max_f64(r2, 1.0); small *= min_f64(r2, 1.0);
+        big *= max_f64(r3, 1.0); small *= min_f64(r3, 1.0);
+    }
+    double X = big * small;
+    if (!(big <= 1.7e308) || !(small >= 1e-290) || !(X < RATIO_TOP) || !(X > RATIO_BOT)) {
+        // a factor product left the normal range, or the ratio its own: the column sum in the log domain (rare)
+        double msum = 0.0;
+        for (int t = 0; t < trips; t++) {
+            const int4 a = rf[t];
+            msum += fast_log(ldsd(a.x)); msum += fast_log(ldsd(a.y)); msum += fast_log(ldsd(a.z)); msum += fast_log(ldsd(a.w));
+        }
+        const double Q = msum + in[v];
+        X = fabs(Q) < 680.0 ? exp(Q) : ratio_encode(Q);          // (a NaN takes the encode branch and stays a NaN: the block is handed back)
+    }
+    stsd(8 * v, X < 1.0 ? -X : X);
+}
+
+__global__ __launch_bounds__(1024, 6) void ldpc_resident_ratio_kernel(ResParams p) {
+    extern __shared__ __align__(16) char lds[];
+    if ((unsigned)(uintptr_t)lds != 0u) __builtin_trap();        // absolute LDS addresses (see ldsd)
+    // control words: [0], [1] "unsatisfied" flag of even / odd iterations; [2] block; [3] hand the block back (NaN); [4] rows near
+    // saturation in this check pass; [5], [6] "more than half of the rows were" of the iteration before, by iteration parity -- every
+    // word is written on one side of a barrier and read on the other (see the note on uniform control flow in ldpc_resident_kernel)
+    int *ctl = reinterpret_cast<int *>(lds + p.ctl_off);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    double *__restrict__ e0row = p.e0 + (int64_t)blockIdx.x * p.n_v;
+    auto pop = [&]() {                                           // thread 0 only
+        const int t = atomicAdd(p.queue, 1);
+        ctl[2] = t < p.B ? t : -1;
+    };
+    if (tid == 0) {
+        stsd(8 * p.n_v, 1.0);                                    // dummy X (row padding; never read: the rows loop to their degree)
+        for (int i = 0; i < 5; i++) stsd(p.roff + 8 * (p.n_r + i), 1.0);   // dummy rho (column padding): neutral in a product, log = 0
+        for (int i = 0; i < 7; i++) if (i != 2) ctl[i] = 0;
+        pop();
+    }
+    __syncthreads();
+    int b = __builtin_amdgcn_readfirstlane(ctl[2]);
+    while (b >= 0) {
+        double *__restrict__ in = p.llr + (int64_t)b * p.n_v;
+        for (int v = tid; v < p.n_v; v += nt) {
+            const double raw = in[v];
+            const double x = clip_nan(raw, -500.0, 500.0);
+            if (x != raw) {                                      // in-place clip (:186); untouched values are not rewritten
+                if (x == x) {
+                    in[v] = x;
+                    if (p.clipped) *p.clipped = 1;
+                } else {
+                    ctl[3] = 1;                                  // NaN
+                }
+            }
+            const double e0 = exp(x);                            // |x| <= 500: a normal number
+            e0row[v] = e0;
+            stsd(8 * v, x < 0.0 ? -e0 : e0);                     // out_llrs = llr (:194)
+        }
+        for (int e = tid; e < p.n_r; e += nt) stsd(p.roff + 8 * e, 1.0);
+        __syncthreads();
+        int k = 0, back = 0;
+        for (; k < p.max_iter; k++) {
+            int *flag = &ctl[k & 1];
+            for (int c = tid; c < p.n_c; c += nt) check_spa_ratio(p, c, ctl, flag);
+            __syncthreads();
+            back = __builtin_amdgcn_readfirstlane(ctl[3] | ctl[5 + (k & 1)]);
+            if (back) break;
+            if (!__builtin_amdgcn_readfirstlane(*flag)) break;   // zero syndrome (:205-206)
+            if (tid == 0) {
+                ctl[(k + 1) & 1] = 0;
+                ctl[5 + ((k + 1) & 1)] = 2 * ctl[4] > p.n_c ? 1 : 0;
+                ctl[4] = 0;
+            }
+            for (int v = tid; v < p.n_v; v += nt) var_node_ratio(p, v, e0row[v], in);
+            __syncthreads();
+        }
+        // Retire: out_llrs = log X (a block that arrived as a codeword: the clipped LLRs themselves, :194)
+        double *__restrict__ orow = p.out + (int64_t)b * p.n_v;
+        int8_t *__restrict__ drow = p.dec ? p.dec + (int64_t)b * p.n_v : nullptr;
+        for (int v = tid; v < p.n_v; v += nt) {
+            const double x = k == 0 ? in[v] : ratio_llr(fabs(ldsd(8 * v)));    // the same thread reloads this entry for the next block
+            orow[v] = x;
+            if (drow) drow[v] = (int8_t)(__builtin_signbit(x) ? 1 : 0);
+        }
+        if (tid == 0) {
+            if (p.iters) p.iters[b] = k;
+            if (back) p.redo_list[atomicAdd(p.redo_count, 1)] = b;
+            for (int i = 0; i < 7; i++) if (i != 2) ctl[i] = 0;
             pop();
         }
         __syncthreads();
@@ -515,11 +703,12 @@ __global__ __launch_bounds__(256) void ldpc_unstage_kernel(const double *__restr
     }
 }
 
-std::atomic<int> g_ldpc_path{-1};                                 // 0 auto, 1 tiled, 2 resident (strict)
+std::atomic<int> g_ldpc_path{-1};                                 // 0 auto, 1 tiled, 2 resident (strict), 3 resident (strict), sum-product by the log-domain row
 int parse_ldpc_path(const char *m) {
     if (!m || !m[0] || strcmp(m, "auto") == 0) return 0;
     if (strcmp(m, "tiled") == 0) return 1;
     if (strcmp(m, "resident") == 0) return 2;
+    if (strcmp(m, "resident-log") == 0) return 3;
     return -2;
 }
 int ldpc_path() {
@@ -553,6 +742,22 @@ int launch_resident(const ResParams &p, int grid, int threads, size_t lds, hipSt
     return CPX_OK;
 }
 
+int launch_ratio(const ResParams &p, int grid, int threads, size_t lds, hipStream_t st) {
+    static bool raised[64] = {};
+    static std::mutex raised_mu;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> lk(raised_mu);
+        if (dev >= 0 && dev < 64 && !raised[dev]) {
+            CPX_HIP(hipFuncSetAttribute((const void *)ldpc_resident_ratio_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+            raised[dev] = true;
+        }
+    }
+    hipLaunchKernelGGL(ldpc_resident_ratio_kernel, dim3((unsigned)grid), dim3((unsigned)threads), lds, st, p);
+    return CPX_OK;
+}
+
 template <int ALG>
 int launch_resident_f32(const ResParams &p, int grid, int threads, size_t lds, hipStream_t st) {
     hipLaunchKernelGGL((ldpc_resident_f32_kernel<ALG>), dim3((unsigned)grid), dim3((unsigned)threads), lds, st, p);   // < 64 KB of LDS
@@ -569,6 +774,11 @@ namespace cpx {
 
 bool ldpc_spa_exact() {
     static const bool v = [] { const char *e = getenv("CPX_LDPC_SPA"); return e && strcmp(e, "exact") == 0; }();
+    return v;
+}
+// CPX_LDPC_SPA=log: the resident path keeps the log-domain one-division row (the round-3 kernel) instead of the ratio-domain kernel (A/B runs)
+static bool ldpc_spa_log() {
+    static const bool v = [] { const char *e = getenv("CPX_LDPC_SPA"); return e && strcmp(e, "log") == 0; }();
     return v;
 }
 
@@ -617,7 +827,7 @@ bool ldpc_resident_path(const cpx_ldpc *c, double *d_llr, int64_t B, int alg, in
     *rc = CPX_OK;
     const int mode = ldpc_path();
     auto reject = [&](const char *why) {
-        if (mode == 2) { set_error("ldpc: resident path forced but not applicable: %s", why); *rc = CPX_EINVAL; return true; }
+        if (mode >= 2) { set_error("ldpc: resident path forced but not applicable: %s", why); *rc = CPX_EINVAL; return true; }
         return false;
     };
     if (mode == 1) return false;
@@ -637,11 +847,19 @@ bool ldpc_resident_path(const cpx_ldpc *c, double *d_llr, int64_t B, int alg, in
     }
     // Outputs.  Block-major (one block per row, the memory layout of the reference's own results): retired blocks go straight
     // to the caller's arrays.  [n_v][B]: they go to a staging buffer and ldpc_unstage_kernel transposes it.
+    // persistent grid: as many workgroups as fit a compute unit (LDS, 2048 threads, 16 workgroups), no more than blocks
+    const int per_cu = std::max(1, std::min({(int)(LDS_BYTES / lds), 2048 / threads, 16}));
+    const int grid = (int)std::min<int64_t>((int64_t)device_cus() * per_cu, B);
+    const bool ratio = !f32 && alg == CPX_LDPC_SPA && !ldpc_spa_exact() && !ldpc_spa_log() && mode != 3;   // ldpc_resident_ratio_kernel + redo launch
     char *slab = nullptr;
     const size_t sz_stage = block_major ? 0 : (sizeof(double) * (size_t)(B * c->n_v) + 255) & ~(size_t)255;
-    if ((*rc = workspace(st, 0, sz_stage + 256, (void **)&slab))) return true;
+    const size_t sz_list = ratio ? (sizeof(int) * (size_t)B + 255) & ~(size_t)255 : 0;
+    const size_t sz_e0 = ratio ? sizeof(double) * (size_t)grid * (size_t)c->n_v : 0;
+    if ((*rc = workspace(st, 0, sz_stage + 256 + sz_list + sz_e0, (void **)&slab))) return true;
     ResParams p;
     p.llr = d_llr; p.iters = d_iters; p.queue = (int *)(slab + sz_stage); p.clipped = d_clipped; p.nanflags = nanflags;
+    p.redo_count = p.queue + 2; p.redo_list = (int *)(slab + sz_stage + 256); p.e0 = (double *)(slab + sz_stage + 256 + sz_list);
+    p.blist = nullptr; p.bcount = nullptr;
     p.out = block_major ? d_out : (double *)slab;
     p.dec = block_major ? d_dec : nullptr;
     p.spa_exact = (!f32 && ldpc_spa_exact()) ? 1 : 0;
@@ -652,13 +870,19 @@ bool ldpc_resident_path(const cpx_ldpc *c, double *d_llr, int64_t B, int alg, in
     p.max_iter = n_iters;
     p.roff = f32 ? res_roff(c->n_v) / 2 : res_roff(c->n_v);
     p.ctl_off = (int)(lds - 64);
-    if (hipMemsetAsync(p.queue, 0, sizeof(int), st) != hipSuccess) { set_error("ldpc: hipMemsetAsync failed"); *rc = CPX_EHIP; return true; }
-    // persistent grid: as many workgroups as fit a compute unit (LDS, 2048 threads, 16 workgroups), no more than blocks
-    const int per_cu = std::max(1, std::min({(int)(LDS_BYTES / lds), 2048 / threads, 16}));
-    const int grid = (int)std::min<int64_t>((int64_t)device_cus() * per_cu, B);
+    if (hipMemsetAsync(p.queue, 0, 4 * sizeof(int), st) != hipSuccess) { set_error("ldpc: hipMemsetAsync failed"); *rc = CPX_EHIP; return true; }
     const int cq = c->cpad / 4;
     int lrc;
-    if (f32) lrc = alg == CPX_LDPC_SPA ? launch_resident_f32<CPX_LDPC_SPA>(p, grid, threads, lds, st)
+    if (ratio) {
+        // every block through the ratio-domain kernel; the few it hands back (a NaN, a saturated iteration) are decoded again, from the
+        // LLRs it left untouched, by the log-domain kernel on a small grid (no block listed: its workgroups leave at once)
+        lrc = launch_ratio(p, grid, threads, lds, st);
+        if (!lrc) {
+            ResParams q = p;
+            q.queue = p.queue + 1; q.blist = p.redo_list; q.bcount = p.redo_count;
+            lrc = launch_resident<CPX_LDPC_SPA, 0>(q, std::min(grid, 64), threads, lds, st);
+        }
+    } else if (f32) lrc = alg == CPX_LDPC_SPA ? launch_resident_f32<CPX_LDPC_SPA>(p, grid, threads, lds, st)
                                        : launch_resident_f32<CPX_LDPC_MSA>(p, grid, threads, lds, st);
     else if (alg == CPX_LDPC_SPA) lrc = launch_resident<CPX_LDPC_SPA, 0>(p, grid, threads, lds, st);
     else if (cq == 1) lrc = launch_resident<CPX_LDPC_MSA, 1>(p, grid, threads, lds, st);
@@ -672,6 +896,7 @@ bool ldpc_resident_path(const cpx_ldpc *c, double *d_llr, int64_t B, int alg, in
                            p.out, B, c->n_v, d_out, d_dec);
     if (hipGetLastError() != hipSuccess) { set_error("ldpc (resident path): launch failed"); *rc = CPX_EHIP; }
     if (f32) note_kernel("ldpc_resident_f32_kernel<%s> threads=%d workgroups/CU=%d", alg == CPX_LDPC_MSA ? "MSA" : "SPA", threads, per_cu);
+    else if (ratio) note_kernel("ldpc_resident_kernel<SPA,ratio> threads=%d workgroups/CU=%d", threads, per_cu);
     else note_kernel("ldpc_resident_kernel<%s,%d> threads=%d workgroups/CU=%d", alg == CPX_LDPC_MSA ? "MSA" : "SPA",
                      alg == CPX_LDPC_MSA && cq <= 4 ? cq : 0, threads, per_cu);
     return true;
@@ -682,7 +907,7 @@ bool ldpc_resident_path(const cpx_ldpc *c, double *d_llr, int64_t B, int alg, in
 extern "C" int cpx_ldpc_set_path(const char *mode) {
     const int v = parse_ldpc_path(mode);
     if (v < 0) {
-        cpx::set_error("cpx_ldpc_set_path: unknown mode '%s' (auto | tiled | resident)", mode);
+        cpx::set_error("cpx_ldpc_set_path: unknown mode '%s' (auto | tiled | resident | resident-log)", mode);
         return CPX_EINVAL;
     }
     g_ldpc_path.store(v, std::memory_order_relaxed);

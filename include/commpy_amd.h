@@ -233,11 +233,14 @@ int cpx_ldpc_bp_decode_batch_bm(const cpx_ldpc *c, double *llr, int64_t B, int a
 int cpx_ldpc_bp_decode_batch_bm_dev(const cpx_ldpc *c, double *d_llr, int64_t B, int alg, int n_iters,
                                     int8_t *d_dec_word, double *d_out_llrs, int32_t *d_iters_done,
                                     void *stream);
-/* Two implementations of the same arithmetic (identical results, tests/test_ldpc_resident_gpu.py): the LDS-resident
- * path (csrc/ldpc_resident.hip: the decoder state of a block lives in the LDS of one compute unit, one persistent launch,
- * blocks retire and are replaced individually) whenever that state fits, else the tiled HBM path (csrc/ldpc.hip).
- * cpx_ldpc_set_path("auto" | "tiled" | "resident") forces one (initial value: environment variable CPX_LDPC_PATH);
- * "resident" fails with CPX_EINVAL instead of falling back.  cpx_last_kernel names what ran. */
+/* Two implementations: the LDS-resident path (csrc/ldpc_resident.hip: the decoder state of a block lives in the LDS of one
+ * compute unit, one persistent launch, blocks retire and are replaced individually) whenever that state fits, else the tiled
+ * HBM path (csrc/ldpc.hip).  Min-sum: the same arithmetic, identical results.  Sum-product: the tiled path and "resident-log"
+ * share the log-domain row (identical results); the default resident kernel keeps the state as likelihood ratios -- no exp / log
+ * inside an iteration, same dec_word, iteration counts and out_llrs contract, blocks it cannot carry (a NaN, an
+ * iteration saturated in more than half of its rows) decoded again by the log-domain kernel (tests/test_ldpc_resident_gpu.py).
+ * cpx_ldpc_set_path("auto" | "tiled" | "resident" | "resident-log") forces one (initial value: environment variable
+ * CPX_LDPC_PATH); the "resident" modes fail with CPX_EINVAL instead of falling back.  cpx_last_kernel names what ran. */
 int cpx_ldpc_set_path(const char *mode);
 
 /* ---- PSK/QAM demodulation ------------------------------------------------------------------------

@@ -1,11 +1,14 @@
 """LDS-resident LDPC path (csrc/ldpc_resident.hip) against the tiled HBM path (csrc/ldpc.hip) and the oracle.
 
-Both paths replace ldpc_bp_decode (/root/reference/commpy/channelcoding/ldpc.py:144-254) with the same float64
-operations per edge in the same order, so dec_word, out_llrs and the executed iterations must be IDENTICAL for both
-algorithms -- whatever slot of whatever workgroup a block lands in.  The other LDPC tests of the suite run through the
-default (resident) path and compare with the oracle; here the two paths are forced and compared with each other on
-batches that exercise slot replacement (more blocks than slots, blocks that converge at very different iterations,
-blocks that never converge), plus special values.
+Both paths replace ldpc_bp_decode (/root/reference/commpy/channelcoding/ldpc.py:144-254).  Min-sum, and sum-product with the
+log-domain row ('tiled' and 'resident-log'): the same float64 operations per edge in the same order, so dec_word, out_llrs and
+the executed iterations must be IDENTICAL -- whatever slot of whatever workgroup a block lands in.  Sum-product on the default
+resident path (round 4: ldpc_resident_ratio_kernel, the state kept as likelihood ratios, no exp / log inside an iteration): the
+same dec_word, iteration counts and NaN pattern, out_llrs inside the banded contract of helpers.spa_contract against the
+log-domain row -- its arithmetic differs by ~1e-16 relative per operation, which 2 atanh amplifies near saturation exactly as
+for the reference's own row.  The other LDPC tests of the suite run through the default path and compare with the oracle;
+here the paths are forced and compared with each other on batches that exercise slot replacement (more blocks than slots,
+blocks that converge at very different iterations, blocks that never converge), plus special values.
 """
 import numpy as np
 import pytest
@@ -31,6 +34,19 @@ def _decode(_lib, path, llr, p, alg, iters):
     return dec, out, its, x, _lib.last_kernel()
 
 
+def _ratio_agrees(a, b, what):
+    """Sum-product, ratio-domain kernel `a` against the log-domain row `b`: (dec, out, iters) each."""
+    from helpers import spa_contract
+    (d1, o1, i1), (d2, o2, i2) = a, b
+    assert np.array_equal(i1, i2), what
+    assert np.array_equal(np.isnan(o1), np.isnan(o2)), what
+    ok = ~np.isnan(o2)                                             # the sign bit of a NaN is nobody's contract (np.signbit of it, :248)
+    assert np.array_equal(d1[ok], d2[ok]), what
+    assert np.array_equal(np.isinf(o1), np.isinf(o2)) and np.array_equal(o1[np.isinf(o2)], o2[np.isinf(o2)]), what
+    fin = np.isfinite(o2)
+    spa_contract(o1[fin], o2[fin], what)
+
+
 def _staggered(rs, B, n, rate, ebn0s):
     ebn0 = rs.choice(ebn0s, size=B)
     sig = 1 / np.sqrt(10 ** (ebn0 / 10.0) * rate * 2)
@@ -47,6 +63,12 @@ def test_resident_equals_tiled_1944(gpu, paths, alg, iters):
     d2, o2, i2, x2, k2 = _decode(paths, "resident", llr, p, alg, iters)
     assert "tiled" in k1 and "ldpc_resident_kernel" in k2 and alg in k2, (k1, k2)
     assert len(set(i1.tolist())) >= min(iters, 5)
+    assert np.array_equal(x1, x2)
+    if alg == "SPA":
+        assert "ratio" in k2, k2
+        _ratio_agrees((d2, o2, i2), (d1, o1, i1), "ratio kernel vs tiled")
+        d2, o2, i2, x2, k2 = _decode(paths, "resident-log", llr, p, alg, iters)
+        assert "ldpc_resident_kernel<SPA,0>" in k2, k2
     assert np.array_equal(i1, i2)
     assert np.array_equal(d1, d2)
     assert np.array_equal(o1, o2)                                   # bit-identical, both algorithms
@@ -64,7 +86,12 @@ def test_resident_other_codes_vs_oracle_and_tiled(gpu, paths, name, n):
         d1, o1, i1, _, _ = _decode(paths, "tiled", llr, p, alg, iters)
         d2, o2, i2, _, k2 = _decode(paths, "resident", llr, p, alg, iters)
         assert "ldpc_resident_kernel" in k2
-        assert np.array_equal(i1, i2) and np.array_equal(d1, d2) and np.array_equal(o1, o2), (name, alg)
+        if alg == "SPA":
+            _ratio_agrees((d2, o2, i2), (d1, o1, i1), name)
+            d3, o3, i3, _, _ = _decode(paths, "resident-log", llr, p, alg, iters)
+            assert np.array_equal(i1, i3) and np.array_equal(d1, d3) and np.array_equal(o1, o3), (name, alg)
+        else:
+            assert np.array_equal(i1, i2) and np.array_equal(d1, d2) and np.array_equal(o1, o2), (name, alg)
         sel = slice(0, 64 * n)
         do, oo, io = oracle.ldpc_bp_decode(llr[sel].copy(), p, alg, iters, True)
         assert np.array_equal(i2[:64], io) and np.array_equal(d2[:, :64], do), (name, alg)
@@ -87,6 +114,10 @@ def test_resident_small_batches_and_special_values(gpu, paths, B):
     for alg, iters in (("MSA", 9), ("SPA", 5)):
         d1, o1, i1, x1, _ = _decode(paths, "tiled", llr, p, alg, iters)
         d2, o2, i2, x2, _ = _decode(paths, "resident", llr, p, alg, iters)
+        if alg == "SPA":                                           # blocks with a zero LLR or a NaN come back through the log-domain kernel
+            _ratio_agrees((d2, o2, i2), (d1, o1, i1), "special values")
+            assert np.array_equal(x1, x2, equal_nan=True)
+            d2, o2, i2, x2, _ = _decode(paths, "resident-log", llr, p, alg, iters)
         assert np.array_equal(i1, i2), alg
         assert np.array_equal(o1, o2, equal_nan=True), alg
         ok = ~np.isnan(o1)                                         # the sign bit of a NaN is nobody's contract (np.signbit of it, :248)
