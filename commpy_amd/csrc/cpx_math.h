@@ -13,16 +13,25 @@ namespace cpx {
 // the LDPC passes exactly as it does through libm); denormals are handled by v_frexp.
 // SPECIAL = false drops the four special-value selects: for arguments known to be finite and >= 1 (the Viterbi branch
 // metrics take log(exp(r) + 1) with |r| <= 500) the result is bit-identical and 4 compares + 8 selects shorter.
-// x / y for NORMAL, well-scaled operands (no denormals, no overflow of the quotient, y != 0): hardware reciprocal, two Newton
-// steps, one residual correction -- 8 instructions against the 12 of the IEEE division sequence (v_div_scale x 2, v_rcp, five
-// v_fma, v_div_fmas, v_div_fixup); the result is within 1 ulp (not always correctly rounded).  Only where a caller's contract
-// allows that and its operands are known to be in range: the sum-product fast row (ldpc_dev.h, 4e-6 budget).
+// x / y for NORMAL, well-scaled operands (no denormals, no overflow of the quotient, y != 0): hardware reciprocal, one Newton
+// step, one residual correction -- 6 instructions against the 12 of the IEEE division sequence (v_div_scale x 2, v_rcp, five
+// v_fma, v_div_fmas, v_div_fixup).  Only where a caller's contract does not need the IEEE sequence's guarantees and its operands
+// are known to be in range: the sum-product rows (ldpc_dev.h, 4e-6 budget), the soft demodulator's quotients.
 __device__ __forceinline__ double div_nr(double x, double y) {
+    // v_rcp_f64 is good to ~2^-25 (measured, scripts/micro/div_nr_check.hip): ONE Newton step brings the reciprocal to ~2^-50 and the
+    // residual step then returns the correctly rounded quotient on every one of 5e8 random operand pairs -- exactly what the form with
+    // two Newton steps (rounds 3 / 4a, 8 instructions) returned, with 6 instructions
     double r = __builtin_amdgcn_rcp(y);
-    double e = __builtin_fma(-y, r, 1.0);
+    const double e = __builtin_fma(-y, r, 1.0);
     r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-y, r, 1.0);
-    r = __builtin_fma(r, e, r);
+    const double q = x * r;
+    return __builtin_fma(__builtin_fma(-y, q, x), r, q);
+}
+
+// No Newton step: v_rcp_f64 + residual (4 instructions): up to 10 ulp off (same measurement).  Only where the quotient's error budget is
+// absolute and generous: e = exp(-|m|) of the ratio-domain sum-product row (2e-15 on m).
+__device__ __forceinline__ double div_nr0(double x, double y) {
+    const double r = __builtin_amdgcn_rcp(y);
     const double q = x * r;
     return __builtin_fma(__builtin_fma(-y, q, x), r, q);
 }

@@ -371,7 +371,7 @@ __device__ __forceinline__ void check_spa_ratio(const ResParams &p, int c, int *
             if (j < deg) {
                 sx ^= __double2hiint(q[u4]);                     // sign bit of the stored X = (out_llr < 0) (:193, :248)
                 const double X = fabs(q[u4]), r = ldsd(rb + 8 * j);
-                const double e = div_nr(min_f64(X, r), max_f64(X, r));      // exp(-|m|), m = out_llr - R (:244-245)
+                const double e = div_nr0(min_f64(X, r), max_f64(X, r));     // exp(-|m|), m = out_llr - R (:244-245); 2e-15 on m
                 const double se = X >= r ? e : -e;               // ... with the sign of m
                 U *= __builtin_copysign(1.0 - e, se);
                 W *= 1.0 + e;

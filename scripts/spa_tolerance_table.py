@@ -6,8 +6,9 @@ the same thing.)
 Inputs: tests/golden/ldpc_c4y.npz -- the BASELINE config-4 chain at Eb/N0 = 8 / 9 / 10 dB, 24 blocks each, decoded by the live
 reference (tests/golden/make_golden.py gen_ldpc_c4y).  Decoders compared with it:
   oracle        oracle/cpx_oracle.c (glibc tanh / atanh, the reference's operation order)          -- CPU, always
-  engine fast   the library's default row: one division per edge, exact-order redo near saturation  -- GPU
-  engine exact  CPX_LDPC_SPA=exact: every row in the reference's operation order                    -- GPU (child process)
+  engine ratio  the library's default: likelihood-ratio state, no exp / log inside an iteration     -- GPU (child process)
+  engine log    CPX_LDPC_SPA=log: the log-domain row, one division per edge, exact-order redo near saturation (round 3)
+  engine exact  CPX_LDPC_SPA=exact: every row in the reference's operation order
 
     python scripts/spa_tolerance_table.py --out gpurun_out/r04           (GPU box;  --cpu-only in the build container)
 
@@ -59,16 +60,16 @@ def main():
         dec_or[t], out_or[t], its_or[t] = d.T, o.T, i
     decoders = {"oracle": (dec_or, out_or, its_or)}
     if not a.cpu_only:
-        for mode in ("fast", "exact"):
-            tmp = "/tmp/spa_tol_%s.npz" % mode
+        for mode, label in (("", "ratio (default)"), ("log", "log-domain fast row"), ("exact", "exact")):
+            tmp = "/tmp/spa_tol_%s.npz" % (mode or "ratio")
             env = dict(os.environ)
-            if mode == "exact":
-                env["CPX_LDPC_SPA"] = "exact"
+            if mode:
+                env["CPX_LDPC_SPA"] = mode
             else:
                 env.pop("CPX_LDPC_SPA", None)
             subprocess.check_call([sys.executable, os.path.abspath(__file__), "--child", tmp], env=env)
             z = np.load(tmp)
-            decoders["engine " + mode] = ({t: z[t + "__dec"] for t in tags}, {t: z[t + "__out"] for t in tags},
+            decoders["engine " + label] = ({t: z[t + "__dec"] for t in tags}, {t: z[t + "__out"] for t in tags},
                                           {t: z[t + "__its"] for t in tags})
     table = {"fixture": "tests/golden/ldpc_c4y.npz (live reference, 3 x 24 blocks of the (1944,1296) code, 64-QAM chain, SPA, 50 iterations)",
              "bands": BANDS, "iteration_buckets": ITS, "decoders": {}}
