@@ -61,12 +61,7 @@ struct ResParams {
     int rstride;             // doubles per row of R: max check degree, made odd (an even stride of 8-byte words is an LDS bank conflict)
     int n_v, n_c, cpad, vpad, max_iter;
     int roff, ctl_off;       // LDS byte offsets of R and of the control words
-    // ratio-domain sum-product (ldpc_resident_ratio_kernel) and the redo launch behind it
-    double *e0;              // [workgroups][n_v] exp(llr) of the block a workgroup is decoding (L2-resident scratch)
-    int *redo_count;         // blocks the ratio kernel hands back (a NaN, a saturated iteration): count ...
-    int *redo_list;          // ... and block indices [B]
-    const int *blist;        // ldpc_resident_kernel: decode blocks blist[0 .. *bcount) instead of 0 .. B-1 (null: all)
-    const int *bcount;
+    double *e0;              // ldpc_resident_ratio_kernel: [workgroups][n_v] exp(llr) of the block a workgroup is decoding (L2-resident scratch)
 };
 
 // LDS accesses by absolute byte address: the kernel declares no static LDS, so its dynamic segment starts at address 0
@@ -224,8 +219,7 @@ __global__ __launch_bounds__(1024, 6) void ldpc_resident_kernel(ResParams p) {
     // next s_barrier while lane 0 was still retiring): wave 0 met the barrier twice per block and the kernel hung.
     auto pop = [&]() {                                           // thread 0 only
         const int t = atomicAdd(p.queue, 1);
-        if (p.blist) ctl[2] = t < *p.bcount ? p.blist[t] : -1;   // the redo launch behind the ratio kernel: listed blocks only
-        else ctl[2] = t < p.B ? t : -1;
+        ctl[2] = t < p.B ? t : -1;
     };
     if (tid == 0) {
         stsd(8 * p.n_v, __builtin_huge_val());                   // dummy Q (row padding)
@@ -345,7 +339,9 @@ __global__ __launch_bounds__(1024, 6) void ldpc_resident_kernel(ResParams p) {
 // live-reference blocks of ldpc_c4y.npz with it in NumPy: dec_word, iteration counts, banded contract all met; near rows 0.03 - 0.7 %).
 // Range: the product of a variable is taken over its factors above and below 1 separately; if either leaves the normal range, or the
 // ratio leaves (2^-990, 2^990), the variable is summed through logarithms and, beyond +-680, stored as the LLR itself (ratio_encode).
-// What the ratio domain cannot carry is handed back (redo_list) and decoded again by ldpc_resident_kernel, from the untouched LLRs:
+// What the ratio domain cannot carry is decoded again at once, by the same workgroup, from the untouched LLRs, with the log-domain row
+// (spa_block_log: the loop of ldpc_resident_kernel<SPA>; a second launch for these blocks ended on its longest block, 0.2 - 0.6 ms of a
+// 4.6 - 8 ms decode, here the queue absorbs them like any other slow block):
 //   * a NaN (an LLR of exactly zero makes one with a SIGN the reference's dec_word reads, see ldpc_dev.h; a NaN input);
 //   * an iteration in which more than half of the rows are near saturation: there the result is decided by how the reference's own
 //     operation sequence rounds (+-500 against 37.4), which the exact-order row reproduces only from log-domain inputs.  Correctly
@@ -439,6 +435,29 @@ __device__ __forceinline__ void var_node_ratio(const ResParams &p, int v, double
     stsd(8 * v, X < 1.0 ? -X : X);
 }
 
+// One block in the log domain inside the ratio kernel: the block loop of ldpc_resident_kernel<SPA, 0> (same functions, same order).
+// Returns the executed iterations; the a-posteriori LLRs are left in the Q slots.
+__device__ __forceinline__ int spa_block_log(const ResParams &p, const double *__restrict__ in, int *ctl, int tid, int nt) {
+    for (int v = tid; v < p.n_v; v += nt) stsd(8 * v, clip_nan(in[v], -500.0, 500.0));       // (clipped in place by the first attempt; a NaN stays)
+    for (int e = tid; e < p.n_r; e += nt) stsd(p.roff + 8 * e, 0.0);
+    if (tid == 0) {
+        for (int i = 0; i < 5; i++) stsd(p.roff + 8 * (p.n_r + i), 0.0);                      // column padding: neutral in a SUM
+        ctl[0] = 0; ctl[1] = 0;
+    }
+    __syncthreads();
+    int k = 0;
+    for (; k < p.max_iter; k++) {
+        int *flag = &ctl[k & 1];
+        for (int c = tid; c < p.n_c; c += nt) check_spa(p, c, flag);
+        __syncthreads();
+        if (!__builtin_amdgcn_readfirstlane(*flag)) break;
+        if (tid == 0) ctl[(k + 1) & 1] = 0;
+        for (int v = tid; v < p.n_v; v += nt) var_node(p, v, reinterpret_cast<const int4 *>(p.col_r + (int64_t)v * p.vpad)[0], in[v]);
+        __syncthreads();
+    }
+    return k;
+}
+
 __global__ __launch_bounds__(1024, 6) void ldpc_resident_ratio_kernel(ResParams p) {
     extern __shared__ __align__(16) char lds[];
     if ((unsigned)(uintptr_t)lds != 0u) __builtin_trap();        // absolute LDS addresses (see ldsd)
@@ -495,17 +514,20 @@ __global__ __launch_bounds__(1024, 6) void ldpc_resident_ratio_kernel(ResParams 
             for (int v = tid; v < p.n_v; v += nt) var_node_ratio(p, v, e0row[v], in);
             __syncthreads();
         }
-        // Retire: out_llrs = log X (a block that arrived as a codeword: the clipped LLRs themselves, :194)
+        if (back) k = spa_block_log(p, in, ctl, tid, nt);        // wave- and workgroup-uniform
+        // Retire: out_llrs = log X (a block that arrived as a codeword: the clipped LLRs themselves, :194; a log-domain block: Q)
         double *__restrict__ orow = p.out + (int64_t)b * p.n_v;
         int8_t *__restrict__ drow = p.dec ? p.dec + (int64_t)b * p.n_v : nullptr;
         for (int v = tid; v < p.n_v; v += nt) {
-            const double x = k == 0 ? in[v] : ratio_llr(fabs(ldsd(8 * v)));    // the same thread reloads this entry for the next block
+            const double s0 = ldsd(8 * v);                       // the same thread reloads this entry for the next block
+            const double x = back ? s0 : (k == 0 ? in[v] : ratio_llr(fabs(s0)));
             orow[v] = x;
             if (drow) drow[v] = (int8_t)(__builtin_signbit(x) ? 1 : 0);
         }
         if (tid == 0) {
             if (p.iters) p.iters[b] = k;
-            if (back) p.redo_list[atomicAdd(p.redo_count, 1)] = b;
+            if (back)
+                for (int i = 0; i < 5; i++) stsd(p.roff + 8 * (p.n_r + i), 1.0);             // column padding: neutral in a PRODUCT again
             for (int i = 0; i < 7; i++) if (i != 2) ctl[i] = 0;
             pop();
         }
@@ -850,16 +872,14 @@ bool ldpc_resident_path(const cpx_ldpc *c, double *d_llr, int64_t B, int alg, in
     // persistent grid: as many workgroups as fit a compute unit (LDS, 2048 threads, 16 workgroups), no more than blocks
     const int per_cu = std::max(1, std::min({(int)(LDS_BYTES / lds), 2048 / threads, 16}));
     const int grid = (int)std::min<int64_t>((int64_t)device_cus() * per_cu, B);
-    const bool ratio = !f32 && alg == CPX_LDPC_SPA && !ldpc_spa_exact() && !ldpc_spa_log() && mode != 3;   // ldpc_resident_ratio_kernel + redo launch
+    const bool ratio = !f32 && alg == CPX_LDPC_SPA && !ldpc_spa_exact() && !ldpc_spa_log() && mode != 3;   // ldpc_resident_ratio_kernel
     char *slab = nullptr;
     const size_t sz_stage = block_major ? 0 : (sizeof(double) * (size_t)(B * c->n_v) + 255) & ~(size_t)255;
-    const size_t sz_list = ratio ? (sizeof(int) * (size_t)B + 255) & ~(size_t)255 : 0;
     const size_t sz_e0 = ratio ? sizeof(double) * (size_t)grid * (size_t)c->n_v : 0;
-    if ((*rc = workspace(st, 0, sz_stage + 256 + sz_list + sz_e0, (void **)&slab))) return true;
+    if ((*rc = workspace(st, 0, sz_stage + 256 + sz_e0, (void **)&slab))) return true;
     ResParams p;
     p.llr = d_llr; p.iters = d_iters; p.queue = (int *)(slab + sz_stage); p.clipped = d_clipped; p.nanflags = nanflags;
-    p.redo_count = p.queue + 2; p.redo_list = (int *)(slab + sz_stage + 256); p.e0 = (double *)(slab + sz_stage + 256 + sz_list);
-    p.blist = nullptr; p.bcount = nullptr;
+    p.e0 = (double *)(slab + sz_stage + 256);
     p.out = block_major ? d_out : (double *)slab;
     p.dec = block_major ? d_dec : nullptr;
     p.spa_exact = (!f32 && ldpc_spa_exact()) ? 1 : 0;
@@ -870,18 +890,11 @@ bool ldpc_resident_path(const cpx_ldpc *c, double *d_llr, int64_t B, int alg, in
     p.max_iter = n_iters;
     p.roff = f32 ? res_roff(c->n_v) / 2 : res_roff(c->n_v);
     p.ctl_off = (int)(lds - 64);
-    if (hipMemsetAsync(p.queue, 0, 4 * sizeof(int), st) != hipSuccess) { set_error("ldpc: hipMemsetAsync failed"); *rc = CPX_EHIP; return true; }
+    if (hipMemsetAsync(p.queue, 0, sizeof(int), st) != hipSuccess) { set_error("ldpc: hipMemsetAsync failed"); *rc = CPX_EHIP; return true; }
     const int cq = c->cpad / 4;
     int lrc;
     if (ratio) {
-        // every block through the ratio-domain kernel; the few it hands back (a NaN, a saturated iteration) are decoded again, from the
-        // LLRs it left untouched, by the log-domain kernel on a small grid (no block listed: its workgroups leave at once)
         lrc = launch_ratio(p, grid, threads, lds, st);
-        if (!lrc) {
-            ResParams q = p;
-            q.queue = p.queue + 1; q.blist = p.redo_list; q.bcount = p.redo_count;
-            lrc = launch_resident<CPX_LDPC_SPA, 0>(q, std::min(grid, 64), threads, lds, st);
-        }
     } else if (f32) lrc = alg == CPX_LDPC_SPA ? launch_resident_f32<CPX_LDPC_SPA>(p, grid, threads, lds, st)
                                        : launch_resident_f32<CPX_LDPC_MSA>(p, grid, threads, lds, st);
     else if (alg == CPX_LDPC_SPA) lrc = launch_resident<CPX_LDPC_SPA, 0>(p, grid, threads, lds, st);

@@ -238,7 +238,7 @@ int cpx_ldpc_bp_decode_batch_bm_dev(const cpx_ldpc *c, double *d_llr, int64_t B,
  * HBM path (csrc/ldpc.hip).  Min-sum: the same arithmetic, identical results.  Sum-product: the tiled path and "resident-log"
  * share the log-domain row (identical results); the default resident kernel keeps the state as likelihood ratios -- no exp / log
  * inside an iteration, same dec_word, iteration counts and out_llrs contract, blocks it cannot carry (a NaN, an
- * iteration saturated in more than half of its rows) decoded again by the log-domain kernel (tests/test_ldpc_resident_gpu.py).
+ * iteration saturated in more than half of its rows) decoded again in place with the log-domain row (tests/test_ldpc_resident_gpu.py).
  * cpx_ldpc_set_path("auto" | "tiled" | "resident" | "resident-log") forces one (initial value: environment variable
  * CPX_LDPC_PATH); the "resident" modes fail with CPX_EINVAL instead of falling back.  cpx_last_kernel names what ran. */
 int cpx_ldpc_set_path(const char *mode);
