@@ -7,7 +7,8 @@ likelihood ratios X_v = exp(out_llr_v), rho_cj = exp(R_cj), so an iteration has 
     rho_j <- (W u_j + U w_j) / (W u_j - U w_j) (= exp(2 atanh(prod_{i != j} tanh(m_i / 2))), the one-division row of ldpc_dev.h)
     X_v   <- exp(llr_v) * prod_j rho_j
 rows near saturation take the exact-order sequence in the log domain exactly as before (and store exp of the result); out_llrs of a
-retired block are llr + sum_j log(rho_j).  This script decodes the live-reference blocks of tests/golden/ldpc_c4y.npz / ldpc_c4x.npz with
+retired block are llr + sum_j log(rho_j) over the rho its last VARIABLE pass used (the kernel returns log X, the same number, and lets a
+saturated slot carry the sum itself).  This script decodes the live-reference blocks of tests/golden/ldpc_c4y.npz / ldpc_c4x.npz with
 that arithmetic in NumPy float64 and checks dec_word, the iteration counts (against the C oracle) and the banded out_llrs contract
 (tests/helpers.py spa_contract) -- i.e. whether the reformulation is numerically admissible -- before any kernel is written.
 
