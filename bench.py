@@ -2,7 +2,7 @@
 """Headline benchmark: soft-decision Viterbi, K=7 rate-1/2 (0o133, 0o171), 1024-bit blocks,
 QPSK + AWGN at Eb/N0 = 3 dB, batch 65536 codewords per GPU (BASELINE.json configs[1]).
 
-    python bench.py --gpus N --steps K --warmup W [--comm rccl|torch]
+    python bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the HIP Viterbi decoder over the whole per-GPU batch with the float64 LLRs
 already resident in HBM.  N > 1 is weak scaling, one process per GPU, every rank decodes its own 65536-codeword batch.
@@ -14,12 +14,15 @@ again with the one collective north_star names -- an RCCL all-gather of the deco
 step) on the decode stream -- in every step and reported as `value_with_gather`; `comm_world` is what RCCL itself
 reports for the communicator (ncclCommCount).
 Collectives (closing barrier, max over ranks, error-count all-reduce, the optional all-gather) go through the
-engine's own RCCL binding (``cpx_comm_*``, commpy_amd.parallel.RankComm); torch is NOT imported.  ``--comm torch``
-uses torch.distributed instead (an explicit choice: if the RCCL communicator cannot be formed the run fails).  Rank 0 prints ONE JSON line with the contract fields plus `roofline`
+engine's own RCCL binding (``cpx_comm_*``, commpy_amd.parallel.RankComm); torch is NOT imported anywhere in this file (round 5:
+the ``--comm torch`` alternative is gone -- if the RCCL communicator cannot be formed the run fails).  Rank 0 prints ONE JSON line with the contract fields plus `roofline`
 (dominant kernel as reported by the library, HIP-event timed on its own stream) and `cpu_baseline`: the UNMODIFIED reference
 timed on the host cores when it is present on the box ($CPX_REFERENCE_PATH, /root/reference, importable `commpy`; kind
 "reference"), else the C oracle -- a line-by-line port of the same function -- on >= 4096 distinct codewords (kind "port");
-the NumPy-vectorised restatement rides along as a labelled secondary.
+the NumPy-vectorised restatement rides along as a labelled secondary.  At N = 1 the line also carries `other_configs`
+(benchmarks/other_configs.py): configs[2] (turbo), one GPU's share of configs[3] (64-QAM soft demodulator -> LDPC min-sum and
+sum-product) and the soft demodulator alone, each device-resident, HIP-event timed for the same K steps and checked against
+the oracle after its timed region -- the headline fields are untouched by it (``--no-other-configs`` leaves it out).
 """
 import argparse
 import ctypes
@@ -37,7 +40,7 @@ MSG_BITS = 1024
 EBN0_DB = 3.0
 ALG_BYTES_PER_CW = 2060 * 8 + 1030 * 1      # float64 LLRs in + uint8 bits out
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: 8.0 TB/s spec
-PMC_FILE = "r04_viterbi_c2_pmc.json"        # written by scripts/collect_pmc.py from rocprofv3 passes over this script
+PMC_FILES = ("r05_viterbi_c2_pmc.json", "r04_viterbi_c2_pmc.json")   # written by scripts/collect_pmc.py from rocprofv3 passes over this script; newest first
 
 
 def synth_inputs(B, seed_msg, seed_noise):
@@ -69,18 +72,29 @@ def usable_cores():
 
 
 def _git_head():
-    """Commit the tree was taken from: `git rev-parse` here, .git_head (scripts/run_gpu_round.sh) on the GPU box, else None."""
+    """(commit, source): the commit the tree was taken from.  Where `.git` exists: `git rev-parse HEAD`, which is also written to
+    `.git_head` so that the stamp travels with the tree ("git").  On the GPU box (a snapshot without `.git`) the stamp is all there
+    is ("stamp": written by the post-commit hook scripts/install_hooks.sh installs, by scripts/run_gpu_round.sh before every
+    gpurun call, and by this function); it names a commit whose SOURCES may differ from the snapshot's only by uncommitted edits --
+    `build_id` in the same line is the digest of the sources the loaded library was really compiled from."""
     import subprocess
+    stamp = os.path.join(ROOT, ".git_head")
+    if os.path.exists(os.path.join(ROOT, ".git")):
+        try:
+            h = subprocess.run(["git", "rev-parse", "HEAD"], cwd=ROOT, capture_output=True, text=True, timeout=20).stdout.strip()
+            if h:
+                try:
+                    with open(stamp, "w") as f:
+                        f.write(h + "\n")
+                except OSError:
+                    pass
+                return h, "git"
+        except Exception:
+            pass
     try:
-        h = subprocess.run(["git", "rev-parse", "HEAD"], cwd=ROOT, capture_output=True, text=True, timeout=20).stdout.strip()
-        if h:
-            return h
-    except Exception:
-        pass
-    try:
-        return open(os.path.join(ROOT, ".git_head")).read().strip() or None
+        return (open(stamp).read().strip() or None), "stamp"
     except OSError:
-        return None
+        return None, None
 
 
 def _find_reference():
@@ -306,8 +320,8 @@ def main():
                     help="accepted for older command lines; N > 1 always times both regions (decode alone -> value, decode + "
                          "RCCL all-gather of the decoded bits on the decode stream -> value_with_gather)")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the second (decode + all-gather) timed region")
-    ap.add_argument("--comm", choices=("rccl", "torch"), default="rccl",
-                    help="collectives of the N > 1 run: the engine's own RCCL binding (default) or torch.distributed")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="N = 1: skip the `other_configs` lines (turbo, LDPC chain, soft demodulator; ~15 s)")
     ap.add_argument("--synth", choices=("device", "host"), default="device",
                     help="where the synthetic input is generated: on the GPU (Philox bits/noise, device encoder and "
                          "modulator; fast, no large host arrays) or on the host (NumPy MT19937, SURVEY 8d seeds)")
@@ -323,21 +337,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     distributed = mode == "rank"
     args.gather = distributed and world > 1 and not args.no_gather
-    torch = dist = comm = None
-    if distributed and args.comm == "torch":
-        # torch first: its bundled HIP runtime (same SONAME) is then shared by libcommpy_amd.so
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    comm = None
     from commpy_amd import _lib
     lib = _lib.load()
     _lib.require_device()
     _lib.check(lib.cpx_set_device(local_rank))
     _lib.set_precision(args.precision)
-    if distributed and args.comm == "rccl":
-        # the engine's own RCCL binding; if the communicator cannot be formed the run FAILS (a silent switch to
-        # torch.distributed would measure torch's collectives under the engine's name -- use --comm torch for those)
+    if distributed:
+        # the engine's own RCCL binding (the only collective path: north_star allows no PyTorch); if the communicator cannot
+        # be formed the run FAILS
         from commpy_amd.parallel import RankComm
         comm = RankComm(rank, world)
 
@@ -357,35 +365,19 @@ def main():
     h_tr, h_md = tr._device_handle(), md._device_handle()
 
     d_full = ctypes.c_void_p()                                      # --gather: [world][B][L] uint8, every rank's bits
-    if dist is not None:
-        # a real (non-null) torch stream made current: the C-ABI launches on it and torch.distributed's collectives
-        # (closing barrier, error-count all-reduce) are ordered after the decodes (the null stream handle would make
-        # the library fall back to its own stream, unordered with respect to them)
-        tstream = torch.cuda.Stream()
-        torch.cuda.set_stream(tstream)
-        stream = ctypes.c_void_p(tstream.cuda_stream)
-        t_y = torch.empty((B, nsym, 2), dtype=torch.float64, device="cuda")
-        t_llr = torch.empty((B, LEN), dtype=torch.float64, device="cuda")
-        t_full = torch.empty((world if args.gather else 1, B, L), dtype=torch.uint8, device="cuda")
-        t_bits = t_full[rank if args.gather else 0]
-        d_y, d_llr, d_bits = (ctypes.c_void_p(t.data_ptr()) for t in (t_y, t_llr, t_bits))
-        d_full = ctypes.c_void_p(t_full.data_ptr())
-        sync = torch.cuda.synchronize
-        barrier = dist.barrier
-    else:
-        stream = None
-        d_y, d_llr = ctypes.c_void_p(), ctypes.c_void_p()
-        _lib.check(lib.cpx_malloc(ctypes.byref(d_y), B * nsym * 16))
-        _lib.check(lib.cpx_malloc(ctypes.byref(d_llr), B * LEN * 8))
-        _lib.check(lib.cpx_malloc(ctypes.byref(d_full), (world if args.gather else 1) * B * L))
-        d_bits = ctypes.c_void_p(d_full.value + (rank * B * L if args.gather else 0))   # this rank's slot (in-place gather)
+    stream = None                                                   # the library's own stream (cpx_default_stream)
+    d_y, d_llr = ctypes.c_void_p(), ctypes.c_void_p()
+    _lib.check(lib.cpx_malloc(ctypes.byref(d_y), B * nsym * 16))
+    _lib.check(lib.cpx_malloc(ctypes.byref(d_llr), B * LEN * 8))
+    _lib.check(lib.cpx_malloc(ctypes.byref(d_full), (world if args.gather else 1) * B * L))
+    d_bits = ctypes.c_void_p(d_full.value + (rank * B * L if args.gather else 0))   # this rank's slot (in-place gather)
 
-        def sync():
-            _lib.check(lib.cpx_stream_sync(None))
+    def sync():
+        _lib.check(lib.cpx_stream_sync(None))
 
-        def barrier():
-            if comm is not None:
-                comm.barrier()                                      # RCCL all-reduce of one word + stream sync
+    def barrier():
+        if comm is not None:
+            comm.barrier()                                          # RCCL all-reduce of one word + stream sync
 
     if args.synth == "host":
         _lib.check(lib.cpx_memcpy_h2d(d_y, _lib.ptr(y), y.nbytes))
@@ -462,10 +454,7 @@ def main():
             _lib.check(lib.cpx_timer_start(tmr, stream))
         _lib.check(lib.cpx_viterbi_decode_batch_dev(h_tr, d_llr, B, LEN, L, T, TB, 1, d_bits, stream))
         if gather:                                                  # the collective north_star names, on the decode stream
-            if comm is not None:
-                comm.allgather_dev(d_bits, d_full, B * L, stream)
-            else:
-                dist.all_gather_into_tensor(t_full.view(-1), t_bits.reshape(-1))
+            comm.allgather_dev(d_bits, d_full, B * L, stream)
         if tmr is not None:
             _lib.check(lib.cpx_timer_stop(tmr, stream))
 
@@ -473,8 +462,7 @@ def main():
         """W warm-up steps, (N > 1: an untimed rehearsal of the whole region,) then EXACTLY K steps between barrier +
         synchronize on both sides; returns (elapsed seconds, MAX over ranks; per-step event times of this rank)."""
         warm = make_timers(1)[0]
-        # warm-up runs exactly what a timed step runs, event records included (the first hipEventRecord of a process
-        # that loaded torch's HIP runtime cost ~70 ms here, which must not land inside the K timed steps)
+        # warm-up runs exactly what a timed step runs, event records included
         for _ in range(max(args.warmup, 1)):
             step(warm, gather)
         barrier(); sync()
@@ -503,10 +491,6 @@ def main():
             print("debug[gather=%s]: per-step launch ms " % gather + " ".join("%.3f" % v for v in ms), file=sys.stderr)
         if comm is not None:
             el = float(comm.allreduce(np.array([el]), "max")[0])                    # MAX over ranks
-        elif dist is not None:
-            tmax = torch.tensor([el], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            el = float(tmax.item())
         for tmr in tmrs + [warm]:
             lib.cpx_timer_destroy(tmr)
         return el, ms
@@ -521,8 +505,6 @@ def main():
         nr, nl, fr = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         _lib.check(lib.cpx_comm_info(comm.h, ctypes.byref(nr), ctypes.byref(nl), ctypes.byref(fr)))
         comm_world = {"nranks": nr.value, "this_rank": fr.value, "source": "ncclCommCount / ncclCommUserRank"}
-    elif dist is not None:
-        comm_world = {"nranks": dist.get_world_size(), "this_rank": dist.get_rank(), "source": "torch.distributed"}
 
     # ---- correctness of what was timed: BER vs the messages, parity vs the oracle on a sample ----
     bits = np.empty((B, L), dtype=np.uint8)
@@ -532,11 +514,7 @@ def main():
 
     def allreduce_i64(v):
         v = np.ascontiguousarray(v, dtype=np.int64)
-        if comm is not None:
-            return comm.allreduce(v)
-        t = torch.tensor(v, dtype=torch.int64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        return t.cpu().numpy()
+        return comm.allreduce(v)
 
     if world > 1:
         # error counts of all shards: an RCCL all-reduce of int64 counters (links.py:252-260), outside the timed region
@@ -587,21 +565,23 @@ def main():
         # kernel and batch; otherwise null.
         traffic = traffic_src = valu = None
         build = _lib.build_id()
-        try:
-            with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
-                tj = json.load(f)
-            same = (tj.get("batch") == B and kernel_name.split("<")[0] in tj.get("kernel", "?") and
-                    args.precision == "fp64-parity" and                  # (the counters were taken in parity mode)   rocprofv3 prints the
-                    # template arguments as numbers ("<6, 109u, 79u, 1, 28>"): the kernel's base name and the batch identify it
-                    bool(build.get("viterbi")) and (tj.get("build_id") or {}).get("viterbi") == build.get("viterbi"))
-            if same:
-                traffic = tj["traffic_bytes_per_launch"]
-                traffic_src = ("profiles/%s (rocprofv3 FETCH_SIZE / WRITE_SIZE passes; gfx950 correction as in the file; "
-                               "recorded at git %s with the same Viterbi sources, build id %s)"
-                               % (PMC_FILE, str(tj.get("git_head"))[:12], build.get("viterbi")))
-                valu = tj.get("valu")
-        except (OSError, ValueError, KeyError):
-            pass
+        for pmc_file in PMC_FILES:
+            try:
+                with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
+                    tj = json.load(f)
+                same = (tj.get("batch") == B and kernel_name.split("<")[0] in tj.get("kernel", "?") and
+                        args.precision == "fp64-parity" and                  # (the counters were taken in parity mode)   rocprofv3 prints the
+                        # template arguments as numbers ("<6, 109u, 79u, 1, 28>"): the kernel's base name and the batch identify it
+                        bool(build.get("viterbi")) and (tj.get("build_id") or {}).get("viterbi") == build.get("viterbi"))
+                if same:
+                    traffic = tj["traffic_bytes_per_launch"]
+                    traffic_src = ("profiles/%s (rocprofv3 FETCH_SIZE / WRITE_SIZE passes; gfx950 correction as in the file; "
+                                   "recorded at git %s with the same Viterbi sources, build id %s)"
+                                   % (pmc_file, str(tj.get("git_head"))[:12], build.get("viterbi")))
+                    valu = tj.get("valu")
+                    break
+            except (OSError, ValueError, KeyError):
+                pass
         out = {
             "metric": "decoded info-bits/s at fixed Eb/N0 (Viterbi K=7 r=1/2, 1024b); BER match",
             "value": value, "unit": "info-bits/s", "n_gpus": world if distributed else 1, "steps": args.steps,
@@ -615,9 +595,9 @@ def main():
                        "parallelism": "codewords sharded x%d, no data-path collective in `value`%s" % (
                            world, "; `value_with_gather`: + one RCCL all-gather of the decoded bits (%d B per rank) per step"
                            % (B * L) if args.gather else ""),
-                       "collectives": ("engine RCCL binding (cpx_comm_*)" if comm is not None else
-                                       "torch.distributed (nccl)" if dist is not None else "none (single process)")},
-            "ber": ber, "oracle_mismatched_bits": mism, "oracle_sample_codewords": checked, "kernel_path_check": path_check, "build_id": build, "git_head": _git_head(),
+                       "collectives": "engine RCCL binding (cpx_comm_*)" if comm is not None else "none (single process)"},
+            "ber": ber, "oracle_mismatched_bits": mism, "oracle_sample_codewords": checked, "kernel_path_check": path_check, "build_id": build,
+            "git_head": _git_head()[0], "git_head_source": _git_head()[1],
             "demod_max_abs_err_vs_oracle": demod_err,
             # the kernel is bound by VALU issue, not by HBM: achieved / peak / frac are the HBM figures the
             # contract asks for, `valu` carries the ceiling that actually binds (from the PMC passes in profiles/)
@@ -650,6 +630,15 @@ def main():
                 "note": "HIP events on rank 0 around decode + ncclAllGather (in place, [world][B][L] uint8 on every GPU)"}
             out["comm_world"] = comm_world
             out["launcher"] = "bench.py (subprocess per rank)" if os.environ.get("CPX_COMM_NONCE") else "external (RANK/WORLD_SIZE set)"
+        # the other decoders north_star names, on their own configurations (N = 1 only; the headline fields above are final)
+        out["other_configs"] = None
+        if world == 1 and not args.no_other_configs and args.precision == "fp64-parity":
+            for d in (d_y, d_llr, d_full):
+                _lib.check(lib.cpx_free(d))
+            d_y = d_llr = d_full = None
+            from benchmarks import other_configs
+            out["other_configs"] = other_configs.run(lib, args.steps, args.warmup,
+                                                     log=(lambda m: print(m, file=sys.stderr)) if os.environ.get("BENCH_DEBUG") else None)
         if not args.no_cpu_baseline and world == 1:                # reported at N = 1 only; the other ranks would idle
             out["cpu_baseline"] = cpu_baseline(tr, llr_s, bits[:ns, :].astype(np.int64))
         else:
@@ -657,9 +646,6 @@ def main():
     if comm is not None:
         comm.barrier()
         comm.close()
-    elif dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
     if out is not None:
         print(json.dumps(out), flush=True)
 

@@ -210,21 +210,9 @@ def bench_config4(lib, scale):
 
 
 def bench_turbo(lib, scale, which, states=4):
-    import warnings
-    from commpy_amd.channelcoding import RandInterlv, Trellis
-    from commpy_amd.devicelink import turbo_encode_gpu
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        # 4 states: BASELINE config 3;  8 states: the LTE / UMTS constituent code (1, 15/13) (SURVEY 8d "optional 8-state")
-        tr = Trellis(np.array([2]), np.array([[1, 7]]), 5, "rsc") if states == 4 else Trellis(np.array([3]), np.array([[1, 0o15]]), 0o13, "rsc")
+    from benchmarks.other_configs import turbo_workload          # the same workload bench.py's `other_configs` line times
     N, B = 1024, int(16384 * scale)
-    il = RandInterlv(N, 1234)
-    rs = np.random.RandomState(20)
-    msgs = rs.randint(0, 2, (B, N))
-    s, p1, p2 = (a[:, :N] * 2.0 - 1 for a in turbo_encode_gpu(msgs, tr, tr, il))   # B distinct codewords (device encoder)
-    nv = 1 / (2 * (1.0 / 3) * 10 ** (1.5 / 10.0))
-    nrs = np.random.RandomState(21)
-    s, p1, p2 = (a + np.sqrt(nv) * nrs.randn(B, N) for a in (s, p1, p2))
+    tr, il, msgs, s, p1, p2, nv = turbo_workload(B, N, states)
     dev = Dev(lib)
     d_s, d_p1, d_p2 = dev.put(s), dev.put(p1), dev.put(p2)
     d_perm = dev.put(np.asarray(il.p_array, dtype=np.int32))

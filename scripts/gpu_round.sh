@@ -6,7 +6,7 @@
 #             x(ldpc PMC passes) r(octx marker trace of the host-API benchmark, CPX_TRACE=1)
 #             c(alibration of FETCH_SIZE / WRITE_SIZE on known byte counts, scripts/micro/fetch_calib.py)
 #             f(uzz: scripts/fuzz_gpu.py for 90 s) L(ong run: bench.py --steps 500) T(olerance table of the sum-product decoder)
-TAG=${1:-r04}
+TAG=${1:-r05}
 SEC=${2:-tsbdklvu}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
