@@ -27,43 +27,15 @@ from commpy_amd import _lib  # noqa: E402
 HBM_PEAK = 8000.0
 
 
-class Dev:
-    """Tiny device-buffer helper on top of the C-ABI."""
-
-    def __init__(self, lib):
-        self.lib = lib
-        self.bufs = []
-
-    def put(self, arr):
-        arr = np.ascontiguousarray(arr)
-        p = ctypes.c_void_p()
-        _lib.check(self.lib.cpx_malloc(ctypes.byref(p), arr.nbytes))
-        _lib.check(self.lib.cpx_memcpy_h2d(p, _lib.ptr(arr), arr.nbytes))
-        self.bufs.append(p)
-        return p
-
-    def empty(self, nbytes):
-        p = ctypes.c_void_p()
-        _lib.check(self.lib.cpx_malloc(ctypes.byref(p), nbytes))
-        self.bufs.append(p)
-        return p
-
-    def get(self, p, shape, dtype):
-        out = np.empty(shape, dtype=dtype)
-        _lib.check(self.lib.cpx_memcpy_d2h(_lib.ptr(out), p, out.nbytes))
-        return out
-
-    def free(self):
-        for p in self.bufs:
-            self.lib.cpx_free(p)
-        self.bufs = []
+from benchmarks.other_configs import Dev, warm  # noqa: E402  (the helpers of bench.py's `other_configs` lines)
 
 
 def timeit(lib, fn, steps=5, warmup=1):
+    """Mean / min milliseconds of `steps` calls, HIP events on the launch stream, after a warm-up that also covers the clock ramp of a
+    fresh process (round 5; round 4 timed 3 - 5 calls after ONE warm-up call and read up to 9 % high)."""
     tm = ctypes.c_void_p()
     _lib.check(lib.cpx_timer_create(ctypes.byref(tm)))
-    for _ in range(warmup):
-        fn()
+    warm(lib, fn, warmup)
     ms = []
     for _ in range(steps):
         _lib.check(lib.cpx_timer_start(tm, None))
@@ -281,19 +253,20 @@ def bench_viterbi_k9(lib, scale):
 
 
 def bench_viterbi_small(lib, scale):
-    from commpy_amd.channelcoding import Trellis, conv_encode_batch
+    """BASELINE config 1, end to end on the device (round 5): Philox messages -> conv_encode('term') -> cpx_bsc_dev(p = 0.05) -> hard
+    Viterbi (commpy_amd.devicelink.DeviceBscLink); the decode alone is what is timed."""
+    from commpy_amd.channelcoding import Trellis
+    from commpy_amd.devicelink import DeviceBscLink
     tr = Trellis(np.array([2]), np.array([[5, 7]]))
     B = int((1 << 20) * scale)
-    rs = np.random.RandomState(1)
-    coded = conv_encode_batch(rs.randint(0, 2, (B, 64)), tr).astype(np.float64)
-    rx = np.where(rs.rand(*coded.shape) <= 0.05, 1 - coded, coded)
-    dev = Dev(lib)
-    d_in, d_out = dev.put(rx), dev.empty(B * 66)
-    h = tr._device_handle()
-    ms, _ = timeit(lib, lambda: _lib.check(lib.cpx_viterbi_decode_batch_dev(h, d_in, B, 132, 66, 67, 10, 0, d_out, None)))
-    emit(_lib.last_kernel(), "config 1: K=3 [[5,7]] 64-bit blocks, hard/BSC(0.05), B=%d" % B, B * 64,
-         "info-bits", ms, B * (132 * 8 + 66), "valu")
-    dev.free()
+    link = DeviceBscLink(tr, 64, tb_depth=10, seed=1)
+    errs = link.run_batch(0.05, B)                                 # generate + decode + count once: the BER of what is timed below
+    ms, _ = timeit(lib, lambda: link.decode(B))
+    emit(_lib.last_kernel(), "config 1: K=3 [[5,7]] 64-bit blocks, hard/BSC(0.05), device-generated, B=%d" % B, B * 64,
+         "info-bits", ms, B * (link.ncoded * 8 + link.L), "valu", {"ber": float(errs.sum()) / (B * 64.0)})
+    ms, _ = timeit(lib, lambda: link.generate(0.05, B))
+    emit("random_bits + conv_encode_ff + binary_channel_kernel<false>", "config 1 generator: messages, encoder, BSC on the device, B=%d" % B,
+         B * 64, "info-bits", ms, B * (64 + 2 * link.ncoded + 8 * link.ncoded), "hbm", dtype="u8")
 
 
 def bench_encoders(lib, scale):

@@ -95,11 +95,23 @@ class Timers:
         return np.asarray(out, dtype=np.float64)
 
 
-def time_steps(lib, fn, steps, warmup):
-    """`warmup` untimed calls, then `steps` calls of fn(), each inside its own event pair; per-step milliseconds."""
+def warm(lib, fn, warmup, min_busy_s=0.03):
+    """`warmup` untimed calls, then more of them until the GPU has been busy for `min_busy_s`: a fresh process raises its clock over
+    the first ~20 ms of work (bench.py's per-step times fall from 1.65 to 1.53 ms over a dozen launches), and W calls of a 0.25 ms
+    kernel are not that -- round 4's builder-run lines timed 3 steps after 1 warm-up call and read 4.28 ms where this reads 3.9."""
     for _ in range(max(warmup, 1)):
         fn()
     _lib.check(lib.cpx_stream_sync(None))
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < min_busy_s:
+        for _ in range(4):
+            fn()
+        _lib.check(lib.cpx_stream_sync(None))
+
+
+def time_steps(lib, fn, steps, warmup):
+    """Warm-up (see warm), then `steps` calls of fn(), each inside its own event pair; per-step milliseconds."""
+    warm(lib, fn, warmup)
     tm = Timers(lib, steps)
     for i in range(steps):
         tm.start(i)
@@ -222,10 +234,11 @@ def run_config4(lib, steps, warmup, B=32768, ebn0=8.0, n_check=24, big_rotation_
 
         for alg, name in ((1, "MSA"), (0, "SPA")):
             # one step = demodulator (writes the LLRs the decoder then clips in place, ldpc.py:186) + decoder; an event pair each
-            for _ in range(max(warmup, 1)):
+            def chain():
                 _lib.check(lib.cpx_demod_soft_scaled_dev(h_md, d_y, B * nsym, float(N0), -1.0, d_neg, None))
                 _lib.check(lib.cpx_ldpc_bp_decode_batch_bm_dev(code, d_neg, B, alg, 50, d_dec, d_out, d_it, None))
-            _lib.check(lib.cpx_stream_sync(None))
+
+            warm(lib, chain, warmup)
             tm = Timers(lib, 2 * steps)
             for i in range(steps):
                 tm.start(2 * i)
@@ -241,10 +254,15 @@ def run_config4(lib, steps, warmup, B=32768, ebn0=8.0, n_check=24, big_rotation_
             its = dev.get(d_it, (B,), np.int32)
             dec = dev.get(d_dec, (B, n), np.int8)
             o_chk = dev.get(d_out, (ncheck, n), np.float64)
-            # parity: the first blocks through the oracle's demodulator AND decoder (bits and iteration counts exact; LLRs: MSA 1e-5,
-            # SPA the banded contract)
+            # parity, kernel by kernel on the SAME inputs: the LLRs the demodulator handed over (read back: the decoder has clipped them
+            # in place, which the oracle's own clip repeats) against the oracle's demodulator, and the decoder's outputs against the
+            # oracle's decoder fed with exactly those LLRs -- bits and iteration counts exact; LLRs: MSA 1e-5, SPA the banded contract.
+            # (Feeding the oracle decoder the ORACLE's LLRs instead compares two decodes of inputs 3e-14 apart: at 8 dB min-sum leaves
+            # most blocks unconverged and amplifies that to 5e-2 over 50 iterations.)
             t0 = time.perf_counter()
-            want_dec, want_out, want_it = oracle.ldpc_bp_decode(llr_chk.copy(), p, name, 50, return_iters=True)
+            llr_eng = dev.get(d_neg, (ncheck * n,), np.float64)
+            demod_err = float(np.max(np.abs(llr_eng - np.clip(llr_chk, -500.0, 500.0))))
+            want_dec, want_out, want_it = oracle.ldpc_bp_decode(llr_eng.copy(), p, name, 50, return_iters=True)
             want_dec, want_out = np.atleast_2d(want_dec.T), np.atleast_2d(want_out.T)     # [blocks][n]
             bits_ok = bool(np.array_equal(want_dec, dec[:ncheck]))
             its_ok = bool(np.array_equal(want_it, its[:ncheck]))
@@ -258,8 +276,10 @@ def run_config4(lib, steps, warmup, B=32768, ebn0=8.0, n_check=24, big_rotation_
                 detail = {"contract": "tests/helpers.py::spa_contract (|LLR|<10: 1e-5; [10,26): 99.95 % within 1e-5, none beyond 2e-4; "
                                       ">=26: sign and finiteness)", "max_abs_llr_err_below_10": float(np.max(np.abs(want_out[below] - o_chk[below]))) if below.any() else 0.0,
                           "violation": why}
-            parity = {"vs": "oracle demodulate + ldpc_bp_decode (modulation.py:100-141, ldpc.py:144-254)", "blocks": int(ncheck),
-                      "dec_word_equal": bits_ok, "iterations_equal": its_ok, "llr_ok": llr_ok, "ok": bits_ok and its_ok and llr_ok,
+            parity = {"vs": "oracle ldpc_bp_decode on the LLRs the device demodulator produced (ldpc.py:144-254); those LLRs vs oracle demodulate "
+                            "(modulation.py:100-141)", "blocks": int(ncheck),
+                      "dec_word_equal": bits_ok, "iterations_equal": its_ok, "llr_ok": llr_ok, "demod_max_abs_err": demod_err,
+                      "ok": bits_ok and its_ok and llr_ok and demod_err <= 1e-5,
                       "oracle_s": round(time.perf_counter() - t0, 2)}
             parity.update(detail)
             E = 7128

@@ -99,6 +99,8 @@ SYMBOLS = {
     "cpx_modulate_dev": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "cpx_awgn_dev": (c_int, [c_void_p, c_int64, c_double, c_double, c_uint64, c_uint64, c_void_p, c_void_p]),
     "cpx_scale_f64_dev": (c_int, [c_void_p, c_int64, c_double, c_void_p, c_void_p]),
+    "cpx_bsc_dev": (c_int, [c_void_p, c_int64, c_double, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p]),
+    "cpx_bec_dev": (c_int, [c_void_p, c_int64, c_double, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p]),
     "cpx_count_errors_dev": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     "cpx_turbo_encode_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_int64, c_int, c_void_p]),

@@ -59,6 +59,7 @@ int ldpc_resident_tables(::cpx_ldpc *c, const int32_t *row_ptr, const int32_t *r
 void ldpc_resident_free(::cpx_ldpc *c);
 // nanflags (min-sum only, else null): [B] bytes, written for every block: 1 = a NaN among its LLRs (ldpc.hip decodes it again)
 // block_major: d_dec / d_out are [B][n_v] (one block per row) instead of [n_v][B]
+int ldpc_forced_path();   // cpx_ldpc_set_path / CPX_LDPC_PATH: 0 auto, 1 'tiled', 2 'resident', 3 'resident-log' (forced modes never substitute another kernel)
 bool ldpc_resident_path(const ::cpx_ldpc *c, double *d_llr, int64_t B, int alg, int n_iters, int8_t *d_dec, double *d_out,
                         int block_major, int32_t *d_iters, int *d_clipped, uint8_t *nanflags, hipStream_t st, int *rc);
 

@@ -404,29 +404,30 @@ __global__ __launch_bounds__(DEMOD_BLOCK) void demod_hard_sep_kernel(const doubl
 
 // ---- constellations of more than MAX_M points (the reference takes any power of two, modulation.py:159-166) -------------------
 // The same formulas with the table read from HBM (wave-uniform addresses: scalar loads) and up to 16 bits per symbol.
-// (nb is a run-time value; the accumulators of bits nb .. 15 collect sums nobody reads.)
-template <bool RCP>
+// Round 5: the exponent is ALWAYS the reference's own division (-(a^2)) / noise_var (round 4 multiplied by a reciprocal here without
+// the "|LLR| >= 600 or non-finite -> redo point by point" rule of the LDS kernels, so near the underflow range the +-inf / NaN pattern
+// and the last bits could differ from modulation.py:134-137), and the kernel is instantiated per bit count (only NB accumulator
+// pairs exist; round 4 kept 16 pairs for every nb).  A completeness path: O(M) exponentials per symbol.
+template <int NB>
 __global__ __launch_bounds__(DEMOD_BLOCK) void demod_soft_any_kernel(const double2 *__restrict__ y, int64_t Ns,
-                                                                     const double2 *__restrict__ cst, int M, int nb,
+                                                                     const double2 *__restrict__ cst, int M,
                                                                      double noise_var, double scale, double *__restrict__ llr) {
-    const double ninv = -1.0 / noise_var;
     for (int64_t i = (int64_t)blockIdx.x * DEMOD_BLOCK + threadIdx.x; i < Ns; i += (int64_t)gridDim.x * DEMOD_BLOCK) {
         const double2 cur = y[i];
-        double num[16], den[16];
+        double num[NB], den[NB];
 #pragma unroll
-        for (int b = 0; b < 16; b++) { num[b] = 0.0; den[b] = 0.0; }
+        for (int b = 0; b < NB; b++) { num[b] = 0.0; den[b] = 0.0; }
         for (int m = 0; m < M; m++) {
             const double2 c = cst[m];
             const double a = hypot(cur.x - c.x, cur.y - c.y);       // abs(current_symbol - symbol)
-            const double e = exp(RCP ? (a * a) * ninv : (-(a * a)) / noise_var);   // (:134,136)
+            const double e = exp((-(a * a)) / noise_var);           // (:134,136)
 #pragma unroll
-            for (int b = 0; b < 16; b++) {
+            for (int b = 0; b < NB; b++) {
                 if ((m >> b) & 1) num[b] += e; else den[b] += e;
             }
         }
 #pragma unroll
-        for (int b = 0; b < 16; b++)
-            if (b < nb) llr[i * nb + nb - 1 - b] = fast_log(num[b] / den[b]) * scale;   // (:137)
+        for (int b = 0; b < NB; b++) llr[i * NB + NB - 1 - b] = fast_log(num[b] / den[b]) * scale;   // (:137)
     }
 }
 
@@ -549,10 +550,14 @@ int cpx_demod_soft_scaled_dev(const cpx_modem *m, const double *d_y, int64_t Ns,
     dim3 grid(grid_for(Ns)), block(DEMOD_BLOCK);
     const bool rcp = noise_var > 1e-290 && noise_var < 1e290;     // 1 / noise_var is a normal number
     if (m->M > MAX_M) {                                           // table too large for the LDS kernels
-        if (rcp) hipLaunchKernelGGL(demod_soft_any_kernel<true>, grid, block, 0, st, y, Ns, c, m->M, m->nbits, noise_var, scale, d_llr);
-        else hipLaunchKernelGGL(demod_soft_any_kernel<false>, grid, block, 0, st, y, Ns, c, m->M, m->nbits, noise_var, scale, d_llr);
+        switch (m->nbits) {
+#define CASE(NB) case NB: hipLaunchKernelGGL(demod_soft_any_kernel<NB>, grid, block, 0, st, y, Ns, c, m->M, noise_var, scale, d_llr); break;
+            CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16)
+#undef CASE
+            default: set_error("demod: unsupported bits per symbol %d", m->nbits); return CPX_ELIMIT;
+        }
         CPX_HIP(hipGetLastError());
-        note_kernel("demod_soft_any_kernel<%s> (%d points)", rcp ? "rcp" : "div", m->M);
+        note_kernel("demod_soft_any_kernel<%d> (%d points, division form)", m->nbits, m->M);
         return CPX_OK;
     }
     if (precision_fast() && noise_var > 1e-30 && noise_var < 1e30 && std::isfinite(scale)) {   // float32 log-sum-exp variants

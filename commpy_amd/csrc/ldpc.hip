@@ -870,6 +870,8 @@ int cpx_ldpc_blob_build(int n_vnodes, int n_cnodes, int64_t n_edges, const int32
     for (int64_t e = 0; e < E; e++) {                                            // increasing e == increasing check
         const int32_t q = fill[edge_var[e]]++;
         b_ce[q] = (int32_t)e;
+        // 5-bit position field: meaningful for checks of up to 32 edges only -- a code beyond that is decoded from edge_var / row_ptr /
+        // col_edge by ldpc_exact_kernel alone (cpx_ldpc_bp_decode_* takes that branch before any consumer of col_cj; forced paths: EINVAL)
         b_cj[q] = (edge_check[e] << 5) | ((int32_t)(e - row_ptr[edge_check[e]]) & 31);
     }
     for (int k = 0; k < n_cnodes; k++)
@@ -998,6 +1000,9 @@ static int ldpc_decode_impl(const cpx_ldpc *c, double *d_llr, int64_t B, int alg
         return CPX_OK;
     };
     if (c->max_cdeg > MAXDEG) {                                   // the general path: every block through the literal kernel
+        // a FORCED path (cpx_ldpc_set_path: tests and benchmarks that name a kernel) is never substituted silently
+        CPX_REQUIRE(ldpc_forced_path() == 0, CPX_EINVAL, "ldpc: path forced (cpx_ldpc_set_path / CPX_LDPC_PATH) but a check of %d > %d edges "
+                    "is only served by the literal kernel", c->max_cdeg, MAXDEG);
         if (d_clipped) CPX_HIP(hipMemsetAsync(d_clipped, 0, sizeof(int), st));
         const int64_t n = B * (int64_t)c->n_v;
         hipLaunchKernelGGL(ldpc_clip_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, st, d_llr, n, d_clipped);

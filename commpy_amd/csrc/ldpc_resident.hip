@@ -352,7 +352,7 @@ __device__ __forceinline__ double spa_ratio_fast(double U, double W, double se) 
     return div_nr(n1 + n2, n1 - n2);                             // exp(2 atanh(x)) = (1 + x) / (1 - x), |x| < 1 - 2^-32: positive, normal
 }
 
-__device__ __forceinline__ void check_spa_ratio(const ResParams &p, int c, int *ctl, int *flag) {
+__device__ __forceinline__ void check_spa_ratio(const ResParams &p, int c, int *ctl, int *flag, int *near_rows) {
     const int deg = p.row_deg[c];
     const int4 *__restrict__ qv = reinterpret_cast<const int4 *>(p.row_q + (int64_t)c * p.cpad);
     const int rb = p.roff + 8 * c * p.rstride;
@@ -383,7 +383,7 @@ __device__ __forceinline__ void check_spa_ratio(const ResParams &p, int c, int *
             if (j < deg && !near) stsd(rb + 8 * j, spa_ratio_fast(U, W, ldsd(rb + 8 * j)));
     }
     if (__builtin_amdgcn_ballot_w64(near) != 0) {
-        if (near) atomicAdd(&ctl[4], 1);
+        if (near) atomicAdd(near_rows, 1);
         double prod = 1.0;
         for (int j = 0; __builtin_amdgcn_ballot_w64(j < deg) != 0; j++)
             if (j < deg && near) prod *= spa_exact_t(ldsd(rb + 8 * j));
@@ -461,9 +461,12 @@ __device__ __forceinline__ int spa_block_log(const ResParams &p, const double *_
 __global__ __launch_bounds__(1024, 6) void ldpc_resident_ratio_kernel(ResParams p) {
     extern __shared__ __align__(16) char lds[];
     if ((unsigned)(uintptr_t)lds != 0u) __builtin_trap();        // absolute LDS addresses (see ldsd)
-    // control words: [0], [1] "unsatisfied" flag of even / odd iterations; [2] block; [3] hand the block back (NaN); [4] rows near
-    // saturation in this check pass; [5], [6] "more than half of the rows were" of the iteration before, by iteration parity -- every
-    // word is written on one side of a barrier and read on the other (see the note on uniform control flow in ldpc_resident_kernel)
+    // control words: [0], [1] "unsatisfied" flag of even / odd iterations; [2] block; [3] hand the block back (NaN); [5], [6] rows near
+    // saturation in the check pass of an even / odd iteration -- every word is written on one side of a barrier and read on the other
+    // (see the note on uniform control flow in ldpc_resident_kernel): the counter of iteration k is read by everybody right after the
+    // barrier that ends check pass k and zeroed by thread 0 one barrier later, while check pass k + 1 counts into the other one.
+    // (Round 4 published "more than half" one iteration late: a block whose LAST executed iteration saturated retired from ratio-domain
+    // state, and every handed-back block ran one wasted check pass.)
     int *ctl = reinterpret_cast<int *>(lds + p.ctl_off);
     const int tid = threadIdx.x, nt = blockDim.x;
     double *__restrict__ e0row = p.e0 + (int64_t)blockIdx.x * p.n_v;
@@ -501,15 +504,16 @@ __global__ __launch_bounds__(1024, 6) void ldpc_resident_ratio_kernel(ResParams 
         int k = 0, back = 0;
         for (; k < p.max_iter; k++) {
             int *flag = &ctl[k & 1];
-            for (int c = tid; c < p.n_c; c += nt) check_spa_ratio(p, c, ctl, flag);
+            for (int c = tid; c < p.n_c; c += nt) check_spa_ratio(p, c, ctl, flag, &ctl[5 + (k & 1)]);
             __syncthreads();
-            back = __builtin_amdgcn_readfirstlane(ctl[3] | ctl[5 + (k & 1)]);
+            back = __builtin_amdgcn_readfirstlane(ctl[3]);       // a NaN: log-domain row, whatever the syndrome says
             if (back) break;
-            if (!__builtin_amdgcn_readfirstlane(*flag)) break;   // zero syndrome (:205-206)
+            if (!__builtin_amdgcn_readfirstlane(*flag)) break;   // zero syndrome (:205-206): the rho of this pass are never used
+            back = 2 * __builtin_amdgcn_readfirstlane(ctl[5 + (k & 1)]) > p.n_c;   // a saturated iteration whose messages WOULD be used
+            if (back) break;
             if (tid == 0) {
                 ctl[(k + 1) & 1] = 0;
-                ctl[5 + ((k + 1) & 1)] = 2 * ctl[4] > p.n_c ? 1 : 0;
-                ctl[4] = 0;
+                ctl[5 + ((k + 1) & 1)] = 0;
             }
             for (int v = tid; v < p.n_v; v += nt) var_node_ratio(p, v, e0row[v], in);
             __syncthreads();
@@ -843,6 +847,8 @@ int ldpc_resident_tables(cpx_ldpc *c, const int32_t *row_ptr, const int32_t *row
 void ldpc_resident_free(cpx_ldpc *c) {
     (void)hipFree(c->d_res_row_deg); (void)hipFree(c->d_res_row_q); (void)hipFree(c->d_res_col_r); (void)hipFree(c->d_res_vgrp); (void)hipFree(c->d_res_row_q32); (void)hipFree(c->d_res_col_r32);
 }
+
+int ldpc_forced_path() { return ldpc_path(); }
 
 bool ldpc_resident_path(const cpx_ldpc *c, double *d_llr, int64_t B, int alg, int n_iters, int8_t *d_dec, double *d_out,
                         int block_major, int32_t *d_iters, int *d_clipped, uint8_t *nanflags, hipStream_t st, int *rc) {

@@ -5,6 +5,7 @@
 //   Modem.modulate     /root/reference/commpy/modulation.py:79-98 (MSB-first label -> constellation point)
 //   random messages    commpy/links.py:229 (np.random.choice((0,1), n)) -- Philox4x32-10 stream instead of MT19937
 //   AWGN               commpy/channels.py:37-55 (noise = (randn + 1j*randn) * scale per component, or real)
+//   BSC / BEC          commpy/channels.py:630-673 (one uniform draw per bit; flipped / erased to -1 where it is <= p) -- round 5
 //   error counting     links.py:252-256 (per-chunk XOR popcount)
 // Bit-exact stages (encode, (de)puncture, modulate, error count) are tested against the host mirror and
 // the reference goldens; the random stages are statistical (different generator than the reference).
@@ -199,6 +200,32 @@ __global__ __launch_bounds__(LS_BLOCK) void awgn_kernel(const double2 *__restric
     }
 }
 
+// ---- binary symmetric / binary erasure channel (channels.py:630-673) ---------------------------------------------------
+// One uniform draw per bit (53 bits, two per Philox call) compared with `<= p` like the reference's `random(n) <= p`:
+// ERASE = false: out = in ^ hit (bsc, :652-673);  ERASE = true: out = hit ? -1 : in (bec, :630-649).  Either output may be null:
+// int8 (the reference's integer bits, -1 = erasure) and / or float64 (what `viterbi_decode(..., 'hard')` is handed).
+template <bool ERASE>
+__global__ __launch_bounds__(LS_BLOCK) void binary_channel_kernel(const uint8_t *__restrict__ in, int64_t n, double p, uint64_t seed,
+                                                                  uint64_t stream, int8_t *__restrict__ out_i8,
+                                                                  double *__restrict__ out_f64) {
+    const int64_t n2 = (n + 1) / 2;
+    for (int64_t i = (int64_t)blockIdx.x * LS_BLOCK + threadIdx.x; i < n2; i += (int64_t)gridDim.x * LS_BLOCK) {
+        const Philox r = philox4x32_10((uint64_t)i, stream, seed);
+        // u01 is uniform on (0, 1] in steps of 2^-53; `u - 2^-53 <= p` is the reference's [0, 1) draw compared with `<= p`
+        const double u[2] = {u01(r.c[0], r.c[1]) - 1.0 / 9007199254740992.0, u01(r.c[2], r.c[3]) - 1.0 / 9007199254740992.0};
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int64_t pos = 2 * i + j;
+            if (pos >= n) break;
+            const int b = in[pos] & 1;
+            const bool hit = u[j] <= p;
+            const int o = ERASE ? (hit ? -1 : b) : (b ^ (hit ? 1 : 0));
+            if (out_i8) out_i8[pos] = (int8_t)o;
+            if (out_f64) out_f64[pos] = (double)o;
+        }
+    }
+}
+
 // ---- error counting: errs[b][c] = popcount(msg[b, c*chunk:(c+1)*chunk] ^ dec[b, same]) (links.py:252-256) --------------
 __global__ __launch_bounds__(LS_BLOCK) void count_errors_kernel(const uint8_t *__restrict__ msg, int64_t msg_stride,
                                                                 const uint8_t *__restrict__ dec, int64_t dec_stride,
@@ -315,6 +342,30 @@ int cpx_awgn_dev(const double *d_x_re_im, int64_t n, double scale_re, double sca
                        reinterpret_cast<double2 *>(d_y_re_im));
     CPX_HIP(hipGetLastError());
     return CPX_OK;
+}
+
+static int binary_channel(bool erase, const uint8_t *d_bits, int64_t n, double p, uint64_t seed, uint64_t stream_id,
+                          int8_t *d_out_i8, double *d_out_f64, void *stream) {
+    const char *who = erase ? "bec" : "bsc";
+    CPX_REQUIRE(n >= 0, CPX_EINVAL, "%s: negative size", who);
+    CPX_REQUIRE(p >= 0.0 && p <= 1.0, CPX_EINVAL, "%s: probability %g outside [0, 1]", who, p);   // (also refuses NaN)
+    if (n == 0) return CPX_OK;
+    CPX_REQUIRE(d_bits && (d_out_i8 || d_out_f64), CPX_EINVAL, "%s: null pointer", who);
+    const dim3 grid(ls_grid((n + 1) / 2)), block(LS_BLOCK);
+    if (erase) hipLaunchKernelGGL(binary_channel_kernel<true>, grid, block, 0, pick_stream(stream), d_bits, n, p, seed, stream_id, d_out_i8, d_out_f64);
+    else hipLaunchKernelGGL(binary_channel_kernel<false>, grid, block, 0, pick_stream(stream), d_bits, n, p, seed, stream_id, d_out_i8, d_out_f64);
+    CPX_HIP(hipGetLastError());
+    return CPX_OK;
+}
+
+int cpx_bsc_dev(const uint8_t *d_bits, int64_t n, double p_t, uint64_t seed, uint64_t stream_id, int8_t *d_out_i8,
+                double *d_out_f64, void *stream) {
+    return binary_channel(false, d_bits, n, p_t, seed, stream_id, d_out_i8, d_out_f64, stream);
+}
+
+int cpx_bec_dev(const uint8_t *d_bits, int64_t n, double p_e, uint64_t seed, uint64_t stream_id, int8_t *d_out_i8,
+                double *d_out_f64, void *stream) {
+    return binary_channel(true, d_bits, n, p_e, seed, stream_id, d_out_i8, d_out_f64, stream);
 }
 
 int cpx_count_errors_dev(const uint8_t *d_msg, int64_t msg_stride, const uint8_t *d_dec, int64_t dec_stride, int64_t B,

@@ -791,7 +791,8 @@ static int viterbi_dispatch(const cpx_trellis *t, const double *d_coded, const D
     if (n_steps <= 0 || n_steps * t->k < L) CPX_HIP(hipMemsetAsync(d_bits, 0, (size_t)(B * L), st));
     if (n_steps <= 0) return CPX_OK;
     note_kernel("");
-    if (general || (viterbi_path_flags() & 16))
+    // (a forced 'general' path does not apply to the fused hard-demodulation entry point: it hands symbols in `dm`, d_coded is null)
+    if (general || (!dm && (viterbi_path_flags() & 16)))
         return viterbi_generic(t, d_coded, B, len, L, n_steps, tb_depth, decoding_type, d_bits, st);
     // 'soft': one flag byte per work item of the launches below (see "NaN among 'soft' inputs"); scratch-arena slot 3
     uint8_t *nanflags = nullptr;

@@ -22,7 +22,8 @@ import numpy as np
 from commpy_amd import _lib
 from commpy_amd.wifi80211 import Wifi80211
 
-__all__ = ['DeviceBuf', 'DeviceWifiLink', 'conv_encode_gpu', 'modulate_gpu', 'turbo_encode_gpu', 'LdpcEncoder',
+__all__ = ['DeviceBuf', 'DeviceWifiLink', 'DeviceBscLink', 'conv_encode_gpu', 'modulate_gpu', 'bsc_gpu', 'bec_gpu', 'puncturing_gpu',
+           'depuncturing_gpu', 'puncture_indices', 'depuncture_indices', 'turbo_encode_gpu', 'LdpcEncoder',
            'gf2_generator', 'triang_ldpc_systematic_encode_gpu']
 
 
@@ -97,6 +98,120 @@ def modulate_gpu(modem, input_bits):
     _lib.check(lib.cpx_modulate_dev(modem._device_handle(), d_bits.ptr, nsym, d_sym.ptr, None))
     _lib.check(lib.cpx_stream_sync(None))
     return d_sym.to_array((nsym,), np.complex128)
+
+
+def puncture_indices(n_positions, punct_vec):
+    """Index table of ``puncturing(message, punct_vec)`` (convcode.py:752-774) for messages of ``n_positions`` bits:
+    ``punctured[j] = message[idx[j]]`` -- what ``cpx_gather_u8_dev`` is given."""
+    from commpy_amd.channelcoding.convcode import puncture_keep_mask
+    return np.flatnonzero(puncture_keep_mask(n_positions, punct_vec)).astype(np.int32)
+
+
+def depuncture_indices(shouldbe, punct_vec, n_punctured):
+    """Index table of ``depuncturing(punctured, punct_vec, shouldbe)`` (convcode.py:777-804): ``out[j] = punctured[idx[j]]`` where
+    ``idx[j] >= 0`` and 0.0 where it is -1 -- what ``cpx_gather_f64_dev`` is given.  ``IndexError`` like the reference's
+    ``punctured[idx - shift2]`` when ``n_punctured`` values cannot fill the pattern."""
+    from commpy_amd.channelcoding.convcode import puncture_keep_mask
+    keep = puncture_keep_mask(shouldbe, punct_vec)
+    if keep.sum() > n_punctured:
+        raise IndexError('depuncturing: message too short for the puncturing pattern')
+    de = -np.ones(int(shouldbe), dtype=np.int32)
+    de[keep] = np.arange(keep.sum(), dtype=np.int32)
+    return de
+
+
+def puncturing_gpu(messages, punct_vec):
+    """``puncturing`` for a batch ``[B, n]`` of bit rows on the GPU (``cpx_gather_u8_dev``); returns uint8 ``[B, n_kept]``."""
+    lib = _lib.load()
+    msgs = np.ascontiguousarray(np.atleast_2d(messages), dtype=np.uint8)
+    B, n = msgs.shape
+    idx = puncture_indices(n, punct_vec)
+    d_in, d_idx, d_out = DeviceBuf.from_array(msgs), DeviceBuf.from_array(idx), DeviceBuf(B * len(idx))
+    _lib.check(lib.cpx_gather_u8_dev(d_in.ptr, B, n, d_idx.ptr, len(idx), d_out.ptr, None))
+    _lib.check(lib.cpx_stream_sync(None))
+    return d_out.to_array((B, len(idx)), np.uint8)
+
+
+def depuncturing_gpu(punctured, punct_vec, shouldbe):
+    """``depuncturing`` for a batch ``[B, n_punctured]`` of float rows on the GPU (``cpx_gather_f64_dev``); float64 ``[B, shouldbe]``."""
+    lib = _lib.load()
+    rows = np.ascontiguousarray(np.atleast_2d(punctured), dtype=np.float64)
+    B, n = rows.shape
+    idx = depuncture_indices(shouldbe, punct_vec, n)
+    d_in, d_idx, d_out = DeviceBuf.from_array(rows), DeviceBuf.from_array(idx), DeviceBuf(B * len(idx) * 8)
+    _lib.check(lib.cpx_gather_f64_dev(d_in.ptr, B, n, d_idx.ptr, len(idx), d_out.ptr, None))
+    _lib.check(lib.cpx_stream_sync(None))
+    return d_out.to_array((B, len(idx)), np.float64)
+
+
+def _binary_channel_gpu(which, input_bits, p, seed, stream_id):
+    lib = _lib.load()
+    bits = np.ascontiguousarray(input_bits, dtype=np.uint8)
+    d_in, d_out = DeviceBuf.from_array(bits), DeviceBuf(bits.size)
+    _lib.check(getattr(lib, which)(d_in.ptr, bits.size, float(p), int(seed), int(stream_id), d_out.ptr, None, None))
+    _lib.check(lib.cpx_stream_sync(None))
+    return d_out.to_array(bits.shape, np.int8)
+
+
+def bsc_gpu(input_bits, p_t, seed=0, stream_id=0):
+    """``bsc(input_bits, p_t)`` (channels.py:652-673) on the GPU: every bit flipped with probability ``p_t``.  The draws come
+    from the Philox stream ``(seed, stream_id)``, not from NumPy's global generator: statistically, not bit-wise, the reference's."""
+    return _binary_channel_gpu("cpx_bsc_dev", input_bits, p_t, seed, stream_id)
+
+
+def bec_gpu(input_bits, p_e, seed=0, stream_id=0):
+    """``bec(input_bits, p_e)`` (channels.py:630-649) on the GPU: every bit erased (-1) with probability ``p_e``."""
+    return _binary_channel_gpu("cpx_bec_dev", input_bits, p_e, seed, stream_id)
+
+
+class DeviceBscLink:
+    """BASELINE config 1 end to end in HBM: random messages -> conv_encode('term') -> BSC(p) -> hard-decision Viterbi -> bit errors
+    (the loop of /root/reference/commpy/channelcoding/tests/test_convcode.py:133-178 with channels.py:652-673 as the channel)."""
+
+    def __init__(self, trellis, block_bits=64, tb_depth=None, seed=1):
+        self.lib = _lib.load()
+        _lib.require_device()
+        if trellis.k != 1:
+            raise ValueError('DeviceBscLink: k = 1 codes')
+        self.trellis, self.nbits, self.seed = trellis, int(block_bits), int(seed)
+        self.ncoded = _encoded_length(self.nbits, trellis, 'term')
+        m = trellis.total_memory
+        self.L = int(self.ncoded * trellis.k / trellis.n)
+        self.n_steps = int((self.L + m) / trellis.k) - 1
+        self.tb = min(5 * m, self.L) if tb_depth is None else int(tb_depth)
+        self._calls = 0
+        self._bufs = None
+
+    def buffers(self, B):
+        if self._bufs is None or self._bufs['B'] != B:
+            self._bufs = {'B': B, 'msg': DeviceBuf(B * self.nbits), 'coded': DeviceBuf(B * self.ncoded),
+                          'rx': DeviceBuf(B * self.ncoded * 8), 'dec': DeviceBuf(B * self.L), 'errs': DeviceBuf(B * 4)}
+        return self._bufs
+
+    def generate(self, p_t, B):
+        """Messages, codewords and the channel output (float64 0.0 / 1.0) of ``B`` blocks, left on the device."""
+        lib, bufs, ck = self.lib, self.buffers(B), _lib.check
+        self._calls += 1
+        rsc = self.trellis.code_type == 'rsc'
+        ck(lib.cpx_random_bits_dev(bufs['msg'].ptr, B * self.nbits, self.seed, 2 * self._calls, None))
+        ck(lib.cpx_conv_encode_batch_dev(self.trellis._device_handle(), bufs['msg'].ptr, B, self.nbits, 1, int(rsc),
+                                         bufs['coded'].ptr, self.ncoded, None))
+        ck(lib.cpx_bsc_dev(bufs['coded'].ptr, B * self.ncoded, float(p_t), self.seed, 2 * self._calls + 1, None, bufs['rx'].ptr, None))
+        return bufs
+
+    def decode(self, B):
+        lib, bufs = self.lib, self.buffers(B)
+        _lib.check(lib.cpx_viterbi_decode_batch_dev(self.trellis._device_handle(), bufs['rx'].ptr, B, self.ncoded, self.L,
+                                                    self.n_steps, self.tb, 0, bufs['dec'].ptr, None))
+
+    def run_batch(self, p_t, B):
+        """Bit errors per block (int32 ``[B]``) of ``B`` transmissions over a BSC with transition probability ``p_t``."""
+        lib, bufs = self.lib, self.generate(p_t, B)
+        self.decode(B)
+        _lib.check(lib.cpx_count_errors_dev(bufs['msg'].ptr, self.nbits, bufs['dec'].ptr, self.L, B, 1, self.nbits,
+                                            bufs['errs'].ptr, None))
+        _lib.check(lib.cpx_stream_sync(None))
+        return bufs['errs'].to_array((B,), np.int32)
 
 
 def turbo_encode_gpu(msg_bits, trellis1, trellis2, interleaver, mode=0):
@@ -268,17 +383,10 @@ class DeviceWifiLink:
             self.nde = self.ncoded
             self.de_idx = None
         else:
-            from commpy_amd.channelcoding.convcode import puncture_keep_mask
-            keep = puncture_keep_mask(self.ncoded, pvec)
-            self.keep_idx = np.flatnonzero(keep).astype(np.int32)
+            self.keep_idx = puncture_indices(self.ncoded, pvec)
             self.ntx = len(self.keep_idx)
             self.nde = math.ceil(self.ntx * self.coding[0] / self.coding[1] * 2)
-            keep2 = puncture_keep_mask(self.nde, pvec)
-            de = -np.ones(self.nde, dtype=np.int32)
-            de[keep2] = np.arange(keep2.sum(), dtype=np.int32)
-            if keep2.sum() > self.ntx:
-                raise IndexError('depuncturing: message too short for the puncturing pattern')
-            self.de_idx = de
+            self.de_idx = depuncture_indices(self.nde, pvec, self.ntx)
         nb = self.modem.num_bits_symbol
         if self.ntx % nb:
             raise ValueError('send_chunk does not give an integer number of symbols')

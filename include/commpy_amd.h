@@ -286,6 +286,11 @@ int cpx_demod_hard_dev(const cpx_modem *m, const double *d_y_re_im, int64_t Ns, 
  *   cpx_gather_f64_dev        out[b][j] = idx[j] >= 0 ? in[b][idx[j]] : 0: depuncturing (convcode.py:777-804)
  *   cpx_modulate_dev          Modem.modulate modulation.py:79-98: nb bits MSB-first -> constellation point
  *   cpx_awgn_dev              y = x + scale_re*n_re + 1j*scale_im*n_im, n ~ N(0,1) (channels.py:37-55)
+ *   cpx_bsc_dev / cpx_bec_dev bsc(input_bits, p_t) commpy/channels.py:652-673 / bec(input_bits, p_e) :630-649: one uniform
+ *                             draw per bit (Philox stream (seed, stream_id)), flipped / erased to -1 where the draw is
+ *                             <= p.  Outputs: int8 (the reference's integer bits) and / or float64 (what
+ *                             viterbi_decode(..., 'hard') takes, BASELINE config 1); either may be NULL.  p outside
+ *                             [0, 1] (or NaN): CPX_EINVAL
  *   cpx_count_errors_dev      errs[b][c] = sum(msg[b, chunk c] ^ dec[b, chunk c]) (links.py:252-256)
  *   cpx_scale_f64_dev         y = a*x, e.g. the sign flip between Modem.demodulate (log P1/P0) and ldpc_bp_decode
  *                             (log P0/P1), test_ldpc.py:53-54
@@ -301,6 +306,10 @@ int cpx_modulate_dev(const cpx_modem *m, const uint8_t *d_bits, int64_t nsym, do
 int cpx_awgn_dev(const double *d_x_re_im, int64_t n, double scale_re, double scale_im, uint64_t seed,
                  uint64_t stream_id, double *d_y_re_im, void *stream);
 int cpx_scale_f64_dev(const double *d_x, int64_t n, double a, double *d_y, void *stream);
+int cpx_bsc_dev(const uint8_t *d_bits, int64_t n, double p_t, uint64_t seed, uint64_t stream_id, int8_t *d_out_i8,
+                double *d_out_f64, void *stream);
+int cpx_bec_dev(const uint8_t *d_bits, int64_t n, double p_e, uint64_t seed, uint64_t stream_id, int8_t *d_out_i8,
+                double *d_out_f64, void *stream);
 int cpx_count_errors_dev(const uint8_t *d_msg, int64_t msg_stride, const uint8_t *d_dec, int64_t dec_stride,
                          int64_t B, int64_t nchunks, int64_t chunk, int32_t *d_errs, void *stream);
 

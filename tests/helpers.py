@@ -114,7 +114,53 @@ def spa_contract(out, want, what=""):
         if not m.any():
             continue
         got = float(np.mean(dev[m] <= 1e-5))
-        assert got >= frac or (1 - got) * m.sum() <= 1, (what, lo, hi, got, float(dev[m].max()))   # (one stray value in a small band is not a rate)
+        # (a band of fewer than 2000 values cannot resolve 99.95 %: there ONE stray value is allowed; a populated band gets no escape)
+        assert got >= frac or (m.sum() < 2000 and (1 - got) * m.sum() <= 1), (what, lo, hi, got, float(dev[m].max()))
         assert float(dev[m].max()) <= hard, (what, lo, hi, float(dev[m].max()))
     big = np.abs(want) >= 26.0
     assert np.array_equal(np.signbit(out[big]), np.signbit(want[big])), what
+
+
+# ---- round 5: the banded contract above is what ANY libm delivers against NumPy; it must not be the only thing that
+# stands between a precision regression of one of the engine's own rows and a green suite.  Two tighter, engine-internal bounds, set from
+# measurements on the very batches the tests use (scripts/spa_rows_table.py -> profiles/r05_spa_rows_table.json):
+#   * a row against the C ORACLE (same operation order, glibc instead of the device libm), `spa_strict`: below |LLR| = 26 EVERY value
+#     within 1e-5 -- north_star's number; measured 3.6e-7 for the log-domain rows and for the ratio kernel --; above, where a clip flip
+#     moves a block's large LLRs (single values 463 off), sign / finiteness and a regression floor on the fraction within 1e-5
+#     (measured 0.9985 in [26, 50) and 0.984 above on the 128-block chain at 8 dB: floors 0.995 / 0.97);
+#   * the ratio-domain kernel against the log-domain row, `spa_rows_agree`: |LLR| < 10 within 1e-8 (measured 8.7e-10); [10, 26): at
+#     least 99.999 % within 1e-6 and none beyond 5e-5 (measured: 2 of 1.4 M beyond 1e-6, worst 1.75e-5); [26, 50) and above: at least
+#     99.99 % within 1e-5, none beyond 1e-2 / 5e-2 (measured 0.99997, worst 3.1e-3 / 5.2e-3); signs, NaN and inf positions equal.
+def spa_strict(out, want, what="", floors=(0.995, 0.97)):
+    out, want = np.asarray(out), np.asarray(want)
+    assert np.array_equal(np.isfinite(out), np.isfinite(want)), what
+    fin = np.isfinite(want)
+    dev, mag = np.abs(out[fin] - want[fin]), np.abs(want[fin])
+    low = mag < 26.0
+    if low.any():
+        assert float(dev[low].max()) <= 1e-5, (what, "|LLR| < 26", float(dev[low].max()))
+    for (lo, hi), floor in zip(((26.0, 50.0), (50.0, np.inf)), floors):
+        m = (mag >= lo) & (mag < hi)
+        if m.sum() >= 2000:
+            got = float(np.mean(dev[m] <= 1e-5))
+            assert got >= floor, (what, lo, hi, got)
+    assert np.array_equal(np.signbit(out[fin][~low]), np.signbit(want[fin][~low])), what
+
+
+SPA_ROW_BANDS = ((0.0, 10.0, 1e-8, 1.0, 1e-8), (10.0, 26.0, 1e-6, 0.99999, 5e-5), (26.0, 50.0, 1e-5, 0.9999, 1e-2),
+                 (50.0, np.inf, 1e-5, 0.9999, 5e-2))
+
+
+def spa_rows_agree(out, want, what=""):
+    """Ratio-domain sum-product kernel `out` against the log-domain row `want` (finite values, same shape)."""
+    out, want = np.asarray(out), np.asarray(want)
+    dev, mag = np.abs(out - want).ravel(), np.abs(want).ravel()
+    assert np.all(np.isfinite(out)), what
+    for lo, hi, tol, frac, hard in SPA_ROW_BANDS:
+        m = (mag >= lo) & (mag < hi)
+        if not m.any():
+            continue
+        got = float(np.mean(dev[m] <= tol))
+        assert got >= frac or (m.sum() < 20000 and np.sum(dev[m] > tol) <= 1), (what, lo, hi, got, float(dev[m].max()))
+        assert float(dev[m].max()) <= hard, (what, lo, hi, float(dev[m].max()))
+    assert np.array_equal(np.signbit(out), np.signbit(want)), what

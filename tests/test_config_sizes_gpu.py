@@ -246,9 +246,21 @@ def test_config4_chain_128_blocks_vs_oracle(gpu):
         else:
             # engine vs oracle: two implementations of the same class (neither has NumPy's tanh): the banded contract that
             # both meet against the reference (helpers.spa_contract) must hold between them as well
-            from helpers import spa_contract
+            from commpy_amd import _lib
+            from helpers import spa_contract, spa_strict
             spa_contract(out, oo, "128 blocks, engine vs oracle")
             assert np.all(np.isfinite(out)) and np.array_equal(np.signbit(out), np.signbit(oo))
+            # round 5: the STRICT bound -- every value below |LLR| = 26 within 1e-5 of the oracle -- for the default
+            # (ratio-domain) kernel and, forced, for both log-domain rows
+            spa_strict(out, oo, "128 blocks, default kernel vs oracle")
+            try:
+                for path in ("resident-log", "tiled"):
+                    _lib.ldpc_set_path(path)
+                    d2, o2, i2 = ldpc_bp_decode(llr.copy(), p, alg, 50, return_iterations=True)
+                    assert np.array_equal(i2, io) and np.array_equal(d2, do), path
+                    spa_strict(o2, oo, "128 blocks, %s vs oracle" % path)
+            finally:
+                _lib.ldpc_set_path(None)
 
 
 def test_ldpc_saturation_case_l026(gpu):

@@ -36,7 +36,7 @@ def _decode(_lib, path, llr, p, alg, iters):
 
 def _ratio_agrees(a, b, what):
     """Sum-product, ratio-domain kernel `a` against the log-domain row `b`: (dec, out, iters) each."""
-    from helpers import spa_contract
+    from helpers import spa_contract, spa_rows_agree
     (d1, o1, i1), (d2, o2, i2) = a, b
     assert np.array_equal(i1, i2), what
     assert np.array_equal(np.isnan(o1), np.isnan(o2)), what
@@ -45,6 +45,7 @@ def _ratio_agrees(a, b, what):
     assert np.array_equal(np.isinf(o1), np.isinf(o2)) and np.array_equal(o1[np.isinf(o2)], o2[np.isinf(o2)]), what
     fin = np.isfinite(o2)
     spa_contract(o1[fin], o2[fin], what)
+    spa_rows_agree(o1[fin], o2[fin], what)                         # round 5: the tight row-vs-row bound (helpers.SPA_ROW_BANDS)
 
 
 def _staggered(rs, B, n, rate, ebn0s):
