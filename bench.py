@@ -500,6 +500,30 @@ def main():
     elapsed_g = gather_ms = None
     if args.gather:
         elapsed_g, gather_ms = timed_region(True)                  # `value_with_gather`: the same K steps + the all-gather
+    # Clock evidence (round 5), untimed: the same K steps once more with the engine's shader-clock probe (one sleeping wavefront on its own
+    # stream, cpx_sclk_probe_*) running alongside: average sclk over the interval and the per-launch times measured DURING it.  sclk x
+    # time = cycles per launch, which is what rocprofv3's GRBM_GUI_ACTIVE / 8 reports for the same kernel at the lower clock it runs
+    # at under the profiler (profiles/README.md) -- recorded instead of argued.
+    clock = None
+    try:
+        probe = ctypes.c_void_p()
+        _lib.check(lib.cpx_sclk_probe_start(ctypes.byref(probe), max(0.5, 0.9 * args.steps * float(np.median(kernel_ms)))))
+        tm2 = make_timers(args.steps)
+        for k in range(args.steps):
+            step(tm2[k], False)
+        sync()
+        ms2 = read_timers(tm2)
+        for tmr in tm2:
+            lib.cpx_timer_destroy(tmr)
+        mhz, ival = ctypes.c_double(), ctypes.c_double()
+        _lib.check(lib.cpx_sclk_probe_read(probe, ctypes.byref(mhz), ctypes.byref(ival)))
+        clock = {"sclk_mhz": mhz.value, "probe_interval_ms": ival.value, "kernel_ms_avg_during_probe": float(np.mean(ms2)),
+                 "kernel_ms_median_during_probe": float(np.median(ms2)),
+                 "shader_cycles_per_launch": mhz.value * 1e3 * float(np.median(ms2)),
+                 "how": "cpx_sclk_probe: s_memtime (shader-clock counter) over s_memrealtime (constant-rate counter) of one sleeping "
+                        "wavefront on its own stream while the same K steps ran again, outside the timed region"}
+    except Exception as exc:                                       # evidence, never a reason to lose the line
+        clock = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
     comm_world = None
     if comm is not None:
         nr, nl, fr = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
@@ -615,6 +639,7 @@ def main():
                          "steady_state": {"ms_per_launch_median": float(np.median(kernel_ms)),
                                           "info_bits_per_s_per_gpu": B * MSG_BITS / (float(np.median(kernel_ms)) * 1e-3)},
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_CW * B,
+                         "clock": clock,
                          "valu": valu,
                          "note": "serial float64 add-compare-select recursion: VALU-issue bound (valu.busy_frac), the HBM "
                                  "fraction is reported because the metric asks for it"},

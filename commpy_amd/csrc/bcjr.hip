@@ -106,6 +106,24 @@ __device__ __forceinline__ double group_sum(double v) {
     return v;
 }
 
+// NumPy's float64 add.reduce over the S state values of a codeword (turbo.py:110-111, :155-156), evaluated in EVERY lane of the
+// group -- the order matters to the literal kernel below: fewer than 8 values are added sequentially from index 0, eight or more
+// through eight accumulators r[j] = a[j] (+ a[j + 8]) combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) (bcjr_exact.hip np_sum_leaf).
+// IEEE addition is commutative, so a butterfly whose partners are the tree's siblings gives every lane that very value.
+template <int LGS>
+__device__ __forceinline__ double np_group_sum(double v) {
+    if (LGS == 1) return v + dppd<0xB1>(v);                       // a0 + a1
+    if (LGS == 2) {                                               // ((a0 + a1) + a2) + a3: quad broadcasts
+        const double q0 = dppd<0x00>(v), q1 = dppd<0x55>(v), q2 = dppd<0xAA>(v), q3 = dppd<0xFF>(v);
+        return ((q0 + q1) + q2) + q3;
+    }
+    if (LGS == 4) v += dppd<0x128>(v);                            // row_ror:8 -- r[j] = a[j] + a[j + 8]
+    v += dppd<0xB1>(v);                                           // r0 + r1, r2 + r3, ...
+    v += dppd<0x4E>(v);                                           // (r0 + r1) + (r2 + r3), ...
+    v += dppd<0x141>(v);                                          // row_half_mirror: the two quads of eight lanes
+    return v;
+}
+
 // One wavefront of a pair.  GW = codewords decoded by the pair (power of two, <= 64/S and <= 16): when the batch
 // cannot fill the chip the host picks GW < 64/S (idle lanes, more pairs).
 template <int LGS>
@@ -263,6 +281,8 @@ struct PassIO {
     double nv2;
     double *ckpt;                 // this pair's checkpoint rows [nchunks + 1][64]
     uint8_t *flags;               // "detect and redo": one byte per codeword of the pair, set to 1 (never cleared here); may be null
+    bool abort_ok;                // map_decode (round 5): its redo launch decodes a WHOLE pair again as soon as one codeword of it is flagged,
+                                  // so a wave that has raised a flag may stop working (its pair's outputs are garbage until then)
 };
 constexpr unsigned OOB = 0x80000000u;
 typedef unsigned bcjr_v2u __attribute__((ext_vector_type(2)));
@@ -323,7 +343,7 @@ __device__ __forceinline__ double signed_q(double r, double k4) { return __built
 // P(bit = 0) from the a-priori LLR, as the reference writes it (turbo.py:239)
 __device__ __forceinline__ double prior0(double L) { return 1.0 / (1.0 + exp(L)); }
 
-template <int LGS, bool PRE>
+template <int LGS, bool PRE, bool LIT = false>
 __device__ __forceinline__ void stage_chunk(const Ctx<LGS> &c, const RawChunk &rc, double nv2, int ncw) {
     const int GW = c.GW;
     const double k4 = -4.0 / nv2;
@@ -334,6 +354,23 @@ __device__ __forceinline__ void stage_chunk(const Ctx<LGS> &c, const RawChunk &r
         item_of(c.lane, q, gg, tl);
         if (gg < GW) {
             const double r0 = rc.r0[q], r1 = rc.r1[q], li = rc.li[q];
+            if (LIT) {
+                // the LITERAL kernel (map_literal_kernel): _compute_branch_prob as written (:62-76) -- four absolute probabilities,
+                // underflow included -- and the priors of :239-240
+                double g[4];
+#pragma unroll
+                for (int cc = 0; cc < 4; cc++) {
+                    const double x = r0 - (double)(2 * (cc >> 1) - 1);   // code_symbol = 2 * code_bit - 1 (:67-71)
+                    const double y = r1 - (double)(2 * (cc & 1) - 1);
+                    g[cc] = exp(-(x * x + y * y) / nv2);                 // (:74); nv2 = 2 * noise_variance
+                }
+                const double p0 = prior0(li);
+                double2 *row = reinterpret_cast<double2 *>(c.gam + tl * c.GS + gg * 4);
+                row[0] = make_double2(g[0], g[1]);
+                row[1] = make_double2(g[2], g[3]);
+                *reinterpret_cast<double2 *>(c.pri + tl * c.PS + gg * 2) = make_double2(p0, 1.0 - p0);
+                continue;
+            }
             const double qa = PRE ? fabs(r0) : exp(k4 * fabs(r0)), qb = PRE ? fabs(r1) : exp(k4 * fabs(r1));
             if (!PRE) {                                           // (A); turbo_decode checks the received values once, at its start
                 const double u0 = fabs(r0) + 1.0, u1 = fabs(r1) + 1.0;
@@ -368,15 +405,16 @@ __device__ __forceinline__ void stage_chunk(const Ctx<LGS> &c, const RawChunk &r
 
 // branch weights of this lane for the beta recursion at step tl: "lo"/"hi" are the branches into successor s>>1 /
 // 2|(s>>1) on the shift-register fast path, the branches of input 0 / 1 otherwise
-template <int LGS, bool SR>
+// (LIT: w_lo / w_hi are the bare priors -- the literal kernel multiplies (beta * gamma) * prior in the reference's order)
+template <int LGS, bool SR, bool LIT = false>
 __device__ __forceinline__ void beta_w(const Ctx<LGS> &c, int tl, double &g_lo, double &g_hi, double &w_lo, double &w_hi) {
     const double *it = c.gam + tl * c.GS + c.g * 4, *pr = c.pri + tl * c.PS + c.g * 2;
     if (LGS == 2 && SR) {
         g_lo = it[c.o_glo]; g_hi = it[c.o_ghi];
-        w_lo = g_lo * pr[c.ilo]; w_hi = g_hi * pr[1 - c.ilo];
+        w_lo = LIT ? pr[c.ilo] : g_lo * pr[c.ilo]; w_hi = LIT ? pr[1 - c.ilo] : g_hi * pr[1 - c.ilo];
     } else {
         g_lo = it[c.code[0]]; g_hi = it[c.code[1]];
-        w_lo = g_lo * pr[0]; w_hi = g_hi * pr[1];
+        w_lo = LIT ? pr[0] : g_lo * pr[0]; w_hi = LIT ? pr[1] : g_hi * pr[1];
     }
 }
 
@@ -386,6 +424,13 @@ __device__ __forceinline__ void alpha_w(const Ctx<LGS> &c, int tl, double &w0, d
     const double *it = c.gam + tl * c.GS + c.g * 4, *pr = c.pri + tl * c.PS + c.g * 2;
     w0 = it[c.pcode[0]] * pr[c.pin[0]];
     w1 = it[c.pcode[1]] * pr[c.pin[1]];
+}
+// literal kernel: gamma and prior of the two incoming branches, separately
+template <int LGS>
+__device__ __forceinline__ void alpha_gp(const Ctx<LGS> &c, int tl, double &g0, double &g1, double &p0, double &p1) {
+    const double *it = c.gam + tl * c.GS + c.g * 4, *pr = c.pri + tl * c.PS + c.g * 2;
+    g0 = it[c.pcode[0]]; p0 = pr[c.pin[0]];
+    g1 = it[c.pcode[1]]; p1 = pr[c.pin[1]];
 }
 
 // beta of this lane's two successors (see beta_w for the order)
@@ -402,7 +447,7 @@ __device__ __forceinline__ void beta_nbrs(const Ctx<LGS> &c, double b, double &l
 // One beta step (:106-108): b <- sum_i b[next(s,i)] * gamma(code(s,i)) * prior(i).  X: the branch products
 // x_i = a_own * gamma_i * b[next(s,i)] of (:141-143) are parked at slot i of c.xs (a_own = alpha of this lane's state
 // at the step, b = beta of the step's upper time before the update).
-template <int LGS, bool SR, bool X>
+template <int LGS, bool SR, bool X, bool LIT = false>
 __device__ __forceinline__ void beta_step(const Ctx<LGS> &c, int tl, double &b, double a_own, double g_lo, double g_hi,
                                           double w_lo, double w_hi) {
     double lo, hi;
@@ -413,12 +458,28 @@ __device__ __forceinline__ void beta_step(const Ctx<LGS> &c, int tl, double &b, 
         xo[s_lo * 64] = (a_own * g_lo) * lo;
         xo[(1 - s_lo) * 64] = (a_own * g_hi) * hi;
     }
+    if (LIT) {
+        // (:106-111) literally: acc = (b[next] * gamma) * prior summed over the two inputs (two terms: the order of the addition does
+        // not matter), then the column divided by its NumPy-ordered sum -- EVERY step, IEEE division, 0 / 0 = NaN as in the reference
+        b = (lo * g_lo) * w_lo + (hi * g_hi) * w_hi;
+        b = b / np_group_sum<LGS>(b);
+        return;
+    }
     b = __builtin_fma(hi, w_hi, lo * w_lo);
     if ((tl & (KNORM - 1)) == 0) {
         const double sum = group_sum<LGS>(b);
         flag_or(c.bad_s, c.active && !(sum >= T_SMALL));          // (C)
         b = b * __builtin_amdgcn_rcp(sum);
     }
+}
+
+// literal kernel (:136-138, :155-158): (alpha[pred] * gamma) * prior over the two incoming branches, column / its NumPy-ordered sum
+template <int LGS, bool SR>
+__device__ __forceinline__ void alpha_step_lit(const Ctx<LGS> &c, double &a, double g0, double g1, double p0, double p1) {
+    double ap0, ap1;
+    exchange_pred<LGS, SR>(c, a, ap0, ap1);
+    a = (ap0 * g0) * p0 + (ap1 * g1) * p1;
+    a = a / np_group_sum<LGS>(a);
 }
 
 template <int LGS, bool SR>
@@ -435,29 +496,50 @@ __device__ __forceinline__ void alpha_step(const Ctx<LGS> &c, int tl, double &a,
 
 // beta over the `len` staged steps, downwards.  X: also parks the branch products; arow[tl] = alpha of this lane's state
 // at step tl (full chunks: registers; the partial last chunk of a block runs rolled and keeps them in c.rw)
-template <int LGS, bool SR, bool X>
+template <int LGS, bool SR, bool X, bool LIT = false>
 __device__ __forceinline__ void beta_chunk(const Ctx<LGS> &c, double &b, int len, const double (&arow)[CH]) {
     if (len == CH) {
         double gl[CH], gh[CH], wl[CH], wh[CH];
 #pragma unroll
-        for (int tl = 0; tl < CH; tl++) beta_w<LGS, SR>(c, tl, gl[tl], gh[tl], wl[tl], wh[tl]);
+        for (int tl = 0; tl < CH; tl++) beta_w<LGS, SR, LIT>(c, tl, gl[tl], gh[tl], wl[tl], wh[tl]);
         asm volatile("" ::: "memory");
 #pragma unroll
-        for (int tl = CH - 1; tl >= 0; --tl) beta_step<LGS, SR, X>(c, tl, b, arow[tl], gl[tl], gh[tl], wl[tl], wh[tl]);
+        for (int tl = CH - 1; tl >= 0; --tl) beta_step<LGS, SR, X, LIT>(c, tl, b, arow[tl], gl[tl], gh[tl], wl[tl], wh[tl]);
     } else {
 #pragma unroll 1
         for (int tl = len - 1; tl >= 0; --tl) {
             double gl, gh, wl, wh;
-            beta_w<LGS, SR>(c, tl, gl, gh, wl, wh);
-            beta_step<LGS, SR, X>(c, tl, b, X ? c.rw[tl * 64 + c.lane] : 0.0, gl, gh, wl, wh);
+            beta_w<LGS, SR, LIT>(c, tl, gl, gh, wl, wh);
+            beta_step<LGS, SR, X, LIT>(c, tl, b, X ? c.rw[tl * 64 + c.lane] : 0.0, gl, gh, wl, wh);
         }
     }
     asm volatile("" ::: "memory");
 }
 
 // alpha over the `len` staged steps, upwards; KEEP: arow[tl] (c.rw for a partial chunk) = alpha before step tl
-template <int LGS, bool SR, bool KEEP>
+template <int LGS, bool SR, bool KEEP, bool LIT = false>
 __device__ __forceinline__ void alpha_chunk(const Ctx<LGS> &c, double &a, int len, double (&arow)[CH]) {
+    if (LIT) {                                                    // the literal kernel: LDS operands read step by step
+        if (len == CH) {
+#pragma unroll
+            for (int tl = 0; tl < CH; tl++) {
+                double g0, g1, p0, p1;
+                alpha_gp<LGS>(c, tl, g0, g1, p0, p1);
+                if (KEEP) arow[tl] = a;
+                alpha_step_lit<LGS, SR>(c, a, g0, g1, p0, p1);
+            }
+        } else {
+#pragma unroll 1
+            for (int tl = 0; tl < len; tl++) {
+                double g0, g1, p0, p1;
+                alpha_gp<LGS>(c, tl, g0, g1, p0, p1);
+                if (KEEP) c.rw[tl * 64 + c.lane] = a;
+                alpha_step_lit<LGS, SR>(c, a, g0, g1, p0, p1);
+            }
+        }
+        asm volatile("" ::: "memory");
+        return;
+    }
     if (len == CH) {
         double w0[CH], w1[CH];
 #pragma unroll
@@ -481,7 +563,7 @@ __device__ __forceinline__ void alpha_chunk(const Ctx<LGS> &c, double &a, int le
 }
 
 // time-parallel epilogue of a phase-2 chunk: app sums in state order, L = L_int + log(app1/app0) (:145)
-template <int LGS, bool BITS>
+template <int LGS, bool BITS, bool LIT = false>
 __device__ __forceinline__ void epilogue(const Ctx<LGS> &c, const PassIO &io, const double (&li)[2], int t_lo, int len) {
     constexpr int S = Ctx<LGS>::S;
     asm volatile("" ::: "memory");
@@ -506,7 +588,9 @@ __device__ __forceinline__ void epilogue(const Ctx<LGS> &c, const PassIO &io, co
         // instead of the log (45 instructions per item: ablation 4.53 -> 4.23 ms per config-3 decode with all twelve logs gone); the
         // priors differ from the reference's log -> exp round trip by its own rounding (~|E| 1e-16 relative).
         double L;
-        if (io.pout) {
+        if (LIT) {
+            L = li[q] + log(app1 / app0);                         // (:145) as written: 0 / 0, log 0 and log inf give the reference's NaN / -+inf
+        } else if (io.pout) {
             // ... as 1 / (1 + r), r = app1 / app0 -- the reference's own last two operations with r in the place of e^{log r}: the exact
             // zeros of its priors (1 + e rounds to 1 below e = 2^-53: p1 = 0; e = inf: p0 = 0) fall where the reference has them, which
             // app0 / (app0 + app1) does not guarantee (caught by the extreme-regime fixtures)
@@ -541,7 +625,7 @@ __device__ __forceinline__ void pair_sync() {
 }
 
 // One MAP pass over the GW codewords of this pair of wavefronts.  Collective over the workgroup (one pair_sync).
-template <int LGS, bool SR, bool PRE>
+template <int LGS, bool SR, bool PRE, bool LIT = false>
 __device__ void map_pass(const Ctx<LGS> &c, const PassIO &io) {
     const int N = io.N;
     const int K = (N + CH - 1) / CH, K1 = K / 2;                  // F: chunks [0,K1) then [K1,K); R: [K1,K) then [0,K1)
@@ -565,16 +649,22 @@ __device__ void map_pass(const Ctx<LGS> &c, const PassIO &io) {
     fetch(X, 0);
     fetch(Y, 1);
     // runs step(i, set) for i = i0 .. i1-1, alternating X, Y; an odd count ends with the sets swapped by value (once per phase)
+    // ... and stops (returns true) as soon as this wave has raised a "detect and redo" flag where the redo covers the whole pair
+    // (io.abort_ok): above Es/N0 ~ 14 dB flag (A) fires in the first chunk of every pair and the fast pass costs next to nothing
+    // (8.6 us for a fully flagged config-3 batch, profiles/r05_map_highsnr_pmc.json)
+    auto dead = [&]() { return !LIT && io.abort_ok && (c.bad_s | c.bad_i0 | c.bad_i1) != 0; };
     auto run = [&](int i0, int i1, auto &&step) {
         int i = i0;
         for (; i + 1 < i1; i += 2) {
             step(i, X);
             step(i + 1, Y);
+            if (dead()) return true;
         }
         if (i < i1) {
             step(i, X);
             const RawChunk t = X; X = Y; Y = t;
         }
+        return dead();
     };
     // Phase 2 of either wave, one chunk: alpha over the chunk (kept per step), then beta over it with the branch products,
     // then the epilogue.  One of the two recursions continues the wave's own chain, the other starts from the partner's
@@ -591,50 +681,50 @@ __device__ void map_pass(const Ctx<LGS> &c, const PassIO &io) {
         double a = (c.s == 0) ? 1.0 : 0.0;                        // f_state_metrics[0][0] = 1 (:221)
         run(0, K1, [&](int i, RawChunk &S) {
             ck_st(i, a);                                          // alpha at time i*CH (read by R in phase 2)
-            stage_chunk<LGS, PRE>(c, S, io.nv2, io.ncw);
+            stage_chunk<LGS, PRE, LIT>(c, S, io.nv2, io.ncw);
             fetch(S, i + 2);
-            alpha_chunk<LGS, SR, false>(c, a, CH, arow);          // chunks below K1 are full
+            alpha_chunk<LGS, SR, false, LIT>(c, a, CH, arow);          // chunks below K1 are full
         });
-        pair_sync();
+        pair_sync();                                              // (a stopped wave still meets the workgroup here)
         // ---------------- phase 2: chunks K1 .. K-1: own alpha, beta from R's checkpoint, combine ----------------
-        run(K1, K, [&](int k, RawChunk &S) {
+        if (!dead() && !run(K1, K, [&](int k, RawChunk &S) {
             const int len = clen(k);
             double b = ck_ld(k + 1);                              // beta at the upper boundary of chunk k
-            epilogue<LGS, !PRE>(c, io, li_prev, t_prev, len_prev);
-            stage_chunk<LGS, PRE>(c, S, io.nv2, io.ncw);
+            epilogue<LGS, !PRE, LIT>(c, io, li_prev, t_prev, len_prev);
+            stage_chunk<LGS, PRE, LIT>(c, S, io.nv2, io.ncw);
             li_prev[0] = S.li[0]; li_prev[1] = S.li[1];
             fetch(S, k + 2);
-            alpha_chunk<LGS, SR, true>(c, a, len, arow);
-            beta_chunk<LGS, SR, true>(c, b, len, arow);
+            alpha_chunk<LGS, SR, true, LIT>(c, a, len, arow);
+            beta_chunk<LGS, SR, true, LIT>(c, b, len, arow);
             t_prev = k * CH; len_prev = len;
-        });
-        epilogue<LGS, !PRE>(c, io, li_prev, t_prev, len_prev);
+        }))
+            epilogue<LGS, !PRE, LIT>(c, io, li_prev, t_prev, len_prev);
     } else {
         // ---------------- phase 1: beta over chunks K-1 .. K1, checkpoint before every chunk ----------------
         double b = 1.0;                                           // b_state_metrics[:, N] = 1 (:225)
         run(0, K - K1, [&](int i, RawChunk &S) {
             const int k = K - 1 - i;
             ck_st(k + 1, b);                                      // beta at the upper boundary of chunk k (read by F)
-            stage_chunk<LGS, PRE>(c, S, io.nv2, io.ncw);
+            stage_chunk<LGS, PRE, LIT>(c, S, io.nv2, io.ncw);
             fetch(S, i + 2);
-            beta_chunk<LGS, SR, false>(c, b, clen(k), arow);
+            beta_chunk<LGS, SR, false, LIT>(c, b, clen(k), arow);
         });
         pair_sync();
         // ---------------- phase 2: chunks K1-1 .. 0 (all full): alpha from F's checkpoint, own beta, combine ----------------
-        run(K - K1, K, [&](int i, RawChunk &S) {
+        if (!dead() && !run(K - K1, K, [&](int i, RawChunk &S) {
             const int k = K - 1 - i;
             double a = ck_ld(k);                                  // alpha at the lower boundary of chunk k
-            epilogue<LGS, !PRE>(c, io, li_prev, t_prev, len_prev);      // of the previous chunk (see the forward wave)
-            stage_chunk<LGS, PRE>(c, S, io.nv2, io.ncw);
+            epilogue<LGS, !PRE, LIT>(c, io, li_prev, t_prev, len_prev);      // of the previous chunk (see the forward wave)
+            stage_chunk<LGS, PRE, LIT>(c, S, io.nv2, io.ncw);
             li_prev[0] = S.li[0]; li_prev[1] = S.li[1];
             fetch(S, i + 2);
-            alpha_chunk<LGS, SR, true>(c, a, CH, arow);           // arow[tl] = alpha at time k*CH + tl
-            beta_chunk<LGS, SR, true>(c, b, CH, arow);
+            alpha_chunk<LGS, SR, true, LIT>(c, a, CH, arow);           // arow[tl] = alpha at time k*CH + tl
+            beta_chunk<LGS, SR, true, LIT>(c, b, CH, arow);
             t_prev = k * CH; len_prev = CH;
-        });
-        epilogue<LGS, !PRE>(c, io, li_prev, t_prev, len_prev);
+        }))
+            epilogue<LGS, !PRE, LIT>(c, io, li_prev, t_prev, len_prev);
     }
-    publish_flags<LGS>(c, io.flags, io.ncw);
+    if (!LIT) publish_flags<LGS>(c, io.flags, io.ncw);
 }
 
 struct MapParams {
@@ -671,7 +761,48 @@ __global__ __launch_bounds__(128 * NPAIR) void map_decode_kernel(MapParams p) {
     io.want_bits = p.want_bits;
     io.ckpt = p.scratch + pair * (K + 1) * 64;
     io.flags = p.flags ? p.flags + cw0 : nullptr;
+    io.abort_ok = io.flags != nullptr;
     map_pass<LGS, SR, false>(c, io);                              // L_ext and the hard decisions leave in the pass's epilogue
+}
+
+// ---- the LITERAL wave-parallel kernel: the redo path behind map_decode_kernel (round 5) ------------------------------------------
+// Round 3's redo path (bcjr_exact.hip, one codeword per LANE, state vectors in HBM scratch) is literal but serial: 7 ms per flagged
+// codeword, 28 ms when flag (A) sends a whole batch there -- which it does above Es/N0 ~ 14 dB (sigma^2 = 0.01: 0.35 -> 28 ms, a silent
+// 80 x cliff).  This is the same reference arithmetic -- absolute gamma, priors 1 / (1 + e^L) and 1 - p0, (metric * gamma) * prior
+// summed over the two branches, every column divided by its NumPy-ordered sum at every step, app sums in state order, L_int +
+// log(app1 / app0) -- on the wave-pair mapping of map_decode_kernel: one state per lane, forward and reverse wave, checkpoints, the
+// recomputed chain "by the same operations", so every value is the one the sequential reference loop produces, underflow, 0 / 0 and
+// log 0 included (tests/test_abnormal_golden_gpu.py).  A pair none of whose codewords is flagged only joins the workgroup's one
+// barrier and leaves; a pair with a flagged codeword decodes all GW of them again (literal results for the unflagged ones are as valid
+// as the fast ones).  `redo` (may be null) counts the flagged codewords for cpx_last_kernel's string: a DEVICE word (the first
+// version incremented a pinned host word: 1024 atomics over PCIe cost ~1 ms of a 1.5 ms launch, whatever the arithmetic did).
+template <int LGS, bool SR>
+__global__ __launch_bounds__(128 * NPAIR) void map_literal_kernel(MapParams p, unsigned *redo) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int64_t pair = (int64_t)blockIdx.x * (blockDim.x >> 7) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 7));
+    const int64_t cw0 = pair * p.GW, left = p.B - cw0;
+    const int ncw = (int)(left < p.GW ? left : p.GW);
+    const int lane = threadIdx.x & 63;
+    const unsigned long long hit = __ballot(lane < ncw && p.flags[cw0 + (lane < ncw ? lane : 0)] != 0);
+    if (hit == 0) {                                               // pair-uniform: both waves of the pair read the same bytes
+        pair_sync();                                              // the other pairs of the workgroup meet here once (map_pass)
+        return;
+    }
+    if (redo && (threadIdx.x & 127) == 0) atomicAdd(redo, (unsigned)__popcll(hit));
+    Ctx<LGS> c;
+    init_ctx<LGS>(c, p.tb, smem, p.GW);
+    const int64_t K = (p.N + CH - 1) / CH, o0 = cw0 * p.N;
+    PassIO io;
+    io.N = (int)p.N; io.sstride = io.pstride = io.lstride = io.N; io.ext = false; io.pout = false;
+    io.ncw = ncw; io.nv2 = p.nv2;
+    io.rsys = pass_buffer(p.sys + o0, OOB); io.rpar = pass_buffer(p.par + o0, OOB);
+    io.rlin = pass_buffer(p.Lin + o0, OOB); io.rout = pass_buffer(p.Lout + o0, OOB);
+    io.rbits = pass_buffer(p.bits ? p.bits + o0 : nullptr, p.bits ? OOB : 0u);
+    io.osys = io.opar = io.olin = io.oout = 0u;
+    io.want_bits = p.want_bits;
+    io.ckpt = p.scratch + pair * (K + 1) * 64;
+    io.flags = nullptr; io.abort_ok = false;
+    map_pass<LGS, SR, false, true>(c, io);
 }
 
 struct TurboParams {
@@ -720,6 +851,7 @@ __global__ __launch_bounds__(128 * NPAIR) void turbo_pass_kernel(TurboParams p, 
     io.ncw = (int)(left < p.GW ? left : p.GW);
     io.ckpt = p.ckpt + pair * (K + 1) * 64;
     io.flags = p.flags ? p.flags + cw0 : nullptr;
+    io.abort_ok = false;                                          // turbo's redo is per codeword: the other codewords of a pair must be finished
     io.ext = true;                                                // the pass writes E = L - L_int (:318, :328) ...
     io.pout = pout != 0;                                          // ... or prior0(E) directly (epilogue)
     double *base = p.larr + cw0 * ls;                              // the pair's first codeword
@@ -884,11 +1016,9 @@ int cpx_map_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const do
     if ((rc = workspace(st, 0, sizeof(double) * (size_t)(nblocks * np * (K + 1) * 64), (void **)&p.scratch))) return rc;
     // "detect and redo": one flag byte per codeword (scratch-arena slot 3), zeroed here, set by the kernel, consumed by the
     // absolute-scale redo launch below; blocks too long for that path's scratch are decoded by the fast kernel alone
-    p.flags = nullptr;
-    if (bcjr_exact_supported(t->S, N, 0)) {
-        if ((rc = workspace(st, 3, (size_t)B, (void **)&p.flags))) return rc;
-        CPX_HIP(hipMemsetAsync(p.flags, 0, (size_t)B, st));
-    }
+    // (round 5: the redo launch is the wave-parallel literal kernel below, which needs no per-lane scratch: no block-length limit)
+    if ((rc = workspace(st, 3, (size_t)B, (void **)&p.flags))) return rc;
+    CPX_HIP(hipMemsetAsync(p.flags, 0, (size_t)B, st));
     dim3 grid((unsigned)nblocks), block(128 * np);
     switch (p.tb.lgS) {
 #define CASE(LG) case LG: hipLaunchKernelGGL((map_decode_kernel<LG, false>), grid, block, sizeof(double) * 2 * np * wave_lds_doubles<LG>(GW), st, p); break;
@@ -901,8 +1031,22 @@ int cpx_map_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const do
         default: set_error("map_decode: unsupported state count"); return CPX_ELIMIT;
     }
     CPX_HIP(hipGetLastError());
-    if (p.flags && (rc = bcjr_exact_map(t, d_sys, d_par, d_L_int, B, N, p.nv2, want_bits, d_L_ext, d_bits, p.flags, st))) return rc;
-    note_kernel("map_decode_kernel<%d,%s> (%d wave pairs per workgroup, %d codewords per pair)", p.tb.lgS, (p.tb.lgS == 2 && p.tb.sr4) ? "true" : "false", np, GW);
+    // redo: pairs with a flagged codeword, literally (map_literal_kernel), same launch geometry
+    unsigned *redo = redo_counter(st);
+    switch (p.tb.lgS) {
+#define CASE(LG) case LG: hipLaunchKernelGGL((map_literal_kernel<LG, false>), grid, block, sizeof(double) * 2 * np * wave_lds_doubles<LG>(GW), st, p, redo); break;
+        case 2:
+            if (p.tb.sr4) hipLaunchKernelGGL((map_literal_kernel<2, true>), grid, block, sizeof(double) * 2 * np * wave_lds_doubles<2>(GW), st, p, redo);
+            else hipLaunchKernelGGL((map_literal_kernel<2, false>), grid, block, sizeof(double) * 2 * np * wave_lds_doubles<2>(GW), st, p, redo);
+            break;
+        CASE(1) CASE(3) CASE(4)
+#undef CASE
+        default: break;
+    }
+    CPX_HIP(hipGetLastError());
+    redo_publish(st);
+    note_kernel("map_decode_kernel<%d,%s> (%d wave pairs per workgroup, %d codewords per pair) + map_literal_kernel", p.tb.lgS, (p.tb.lgS == 2 && p.tb.sr4) ? "true" : "false", np, GW);
+    note_redo((long long)B, "codewords flagged (their pairs decoded literally)");
     return CPX_OK;
 }
 

@@ -18,6 +18,12 @@ hipStream_t lib_stream();   // lazily created per-process stream of the current 
 // that benchmarks and tests report what really ran instead of re-deriving the dispatch rules
 void note_kernel(const char *fmt, ...);
 const char *last_kernel_name();
+// redo counter of "detect and redo" paths: redo_counter() = a device word zeroed on `st` for the redo kernel to atomicAdd into,
+// redo_publish() copies it to a pinned host word behind that kernel; note_redo() AFTER the final note_kernel() makes cpx_last_kernel
+// append "redo: <word> of <total> <what>" (null: no counter available)
+unsigned *redo_counter(hipStream_t st);
+void redo_publish(hipStream_t st);
+void note_redo(long long total, const char *what);
 // CPX_EINVAL unless the current device is the one the handle's tables were created on
 int check_handle_device(int handle_device, const char *what);
 int ensure_device();        // CPX_OK if a HIP device is usable

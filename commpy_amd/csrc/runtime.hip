@@ -37,11 +37,53 @@ hipStream_t lib_stream() {
 
 static thread_local char g_kernel[160] = "";
 
+// "detect and redo" made visible (round 5): a decoder whose redo launch counts the items it decoded again gets a device word here,
+// the count is copied to a pinned host word behind the launch (same stream), and cpx_last_kernel appends "redo: n of N" READING THAT
+// WORD AT THAT MOMENT: meaningful once the stream the decode was issued on has been synchronised.
+static thread_local unsigned *g_redo_word = nullptr;
+static thread_local long long g_redo_total = -1;
+static thread_local char g_redo_what[48] = "";
+
 void note_kernel(const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap);
     va_end(ap);
+    g_redo_total = -1;
+}
+
+static thread_local unsigned *g_redo_dev = nullptr;
+static thread_local int g_redo_dev_device = -1;
+
+// a DEVICE word, zeroed on `st` (the kernel atomicAdds into it); redo_publish() copies it to the pinned host word on the same stream
+unsigned *redo_counter(hipStream_t st) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (!g_redo_word) {
+        void *p = nullptr;
+        if (hipHostMalloc(&p, 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        g_redo_word = static_cast<unsigned *>(p);
+        *g_redo_word = 0;
+    }
+    if (!g_redo_dev || g_redo_dev_device != dev) {               // (a thread that moved to another device: the old word is left to the driver)
+        void *p = nullptr;
+        if (hipMalloc(&p, 64) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        g_redo_dev = static_cast<unsigned *>(p);
+        g_redo_dev_device = dev;
+    }
+    if (hipMemsetAsync(g_redo_dev, 0, sizeof(unsigned), st) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return g_redo_dev;
+}
+
+void redo_publish(hipStream_t st) {
+    if (g_redo_dev && g_redo_word &&
+        hipMemcpyAsync(g_redo_word, g_redo_dev, sizeof(unsigned), hipMemcpyDeviceToHost, st) != hipSuccess)
+        (void)hipGetLastError();
+}
+
+void note_redo(long long total, const char *what) {
+    g_redo_total = g_redo_word ? total : -1;
+    snprintf(g_redo_what, sizeof(g_redo_what), "%s", what);
 }
 
 const char *last_kernel_name() { return g_kernel; }
@@ -141,7 +183,10 @@ int cpx_get_device(int *device) {
 
 int cpx_last_kernel(char *name, int cap) {
     CPX_REQUIRE(name && cap > 0, CPX_EINVAL, "cpx_last_kernel: null buffer");
-    snprintf(name, (size_t)cap, "%s", g_kernel);
+    if (g_redo_total >= 0 && g_redo_word)
+        snprintf(name, (size_t)cap, "%s; redo: %u of %lld %s", g_kernel, *(volatile unsigned *)g_redo_word, g_redo_total, g_redo_what);
+    else
+        snprintf(name, (size_t)cap, "%s", g_kernel);
     return CPX_OK;
 }
 
@@ -422,6 +467,63 @@ int cpx_timer_destroy(void *timer) {
     (void)hipEventDestroy(t->a);
     (void)hipEventDestroy(t->b);
     delete t;
+    return CPX_OK;
+}
+
+// ---- shader-clock probe (round 5) ------------------------------------------------------------------------------------------
+// One wavefront on a stream of its own that mostly sleeps and, when `spin_ms` of the constant-rate reference clock
+// (s_memrealtime; hipDeviceAttributeWallClockRate) have passed, stores how far the SHADER-clock counter (s_memtime: on the gfx9
+// family a free-running counter of the shader core clock) advanced meanwhile: their quotient is the average sclk of that interval,
+// i.e. of whatever ran on the other streams during it.  profiles/README.md used to ARGUE that rocprofv3 pins ~2.1 GHz where an
+// unprofiled run boosts to 2.4 GHz (same cycle count, 1.69 vs 1.55 ms per launch); bench.py now RECORDS the clock next to the time.
+struct cpx_sclk_probe_t {
+    hipStream_t st;
+    uint64_t *d;          // device: r0, c0, r1, c1
+    int ref_khz;
+};
+
+__global__ void sclk_probe_kernel(uint64_t *out, uint64_t ref_ticks) {
+    const uint64_t r0 = __builtin_amdgcn_s_memrealtime();
+    const uint64_t c0 = __builtin_amdgcn_s_memtime();
+    uint64_t r;
+    do {
+        __builtin_amdgcn_s_sleep(32);                            // ~2000 cycles asleep per poll: the probe takes no issue slots to speak of
+        r = __builtin_amdgcn_s_memrealtime();
+    } while (r - r0 < ref_ticks);
+    const uint64_t c1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) { out[0] = r0; out[1] = c0; out[2] = r; out[3] = c1; }
+}
+
+int cpx_sclk_probe_start(void **probe, double spin_ms) {
+    CPX_REQUIRE(probe && spin_ms > 0.0 && spin_ms <= 10000.0, CPX_EINVAL, "cpx_sclk_probe_start: bad argument");
+    int rc = ensure_device();
+    if (rc) return rc;
+    int dev = 0, khz = 0;
+    CPX_HIP(hipGetDevice(&dev));
+    CPX_HIP(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev));
+    CPX_REQUIRE(khz > 0, CPX_EHIP, "cpx_sclk_probe_start: the device reports no wall-clock rate");
+    cpx_sclk_probe_t *q = new cpx_sclk_probe_t;
+    q->ref_khz = khz;
+    CPX_HIP(hipStreamCreateWithFlags(&q->st, hipStreamNonBlocking));
+    CPX_HIP(hipMalloc((void **)&q->d, 4 * sizeof(uint64_t)));
+    hipLaunchKernelGGL(sclk_probe_kernel, dim3(1), dim3(64), 0, q->st, q->d, (uint64_t)(spin_ms * (double)khz));
+    CPX_HIP(hipGetLastError());
+    *probe = q;
+    return CPX_OK;
+}
+
+int cpx_sclk_probe_read(void *probe, double *sclk_mhz, double *interval_ms) {
+    cpx_sclk_probe_t *q = (cpx_sclk_probe_t *)probe;
+    CPX_REQUIRE(q, CPX_EINVAL, "cpx_sclk_probe_read: null probe");
+    uint64_t h[4] = {0, 0, 0, 0};
+    CPX_HIP(hipStreamSynchronize(q->st));
+    CPX_HIP(hipMemcpy(h, q->d, sizeof(h), hipMemcpyDeviceToHost));
+    const double dt_ms = (double)(h[2] - h[0]) / (double)q->ref_khz;
+    if (interval_ms) *interval_ms = dt_ms;
+    if (sclk_mhz) *sclk_mhz = dt_ms > 0.0 ? (double)(h[3] - h[1]) / dt_ms * 1e-3 : 0.0;
+    (void)hipFree(q->d);
+    (void)hipStreamDestroy(q->st);
+    delete q;
     return CPX_OK;
 }
 

@@ -86,6 +86,12 @@ int cpx_timer_start(void *timer, void *stream);
 int cpx_timer_stop(void *timer, void *stream);
 int cpx_timer_elapsed_ms(void *timer, float *ms);   /* synchronises on the stop event */
 int cpx_timer_destroy(void *timer);
+/* Shader-clock probe (round 5; measurement support, no reference counterpart): cpx_sclk_probe_start launches one mostly sleeping
+ * wavefront on a stream of its own for `spin_ms` milliseconds of the constant-rate device clock; cpx_sclk_probe_read waits for it
+ * and returns the average shader clock (MHz) over the interval it really covered (`interval_ms`) -- the clock the kernels on the
+ * OTHER streams ran at meanwhile -- and frees the probe.  bench.py records it next to its per-launch times. */
+int cpx_sclk_probe_start(void **probe, double spin_ms);
+int cpx_sclk_probe_read(void *probe, double *sclk_mhz, double *interval_ms);
 
 /* ---- convolutional codes: Viterbi ---------------------------------------------------------------
  * cpx_trellis_create: device copy of the code description built by the host Trellis class.

@@ -70,6 +70,16 @@ def main():
     subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--"] + cmd,
                    cwd="/tmp", env=env, timeout=a.timeout, stdout=open(os.path.join(out, a.name + "_trace.log"), "w"),
                    stderr=subprocess.STDOUT)
+    # bench.py's own line from INSIDE the profiled run (round 5): its shader-clock probe and per-launch event times under rocprofv3
+    profiled_line = None
+    try:
+        for ln in open(os.path.join(out, a.name + "_trace.log"), errors="replace"):
+            if ln.startswith("{") and '"roofline"' in ln:
+                j = json.loads(ln)
+                profiled_line = {"ms_per_step": j.get("ms_per_step"), "kernel_ms_avg": j["roofline"].get("kernel_ms_avg"),
+                                 "kernel_ms_median": j["roofline"].get("kernel_ms_median"), "clock": j["roofline"].get("clock")}
+    except (OSError, ValueError, KeyError):
+        pass
     stats = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)
     if stats:
         shutil.copy(stats[0], os.path.join(out, a.name + "_kernel_stats.csv"))
@@ -119,7 +129,7 @@ def main():
 
     # ---- derived ----
     res = {"name": a.name, "command": " ".join(cmd), "batch": a.batch, "fetch_scale": a.fetch_scale,
-           "git_head": head, "build_id": build_id,
+           "git_head": head, "build_id": build_id, "bench_line_under_kernel_trace": profiled_line,
            "units": "FETCH_SIZE / WRITE_SIZE in KiB per dispatch; SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* in quad-cycles "
                     "summed over waves; GRBM_GUI_ACTIVE in cycles summed over the 8 XCDs",
            "kernels": {}}
@@ -131,6 +141,10 @@ def main():
             e["traffic_bytes_per_launch"] = e["fetch_bytes_per_launch"] + e["write_bytes_per_launch"]
         # GRBM_GUI_ACTIVE comes back summed over the 8 XCDs (32.2 M for a 1.85 ms kernel = 8 x 4.03 M cycles)
         cycles = (v.get("GRBM_GUI_ACTIVE", 0) / N_XCD) or (v.get("duration_ns_avg", 0) * 1e-9 * CLOCK_HZ)
+        if v.get("GRBM_GUI_ACTIVE") and v.get("duration_ns_avg"):
+            # the clock the kernel ran at under the profiler: cycles of the PMC pass over the duration of the kernel-trace pass
+            e["sclk_mhz_under_profiler"] = v["GRBM_GUI_ACTIVE"] / N_XCD / (v["duration_ns_avg"] * 1e-9) * 1e-6
+            e["shader_cycles_per_launch"] = v["GRBM_GUI_ACTIVE"] / N_XCD
         if cycles and "SQ_ACTIVE_INST_VALU" in v:
             simds = min(SIMDS, v.get("SQ_WAVES", SIMDS)) or SIMDS
             e["valu"] = {"insts_per_launch": v.get("SQ_INSTS_VALU"),
@@ -145,7 +159,8 @@ def main():
     if res["kernels"]:
         dom = max(res["kernels"].items(), key=lambda kv: kv[1].get("duration_ns_avg", 0) * kv[1].get("calls", 1))
         res["kernel"] = dom[0]
-        for key in ("traffic_bytes_per_launch", "fetch_bytes_per_launch", "write_bytes_per_launch", "valu", "duration_ns_avg"):
+        for key in ("traffic_bytes_per_launch", "fetch_bytes_per_launch", "write_bytes_per_launch", "valu", "duration_ns_avg",
+                    "sclk_mhz_under_profiler", "shader_cycles_per_launch"):
             if key in dom[1]:
                 res[key] = dom[1][key]
     json.dump(res, open(os.path.join(out, a.name + "_pmc.json"), "w"), indent=1)

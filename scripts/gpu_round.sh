@@ -40,7 +40,7 @@ if [[ $SEC == *l* ]]; then
 fi
 if [[ $SEC == *v* ]]; then
   timeout 1500 python scripts/collect_pmc.py --out $OUT --name viterbi_c2 --match viterbi --batch 65536 -- \
-      python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | tail -40
+      python $R/bench.py --steps 25 --warmup 5 --no-cpu-baseline --no-other-configs 2>&1 | tail -40
 fi
 if [[ $SEC == *u* ]]; then
   timeout 1500 python scripts/collect_pmc.py --out $OUT --name turbo_c3 --match _kernel --fetch-scale 2 -- \

@@ -22,7 +22,7 @@ rs = np.random.RandomState(3)
 dev = Dev(lib)
 from commpy_amd.channelcoding import conv_encode_batch  # noqa: E402
 coded = conv_encode_batch(rs.randint(0, 2, (B, N)), tr, "cont")
-for nv in (0.5, 0.05, 0.02, 0.013, 0.01):
+for nv in ([float(v) for v in sys.argv[1].split(',')] if len(sys.argv) > 1 else (0.5, 0.05, 0.02, 0.013, 0.01)):
     sy = 2.0 * coded[:, 0::2] - 1 + np.sqrt(nv) * rs.standard_normal((B, N))
     pa = 2.0 * coded[:, 1::2] - 1 + np.sqrt(nv) * rs.standard_normal((B, N))
     far = np.mean(np.any((np.abs(sy) + 1) ** 2 + (np.abs(pa) + 1) ** 2 > 345 * 2 * nv, axis=1))

@@ -125,3 +125,63 @@ def test_flags_resolve_the_codeword_inside_a_full_pair(gpu):
         assert np.max(np.abs(L[cw][fin] - Lo[fin]), initial=0.0) < 1e-5, (cw, np.max(np.abs(L[cw][fin] - Lo[fin])))
         sure = fin & (np.abs(Lo) > 1e-5)
         assert np.array_equal(bits[cw][sure], bo[sure]), cw
+
+
+@pytest.mark.parametrize("name", ["two_state", "t57", "rsc_legacy_4", "rsc_matrix_4", "rsc_legacy_8", "k5_23_35"])
+def test_literal_wave_kernel_high_snr(gpu, name):
+    """Round 5: the redo path of map_decode is the wave-parallel LITERAL kernel (csrc/bcjr.hip map_literal_kernel: the reference's own
+    operations on the wave-pair mapping).  sigma^2 = 0.01 flags every codeword (flag (A)); valid codewords give finite LLRs, random
+    +-1 symbols (parity contradictions: every step loses e^-100) give the reference's NaN / +-inf pattern.  Every state count the
+    fast kernels serve (2, 4 -- shift-register and general --, 8, 16), a block length that is no multiple of the chunk, a batch that
+    leaves the last pair partly empty; sampled codewords against the oracle."""
+    from commpy_amd import _lib
+    from commpy_amd.channelcoding import Trellis, conv_encode_batch, map_decode
+    tr = Trellis(np.array([1]), np.array([[1, 3]])) if name == "two_state" else make_trellis(name)
+    rs = np.random.RandomState(len(name))
+    B, N, nv = 16 * 70 + 5, 203, 0.01
+    coded = conv_encode_batch(rs.randint(0, 2, (B, N)), tr, "cont")
+    sy = 2.0 * coded[:, 0::2] - 1 + np.sqrt(nv) * rs.standard_normal((B, N))
+    pa = 2.0 * coded[:, 1::2] - 1 + np.sqrt(nv) * rs.standard_normal((B, N))
+    junk = rs.rand(B) < 0.3                                        # not codewords at all
+    sy[junk] = rs.choice([-1.0, 1.0], size=(int(junk.sum()), N)) + 0.1 * rs.standard_normal((int(junk.sum()), N))
+    li = rs.randn(B, N) * 3.0
+    li[rs.rand(B) < 0.1] *= 60.0                                   # priors of e^-+180 and beyond: exp overflow, 1 - p0 cancelling
+    L, bits = map_decode(sy, pa, tr, nv, li, "decode")
+    note = _lib.last_kernel()
+    assert "map_literal_kernel" in note and ("redo: %d of %d" % (B, B)) in note, note
+    nan_seen = inf_seen = 0
+    for cw in list(range(0, 40)) + list(range(B - 24, B)) + list(rs.randint(0, B, 40)):
+        Lo, bo = oracle.map_decode(sy[cw], pa[cw], tr, nv, li[cw], "decode")
+        assert np.array_equal(np.isnan(L[cw]), np.isnan(Lo)) and np.array_equal(np.isposinf(L[cw]), np.isposinf(Lo)) and \
+            np.array_equal(np.isneginf(L[cw]), np.isneginf(Lo)), (name, cw)
+        fin = np.isfinite(Lo)
+        assert np.all(np.abs(L[cw][fin] - Lo[fin]) <= TOL + 1e-9 * np.abs(Lo[fin])), (name, cw, np.max(np.abs(L[cw][fin] - Lo[fin])))
+        sure = ~fin | (np.abs(Lo) > TOL)
+        assert np.array_equal(bits[cw][sure], bo[sure]), (name, cw)
+        nan_seen += int(np.isnan(Lo).any())
+        inf_seen += int(np.isinf(Lo).any())
+    assert nan_seen + inf_seen > 0, "the batch was meant to reach the reference's non-finite regime"
+
+
+def test_literal_kernel_nothing_flagged_and_long_blocks(gpu):
+    """Ordinary inputs raise no flag: the literal launch leaves at once ("redo: 0 of B").  And a block far beyond what the round-3
+    per-lane scratch of the redo path admitted still gets its flagged codeword redone (no block-length limit any more)."""
+    from commpy_amd import _lib
+    from commpy_amd.channelcoding import map_decode
+    tr = make_trellis("rsc_legacy_4")
+    rs = np.random.RandomState(8)
+    B, N, nv = 64, 256, 0.6
+    sy, pa = rs.randn(B, N) + 1.0, rs.randn(B, N) - 1.0
+    L, _ = map_decode(sy, pa, tr, nv, np.zeros((B, N)), "compute")
+    assert "redo: 0 of %d" % B in _lib.last_kernel(), _lib.last_kernel()
+    assert np.max(np.abs(L[5] - oracle.map_decode(sy[5], pa[5], tr, nv, np.zeros(N), "compute")[0])) < TOL
+    B, N = 3, 300000
+    sy, pa = rs.randn(B, N) * 0.5 + 1.0, rs.randn(B, N) * 0.5 - 1.0
+    sy[1, 1234] = 24.0                                             # flag (A) for codeword 1; its far branches underflow, the near ones do not
+    L, _ = map_decode(sy, pa, tr, 0.5, np.zeros((B, N)), "compute")
+    assert "redo: 1 of 3" in _lib.last_kernel(), _lib.last_kernel()
+    Lo = oracle.map_decode(sy[1], pa[1], tr, 0.5, np.zeros(N), "compute")[0]
+    assert np.array_equal(np.isnan(L[1]), np.isnan(Lo)) and np.array_equal(np.isinf(L[1]), np.isinf(Lo))
+    fin = np.isfinite(Lo)
+    assert fin.sum() > N // 2 and np.max(np.abs(L[1][fin] - Lo[fin])) < TOL
+    assert np.max(np.abs(L[2] - oracle.map_decode(sy[2], pa[2], tr, 0.5, np.zeros(N), "compute")[0])) < TOL   # its unflagged pair mates too
