@@ -506,6 +506,9 @@ def main():
     # at under the profiler (profiles/README.md) -- recorded instead of argued.
     clock = None
     try:
+        for _ in range(max(args.warmup, 5)):                       # the host read the timers meanwhile: no idle clock in the interval
+            step(None, False)
+        sync()
         probe = ctypes.c_void_p()
         _lib.check(lib.cpx_sclk_probe_start(ctypes.byref(probe), max(0.5, 0.9 * args.steps * float(np.median(kernel_ms)))))
         tm2 = make_timers(args.steps)
