@@ -31,10 +31,18 @@ __device__ __forceinline__ void ntstore(double v, double *p) { __builtin_nontemp
 //                                                                  of results that are themselves ~|v|/2 << 1)
 //   2 atanh(x) = log((1 + x) / (1 - x))                            (1 - x is exact for x > 1/2; x = +-1 gives +-inf)
 // The decoder's sensitivity to the last ulp of these functions is the same either way ("LDPC-SPA note").
+// Round 5: near saturation the quotient form loses to a real tanh -- (1 - e) and (1 + e) are each rounded before the division, up to
+// 1.5 ulp of a result whose distance from 1 is what 2 atanh amplifies -- and that, not the libm, was why the engine's exact-order
+// row missed the reference on TWICE as many saturated values as the glibc oracle (1.70 % against 0.90 % in [50, 100), 13.6 % against
+// 6.7 % above 100 on the 72 live-reference blocks; reproduced on the CPU by putting this very formula into the oracle, and undone by
+// the form below: profiles/r05_spa_tolerance.md).  fdlibm's own large-argument form, tanh(x) = 1 - 2 / (expm1(2x) + 2), rewritten in
+// e = exp(-|v|): 1 - 2e / (1 + e) -- the small term carries the roundings, the result is within ~0.5 ulp from e <= 1/8 on.
+__device__ __forceinline__ double tanh_from_e(double e) {
+    return e <= 0.125 ? 1.0 - (2.0 * e) / (1.0 + e) : (1.0 - e) / (1.0 + e);
+}
 __device__ __forceinline__ double tanh_half(double v) {
     const double e = exp(-fabs(v));
-    const double t = (1.0 - e) / (1.0 + e);
-    return __builtin_copysign(t, v);                              // NaN propagates through exp
+    return __builtin_copysign(tanh_from_e(e), v);                 // NaN propagates through exp (e <= 0.125 is false for a NaN)
 }
 __device__ __forceinline__ double atanh_twice(double x) { return fast_log((1.0 + x) / (1.0 - x)); }
 
@@ -85,7 +93,7 @@ __device__ __forceinline__ double spa_out_fast(double U, double W, double se) {
 // operation of the loop passes a NaN on with its sign.  A NaN never takes the fast row (spa_row_near sees U or W).
 __device__ __forceinline__ double spa_exact_t(double se) {        // == tanh_half(m) of the edge, from its stored e
     const double e = fabs(se);
-    const double t = __builtin_copysign((1.0 - e) / (1.0 + e), se);
+    const double t = __builtin_copysign(tanh_from_e(e), se);
     return se == se ? t : __builtin_nan("");                      // np.tanh(NaN) is +NaN
 }
 __device__ __forceinline__ double spa_out_exact(double t, double prod) {

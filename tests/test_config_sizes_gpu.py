@@ -168,6 +168,7 @@ def test_spa_tolerance_contract_engine_vs_reference(gpu):
     from helpers import spa_contract
     g = golden("ldpc_c4y")
     p = ldpc_params("n1944")
+    devs, mags = [], []
     for t in ("e8", "e9", "e10"):
         llr = g[t + "__llr"].reshape(-1)
         dec, out, its = ldpc_bp_decode(llr.copy(), p, "SPA", int(g["iters"]), return_iterations=True)
@@ -175,6 +176,20 @@ def test_spa_tolerance_contract_engine_vs_reference(gpu):
         _, _, io = oracle.ldpc_bp_decode(llr.copy(), p, "SPA", int(g["iters"]), True)
         assert np.array_equal(its, io), t
         spa_contract(out.T, g[t + "__out"], "engine " + t)
+        devs.append(np.abs(out.T - g[t + "__out"]).ravel())
+        mags.append(np.abs(g[t + "__out"]).ravel())
+    # Round 5: above |LLR| = 26 the contract promises signs only, but the engine must not be FURTHER from the reference than the glibc
+    # oracle is.  Rounds 1-4 it was, by 2 x: the exact-order row formed tanh(m / 2) as (1 - e) / (1 + e), up to 1.5 ulp from a real
+    # tanh exactly where 2 atanh amplifies it (csrc/ldpc_dev.h tanh_from_e).  Pooled over the 72 blocks, fraction beyond 1e-5:
+    #   band        oracle    engine r04   engine r05 (measured: profiles/r05_spa_tolerance.md)   asserted here
+    #   [26, 50)    0.092 %   0.147 %      ~0.09 %                                                  <= 0.12 %
+    #   [50, 100)   0.90 %    1.70 %       ~0.90 %                                                  <= 1.2 %
+    #   >= 100      6.7 %     13.6 %       ~6.7 %                                                   <= 9 %
+    dev, mag = np.concatenate(devs), np.concatenate(mags)
+    for lo, hi, cap in ((26.0, 50.0, 0.0012), (50.0, 100.0, 0.012), (100.0, np.inf, 0.09)):
+        m = (mag >= lo) & (mag < hi)
+        frac = float(np.mean(dev[m] > 1e-5))
+        assert frac <= cap, (lo, hi, frac, cap)
 
 
 def test_config4_chain_reference_blocks(gpu):
