@@ -125,13 +125,15 @@ def spa_contract(out, want, what=""):
 # stands between a precision regression of one of the engine's own rows and a green suite.  Two tighter, engine-internal bounds, set from
 # measurements on the very batches the tests use (scripts/spa_rows_table.py -> profiles/r05_spa_rows_table.json):
 #   * a row against the C ORACLE (same operation order, glibc instead of the device libm), `spa_strict`: below |LLR| = 26 EVERY value
-#     within 1e-5 -- north_star's number; measured 3.6e-7 for the log-domain rows and for the ratio kernel --; above, where a clip flip
-#     moves a block's large LLRs (single values 463 off), sign / finiteness and a regression floor on the fraction within 1e-5
-#     (measured 0.9985 in [26, 50) and 0.984 above on the 128-block chain at 8 dB: floors 0.995 / 0.97);
+#     within 1e-5 -- north_star's number; measured 8.5e-7 for the log-domain rows and for the ratio kernel --; above, sign / finiteness,
+#     a floor on the fraction within 1e-5 and a hard cap.  (Until the tanh form of round 5 -- csrc/ldpc_dev.h tanh_from_e -- the
+#     engine's clip flips fell on other blocks than the oracle's: 0.9985 / 0.984 within 1e-5 in [26, 50) / above, single values 463
+#     off.  With it the two flip together: measured 0.9995 / 0.9997, worst 1.9e-3 / 9.2e-4 on the 128-block chain at 8 dB -- floors
+#     0.999 / 0.999, caps 0.05.)
 #   * the ratio-domain kernel against the log-domain row, `spa_rows_agree`: |LLR| < 10 within 1e-8 (measured 8.7e-10); [10, 26): at
 #     least 99.999 % within 1e-6 and none beyond 5e-5 (measured: 2 of 1.4 M beyond 1e-6, worst 1.75e-5); [26, 50) and above: at least
 #     99.99 % within 1e-5, none beyond 1e-2 / 5e-2 (measured 0.99997, worst 3.1e-3 / 5.2e-3); signs, NaN and inf positions equal.
-def spa_strict(out, want, what="", floors=(0.995, 0.97)):
+def spa_strict(out, want, what="", floors=(0.999, 0.999), cap=0.05):
     out, want = np.asarray(out), np.asarray(want)
     assert np.array_equal(np.isfinite(out), np.isfinite(want)), what
     fin = np.isfinite(want)
@@ -144,6 +146,8 @@ def spa_strict(out, want, what="", floors=(0.995, 0.97)):
         if m.sum() >= 2000:
             got = float(np.mean(dev[m] <= 1e-5))
             assert got >= floor, (what, lo, hi, got)
+        if m.any():
+            assert float(dev[m].max()) <= cap, (what, lo, hi, float(dev[m].max()))
     assert np.array_equal(np.signbit(out[fin][~low]), np.signbit(want[fin][~low])), what
 
 
