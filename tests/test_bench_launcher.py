@@ -121,3 +121,42 @@ def test_id_exchange_rejects_a_file_of_another_launch(tmp_path):
         else:
             os.environ["CPX_COMM_NONCE"] = old
     assert parallel._launcher_start_ticks().isdigit() and int(parallel._launcher_start_ticks()) > 0
+
+
+def test_bench_gpus_2_end_to_end_against_the_host_stand_in(tmp_path):
+    """`bench.py --gpus 2` has never run with two ranks on hardware (one GPU per lease; SCALE_r01..r04 skipped).  Here its rank
+    path runs END TO END in two real processes started by bench.py's own launcher, against tests/fake_engine.py -- a host
+    stand-in for the C-ABI that lives in tests/ only (the product has no CPU fallback): RankComm's nonce rendezvous,
+    cpx_comm_init_rank -> allgather_dev -> allreduce -> cpx_comm_info, the in-place gather layout and its checksum exchange, and
+    the N > 1 fields of the JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "CPX_COMM_NONCE")}
+    env["CPX_FAKE_DIR"] = str(tmp_path)
+    env["CPX_FAKE_DEVICES"] = "2"
+    out_path = tmp_path / "stdout.txt"
+    with open(out_path, "w") as fo:
+        import contextlib
+        argv = [sys.executable, os.path.join(ROOT, "tests", "fake_engine.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                "--batch", "48", "--no-cpu-baseline"]
+        # bench.launch_ranks inherits stdout: run it in a child so that rank 0's line lands in a file
+        code = ("import sys; sys.path.insert(0, %r); import bench; sys.exit(bench.launch_ranks(2, %r, timeout=240))" % (ROOT, argv))
+        r = subprocess.run([sys.executable, "-c", code], env=env, stdout=fo, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in open(out_path).read().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines                                      # ONE line, from rank 0
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["scaling"] == "weak"
+    assert j["config"]["batch_per_gpu"] == 48 and "x2" in j["config"]["parallelism"]
+    assert j["config"]["collectives"] == "engine RCCL binding (cpx_comm_*)"
+    assert j["value"] > 0 and j["value_with_gather"] > 0 and j["ms_per_step_with_gather"] > 0
+    assert j["comm_world"] == {"nranks": 2, "this_rank": 0, "source": "ncclCommCount / ncclCommUserRank"}
+    assert j["gather"]["all_slots_ok_on_all_ranks"] is True and j["gather"]["bytes_per_rank_per_step"] == 48 * 1030
+    assert j["oracle_mismatched_bits"] == 0 and j["cpu_baseline"] is None and j["other_configs"] is None
+    assert j["launcher"] == "bench.py (subprocess per rank)"
+    assert 0.0 <= j["ber"] < 0.05
+    for rank in (0, 1):
+        calls = json.load(open(tmp_path / ("calls_rank%d.json" % rank)))
+        for name in ("cpx_comm_init_rank", "cpx_comm_allgather_u8", "cpx_comm_allreduce_i64", "cpx_comm_allreduce_f64", "cpx_comm_info",
+                     "cpx_comm_destroy"):
+            assert name in calls, (rank, name)
+        assert calls.index("cpx_comm_init_rank") < calls.index("cpx_comm_allgather_u8") < calls.index("cpx_comm_info")
+        assert ("cpx_comm_unique_id" in calls) == (rank == 0)          # rank 0 makes the id, rank 1 reads it from the nonce-keyed file
