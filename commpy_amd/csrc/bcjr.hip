@@ -774,21 +774,26 @@ __global__ __launch_bounds__(128 * NPAIR) void map_decode_kernel(MapParams p) {
 // recomputed chain "by the same operations", so every value is the one the sequential reference loop produces, underflow, 0 / 0 and
 // log 0 included (tests/test_abnormal_golden_gpu.py).  A pair none of whose codewords is flagged only joins the workgroup's one
 // barrier and leaves; a pair with a flagged codeword decodes all GW of them again (literal results for the unflagged ones are as valid
-// as the fast ones).  `redo` (may be null) counts the flagged codewords for cpx_last_kernel's string: a DEVICE word (the first
-// version incremented a pinned host word: 1024 atomics over PCIe cost ~1 ms of a 1.5 ms launch, whatever the arithmetic did).
+// as the fast ones).  `redo` counts the flagged codewords for cpx_last_kernel's string in a DEVICE word that the launch's last
+// workgroup publishes (cpx_internal.h redo_finish; the first version incremented a pinned host word from every pair: 1024 atomics
+// over PCIe cost ~1 ms of a 1.5 ms launch, whatever the arithmetic did).
 template <int LGS, bool SR>
-__global__ __launch_bounds__(128 * NPAIR) void map_literal_kernel(MapParams p, unsigned *redo) {
+__global__ __launch_bounds__(128 * NPAIR) void map_literal_kernel(MapParams p, RedoCounter redo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int64_t pair = (int64_t)blockIdx.x * (blockDim.x >> 7) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 7));
     const int64_t cw0 = pair * p.GW, left = p.B - cw0;
     const int ncw = (int)(left < p.GW ? left : p.GW);
     const int lane = threadIdx.x & 63;
     const unsigned long long hit = __ballot(lane < ncw && p.flags[cw0 + (lane < ncw ? lane : 0)] != 0);
+    __shared__ unsigned wg_redo;
+    if (threadIdx.x == 0) wg_redo = 0;
+    __syncthreads();
+    if ((threadIdx.x & 127) == 0 && hit != 0) atomicAdd(&wg_redo, (unsigned)__popcll(hit));
     if (hit == 0) {                                               // pair-uniform: both waves of the pair read the same bytes
         pair_sync();                                              // the other pairs of the workgroup meet here once (map_pass)
+        redo_finish(redo, wg_redo);
         return;
     }
-    if (redo && (threadIdx.x & 127) == 0) atomicAdd(redo, (unsigned)__popcll(hit));
     Ctx<LGS> c;
     init_ctx<LGS>(c, p.tb, smem, p.GW);
     const int64_t K = (p.N + CH - 1) / CH, o0 = cw0 * p.N;
@@ -803,6 +808,7 @@ __global__ __launch_bounds__(128 * NPAIR) void map_literal_kernel(MapParams p, u
     io.ckpt = p.scratch + pair * (K + 1) * 64;
     io.flags = nullptr; io.abort_ok = false;
     map_pass<LGS, SR, false, true>(c, io);
+    redo_finish(redo, wg_redo);
 }
 
 struct TurboParams {
@@ -945,6 +951,81 @@ __global__ __launch_bounds__(256) void turbo_stage_kernel(TurboParams p, int mod
     }
 }
 
+// ---- turbo_decode, the LITERAL redo (round 5): flagged pairs decode their codewords again, all iterations, in ONE launch -----------
+// Round 3's redo (bcjr_exact.hip turbo_exact_kernel, one codeword per lane) costs 2 x iterations x 7 ms for ANY number of flagged
+// codewords.  A pair's codewords are independent of every other pair's, so here a flagged pair runs the reference's whole loop
+// (turbo.py:300-331) by itself: map_pass<LIT> for MAP 1 and MAP 2 -- the literal wave-parallel pass of map_literal_kernel -- and
+// between them, elementwise in the pair's own rows of the slab (the fast sequence is done with them), what the reference writes:
+//   L_ext_1 = L_ext_1 - L_int_1 (:318), L_int_2 = interlv(L_ext_1) (:319), L_int_1 = deinterlv(L_2 - L_int_2) (:328-329),
+//   decoded_bits = deinterlv(L_2 > 0) of the last iteration (:148-152, :331).
+// Slab arrays reused: 0 L_int_1, 1 a pass's output (L_int + log(app1 / app0), i.e. L_ext_1 before the subtraction / L_2), 2 L_int_2,
+// 4 interlv(sys_symbols) as RAW symbols.  ONE pair per workgroup (a pair that is not flagged leaves at once; the barriers below only
+// ever meet the two waves of a pair), a rare path: speed is what the wave-parallel pass gives (~0.5 ms per MAP pass of a full
+// config-3 batch against 7 ms per flagged codeword before), not a goal of its own.
+template <int LGS, bool SR>
+__global__ __launch_bounds__(128) void turbo_literal_kernel(TurboParams p, RedoCounter redo) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int64_t pair = blockIdx.x;
+    const int64_t N = p.N, K = (N + CH - 1) / CH, cw0 = pair * p.GW, left = p.B - cw0, ls = 7 * N;
+    const int ncw = (int)(left < p.GW ? left : p.GW);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long hit = __ballot(lane < ncw && p.flags[cw0 + (lane < ncw ? lane : 0)] != 0);
+    if (hit == 0) {
+        redo_finish(redo, 0u);
+        return;
+    }
+    Ctx<LGS> c;
+    init_ctx<LGS>(c, p.tb, smem, p.GW);
+    double *slab = p.larr + cw0 * ls;
+    auto at = [&](int a, int g, int64_t t) -> double & { return slab[((int64_t)g * 7 + a) * N + t]; };
+    // elementwise work: the pair's codewords alternate between its two waves
+    for (int g = wave; g < ncw; g += 2)
+        for (int64_t t = lane; t < N; t += 64) {
+            at(0, g, t) = p.Lint ? p.Lint[(cw0 + g) * N + t] : 0.0;                   // L_int_1 (:305-308)
+            at(4, g, t) = p.sys[(cw0 + g) * N + p.perm[t]];                           // interlv(sys_symbols) (:310)
+        }
+    pair_sync();
+    PassIO io;
+    io.N = (int)N; io.nv2 = p.nv2; io.want_bits = 0; io.ncw = ncw;
+    io.ckpt = p.ckpt + pair * (K + 1) * 64;
+    io.flags = nullptr; io.abort_ok = false; io.ext = false; io.pout = false;
+    io.rbits = pass_buffer(nullptr, 0u);
+    io.rlin = io.rout = pass_buffer(slab, OOB);
+    io.lstride = (int)ls;
+    const unsigned nb = (unsigned)N * 8u;
+    io.oout = nb;                                                                     // array 1
+    for (int it = 0; it < p.n_iter; it++) {
+        // MAP 1 (:315): sys, non_sys_1 straight from the caller's arrays, L_int_1 from array 0
+        io.rsys = pass_buffer(p.sys + cw0 * N, OOB); io.osys = 0u; io.sstride = (int)N;
+        io.rpar = pass_buffer(p.p1 + cw0 * N, OOB); io.opar = 0u; io.pstride = (int)N;
+        io.olin = 0u;
+        map_pass<LGS, SR, false, true>(c, io);
+        pair_sync();
+        for (int g = wave; g < ncw; g += 2)
+            for (int64_t t = lane; t < N; t += 64) {
+                const int64_t s2 = p.perm[t];
+                at(2, g, t) = at(1, g, s2) - at(0, g, s2);                            // L_int_2 = interlv(L_ext_1 - L_int_1) (:318-319)
+            }
+        pair_sync();
+        // MAP 2 (:326): interleaved systematic symbols (array 4), non_sys_2, L_int_2 (array 2)
+        io.rsys = pass_buffer(slab, OOB); io.osys = 4u * nb; io.sstride = (int)ls;
+        io.rpar = pass_buffer(p.p2 + cw0 * N, OOB); io.opar = 0u; io.pstride = (int)N;
+        io.olin = 2u * nb;
+        map_pass<LGS, SR, false, true>(c, io);
+        pair_sync();
+        const bool last = it == p.n_iter - 1;
+        for (int g = wave; g < ncw; g += 2)
+            for (int64_t t = lane; t < N; t += 64) {
+                const int64_t d = p.perm[t];
+                const double L2 = at(1, g, t);
+                at(0, g, d) = L2 - at(2, g, t);                                       // L_int_1 = deinterlv(L_2 - L_int_2) (:328-329)
+                if (last) p.bits[(cw0 + g) * N + d] = (uint8_t)(L2 > 0 ? 1 : 0);      // 'decode' (:148-152), deinterlv (:331)
+            }
+        pair_sync();
+    }
+    redo_finish(redo, (unsigned)__popcll(hit));
+}
+
 // codewords per pair of wavefronts: full wavefronts as soon as the batch gives every SIMD of the chip its two waves; for
 // smaller batches fewer codewords per pair (idle lanes) spread the work over more SIMDs.
 int pick_gw(int S, int64_t B) {
@@ -1032,7 +1113,7 @@ int cpx_map_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const do
     }
     CPX_HIP(hipGetLastError());
     // redo: pairs with a flagged codeword, literally (map_literal_kernel), same launch geometry
-    unsigned *redo = redo_counter(st);
+    const RedoCounter redo = redo_counter();
     switch (p.tb.lgS) {
 #define CASE(LG) case LG: hipLaunchKernelGGL((map_literal_kernel<LG, false>), grid, block, sizeof(double) * 2 * np * wave_lds_doubles<LG>(GW), st, p, redo); break;
         case 2:
@@ -1044,7 +1125,6 @@ int cpx_map_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const do
         default: break;
     }
     CPX_HIP(hipGetLastError());
-    redo_publish(st);
     note_kernel("map_decode_kernel<%d,%s> (%d wave pairs per workgroup, %d codewords per pair) + map_literal_kernel", p.tb.lgS, (p.tb.lgS == 2 && p.tb.sr4) ? "true" : "false", np, GW);
     note_redo((long long)B, "codewords flagged (their pairs decoded literally)");
     return CPX_OK;
@@ -1077,11 +1157,10 @@ int cpx_turbo_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const 
     CPX_REQUIRE(nblocks < (1ll << 31), CPX_ELIMIT, "turbo_decode: batch too large");
     if ((rc = workspace(st, 0, sizeof(double) * (size_t)(nblocks * np * (K + 1) * 64), (void **)&p.ckpt))) return rc;
     if ((rc = workspace(st, 1, sizeof(double) * (size_t)(B * 7 * N), (void **)&p.larr))) return rc;
-    p.flags = nullptr;                                             // "detect and redo", as in cpx_map_decode_batch_dev
-    if (bcjr_exact_supported(t->S, N, 1)) {
-        if ((rc = workspace(st, 3, (size_t)B, (void **)&p.flags))) return rc;
-        CPX_HIP(hipMemsetAsync(p.flags, 0, (size_t)B, st));
-    }
+    // "detect and redo", as in cpx_map_decode_batch_dev (round 5: redone by turbo_literal_kernel, no block-length limit)
+    if ((rc = workspace(st, 3, (size_t)B, (void **)&p.flags))) return rc;
+    CPX_HIP(hipMemsetAsync(p.flags, 0, (size_t)B, st));
+    CPX_REQUIRE(npairs < (1ll << 31), CPX_ELIMIT, "turbo_decode: batch too large");
     dim3 grid((unsigned)nblocks), block(128 * np);
     // one launch per MAP pass, one small launch per stage (see turbo_pass_kernel)
     const int lds_n = (N * 8 * 4 <= 64 * 1024) ? (int)N : 0;
@@ -1115,10 +1194,23 @@ int cpx_turbo_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const 
     CPX_HIP(hipGetLastError());
     note_kernel("turbo_pass_kernel<%d,%s> x %d + turbo_stage_kernel (%d wave pairs per workgroup, %d codewords per pair)", p.tb.lgS,
                 (p.tb.lgS == 2 && p.tb.sr4) ? "true" : "false", 2 * n_iter, np, GW);
-    char kname[200];
-    snprintf(kname, sizeof(kname), "%s", last_kernel_name());
-    if (p.flags && (rc = bcjr_exact_turbo(t, d_sys, d_p1, d_p2, d_L_int_or_null, d_perm, B, N, p.nv2, n_iter, d_bits, p.flags, st))) return rc;
-    note_kernel("%s", kname);
+    // redo: one launch; a pair with a flagged codeword decodes its codewords again, literally, all iterations (turbo_literal_kernel)
+    const RedoCounter redo = redo_counter();
+    {
+        const dim3 lgrid((unsigned)npairs), lblock(128);
+        switch (p.tb.lgS) {
+#define CASE(LG) case LG: hipLaunchKernelGGL((turbo_literal_kernel<LG, false>), lgrid, lblock, sizeof(double) * 2 * wave_lds_doubles<LG>(GW), st, p, redo); break;
+            case 2:
+                if (p.tb.sr4) hipLaunchKernelGGL((turbo_literal_kernel<2, true>), lgrid, lblock, sizeof(double) * 2 * wave_lds_doubles<2>(GW), st, p, redo);
+                else hipLaunchKernelGGL((turbo_literal_kernel<2, false>), lgrid, lblock, sizeof(double) * 2 * wave_lds_doubles<2>(GW), st, p, redo);
+                break;
+            CASE(1) CASE(3) CASE(4)
+#undef CASE
+            default: break;
+        }
+        CPX_HIP(hipGetLastError());
+    }
+    note_redo((long long)B, "codewords flagged (their pairs decoded literally)");
     return CPX_OK;
 }
 

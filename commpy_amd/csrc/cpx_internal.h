@@ -18,11 +18,29 @@ hipStream_t lib_stream();   // lazily created per-process stream of the current 
 // that benchmarks and tests report what really ran instead of re-deriving the dispatch rules
 void note_kernel(const char *fmt, ...);
 const char *last_kernel_name();
-// redo counter of "detect and redo" paths: redo_counter() = a device word zeroed on `st` for the redo kernel to atomicAdd into,
-// redo_publish() copies it to a pinned host word behind that kernel; note_redo() AFTER the final note_kernel() makes cpx_last_kernel
-// append "redo: <word> of <total> <what>" (null: no counter available)
-unsigned *redo_counter(hipStream_t st);
-void redo_publish(hipStream_t st);
+// redo counter of "detect and redo" paths: `dev` = two device words {count, workgroups done}, zero between launches; `host` = a pinned
+// host word.  The redo kernel adds its flagged items to dev[0] and calls redo_finish() at its end: the last workgroup publishes the
+// count to *host and zeroes the device words.  note_redo() AFTER the final note_kernel() makes cpx_last_kernel append
+// "redo: <host word> of <total> <what>" (pointers null: no counter available)
+struct RedoCounter { unsigned *dev, *host; };
+RedoCounter redo_counter();
+#ifdef __HIPCC__
+// collective over the workgroup (one __syncthreads); `mine` = this workgroup's contribution, added by thread 0
+__device__ __forceinline__ void redo_finish(RedoCounter rc, unsigned mine) {
+    __syncthreads();
+    if (threadIdx.x == 0 && rc.dev) {
+        if (mine) atomicAdd(&rc.dev[0], mine);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const unsigned prev = atomicAdd(&rc.dev[1], 1u);
+        if (prev == gridDim.x - 1) {                              // the last workgroup of the launch
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const unsigned total = atomicExch(&rc.dev[0], 0u);
+            atomicExch(&rc.dev[1], 0u);
+            __hip_atomic_store(rc.host, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+#endif
 void note_redo(long long total, const char *what);
 // CPX_EINVAL unless the current device is the one the handle's tables were created on
 int check_handle_device(int handle_device, const char *what);

@@ -55,30 +55,28 @@ void note_kernel(const char *fmt, ...) {
 static thread_local unsigned *g_redo_dev = nullptr;
 static thread_local int g_redo_dev_device = -1;
 
-// a DEVICE word, zeroed on `st` (the kernel atomicAdds into it); redo_publish() copies it to the pinned host word on the same stream
-unsigned *redo_counter(hipStream_t st) {
+// {device words [count, workgroups done] -- zero between launches: the kernel's last workgroup resets them --, pinned host word}.
+// No memset and no copy on the stream: the redo kernel's LAST workgroup stores the count to the host word itself (round 5b; a
+// memset + a 4-byte D2H copy per decode cost ~8 us of a 0.33 ms map_decode).
+RedoCounter redo_counter() {
+    RedoCounter rc{nullptr, nullptr};
     int dev = -1;
-    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return rc; }
     if (!g_redo_word) {
         void *p = nullptr;
-        if (hipHostMalloc(&p, 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipHostMalloc(&p, 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return rc; }
         g_redo_word = static_cast<unsigned *>(p);
         *g_redo_word = 0;
     }
-    if (!g_redo_dev || g_redo_dev_device != dev) {               // (a thread that moved to another device: the old word is left to the driver)
+    if (!g_redo_dev || g_redo_dev_device != dev) {               // (a thread that moved to another device: the old words are left to the driver)
         void *p = nullptr;
-        if (hipMalloc(&p, 64) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipMalloc(&p, 64) != hipSuccess || hipMemset(p, 0, 64) != hipSuccess) { (void)hipGetLastError(); return rc; }
         g_redo_dev = static_cast<unsigned *>(p);
         g_redo_dev_device = dev;
     }
-    if (hipMemsetAsync(g_redo_dev, 0, sizeof(unsigned), st) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    return g_redo_dev;
-}
-
-void redo_publish(hipStream_t st) {
-    if (g_redo_dev && g_redo_word &&
-        hipMemcpyAsync(g_redo_word, g_redo_dev, sizeof(unsigned), hipMemcpyDeviceToHost, st) != hipSuccess)
-        (void)hipGetLastError();
+    rc.dev = g_redo_dev;
+    rc.host = g_redo_word;
+    return rc;
 }
 
 void note_redo(long long total, const char *what) {

@@ -185,3 +185,32 @@ def test_literal_kernel_nothing_flagged_and_long_blocks(gpu):
     fin = np.isfinite(Lo)
     assert fin.sum() > N // 2 and np.max(np.abs(L[1][fin] - Lo[fin])) < TOL
     assert np.max(np.abs(L[2] - oracle.map_decode(sy[2], pa[2], tr, 0.5, np.zeros(N), "compute")[0])) < TOL   # its unflagged pair mates too
+
+
+@pytest.mark.parametrize("name,n_iter", [("rsc_legacy_4", 3), ("rsc_legacy_8", 2), ("rsc_matrix_4", 1)])
+def test_turbo_literal_redo_high_snr(gpu, name, n_iter):
+    """Round 5: turbo_decode's redo is ONE launch in which every pair with a flagged codeword runs the reference's whole loop again with
+    the literal wave-parallel pass (csrc/bcjr.hip turbo_literal_kernel).  sigma^2 = 0.01 flags everything (flag (A), raised by the slab
+    initialisation); a third of the batch is not a codeword at all (NaN / inf LLRs inside the reference's loop, whose comparisons
+    `lappr > 0` then read False).  Decoded bits equal the oracle's on sampled codewords, priors included."""
+    from commpy_amd import _lib
+    from commpy_amd.channelcoding import RandInterlv, turbo_decode
+    from commpy_amd.devicelink import turbo_encode_gpu
+    tr = make_trellis(name)
+    rs = np.random.RandomState(40 + n_iter)
+    B, N, nv = 16 * 9 + 3, 141, 0.01
+    il = RandInterlv(N, 77)
+    msgs = rs.randint(0, 2, (B, N))
+    s, p1, p2 = (a[:, :N] * 2.0 - 1 + np.sqrt(nv) * rs.standard_normal((B, N)) for a in turbo_encode_gpu(msgs, tr, tr, il))
+    junk = rs.rand(B) < 0.3
+    s[junk] = rs.choice([-1.0, 1.0], size=(int(junk.sum()), N)) + 0.1 * rs.standard_normal((int(junk.sum()), N))
+    Lint = rs.randn(B, N) * 2.0
+    for use_L in (False, True):
+        dec = turbo_decode(s, p1, p2, tr, nv, n_iter, il, Lint if use_L else None)
+        note = _lib.last_kernel()
+        assert ("redo: %d of %d" % (B, B)) in note, note
+        for cw in list(range(24)) + list(range(B - 8, B)):
+            want = oracle.turbo_decode(s[cw], p1[cw], p2[cw], tr, nv, n_iter, il, Lint[cw] if use_L else None)
+            assert np.array_equal(dec[cw], want), (name, use_L, cw, int(np.sum(dec[cw] != want)))
+    # (what the bits ARE is the reference's business: at this noise variance its probability-domain loop overflows e^L after the first
+    # iteration and returns zeros even for clean codewords -- the oracle and the engine agree on that, which is the point)
