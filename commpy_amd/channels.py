@@ -105,13 +105,18 @@ def bsc(input_bits, p_t):
 
 
 def awgn(input_signal, snr_dB, rate=1.0):
-    """Add white Gaussian noise at the given SNR (dB) (channels.py:676-708)."""
-    input_signal = asarray(input_signal)
-    avg_energy = sum(abs(input_signal) * abs(input_signal)) / len(input_signal)
-    snr_linear = 10 ** (snr_dB / 10.0)
-    noise_variance = avg_energy / (2 * rate * snr_linear)
-    if not isrealobj(input_signal):
-        noise = (sqrt(noise_variance) * randn(len(input_signal))) + (sqrt(noise_variance) * randn(len(input_signal)) * 1j)
-    else:
-        noise = sqrt(2 * noise_variance) * randn(len(input_signal))      # real signal: full variance on one axis (:703)
-    return input_signal + noise
+    """White Gaussian noise at ``snr_dB`` relative to the signal's own mean energy (channels.py:676-708).
+
+    The noise power per real dimension is ``mean(|x|^2) / (2 * rate * 10^(snr_dB / 10))``; a complex signal gets that on each axis,
+    a real one twice that on its single axis.  The draws come from NumPy's global generator in the reference's order (all real
+    parts, then all imaginary parts) and the mean energy is NumPy's pairwise ``sum`` (the reference module imports ``sum`` from
+    numpy), so a seeded call returns the reference's samples bit for bit (tests/test_links_host.py)."""
+    x = asarray(input_signal)
+    n = len(x)
+    energy = abs(x) * abs(x)
+    per_axis = (energy.sum() / n) / (2 * rate * 10 ** (snr_dB / 10.0))
+    if isinstance(x[0], complex):                                  # (the reference's own type test: element 0 decides)
+        sigma = sqrt(per_axis)
+        re, im = randn(n), randn(n)
+        return x + (sigma * re + sigma * im * 1j)
+    return x + sqrt(2 * per_axis) * randn(n)

@@ -1016,6 +1016,30 @@ def gen_ldpc_c4y():
 
 GENS["ldpc_c4y"] = gen_ldpc_c4y
 
+# ----------------------------------------------------------------------------------------------
+# Host channel helpers (round 5): awgn / bsc / bec of commpy/channels.py:630-708 under a seeded global NumPy generator
+def gen_channels():
+    from commpy.channels import awgn, bec, bsc
+    rs = np.random.RandomState(77)
+    out = {}
+    xr = rs.randn(257)
+    xc = rs.randn(131) + 1j * rs.randn(131)
+    bits = rs.randint(0, 2, 500)
+    for tag, x, snr, rate in (("real", xr, 4.5, 0.5), ("cplx", xc, 11.0, 2.0 / 3), ("ones", np.ones(64), 0.0, 1.0)):
+        np.random.seed(1234)
+        out["awgn_%s__x" % tag], out["awgn_%s__par" % tag] = x, np.array([snr, rate])
+        out["awgn_%s__y" % tag] = awgn(x, snr, rate)
+    for p in (0.0, 0.07, 0.5, 1.0):
+        np.random.seed(4321)
+        out["bsc_%g" % p] = bsc(bits, p)
+        np.random.seed(4321)
+        out["bec_%g" % p] = bec(bits, p)
+    out["bits"] = bits
+    save("channels", **out)
+
+
+GENS["channels"] = gen_channels
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)

@@ -236,3 +236,20 @@ def test_wifi_custom_receiver_gets_1d_arrays(monkeypatch):
     w3 = Wifi80211(2)                                                            # rate 3/4: the depuncturing branch
     w3.link_performance(SISOFlatChannel(fading_param=(1 + 0j, 0j)), np.array([5.0]), 2, 10 ** 9, 60, receiver=receiver,
                         stop_on_surpass_error=False)
+
+
+def test_channel_helpers_equal_the_reference_under_a_seed():
+    """awgn / bsc / bec (channels.py:630-708) draw from NumPy's global generator: with the reference's seed they return the reference's
+    samples bit for bit (tests/golden/channels.npz, generated by the live reference; round 5 -- awgn was rewritten, not copied)."""
+    from helpers import golden
+    g = golden("channels")
+    for tag in ("real", "cplx", "ones"):
+        snr, rate = g["awgn_%s__par" % tag]
+        np.random.seed(1234)
+        got = awgn(g["awgn_%s__x" % tag], float(snr), float(rate))
+        assert got.dtype == g["awgn_%s__y" % tag].dtype and np.array_equal(got, g["awgn_%s__y" % tag]), tag
+    for p in (0.0, 0.07, 0.5, 1.0):
+        np.random.seed(4321)
+        assert np.array_equal(bsc(g["bits"], p), g["bsc_%g" % p]), p
+        np.random.seed(4321)
+        assert np.array_equal(bec(g["bits"], p), g["bec_%g" % p]), p
