@@ -6,6 +6,8 @@
 #             x(ldpc PMC passes) r(octx marker trace of the host-API benchmark, CPX_TRACE=1)
 #             c(alibration of FETCH_SIZE / WRITE_SIZE on known byte counts, scripts/micro/fetch_calib.py)
 #             f(uzz: scripts/fuzz_gpu.py for 90 s) L(ong run: bench.py --steps 500) T(olerance table of the sum-product decoder)
+#             o(ther_configs on their own) h(igh-SNR map_decode probe + PMC of the literal kernel) R(ow-vs-row sum-product table)
+#             P(robe check: does the shader-clock probe disturb what it measures)
 TAG=${1:-r05}
 SEC=${2:-tsbdklvu}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -58,6 +60,20 @@ if [[ $SEC == *x* ]]; then
 fi
 if [[ $SEC == *T* ]]; then
   timeout 600 python scripts/spa_tolerance_table.py --out $OUT 2>&1 | tail -3
+fi
+if [[ $SEC == *o* ]]; then
+  timeout 600 python benchmarks/other_configs.py --steps 20 --warmup 5 2>&1 | grep "^{" | tee $OUT/bench_other_configs.jsonl | cut -c1-260
+fi
+if [[ $SEC == *h* ]]; then
+  timeout 300 python scripts/micro/map_highsnr_probe.py 2>&1 | tee $OUT/map_highsnr_probe.txt
+  timeout 900 python scripts/collect_pmc.py --out $OUT --name map_highsnr --match map_ --fetch-scale 2 -- \
+      python $R/scripts/micro/map_highsnr_probe.py 0.01 2>&1 | tail -5
+fi
+if [[ $SEC == *R* ]]; then
+  timeout 300 python scripts/spa_rows_table.py --out $OUT > $OUT/spa_rows.txt 2>&1; tail -2 $OUT/spa_rows.txt | cut -c1-200
+fi
+if [[ $SEC == *P* ]]; then
+  timeout 300 python scripts/micro/sclk_probe_check.py 2>&1 | tee $OUT/sclk_probe_check.txt
 fi
 if [[ $SEC == *c* ]]; then
   timeout 600 python scripts/micro/fetch_calib.py --out $OUT 2>&1 | tail -3

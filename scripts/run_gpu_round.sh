@@ -6,5 +6,5 @@ cd $R
 head=$(git rev-parse HEAD)
 if ! git diff --quiet HEAD -- . ':!profiles' ':!*.md'; then head="$head+dirty"; fi
 echo "$head" > .git_head
-TAG=${1:-r05}; SEC=${2:-tsbdklvumxcfLT}; TMO=${3:-1500}
+TAG=${1:-r05}; SEC=${2:-tsbdklvumxcfLTohRP}; TMO=${3:-1500}
 exec /usr/local/graft/bin/gpurun --timeout $TMO -- "bash scripts/gpu_round.sh $TAG $SEC"
