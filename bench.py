@@ -506,7 +506,10 @@ def main():
     # at under the profiler (profiles/README.md) -- recorded instead of argued.
     clock = None
     try:
-        for _ in range(max(args.warmup, 5)):                       # the host read the timers meanwhile: no idle clock in the interval
+        probe = ctypes.c_void_p()                                   # a throw-away probe first: its one-time costs (stream, buffer, code
+        _lib.check(lib.cpx_sclk_probe_start(ctypes.byref(probe), 0.2))   # object) must not leave the GPU idle in front of the real interval
+        _lib.check(lib.cpx_sclk_probe_read(probe, None, None))
+        for _ in range(max(args.warmup, 8)):                       # the host read the timers meanwhile: no idle clock in the interval
             step(None, False)
         sync()
         probe = ctypes.c_void_p()

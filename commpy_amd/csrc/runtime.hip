@@ -492,6 +492,14 @@ __global__ void sclk_probe_kernel(uint64_t *out, uint64_t ref_ticks) {
     if (threadIdx.x == 0) { out[0] = r0; out[1] = c0; out[2] = r; out[3] = c1; }
 }
 
+// (stream and result buffer are created once per thread and device and kept: the first version created them per call, and the host
+//  time that took -- plus the probe kernel's first-launch cost -- left the GPU idle long enough to drop its clock right before the
+//  interval it was meant to measure: 2246 MHz / 1.60 ms in the first repetition of scripts/micro/sclk_probe_check.py, 2380 MHz / 1.54 ms
+//  in every later one)
+static thread_local hipStream_t g_probe_stream = nullptr;
+static thread_local uint64_t *g_probe_buf = nullptr;
+static thread_local int g_probe_dev = -1;
+
 int cpx_sclk_probe_start(void **probe, double spin_ms) {
     CPX_REQUIRE(probe && spin_ms > 0.0 && spin_ms <= 10000.0, CPX_EINVAL, "cpx_sclk_probe_start: bad argument");
     int rc = ensure_device();
@@ -500,10 +508,15 @@ int cpx_sclk_probe_start(void **probe, double spin_ms) {
     CPX_HIP(hipGetDevice(&dev));
     CPX_HIP(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev));
     CPX_REQUIRE(khz > 0, CPX_EHIP, "cpx_sclk_probe_start: the device reports no wall-clock rate");
+    if (!g_probe_stream || g_probe_dev != dev) {
+        CPX_HIP(hipStreamCreateWithFlags(&g_probe_stream, hipStreamNonBlocking));
+        CPX_HIP(hipMalloc((void **)&g_probe_buf, 4 * sizeof(uint64_t)));
+        g_probe_dev = dev;
+    }
     cpx_sclk_probe_t *q = new cpx_sclk_probe_t;
     q->ref_khz = khz;
-    CPX_HIP(hipStreamCreateWithFlags(&q->st, hipStreamNonBlocking));
-    CPX_HIP(hipMalloc((void **)&q->d, 4 * sizeof(uint64_t)));
+    q->st = g_probe_stream;
+    q->d = g_probe_buf;
     hipLaunchKernelGGL(sclk_probe_kernel, dim3(1), dim3(64), 0, q->st, q->d, (uint64_t)(spin_ms * (double)khz));
     CPX_HIP(hipGetLastError());
     *probe = q;
@@ -519,9 +532,7 @@ int cpx_sclk_probe_read(void *probe, double *sclk_mhz, double *interval_ms) {
     const double dt_ms = (double)(h[2] - h[0]) / (double)q->ref_khz;
     if (interval_ms) *interval_ms = dt_ms;
     if (sclk_mhz) *sclk_mhz = dt_ms > 0.0 ? (double)(h[3] - h[1]) / dt_ms * 1e-3 : 0.0;
-    (void)hipFree(q->d);
-    (void)hipStreamDestroy(q->st);
-    delete q;
+    delete q;                                                     // (stream and buffer stay with the thread)
     return CPX_OK;
 }
 
