@@ -73,7 +73,8 @@ __global__ __launch_bounds__(DEMOD_BLOCK) void demod_soft_kernel(const double2 *
 // exponentials of an axis form a geometric progression of geometric progressions,
 //     e[j+1] = e[j] rho[j],  rho[j] = exp((2 d (x - p[j]) - d^2) / N0),  rho[j+1] = rho[j] Q,  Q = exp(-2 d^2 / N0)
 // (and the mirror image downwards), so FOUR exp per axis -- the two middle levels and their two first ratios -- give all R values,
-// the rest by two multiplications per level: 64-QAM 8 instead of 16 exp per symbol, 256-QAM 8 instead of 32.  Starting in the
+// the rest by two multiplications per level: 64-QAM 8 instead of 16 exp per symbol, 256-QAM 8 instead of 32 (round 5: TWO exp and a
+// division per axis, see axis_gp).  Starting in the
 // middle keeps every factor that matters a normal number: the results carry a few more roundings than exp itself (~1e-15 on an
 // LLR).  Where they could not -- a middle-level exponential below 1e-290, an axis whose sum is below 1e-30, or anything non-finite --
 // the symbol joins the point-by-point redo below (which the +-600 rule already sends the deep-underflow cases to); with both
@@ -83,22 +84,28 @@ __device__ __forceinline__ bool axis_gp(double v, const double *ax, double d, do
                                         double Q, double (&e)[1 << NH], double &sum) {
     constexpr int R = 1 << NH, JL = R / 2 - 1, JH = R / 2;
     constexpr int GL = JL ^ (JL >> 1), GH = JH ^ (JH >> 1);       // labels of the two middle levels
-    const double dl = v - ax[GL], dh = v - ax[GH];
+    // Round 5: TWO exp per axis.  With rho = e[JH] / e[JL] = exp((2 d (x - p[JL]) - d^2) / N0), the ratio between the two middle levels,
+    // the upper middle level is e[JL] rho, the first ratio upwards rho Q and the first ratio downwards Q / rho: the second middle
+    // exponential and both outward ratios of round 4's four-exp form follow from ONE exponential and one division (37 + 37 + 37
+    // instructions -> 12 + 4).  rho itself must be a well-scaled normal number (it overflows only beyond Es/N0 ~ 33 dB, where the
+    // middle exponential has long failed its own test); it joins the guard.
+    const double dl = v - ax[GL];
     const double el = exp(RCP ? (dl * dl) * ninv : (-(dl * dl)) / noise_var);
-    const double eh = exp(RCP ? (dh * dh) * ninv : (-(dh * dh)) / noise_var);
+    const double rho = exp(c1 * dl - c2);
+    const double eh = el * rho;
     e[GL] = el;
     e[GH] = eh;
-    double cur = eh, r = exp(c1 * dh - c2);
+    double cur = eh, r = rho * Q;
 #pragma unroll
     for (int j = JH + 1; j < R; j++) { cur *= r; e[j ^ (j >> 1)] = cur; r *= Q; }
     cur = el;
-    r = exp(-c1 * dl - c2);
+    r = Q / rho;
 #pragma unroll
     for (int j = JL - 1; j >= 0; j--) { cur *= r; e[j ^ (j >> 1)] = cur; r *= Q; }
     sum = 0.0;
 #pragma unroll
     for (int a = 0; a < R; a++) sum += e[a];                      // label order, like the plain path
-    return !(fmin(el, eh) >= 1e-290) || !(sum >= 1e-30);
+    return !(fmin(el, eh) >= 1e-290) || !(rho > 1e-290 && rho < 1e290) || !(sum >= 1e-30);
 }
 
 template <int NH, bool RCP, bool GP>
