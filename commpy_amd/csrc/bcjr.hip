@@ -41,6 +41,7 @@
 #include "cpx_math.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 using namespace cpx;
 
@@ -302,6 +303,35 @@ __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, unsigned voff, 
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(bcjr_v2u, v), r, voff, soff, 0);
 }
 
+// ---- "fp32-fast" turbo decoding (cpx_set_precision; NOT the parity mode; round 5) ---------------------------------------------------
+// The arithmetic of a pass stays float64; what changes is the SLAB between the passes: float32 arrays, so that a pass reads 12 instead
+// of 24 bytes per step and wave and the interleave stages move half the bytes.  A prior cannot be stored as p0 in float32 (1 - p0
+// would lose everything below 6e-8: every |L| > 16.6 would become a hard decision), so the slab carries the SMALLER of (p0, p1) with
+// the sign bit saying which: q = +p1 when p1 <= 1/2, q = -p0 otherwise; the other one is 1 - |q|.  Channel factors and the LLRs of the
+// last two passes are plain float32.  Contract: tests/test_fp32_fast_gpu.py (bit error rate and fraction of differing bits against
+// the float64 decode), DESIGN 4.2.
+template <bool S32>
+__device__ __forceinline__ double slab_ld(__amdgpu_buffer_rsrc_t r, unsigned m, unsigned elem, unsigned soff) {
+    if (S32) return (double)__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, item_off(m, elem * 4u), soff, 0));
+    return buf_ld(r, item_off(m, elem * 8u), soff);
+}
+template <bool S32>
+__device__ __forceinline__ void slab_st(__amdgpu_buffer_rsrc_t r, unsigned m, unsigned elem, unsigned soff, double v) {
+    if (S32) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)v), r, item_off(m, elem * 4u), soff, 0);
+    else buf_st(r, item_off(m, elem * 8u), soff, v);
+}
+// float32 slab: the prior of odds r = P1 / P0 (p0 = 1 / (1 + r); the smaller of the two, signed)
+__device__ __forceinline__ double enc_prior_odds(double r) {
+    const double p0 = 1.0 / (1.0 + r);
+    return r <= 1.0 ? r * p0 : -p0;
+}
+__device__ __forceinline__ void dec_prior(double q, double &p0, double &p1) {
+    const double v = fabs(q), w = 1.0 - v;
+    const bool neg = __double2hiint(q) < 0;                       // the sign BIT: -0.0 means p0 = 0
+    p0 = neg ? v : w;
+    p1 = neg ? w : v;
+}
+
 __device__ __forceinline__ double ld_off(const double *base, unsigned elem) {
     return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + (elem * 8u));
 }
@@ -309,7 +339,7 @@ __device__ __forceinline__ void st_off(double *base, unsigned elem, double v) {
     *reinterpret_cast<double *>(reinterpret_cast<char *>(base) + (elem * 8u)) = v;
 }
 
-template <int LGS>
+template <int LGS, bool S32 = false>
 __device__ __forceinline__ void load_raw(const Ctx<LGS> &c, const PassIO &io, RawChunk &rc, int t0, int len) {
 #pragma unroll
     for (int q = 0; q < 2; q++) {
@@ -317,9 +347,9 @@ __device__ __forceinline__ void load_raw(const Ctx<LGS> &c, const PassIO &io, Ra
         item_of(c.lane, q, gg, tl);
         const unsigned t = (unsigned)(t0 + tl);                   // 0-based step index
         const unsigned m = item_mask(gg, io.ncw, tl, len);        // no such item: zeros
-        rc.r0[q] = buf_ld(io.rsys, item_off(m, ((unsigned)(gg * io.sstride) + t) * 8u), io.osys);
-        rc.r1[q] = buf_ld(io.rpar, item_off(m, ((unsigned)(gg * io.pstride) + t) * 8u), io.opar);
-        rc.li[q] = buf_ld(io.rlin, item_off(m, ((unsigned)(gg * io.lstride) + t) * 8u), io.olin);
+        rc.r0[q] = slab_ld<S32>(io.rsys, m, (unsigned)(gg * io.sstride) + t, io.osys);
+        rc.r1[q] = slab_ld<S32>(io.rpar, m, (unsigned)(gg * io.pstride) + t, io.opar);
+        rc.li[q] = slab_ld<S32>(io.rlin, m, (unsigned)(gg * io.lstride) + t, io.olin);
     }
 }
 
@@ -343,7 +373,7 @@ __device__ __forceinline__ double signed_q(double r, double k4) { return __built
 // P(bit = 0) from the a-priori LLR, as the reference writes it (turbo.py:239)
 __device__ __forceinline__ double prior0(double L) { return 1.0 / (1.0 + exp(L)); }
 
-template <int LGS, bool PRE, bool LIT = false>
+template <int LGS, bool PRE, bool LIT = false, bool S32 = false>
 __device__ __forceinline__ void stage_chunk(const Ctx<LGS> &c, const RawChunk &rc, double nv2, int ncw) {
     const int GW = c.GW;
     const double k4 = -4.0 / nv2;
@@ -381,7 +411,8 @@ __device__ __forceinline__ void stage_chunk(const Ctx<LGS> &c, const RawChunk &r
             // in a kernel that waits for memory -- and the slab holds THAT; a pass never needs L_int itself (it writes L - L_int).
             // That is an exp and a division per item and staging, a quarter of a pass's instructions.  (A codeword slot past the end
             // of the batch reads zeros: it gets the prior of L_int = 0.)
-            const double p0 = PRE ? (gg < ncw ? li : 0.5) : prior0(li), p1 = 1.0 - p0;
+            double p0 = PRE ? (gg < ncw ? li : 0.5) : prior0(li), p1 = 1.0 - p0;
+            if (PRE && S32) dec_prior(gg < ncw ? li : 0.5, p0, p1);   // float32 slab: the smaller of (p0, p1), signed
             // sign of the received value; the sign BIT, so that an underflowed factor stored as -0.0 keeps its sign
             const bool n0 = PRE ? __double2hiint(r0) < 0 : r0 < 0.0, n1 = PRE ? __double2hiint(r1) < 0 : r1 < 0.0;
             const double a0 = n0 ? 1.0 : qa, a1 = n0 ? qa : 1.0;  // systematic bit 0 (c0 = -1) / 1 (c0 = +1)
@@ -563,7 +594,7 @@ __device__ __forceinline__ void alpha_chunk(const Ctx<LGS> &c, double &a, int le
 }
 
 // time-parallel epilogue of a phase-2 chunk: app sums in state order, L = L_int + log(app1/app0) (:145)
-template <int LGS, bool BITS, bool LIT = false>
+template <int LGS, bool BITS, bool LIT = false, bool S32 = false>
 __device__ __forceinline__ void epilogue(const Ctx<LGS> &c, const PassIO &io, const double (&li)[2], int t_lo, int len) {
     constexpr int S = Ctx<LGS>::S;
     asm volatile("" ::: "memory");
@@ -595,7 +626,7 @@ __device__ __forceinline__ void epilogue(const Ctx<LGS> &c, const PassIO &io, co
             // zeros of its priors (1 + e rounds to 1 below e = 2^-53: p1 = 0; e = inf: p0 = 0) fall where the reference has them, which
             // app0 / (app0 + app1) does not guarantee (caught by the extreme-regime fixtures)
             const double r = app1 / app0;
-            L = 1.0 / (1.0 + r);
+            L = S32 ? enc_prior_odds(r) : 1.0 / (1.0 + r);
             flag_or(q ? c.bad_i1 : c.bad_i0, ok && (!(r > 0.0 && r < __builtin_huge_val()) || !(fmax(app0, app1) >= T_SMALL)));   // (D): log r not finite; (E)
         } else {
 #ifdef CPX_AB_NO_EPILOG_LOG                                        /* ablation builds only (experiments/README.md): what the logarithm costs */
@@ -607,7 +638,7 @@ __device__ __forceinline__ void epilogue(const Ctx<LGS> &c, const PassIO &io, co
             L = io.ext ? lr : li[q] + lr;
         }
         const unsigned t = (unsigned)(t_lo + tl);
-        buf_st(io.rout, item_off(m, ((unsigned)(gg * io.lstride) + t) * 8u), io.oout, L);
+        slab_st<S32>(io.rout, m, (unsigned)(gg * io.lstride) + t, io.oout, L);
         if (BITS) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)((io.want_bits && L > 0) ? 1 : 0), io.rbits,
                                              item_off(m, (unsigned)(gg * io.N) + t), 0, 0);               // (:148-152)
     }
@@ -625,7 +656,7 @@ __device__ __forceinline__ void pair_sync() {
 }
 
 // One MAP pass over the GW codewords of this pair of wavefronts.  Collective over the workgroup (one pair_sync).
-template <int LGS, bool SR, bool PRE, bool LIT = false>
+template <int LGS, bool SR, bool PRE, bool LIT = false, bool S32 = false>
 __device__ void map_pass(const Ctx<LGS> &c, const PassIO &io) {
     const int N = io.N;
     const int K = (N + CH - 1) / CH, K1 = K / 2;                  // F: chunks [0,K1) then [K1,K); R: [K1,K) then [0,K1)
@@ -644,7 +675,7 @@ __device__ void map_pass(const Ctx<LGS> &c, const PassIO &io) {
     // issuing VALU 53 % of the time, 22 % of the wave cycles in s_waitcnt and 29 % ready-but-not-issued.
     auto seq = [&](int i) { return c.fwd ? i : K - 1 - i; };
     // (past the end of the walk the last chunk is requested again: an `if` around the loads would bring the uncounted wait back)
-    auto fetch = [&](RawChunk &S, int i) { const int k = seq(i < K ? i : K - 1); load_raw<LGS>(c, io, S, k * CH, clen(k)); };
+    auto fetch = [&](RawChunk &S, int i) { const int k = seq(i < K ? i : K - 1); load_raw<LGS, S32>(c, io, S, k * CH, clen(k)); };
     RawChunk X, Y;
     fetch(X, 0);
     fetch(Y, 1);
@@ -681,7 +712,7 @@ __device__ void map_pass(const Ctx<LGS> &c, const PassIO &io) {
         double a = (c.s == 0) ? 1.0 : 0.0;                        // f_state_metrics[0][0] = 1 (:221)
         run(0, K1, [&](int i, RawChunk &S) {
             ck_st(i, a);                                          // alpha at time i*CH (read by R in phase 2)
-            stage_chunk<LGS, PRE, LIT>(c, S, io.nv2, io.ncw);
+            stage_chunk<LGS, PRE, LIT, S32>(c, S, io.nv2, io.ncw);
             fetch(S, i + 2);
             alpha_chunk<LGS, SR, false, LIT>(c, a, CH, arow);          // chunks below K1 are full
         });
@@ -690,22 +721,22 @@ __device__ void map_pass(const Ctx<LGS> &c, const PassIO &io) {
         if (!dead() && !run(K1, K, [&](int k, RawChunk &S) {
             const int len = clen(k);
             double b = ck_ld(k + 1);                              // beta at the upper boundary of chunk k
-            epilogue<LGS, !PRE, LIT>(c, io, li_prev, t_prev, len_prev);
-            stage_chunk<LGS, PRE, LIT>(c, S, io.nv2, io.ncw);
+            epilogue<LGS, !PRE, LIT, S32>(c, io, li_prev, t_prev, len_prev);
+            stage_chunk<LGS, PRE, LIT, S32>(c, S, io.nv2, io.ncw);
             li_prev[0] = S.li[0]; li_prev[1] = S.li[1];
             fetch(S, k + 2);
             alpha_chunk<LGS, SR, true, LIT>(c, a, len, arow);
             beta_chunk<LGS, SR, true, LIT>(c, b, len, arow);
             t_prev = k * CH; len_prev = len;
         }))
-            epilogue<LGS, !PRE, LIT>(c, io, li_prev, t_prev, len_prev);
+            epilogue<LGS, !PRE, LIT, S32>(c, io, li_prev, t_prev, len_prev);
     } else {
         // ---------------- phase 1: beta over chunks K-1 .. K1, checkpoint before every chunk ----------------
         double b = 1.0;                                           // b_state_metrics[:, N] = 1 (:225)
         run(0, K - K1, [&](int i, RawChunk &S) {
             const int k = K - 1 - i;
             ck_st(k + 1, b);                                      // beta at the upper boundary of chunk k (read by F)
-            stage_chunk<LGS, PRE, LIT>(c, S, io.nv2, io.ncw);
+            stage_chunk<LGS, PRE, LIT, S32>(c, S, io.nv2, io.ncw);
             fetch(S, i + 2);
             beta_chunk<LGS, SR, false, LIT>(c, b, clen(k), arow);
         });
@@ -714,15 +745,15 @@ __device__ void map_pass(const Ctx<LGS> &c, const PassIO &io) {
         if (!dead() && !run(K - K1, K, [&](int i, RawChunk &S) {
             const int k = K - 1 - i;
             double a = ck_ld(k);                                  // alpha at the lower boundary of chunk k
-            epilogue<LGS, !PRE, LIT>(c, io, li_prev, t_prev, len_prev);      // of the previous chunk (see the forward wave)
-            stage_chunk<LGS, PRE, LIT>(c, S, io.nv2, io.ncw);
+            epilogue<LGS, !PRE, LIT, S32>(c, io, li_prev, t_prev, len_prev);      // of the previous chunk (see the forward wave)
+            stage_chunk<LGS, PRE, LIT, S32>(c, S, io.nv2, io.ncw);
             li_prev[0] = S.li[0]; li_prev[1] = S.li[1];
             fetch(S, i + 2);
             alpha_chunk<LGS, SR, true, LIT>(c, a, CH, arow);           // arow[tl] = alpha at time k*CH + tl
             beta_chunk<LGS, SR, true, LIT>(c, b, CH, arow);
             t_prev = k * CH; len_prev = CH;
         }))
-            epilogue<LGS, !PRE, LIT>(c, io, li_prev, t_prev, len_prev);
+            epilogue<LGS, !PRE, LIT, S32>(c, io, li_prev, t_prev, len_prev);
     }
     if (!LIT) publish_flags<LGS>(c, io.flags, io.ncw);
 }
@@ -842,7 +873,7 @@ __device__ __forceinline__ int64_t slab_off(const TurboParams &p, int a, int64_t
 // where the stand-alone pass has 33 %).  As its own kernel the pass keeps the register allocation of map_decode_kernel (224
 // VGPRs, no scratch); a kernel boundary costs ~2 us, 25 of them per decode.  Measured, same box: 5.24 ms (persistent) -> 4.82 ms
 // (launch per pass, row slab) -> chunked slab: see DESIGN.md 4.2.
-template <int LGS, bool SR>
+template <int LGS, bool SR, bool S32 = false>
 __global__ __launch_bounds__(128 * NPAIR) void turbo_pass_kernel(TurboParams p, int second, int pout) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Ctx<LGS> c;
@@ -860,17 +891,18 @@ __global__ __launch_bounds__(128 * NPAIR) void turbo_pass_kernel(TurboParams p, 
     io.abort_ok = false;                                          // turbo's redo is per codeword: the other codewords of a pair must be finished
     io.ext = true;                                                // the pass writes E = L - L_int (:318, :328) ...
     io.pout = pout != 0;                                          // ... or prior0(E) directly (epilogue)
-    double *base = p.larr + cw0 * ls;                              // the pair's first codeword
+    constexpr unsigned ES = S32 ? 4u : 8u;                         // bytes per slab element ("fp32-fast": float32 slab)
+    const char *base = reinterpret_cast<const char *>(p.larr) + cw0 * ls * ES;   // the pair's first codeword
     //   first  half-iteration: [L_ext_1, _] = map_decode(sys,   non_sys_1, trellis, nv, L_int_1, 'compute')   (:315)
     //   second half-iteration: [L_2, bits]  = map_decode(sys_i, non_sys_2, trellis, nv, L_int_2, mode)        (:326)
     io.rsys = io.rpar = io.rlin = io.rout = pass_buffer(base, io.ncw > 0 ? OOB : 0u);
     io.rbits = pass_buffer(nullptr, 0u);
-    const unsigned nb = (unsigned)N * 8u;
+    const unsigned nb = (unsigned)N * ES;
     io.osys = __builtin_amdgcn_readfirstlane((second ? 4u : 3u) * nb);
     io.opar = __builtin_amdgcn_readfirstlane((second ? 6u : 5u) * nb);
     io.olin = __builtin_amdgcn_readfirstlane((second ? 2u : 0u) * nb);
     io.oout = nb;
-    map_pass<LGS, SR, true>(c, io);
+    map_pass<LGS, SR, true, false, S32>(c, io);
 }
 
 // mode 0: slab initialisation (:305-310) + flag (A);  1: L_int_2 = interlv(E_1) (:318-319);  2: L_int_1 = deinterlv(E_2)
@@ -878,6 +910,7 @@ __global__ __launch_bounds__(128 * NPAIR) void turbo_pass_kernel(TurboParams p, 
 // (:148-152, :331).  One wavefront per codeword, four per workgroup; `lds_n`
 // doubles of LDS per wavefront when a codeword's array fits -- the permutations then go THROUGH LDS: coalesced read, LDS
 // scatter / gather, coalesced write (round 1 gathered from HBM: a 64-byte line per 8-byte element) -- else 0.
+template <bool S32>
 __global__ __launch_bounds__(256) void turbo_stage_kernel(TurboParams p, int mode, int lds_n, int keep_l, int pin) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -886,7 +919,13 @@ __global__ __launch_bounds__(256) void turbo_stage_kernel(TurboParams p, int mod
     const int64_t N = p.N;
     double *buf = reinterpret_cast<double *>(smem) + (size_t)wv * lds_n;
     const bool in_lds = lds_n >= N;
-    auto at = [&](int a, int64_t t) -> double & { return p.larr[slab_off(p, a, cwg, t)]; };
+    // the slab is float64, or float32 in the "fp32-fast" mode (see slab_ld): element access through ld / st
+    using T = typename std::conditional<S32, float, double>::type;
+    T *slab = reinterpret_cast<T *>(p.larr);
+    auto ld = [&](int a, int64_t t) -> double { return (double)slab[slab_off(p, a, cwg, t)]; };
+    auto st = [&](int a, int64_t t, double v) { slab[slab_off(p, a, cwg, t)] = (T)v; };
+    // what a pass reads as its prior: P(bit = 0) (float64 slab), or the smaller of (p0, p1), signed (float32 slab)
+    auto prior_of = [&](double L) -> double { return S32 ? enc_prior_odds(exp(L)) : prior0(L); };
     if (mode == 0) {
         const double k4 = -4.0 / p.nv2;
         // (A) of "detect and redo" for every received value on its own: |r| > sqrt(T_A nv2 / 2) - 1 bounds
@@ -896,58 +935,58 @@ __global__ __launch_bounds__(256) void turbo_stage_kernel(TurboParams p, int mod
         bool far = false;
 #pragma unroll 2
         for (int64_t t = lane; t < N; t += 64) {
-            at(0, t) = prior0(p.Lint ? p.Lint[cwg * N + t] : 0.0); // prior of L_int_1 (:305-308, :239)
+            st(0, t, prior_of(p.Lint ? p.Lint[cwg * N + t] : 0.0)); // prior of L_int_1 (:305-308, :239)
             const double r1 = y1[t], r2 = y2[t], rs = sy[t];
             far = far || !(fabs(r1) <= rmax) || !(fabs(r2) <= rmax) || !(fabs(rs) <= rmax);
-            at(5, t) = signed_q(r1, k4);
-            at(6, t) = signed_q(r2, k4);
+            st(5, t, signed_q(r1, k4));
+            st(6, t, signed_q(r2, k4));
             const double v = signed_q(rs, k4);
-            at(3, t) = v;
+            st(3, t, v);
             if (in_lds) buf[t] = v;
         }
         if (p.flags && __ballot(far) != 0 && lane == 0) p.flags[cwg] = 1;
         asm volatile("" ::: "memory");                             // LDS operations of one wave execute in order
         if (in_lds) {
 #pragma unroll 4
-            for (int64_t t = lane; t < N; t += 64) at(4, t) = buf[p.perm[t]];               // interlv(sys) (:310)
+            for (int64_t t = lane; t < N; t += 64) st(4, t, buf[p.perm[t]]);                // interlv(sys) (:310)
         } else {
 #pragma unroll 2
-            for (int64_t t = lane; t < N; t += 64) at(4, t) = signed_q(sy[p.perm[t]], k4);
+            for (int64_t t = lane; t < N; t += 64) st(4, t, signed_q(sy[p.perm[t]], k4));
         }
     } else if (mode == 1) {
         if (in_lds) {
 #pragma unroll 4
-            for (int64_t t = lane; t < N; t += 64) buf[t] = at(1, t);
+            for (int64_t t = lane; t < N; t += 64) buf[t] = ld(1, t);
             asm volatile("" ::: "memory");
 #pragma unroll 4
             for (int64_t t = lane; t < N; t += 64) {
                 const double L = buf[p.perm[t]];
-                at(2, t) = pin ? L : prior0(L);                     // pin: the pass already wrote prior0(E) (turbo_pass_kernel, pout)
-                if (keep_l) at(0, t) = L;                           // the last L_int_2 itself, for the final decision (mode 3)
+                st(2, t, pin ? L : prior_of(L));                    // pin: the pass already wrote the prior (turbo_pass_kernel, pout)
+                if (keep_l) st(0, t, L);                            // the last L_int_2 itself, for the final decision (mode 3)
             }
         } else {
 #pragma unroll 4
             for (int64_t t = lane; t < N; t += 64) {
-                const double L = at(1, p.perm[t]);
-                at(2, t) = pin ? L : prior0(L);
-                if (keep_l) at(0, t) = L;
+                const double L = ld(1, p.perm[t]);
+                st(2, t, pin ? L : prior_of(L));
+                if (keep_l) st(0, t, L);
             }
         }
     } else if (mode == 2) {
         if (in_lds) {
 #pragma unroll 4
-            for (int64_t t = lane; t < N; t += 64) buf[p.perm[t]] = at(1, t);
+            for (int64_t t = lane; t < N; t += 64) buf[p.perm[t]] = ld(1, t);
             asm volatile("" ::: "memory");
 #pragma unroll 4
-            for (int64_t t = lane; t < N; t += 64) at(0, t) = pin ? buf[t] : prior0(buf[t]);
+            for (int64_t t = lane; t < N; t += 64) st(0, t, pin ? buf[t] : prior_of(buf[t]));
         } else {
 #pragma unroll 4
-            for (int64_t t = lane; t < N; t += 64) at(0, p.perm[t]) = pin ? at(1, t) : prior0(at(1, t));
+            for (int64_t t = lane; t < N; t += 64) st(0, p.perm[t], pin ? ld(1, t) : prior_of(ld(1, t)));
         }
     } else {
 #pragma unroll 4
         for (int64_t t = lane; t < N; t += 64)
-            p.bits[cwg * N + p.perm[t]] = (uint8_t)((p.n_iter > 0 && at(0, t) + at(1, t) > 0) ? 1 : 0);   // L_2 = L_int_2 + E_2 (array 0: see mode 1)
+            p.bits[cwg * N + p.perm[t]] = (uint8_t)((p.n_iter > 0 && ld(0, t) + ld(1, t) > 0) ? 1 : 0);   // L_2 = L_int_2 + E_2 (array 0: see mode 1)
     }
 }
 
@@ -1167,16 +1206,24 @@ int cpx_turbo_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const 
     CPX_REQUIRE((B + 3) / 4 < (1ll << 31), CPX_ELIMIT, "turbo_decode: batch too large");
     const dim3 sgrid((unsigned)((B + 3) / 4)), sblock(256);
     const size_t slds = (size_t)lds_n * 8 * 4;
-    auto stage = [&](int mode, int keep_l = 0, int pin = 0) { hipLaunchKernelGGL(turbo_stage_kernel, sgrid, sblock, slds, st, p, mode, lds_n, keep_l, pin); };
+    // "fp32-fast" (cpx_set_precision; not the parity mode): the slab between the passes in float32 (slab_ld), arithmetic unchanged
+    const bool s32 = precision_fast();
+    auto stage = [&](int mode, int keep_l = 0, int pin = 0) {
+        if (s32) hipLaunchKernelGGL(turbo_stage_kernel<true>, sgrid, sblock, slds, st, p, mode, lds_n, keep_l, pin);
+        else hipLaunchKernelGGL(turbo_stage_kernel<false>, sgrid, sblock, slds, st, p, mode, lds_n, keep_l, pin);
+    };
     auto pass = [&](int second, int pout) -> int {
         switch (p.tb.lgS) {
-#define CASE(LG) case LG: hipLaunchKernelGGL((turbo_pass_kernel<LG, false>), grid, block, sizeof(double) * 2 * np * wave_lds_doubles<LG>(GW), st, p, second, pout); break;
+#define LAUNCH(LG, SRV) do { if (s32) hipLaunchKernelGGL((turbo_pass_kernel<LG, SRV, true>), grid, block, sizeof(double) * 2 * np * wave_lds_doubles<LG>(GW), st, p, second, pout); \
+                             else hipLaunchKernelGGL((turbo_pass_kernel<LG, SRV, false>), grid, block, sizeof(double) * 2 * np * wave_lds_doubles<LG>(GW), st, p, second, pout); } while (0)
+#define CASE(LG) case LG: LAUNCH(LG, false); break;
             case 2:
-                if (p.tb.sr4) hipLaunchKernelGGL((turbo_pass_kernel<2, true>), grid, block, sizeof(double) * 2 * np * wave_lds_doubles<2>(GW), st, p, second, pout);
-                else hipLaunchKernelGGL((turbo_pass_kernel<2, false>), grid, block, sizeof(double) * 2 * np * wave_lds_doubles<2>(GW), st, p, second, pout);
+                if (p.tb.sr4) LAUNCH(2, true);
+                else LAUNCH(2, false);
                 break;
             CASE(1) CASE(3) CASE(4)
 #undef CASE
+#undef LAUNCH
             default: set_error("turbo_decode: unsupported state count"); return CPX_ELIMIT;
         }
         return CPX_OK;
@@ -1192,8 +1239,8 @@ int cpx_turbo_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const 
     }
     stage(3);
     CPX_HIP(hipGetLastError());
-    note_kernel("turbo_pass_kernel<%d,%s> x %d + turbo_stage_kernel (%d wave pairs per workgroup, %d codewords per pair)", p.tb.lgS,
-                (p.tb.lgS == 2 && p.tb.sr4) ? "true" : "false", 2 * n_iter, np, GW);
+    note_kernel("turbo_pass_kernel<%d,%s%s> x %d + turbo_stage_kernel (%d wave pairs per workgroup, %d codewords per pair)", p.tb.lgS,
+                (p.tb.lgS == 2 && p.tb.sr4) ? "true" : "false", s32 ? ",f32 slab" : "", 2 * n_iter, np, GW);
     // redo: one launch; a pair with a flagged codeword decodes its codewords again, literally, all iterations (turbo_literal_kernel)
     const RedoCounter redo = redo_counter();
     {

@@ -32,7 +32,7 @@ fi
 if [[ $SEC == *k* ]]; then
   timeout 1200 python benchmarks/bench_kernels.py 2>&1 | tee $OUT/bench_kernels.jsonl | cut -c1-250
   # the fp32-fast precision mode (not the parity mode): the kernels that have a float32 variant
-  CPX_PRECISION=fp32-fast timeout 600 python benchmarks/bench_kernels.py --which ldpc,config4,demod 2>&1 | grep "^{" | tee $OUT/bench_kernels_fp32_fast.jsonl | cut -c1-200
+  CPX_PRECISION=fp32-fast timeout 600 python benchmarks/bench_kernels.py --which ldpc,config4,demod,turbo,turbo8 2>&1 | grep "^{" | tee $OUT/bench_kernels_fp32_fast.jsonl | cut -c1-200
 fi
 if [[ $SEC == *l* ]]; then
   timeout 600 python benchmarks/bench_link.py --mcs 5 2>&1 | tail -1 | tee $OUT/bench_link.jsonl | cut -c1-300

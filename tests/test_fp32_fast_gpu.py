@@ -231,3 +231,47 @@ def test_soft_demod_fast_mode_scaled_and_device_entry(gpu, lib):
         md.demodulate(y, "soft", 1e-40)
         assert "f32" not in lib.last_kernel()
         lib.set_precision(None)
+
+
+@pytest.mark.parametrize("states,N,iters", [(4, 1024, 6), (8, 512, 4), (4, 203, 2)])
+def test_turbo_fast_mode_float32_slab(gpu, lib, states, N, iters):
+    """Round 5: `fp32-fast` turbo decoding keeps the float64 arithmetic of the MAP passes and stores the slab BETWEEN them in float32
+    (channel factors, the smaller of (p0, p1) with a sign, the LLRs of the last two passes): half the bytes per pass and interleave
+    stage.  Not the parity mode: the contract is an unchanged bit error rate and a bounded fraction of bits that differ from the float64
+    decode at the code's operating point (measured ~1e-6: only decisions whose LLR sits within float32 rounding of zero can move)."""
+    import commpy_amd
+    from commpy_amd.channelcoding import RandInterlv, turbo_decode
+    from commpy_amd.devicelink import turbo_encode_gpu
+    tr = make_trellis("rsc_legacy_4" if states == 4 else "rsc_legacy_8")
+    rs = np.random.RandomState(states + N)
+    B = 4096 if N >= 512 else 1500
+    il = RandInterlv(N, 99)
+    msgs = rs.randint(0, 2, (B, N))
+    nv = 1 / (2 * (1.0 / 3) * 10 ** (1.5 / 10.0))
+    s, p1, p2 = (a[:, :N] * 2.0 - 1 + np.sqrt(nv) * rs.standard_normal((B, N)) for a in turbo_encode_gpu(msgs, tr, tr, il))
+    Lint = rs.randn(B, N) * 0.5
+    for use_L in (False, True):
+        ref = turbo_decode(s, p1, p2, tr, nv, iters, il, Lint if use_L else None)
+        assert "f32" not in lib.last_kernel(), lib.last_kernel()
+        commpy_amd.set_precision("fp32-fast")
+        try:
+            fast = turbo_decode(s, p1, p2, tr, nv, iters, il, Lint if use_L else None)
+            assert "f32 slab" in lib.last_kernel(), lib.last_kernel()
+            again = turbo_decode(s, p1, p2, tr, nv, iters, il, Lint if use_L else None)
+        finally:
+            commpy_amd.set_precision("fp64-parity")
+        assert np.array_equal(fast, again)                                           # deterministic
+        assert np.array_equal(turbo_decode(s, p1, p2, tr, nv, iters, il, Lint if use_L else None), ref)   # the switch switches back
+        mism = float(np.mean(fast != ref))
+        ber_ref, ber_fast = float(np.mean(ref != msgs)), float(np.mean(fast != msgs))
+        print("fp32-fast turbo %d states N=%d %d its L_int=%s: bits differing from fp64 %.3e, BER fp64 %.4e, fp32 slab %.4e" % (
+            states, N, iters, use_L, mism, ber_ref, ber_fast))
+        assert mism < 1e-4, mism
+        assert abs(ber_fast - ber_ref) <= 0.05 * ber_ref + 2e-5, (ber_ref, ber_fast)
+    # extreme priors and a clean high-SNR batch: finite arithmetic, no crash, decisions follow the priors / the channel
+    big = np.where(msgs == 1, 60.0, -60.0)
+    commpy_amd.set_precision("fp32-fast")
+    try:
+        assert np.mean(turbo_decode(s, p1, p2, tr, nv, iters, il, big) != msgs) < 1e-3
+    finally:
+        commpy_amd.set_precision("fp64-parity")
