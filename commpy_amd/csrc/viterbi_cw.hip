@@ -29,7 +29,7 @@
 #include "cpx_math.h"
 #include "viterbi_cw_asm.h"
 #ifndef CPX_GEN_GB
-#define CPX_GEN_GB 2      // butterflies per LDS fetch group of the table-driven kernel (measured: 2: 2.14 ms, 4: 2.17, 8: 2.21)
+#define CPX_GEN_GB 2      // (rounds 3 / 4: butterflies per LDS fetch group of the table-driven kernel; unused since the index-mode selection of round 5)
 #endif
 
 #include <atomic>
@@ -99,7 +99,9 @@ struct CwParams {
                                   // 1 = an item's codeword received a NaN (viterbi.hip decodes the item again, NaN-exact)
     int64_t B, len, L, T, Lk, Tp;   // Tp: T rounded up to whole groups of log2(S) steps (row count of dec/best)
     int type, tb;
-    unsigned goff[32];            // table-driven kernel (G0 = G1 = 0): 1024 * (2-bit code of the branch 2j -> j, input 0) per butterfly j
+    unsigned goff[4];             // table-driven kernel (G0 = G1 = 0): per butterfly j the REGISTER OFFSET 2 c_j of the branch metric of its code
+                                  // c_j (the 2-bit code of the branch 2j -> j, input 0), packed eight 4-bit fields per word (round 5: four scalar
+                                  // registers; thirty-two separate ones spilled to VGPR lanes)
 };
 
 // 'soft': the reference's clip lets a NaN through and the codeword's metrics are NaN from that step on (convcode.py:719,
@@ -153,12 +155,12 @@ struct NoHook {
 // after the minimum tree): the fused kernel slots the traceback of the previous step in there.
 // G0 = G1 = 0: TABLE-DRIVEN codes -- any shift-register code whose two generators both tap the input bit and the oldest register bit
 // (every rate-1/2 code of full constraint length).  The four branches of butterfly j then carry the codes c_j, c_j ^ 3, c_j ^ 3, c_j,
-// so one 2-bit number per butterfly describes the code; it arrives as a byte offset goff[j] = 1024 c_j in scalar registers, the
-// step's branch metrics go to a table [4][64 lanes] of pairs (metric of c, metric of c ^ 3) in LDS (bml = this lane's column) and
+// so one 2-bit number per butterfly describes the code; it arrives packed in scalar registers (goff) and selects the branch metric by
+// VGPR index mode (round 5, see the GEN branch below; rounds 3 / 4: an LDS table [4][64 lanes] of pairs (metric of c, metric of c ^ 3) and
 // every butterfly reads its pair from there: 32 16-byte LDS reads + 32 address adds per step more than the compiled-in codes.
 template <int LGS, unsigned G0, unsigned G1, int TYPE, int R, class Hook = NoHook>
 __device__ __forceinline__ void cw_step(double (&pm)[1 << LGS], double r0, double r1, unsigned long long &word, int &best,
-                                        const Hook &hook = Hook(), unsigned char *bml = nullptr, const unsigned *goff = nullptr) {
+                                        const Hook &hook = Hook(), unsigned char *bml = nullptr, const unsigned *gidx = nullptr) {
     constexpr int type = TYPE;
     using C = SrCode<LGS, G0, G1>;
     constexpr bool GEN = G0 == 0 && G1 == 0;
@@ -174,11 +176,6 @@ __device__ __forceinline__ void cw_step(double (&pm)[1 << LGS], double r0, doubl
     bmv[0] = (0.0 + m00) + m10; bmv[1] = (0.0 + m00) + m11;
     bmv[2] = (0.0 + m01) + m10; bmv[3] = (0.0 + m01) + m11;
     unsigned da = 0, db = 0;                                       // decisions of states 0..H-1 / H..S-1
-    if constexpr (GEN) {
-#pragma unroll
-        for (int cc = 0; cc < 4; cc++)                              // entry c = (metric of code c, metric of code c ^ 3): one 16-byte read per butterfly
-            *reinterpret_cast<double2 *>(bml + 1024 * cc) = make_double2(bmv[cc], bmv[cc ^ 3]);   // same wave: LDS executes in order
-    }
     hook.template at<0>();
     auto butterfly = [&](int j, double m_a0, double m_a1, double m_b0, double m_b1) {
         const int x = rotl<LGS>(2 * j, R), y = rotl<LGS>(2 * j + 1, R);
@@ -194,28 +191,83 @@ __device__ __forceinline__ void cw_step(double (&pm)[1 << LGS], double r0, doubl
         }
     };
     if constexpr (GEN) {
-        // the two metrics of a butterfly come from LDS, a group of butterflies at a time (CPX_GEN_GB) and one group ahead of the arithmetic (left to
-        // itself the compiler issues all 64 reads of the step at once: 128 more live registers, 110 of them spilled to AGPRs)
-        constexpr int GB = CPX_GEN_GB, NG = H / GB;
-        double mc[2][GB], mx[2][GB];
-        auto fetch = [&](int g, int w) {
-#pragma unroll
-            for (int u = 0; u < GB; u++) {
-                const double2 v = *reinterpret_cast<const double2 *>(bml + goff[g * GB + u]);
-                mc[w][u] = v.x;                                    // code c_j
-                mx[w][u] = v.y;                                    // code c_j ^ 3
+        // Round 5: the metric of "code c_j of butterfly j" is selected by VGPR INDEX MODE (s_set_gpr_idx_on, GFX9): the step's four
+        // branch metrics sit in eight consecutive registers, the wave-uniform code arrives in a scalar register, and the four additions of
+        // a butterfly read `v[base + 2 c]` / `v[base + 2 (c ^ 3)]` as their first operand -- the scalar unit, idle in this kernel, does the
+        // selecting and the vector unit executes exactly the instructions of a compiled-in code.  (Rounds 3 / 4 parked the metrics as
+        // (c, c ^ 3) pairs in an LDS table and read 16 bytes per butterfly: 32 LDS reads, their address adds and waits per step and
+        // 64 - 98 values spilled to AGPRs: 1.94 ms on the config-2 geometry against 1.55 ms for compiled-in generators.)  The table is
+        // pinned to v[248:255] because an index-mode operand must be named in the asm text; the mode is on for the four additions only
+        // (it would redirect the first operand of EVERY vector instruction), and scripts/micro/gpr_idx_check.hip checks the addressing.
+        typedef double cpx_d4 __attribute__((ext_vector_type(4)));
+        // two tables: the metrics in code order and in REVERSED order -- code c ^ 3 = 3 - c sits at offset 2 c of the reversed one, so ONE
+        // index serves all four additions of a butterfly.  With one wave per SIMD every instruction, scalar or not, costs an issue slot:
+        // the first version (one table; s_bfe_u32 + on + s_xor_b32 + idx + off + three s_nop per butterfly) took 2.21 ms where the LDS
+        // table took 1.94.  Now the mode is switched on once per step with index 0 -- harmless for every other vector instruction --
+        // and a butterfly costs two scalar instructions: its index in, index 0 back.
+        const cpx_d4 tab = {bmv[0], bmv[1], bmv[2], bmv[3]}, rtab = {bmv[3], bmv[2], bmv[1], bmv[0]};
+        asm volatile("s_set_gpr_idx_on 0, 1" ::: "memory");
+        auto acs_pair = [&](int j, double a0, double a1, double b0, double b1) {
+            const int x = rotl<LGS>(2 * j, R), y = rotl<LGS>(2 * j + 1, R);
+            if (TYPE == CPX_VIT_UNQUANTIZED) {
+                pm[x] = acs_select(da, a0, a1);                    // state j     now lives in register rotl(j, R+1) = x
+                pm[y] = acs_select(db, b0, b1);                    // state j+S/2 now lives in register y
+            } else {
+                pm[x] = acs_min(da, a0, a1);
+                pm[y] = acs_min(db, b0, b1);
             }
         };
-        fetch(0, 0);
+        if constexpr (H >= 4 && TYPE != CPX_VIT_UNQUANTIZED) {
+            // two butterflies per statement, additions AND add-compare-selects (acs_min's three instructions, four times): three scalar
+            // instructions per pair.  (Separate statements cost a wait state each: the compiler pads every boundary between two inline-asm
+            // blocks with an s_nop -- 2.2 per butterfly when the selects were statements of their own.)
 #pragma unroll
-        for (int g = 0; g < NG; g++) {
-            if (g == (H / 2) / GB) hook.template at<1>();       // once per step, about half way
-            if (g + 1 < NG) fetch(g + 1, (g + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < H; j += 2) {
+                if (j == H / 2) hook.template at<1>();          // (index 0 while it runs)
+                const int x0 = rotl<LGS>(2 * j, R), y0 = rotl<LGS>(2 * j + 1, R), x1 = rotl<LGS>(2 * j + 2, R), y1 = rotl<LGS>(2 * j + 3, R);
+                const double a = pm[x0], b = pm[y0], c = pm[x1], d = pm[y1];      // predecessors 2j, 2j+1 | 2j+2, 2j+3
+                double a0, a1, b0, b1, c0, c1, d0, d1;             // (the four minima overwrite a0, b0, c0, d0)
+                asm volatile("s_set_gpr_idx_idx %[i0]\n\t"
+                             "v_add_f64 %[a0], v[248:249], %[a]\n\t"   // into state j:       predecessor 2j   + code c      (:629)
+                             "v_add_f64 %[b1], v[248:249], %[b]\n\t"   // into state j + S/2: predecessor 2j+1 + code c
+                             "v_add_f64 %[a1], v[240:241], %[b]\n\t"   // into state j:       predecessor 2j+1 + code c ^ 3
+                             "v_add_f64 %[b0], v[240:241], %[a]\n\t"   // into state j + S/2: predecessor 2j   + code c ^ 3
+                             "s_set_gpr_idx_idx %[i1]\n\t"
+                             "v_add_f64 %[c0], v[248:249], %[c]\n\t"
+                             "v_add_f64 %[d1], v[248:249], %[d]\n\t"
+                             "v_add_f64 %[c1], v[240:241], %[d]\n\t"
+                             "v_add_f64 %[d0], v[240:241], %[c]\n\t"
+                             "s_set_gpr_idx_idx 0\n\t"
+                             "v_cmp_lt_f64 vcc, %[a1], %[a0]\n\tv_addc_co_u32 %[da], vcc, %[da], %[da], vcc\n\tv_min_f64 %[a0], %[a0], %[a1]\n\t"
+                             "v_cmp_lt_f64 vcc, %[b1], %[b0]\n\tv_addc_co_u32 %[db], vcc, %[db], %[db], vcc\n\tv_min_f64 %[b0], %[b0], %[b1]\n\t"
+                             "v_cmp_lt_f64 vcc, %[c1], %[c0]\n\tv_addc_co_u32 %[da], vcc, %[da], %[da], vcc\n\tv_min_f64 %[c0], %[c0], %[c1]\n\t"
+                             "v_cmp_lt_f64 vcc, %[d1], %[d0]\n\tv_addc_co_u32 %[db], vcc, %[db], %[db], vcc\n\tv_min_f64 %[d0], %[d0], %[d1]"
+                             : [a0] "=&v"(a0), [a1] "=&v"(a1), [b0] "=&v"(b0), [b1] "=&v"(b1), [c0] "=&v"(c0), [c1] "=&v"(c1),
+                               [d0] "=&v"(d0), [d1] "=&v"(d1), [da] "+v"(da), [db] "+v"(db)
+                             : [i0] "s"(gidx[j]), [i1] "s"(gidx[j + 1]), [a] "v"(a), [b] "v"(b), [c] "v"(c), [d] "v"(d),
+                               "{v[248:255]}"(tab), "{v[240:247]}"(rtab)
+                             : "vcc");
+                pm[x0] = a0; pm[y0] = b0;                          // state j now lives in register rotl(j, R+1) = x0, state j+S/2 in y0
+                pm[x1] = c0; pm[y1] = d0;
+            }
+        } else {
 #pragma unroll
-            for (int u = 0; u < GB; u++) butterfly(g * GB + u, mc[g & 1][u], mx[g & 1][u], mx[g & 1][u], mc[g & 1][u]);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < H; j++) {
+                if (j == H / 2) hook.template at<1>();
+                const double a = pm[rotl<LGS>(2 * j, R)], b = pm[rotl<LGS>(2 * j + 1, R)];
+                double a0, a1, b0, b1;
+                asm volatile("s_set_gpr_idx_idx %[ic]\n\t"
+                             "v_add_f64 %[a0], v[248:249], %[a]\n\t"
+                             "v_add_f64 %[b1], v[248:249], %[b]\n\t"
+                             "v_add_f64 %[a1], v[240:241], %[b]\n\t"
+                             "v_add_f64 %[b0], v[240:241], %[a]\n\t"
+                             "s_set_gpr_idx_idx 0"
+                             : [a0] "=&v"(a0), [a1] "=&v"(a1), [b0] "=&v"(b0), [b1] "=&v"(b1)
+                             : [ic] "s"(gidx[j]), [a] "v"(a), [b] "v"(b), "{v[248:255]}"(tab), "{v[240:247]}"(rtab));
+                acs_pair(j, a0, a1, b0, b1);
+            }
         }
+        asm volatile("s_set_gpr_idx_off" ::: "memory");
     } else {
 #pragma unroll
         for (int j = 0; j < H; j++) {
@@ -472,8 +524,8 @@ constexpr int FR_RING_DEEP = 64;
 template <int RING, bool MIR> constexpr int fused_slots() { return MIR ? 2 * RING + 2 : RING + 1; }
 template <int RING, bool MIR, bool GEN = false>
 constexpr size_t fused_wave_lds() {
-    // ring + dummy slot(s), staging tile, and for the table-driven codes the step's four branch metrics [4][64]
-    return (size_t)fused_slots<RING, MIR>() * 64 * 8 + (size_t)64 * FR_OBPAD + (GEN ? 4 * 64 * 16 : 0);
+    // ring + dummy slot(s), staging tile
+    return (size_t)fused_slots<RING, MIR>() * 64 * 8 + (size_t)64 * FR_OBPAD;   // (GEN: rounds 3 / 4 kept an LDS table of 4 KB here)
 }
 
 // The traceback walk of one step, cut into four batches of hops that cw_step's hook runs between the phases of the NEXT
@@ -541,13 +593,16 @@ __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_fused_kernel(CwPara
     static_assert(!GEN || (!MIR && std::is_same<F, double>::value), "table-driven codes: unmirrored ring, float64");
     unsigned long long *ring = reinterpret_cast<unsigned long long *>(smem + (size_t)wv * fused_wave_lds<RING, MIR, GEN>());
     unsigned char *obuf = reinterpret_cast<unsigned char *>(ring + fused_slots<RING, MIR>() * 64);
-    unsigned char *bml = obuf + 64 * FR_OBPAD + lane * 16;                         // GEN: this lane's column of the branch-metric table
     unsigned long long *mycol = ring + lane;                                       // slot s of this lane's codeword: mycol[s * 64]
     unsigned char *myrow = obuf + lane * FR_OBPAD;
 
     F pm[S];
 #pragma unroll
     for (int s = 0; s < S; s++) pm[s] = (s == 0) ? (F)0.0 : (F)__builtin_huge_val();   // path_metrics[:,0] = inf, [0][0] = 0 (:705-706)
+    // table-driven codes: the register offset 2 c_j of every butterfly, unpacked once into scalar registers (cw_step, GEN)
+    unsigned gidx[GEN ? S / 2 : 1];
+#pragma unroll
+    for (int j = 0; j < (GEN ? S / 2 : 1); j++) gidx[j] = GEN ? __builtin_amdgcn_ubfe(p.goff[j >> 3], 4 * (j & 7), 4) : 0u;
 
     const double pad = (TYPE == CPX_VIT_UNQUANTIZED) ? -1.0 : 0.0;                // t > L//k -> padding (:722-734)
     const int T = (int)p.T, tmax = (int)((p.Lk < p.T) ? p.Lk : p.T);              // 32-bit step indices, see the ACS kernel
@@ -615,7 +670,7 @@ __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_fused_kernel(CwPara
                 unsigned long long word;
                 int bst;
                 if constexpr (TYPE == CPX_VIT_SOFT) nan_or(nanmask, cur[R].x, cur[R].y);   // (steps > tmax re-read step tmax)
-                cw_step<LGS, G0, G1, TYPE, R>(pm, r0, r1, word, bst, walk, bml, p.goff);   // + hops 0 .. 3/4 H of the walk of step tt - 1
+                cw_step<LGS, G0, G1, TYPE, R>(pm, r0, r1, word, bst, walk, nullptr, gidx);   // + hops 0 .. 3/4 H of the walk of step tt - 1
                 walk.finish();
                 myrow[g * LGS + R] = (unsigned char)((walk.st >> (LGS - 1)) & 1u);   // input bit of the branch into the state at step tt - 1 - H
                 // ring slot of step tt and (mirrored ring) its copy RING slots above; the (at most LGS - 1) steps > T of the last group
@@ -755,11 +810,12 @@ bool tables_match(const cpx_trellis *t) {
 }
 
 // Table-driven codes (cw_step, G0 = G1 = 0): a 2^LGS-state shift-register trellis of rate 1/2 whose butterflies have the form
-// (c, c ^ 3, c ^ 3, c) -- both generators tap the input and the oldest register bit.  Fills goff[j] = 512 c_j.
+// (c, c ^ 3, c ^ 3, c) -- both generators tap the input and the oldest register bit.  Fills goff: field j = 2 c_j.
 template <int LGS>
-bool generic_match(const cpx_trellis *t, unsigned (&goff)[32]) {
+bool generic_match(const cpx_trellis *t, unsigned (&goff)[4]) {
     static_assert((1 << LGS) / 2 <= 32, "goff holds 32 butterflies");
     const int S = 1 << LGS, H = S / 2;
+    for (unsigned &g : goff) g = 0u;
     if (t->S != S || t->I != 2 || t->k != 1 || t->n != 2) return false;
     for (int s = 0; s < S; s++)
         for (int j = 0; j < 2; j++) {
@@ -770,9 +826,9 @@ bool generic_match(const cpx_trellis *t, unsigned (&goff)[32]) {
         const int c = t->pred_code[j * 2 + 0];
         if (c < 0 || c > 3) return false;
         if (t->pred_code[j * 2 + 1] != (c ^ 3) || t->pred_code[(j + H) * 2 + 0] != (c ^ 3) || t->pred_code[(j + H) * 2 + 1] != c) return false;
-        goff[j] = 1024u * (unsigned)c;
+        goff[j >> 3] |= (2u * (unsigned)c) << (4 * (j & 7));
     }
-    for (int j = H; j < 32; j++) goff[j] = 0;
+
     return true;
 }
 
