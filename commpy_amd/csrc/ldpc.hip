@@ -126,16 +126,29 @@ template <int DEG>
 __device__ __forceinline__ void cn_spa_row(double *__restrict__ Rrow, const double *__restrict__ Qt,
                                            const int32_t *__restrict__ ev, int deg, int k, int32_t *st, int spa_exact) {
     // DEG > 0: exact degree, fully unrolled, row in registers;  DEG == 0: any degree, the row's e values parked in R
-    double v[DEG > 0 ? DEG : 1];
+    // Exact degree: every operand of the row is requested before the first one is used (round 5: written edge by edge the compiler
+    // waited for each load in turn -- 22 memory latencies per row, 13 us per row and wavefront, the pass at 1.7 TB/s).
+    double v[DEG > 0 ? DEG : 1], qv[DEG > 0 ? DEG : 1], rv[DEG > 0 ? DEG : 1];
+    if constexpr (DEG > 0) {
+#pragma unroll
+        for (int j = 0; j < DEG; j++) qv[j] = Qt[(int64_t)ev[j] * 64];
+        if (k > 0) {
+#pragma unroll
+            for (int j = 0; j < DEG; j++) rv[j] = ntload(&Rrow[(int64_t)j * 64]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < DEG; j++) rv[j] = 0.0;
+        }
+    }
     int sx = 0;
     double U = 1.0, W = 1.0, emax = 0.0;
 #define CPX_SPA_IN(j)                                                                                 \
     {                                                                                                 \
-        const double q = Qt[(int64_t)ev[j] * 64];                                                     \
+        const double q = DEG > 0 ? qv[DEG > 0 ? (j) : 0] : Qt[(int64_t)ev[j] * 64];                   \
         sx ^= __double2hiint(q);                             /* dec_word = out_llrs < 0 (:193, :248) */ \
         double m = 1.0 * q;                                  /* message_matrix = H.multiply(llr) (:199) */ \
         if (k > 0) {                                                                                  \
-            m = ntload(&Rrow[(int64_t)(j) * 64]) * -1.0;     /* data *= -1 (:244) */                   \
+            m = (DEG > 0 ? rv[DEG > 0 ? (j) : 0] : ntload(&Rrow[(int64_t)(j) * 64])) * -1.0;   /* data *= -1 (:244) */ \
             m += 1.0 * q;                                    /* data += H.multiply(msg_sum + llr).data (:245) */ \
         }                                                                                             \
         double se, u, w;                                                                              \
