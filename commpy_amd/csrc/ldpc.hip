@@ -570,24 +570,34 @@ __global__ __launch_bounds__(LB) void ldpc_move_kernel(Bufs bf, int n_v, int64_t
     }
 }
 
-// End of the decode: every slot still in the working set is retired.
+// End of the decode: every slot still in the working set is retired.  A wave takes 16 consecutive variables of its tile: in the
+// block-major layout a lane then writes 128 contiguous bytes of its block's row (one variable per wave wrote 8 bytes per 15 KB
+// stride: 1.8 GB of traffic for 0.54 GB of data, 0.78 ms for 16 384 blocks of (1944,1296)).
 __global__ __launch_bounds__(LB) void ldpc_final_kernel(Bufs bf, int n_v, int64_t B, double *__restrict__ out,
                                                         int8_t *__restrict__ dec, int64_t sv, int64_t sb) {
     int n_slots, buf;
     effective(bf.ctl, n_slots, buf);
     const int n_tiles = n_slots >> 6;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t nVG = (n_v + 3) >> 2;
+    constexpr int RPW = 16;
+    const int64_t nVG = (n_v + 4 * RPW - 1) / (4 * RPW);
     const int64_t items = nVG * n_tiles;
     for (int64_t idx = blockIdx.x; idx < items; idx += gridDim.x) {
-        const int64_t tile = idx / nVG, v = (idx - tile * nVG) * 4 + w;
-        if (v >= n_v) continue;
+        const int64_t tile = idx / nVG, v0 = ((idx - tile * nVG) * 4 + w) * RPW;
+        if (v0 >= n_v) continue;
         const int64_t slot = tile * 64 + lane;
         if (bf.state[buf][slot] < 0) continue;
-        const double x = bf.Q[buf][(tile * n_v + v) * 64 + lane];
         const int64_t o = bf.orig[buf][slot];
-        out[v * sv + o * sb] = x;
-        dec[v * sv + o * sb] = (int8_t)(__builtin_signbit(x) ? 1 : 0);
+        double x[RPW];
+#pragma unroll
+        for (int u = 0; u < RPW; u++)
+            if (v0 + u < n_v) x[u] = bf.Q[buf][(tile * n_v + v0 + u) * 64 + lane];
+#pragma unroll
+        for (int u = 0; u < RPW; u++)
+            if (v0 + u < n_v) {
+                out[(v0 + u) * sv + o * sb] = x[u];
+                dec[(v0 + u) * sv + o * sb] = (int8_t)(__builtin_signbit(x[u]) ? 1 : 0);
+            }
     }
 }
 

@@ -400,8 +400,23 @@ int cpx_stream_create(void **stream) {
     return CPX_OK;
 }
 
+// The scratch blocks a stream's calls grew go with it: an entry that outlived its stream made cpx_release_workspace()
+// synchronise a destroyed stream (undefined in HIP: std::bad_variant_access from inside the runtime and an abort, found in round 5
+// by running the collectives tests before a test that releases the workspace).
 int cpx_stream_destroy(void *stream) {
-    if (stream) CPX_HIP(hipStreamDestroy((hipStream_t)stream));
+    if (!stream) return CPX_OK;
+    hipStream_t st = (hipStream_t)stream;
+    {
+        std::lock_guard<std::mutex> lk(g_ws_mu);
+        bool synced = false;
+        for (size_t i = 0; i < g_ws.size();) {
+            if (g_ws[i].st != st) { i++; continue; }
+            if (!synced) { (void)hipStreamSynchronize(st); synced = true; }
+            (void)hipFree(g_ws[i].p);
+            g_ws.erase(g_ws.begin() + i);
+        }
+    }
+    CPX_HIP(hipStreamDestroy(st));
     return CPX_OK;
 }
 

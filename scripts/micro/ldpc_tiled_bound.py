@@ -4,7 +4,7 @@ Config-4 code (1944,1296), sum-product, 1 dB (no block converges: every launch w
 path modes.  Run under `rocprofv3 --kernel-trace --stats` the per-kernel averages of the tiled pass kernels give their HBM rate:
     check pass   reads R (k > 0) and writes R: 2 E x 8 B per block, + Q once (n x 8 B; gathered from L2)
     variable pass reads R (E x 8 B) and the channel LLRs, writes Q (2 n x 8 B)
-    python scripts/micro/ldpc_tiled_bound.py [B [paths]]
+    python scripts/micro/ldpc_tiled_bound.py [B [paths [spa|msa]]]
 """
 import json
 import os
@@ -31,14 +31,15 @@ def main():
     d_dec, d_out, d_it = dev.empty(B * n), dev.empty(B * n * 8), dev.empty(B * 4)
     code = _device_code(p)
     iters = 10
+    alg = 1 if len(sys.argv) > 3 and sys.argv[3].lower() == "msa" else 0
     for path in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("tiled", "resident-log", "resident")):
         _lib.ldpc_set_path(path)
         try:
             def step():
-                _lib.check(lib.cpx_ldpc_bp_decode_batch_bm_dev(code, d_src, B, 0, iters, d_dec, d_out, d_it, None))
+                _lib.check(lib.cpx_ldpc_bp_decode_batch_bm_dev(code, d_src, B, alg, iters, d_dec, d_out, d_it, None))
             ms = time_steps(lib, step, 5, 2)
             its = dev.get(d_it, (B,), np.int32)
-            rec = {"path": path, "kernel": _lib.last_kernel(), "B": B, "edges": E, "n": n, "iterations": iters, "ms": float(np.mean(ms)),
+            rec = {"path": path, "alg": "MSA" if alg else "SPA", "kernel": _lib.last_kernel(), "B": B, "edges": E, "n": n, "iterations": iters, "ms": float(np.mean(ms)),
                    "mean_executed_iterations": float(its.mean()),
                    "tiled_bytes_per_iteration_GB": B * (3 * E + 3 * n) * 8 / 1e9}
             print(json.dumps(rec))

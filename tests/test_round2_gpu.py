@@ -300,3 +300,35 @@ def test_soft_demod_near_underflow_follows_the_reference(gpu, m, N0):
     assert np.array_equal(soft[inf], want[inf])
     fin = np.isfinite(want)
     assert np.max(np.abs(soft[fin] - want[fin])) < 1e-9
+
+
+def test_stream_destroy_retires_its_scratch_blocks(gpu):
+    """A caller's stream grows scratch blocks of its own (the arena is keyed by device and stream).  cpx_stream_destroy frees them:
+    round 5 found cpx_release_workspace() synchronising a stream that DeviceGroup.close() had destroyed -- an abort from inside the
+    HIP runtime, visible only when the collectives tests ran before a test that releases the workspace."""
+    from commpy_amd import _lib
+    from commpy_amd.channelcoding.ldpc import _device_code
+    from commpy_amd.devicelink import DeviceBuf
+    lib = _lib.load()
+    p = ldpc_params("wimax1440")
+    code = _device_code(p)
+    B, n = 300, 1440
+    llr = np.random.RandomState(3).randn(B, n) * 2 + 1.5
+    outs = []
+    for use_stream in (True, False, True):
+        s = ctypes.c_void_p()
+        if use_stream:
+            _lib.check(lib.cpx_stream_create(ctypes.byref(s)))
+        d_llr = DeviceBuf.from_array(llr)
+        d_dec, d_out, d_it = DeviceBuf(B * n), DeviceBuf(B * n * 8), DeviceBuf(B * 4)
+        for alg in (1, 0):
+            _lib.check(lib.cpx_ldpc_bp_decode_batch_bm_dev(code, d_llr.ptr, B, alg, 12, d_dec.ptr, d_out.ptr, d_it.ptr, s if use_stream else None))
+        _lib.check(lib.cpx_stream_sync(s if use_stream else None))
+        outs.append((d_dec.to_array((B, n), np.int8), d_out.to_array((B, n), np.float64), d_it.to_array((B,), np.int32)))
+        if use_stream:
+            _lib.check(lib.cpx_stream_destroy(s))
+        _lib.check(lib.cpx_release_workspace())                       # aborted here with the destroyed stream's entries left behind
+        for b in (d_llr, d_dec, d_out, d_it):
+            b.free()
+    for o in outs[1:]:
+        assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(o, outs[0]))
