@@ -217,9 +217,13 @@ __global__ __launch_bounds__(1024, 6) void ldpc_resident_kernel(ResParams p) {
     // queue -- sits in ONE if-block in the middle of the loop body, followed by a barrier.  With a thread-0 block at the end of
     // the body and another at its start the structuriser turned the loop inside out (lanes 1..63 of wave 0 went round to the
     // next s_barrier while lane 0 was still retiring): wave 0 met the barrier twice per block and the kernel hung.
+    // The queue is popped ONE BLOCK AHEAD (round 5): thread 0 publishes the number it fetched while the previous block was being
+    // decoded and requests the next one -- the atomic's round trip (~1.5 us, once per block, with every wave of the workgroup behind a
+    // barrier) is over long before its result is looked at.  A workgroup draws one number more than it decodes; past B they mean "stop".
+    int nxt = 0;
     auto pop = [&]() {                                           // thread 0 only
-        const int t = atomicAdd(p.queue, 1);
-        ctl[2] = t < p.B ? t : -1;
+        ctl[2] = nxt < p.B ? nxt : -1;
+        nxt = atomicAdd(p.queue, 1);
     };
     if (tid == 0) {
         stsd(8 * p.n_v, __builtin_huge_val());                   // dummy Q (row padding)
@@ -230,6 +234,7 @@ __global__ __launch_bounds__(1024, 6) void ldpc_resident_kernel(ResParams p) {
         for (int i = 0; i < 5; i++) stsd(p.roff + 8 * (p.n_r + i), 0.0);
         ctl[0] = 0; ctl[1] = 0;                                  // "unsatisfied" flags of the first block
         ctl[3] = 0;                                              // "a NaN among the LLRs of the current block"
+        nxt = atomicAdd(p.queue, 1);
         pop();
     }
     __syncthreads();
@@ -248,18 +253,28 @@ __global__ __launch_bounds__(1024, 6) void ldpc_resident_kernel(ResParams p) {
     int b = __builtin_amdgcn_readfirstlane(ctl[2]);
     while (b >= 0) {
         double *__restrict__ in = p.llr + (int64_t)b * p.n_v;
-        for (int v = tid; v < p.n_v; v += nt) {
-            const double raw = in[v];
-            const double x = clip_nan(raw, -500.0, 500.0);
-            if (x != raw) {                                      // in-place clip (:186); untouched values are not rewritten
-                if (x == x) {
-                    in[v] = x;
-                    if (p.clipped) *p.clipped = 1;
-                } else {
-                    ctl[3] = 1;                                  // NaN: min-sum decodes the block again (see ResParams::nanflags)
+        // four LLRs per thread are requested before the first is used (round 5: one at a time, a block began with ceil(n_v / nt)
+        // memory latencies in a row -- three for (1944,1296) -- with the whole workgroup waiting behind the barrier below)
+        for (int v0 = tid; v0 < p.n_v; v0 += 4 * nt) {
+            double rawv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) rawv[u] = in[v0 + u * nt < p.n_v ? v0 + u * nt : v0];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int v = v0 + u * nt;
+                if (v >= p.n_v) break;
+                const double raw = rawv[u];
+                const double x = clip_nan(raw, -500.0, 500.0);
+                if (x != raw) {                                  // in-place clip (:186); untouched values are not rewritten
+                    if (x == x) {
+                        in[v] = x;
+                        if (p.clipped) *p.clipped = 1;
+                    } else {
+                        ctl[3] = 1;                              // NaN: min-sum decodes the block again (see ResParams::nanflags)
+                    }
                 }
+                stsd(8 * v, x);                                  // out_llrs = llr (:194)
             }
-            stsd(8 * v, x);                                      // out_llrs = llr (:194)
         }
         for (int e = tid; e < p.n_r; e += nt) stsd(p.roff + 8 * e, 0.0);
         __syncthreads();
@@ -470,34 +485,44 @@ __global__ __launch_bounds__(1024, 6) void ldpc_resident_ratio_kernel(ResParams 
     int *ctl = reinterpret_cast<int *>(lds + p.ctl_off);
     const int tid = threadIdx.x, nt = blockDim.x;
     double *__restrict__ e0row = p.e0 + (int64_t)blockIdx.x * p.n_v;
+    int nxt = 0;                                                 // popped one block ahead (see ldpc_resident_kernel)
     auto pop = [&]() {                                           // thread 0 only
-        const int t = atomicAdd(p.queue, 1);
-        ctl[2] = t < p.B ? t : -1;
+        ctl[2] = nxt < p.B ? nxt : -1;
+        nxt = atomicAdd(p.queue, 1);
     };
     if (tid == 0) {
         stsd(8 * p.n_v, 1.0);                                    // dummy X (row padding; never read: the rows loop to their degree)
         for (int i = 0; i < 5; i++) stsd(p.roff + 8 * (p.n_r + i), 1.0);   // dummy rho (column padding): neutral in a product, log = 0
         for (int i = 0; i < 7; i++) if (i != 2) ctl[i] = 0;
+        nxt = atomicAdd(p.queue, 1);
         pop();
     }
     __syncthreads();
     int b = __builtin_amdgcn_readfirstlane(ctl[2]);
     while (b >= 0) {
         double *__restrict__ in = p.llr + (int64_t)b * p.n_v;
-        for (int v = tid; v < p.n_v; v += nt) {
-            const double raw = in[v];
-            const double x = clip_nan(raw, -500.0, 500.0);
-            if (x != raw) {                                      // in-place clip (:186); untouched values are not rewritten
-                if (x == x) {
-                    in[v] = x;
-                    if (p.clipped) *p.clipped = 1;
-                } else {
-                    ctl[3] = 1;                                  // NaN
+        for (int v0 = tid; v0 < p.n_v; v0 += 4 * nt) {           // four requests in flight per thread (see ldpc_resident_kernel)
+            double rawv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) rawv[u] = in[v0 + u * nt < p.n_v ? v0 + u * nt : v0];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int v = v0 + u * nt;
+                if (v >= p.n_v) break;
+                const double raw = rawv[u];
+                const double x = clip_nan(raw, -500.0, 500.0);
+                if (x != raw) {                                  // in-place clip (:186); untouched values are not rewritten
+                    if (x == x) {
+                        in[v] = x;
+                        if (p.clipped) *p.clipped = 1;
+                    } else {
+                        ctl[3] = 1;                              // NaN
+                    }
                 }
+                const double e0 = exp(x);                        // |x| <= 500: a normal number
+                e0row[v] = e0;
+                stsd(8 * v, x < 0.0 ? -e0 : e0);                 // out_llrs = llr (:194)
             }
-            const double e0 = exp(x);                            // |x| <= 500: a normal number
-            e0row[v] = e0;
-            stsd(8 * v, x < 0.0 ? -e0 : e0);                     // out_llrs = llr (:194)
         }
         for (int e = tid; e < p.n_r; e += nt) stsd(p.roff + 8 * e, 1.0);
         __syncthreads();
@@ -633,33 +658,43 @@ __global__ __launch_bounds__(1024, 8) void ldpc_resident_f32_kernel(ResParams p)
     if ((unsigned)(uintptr_t)lds != 0u) __builtin_trap();
     int *ctl = reinterpret_cast<int *>(lds + p.ctl_off);
     const int tid = threadIdx.x, nt = blockDim.x;
+    int nxt = 0;                                                 // popped one block ahead (see ldpc_resident_kernel)
     auto pop = [&]() {                                           // thread 0 only (control flow: see ldpc_resident_kernel)
-        const int t = atomicAdd(p.queue, 1);
-        ctl[2] = t < p.B ? t : -1;
+        ctl[2] = nxt < p.B ? nxt : -1;
+        nxt = atomicAdd(p.queue, 1);
     };
     if (tid == 0) {
         stsf(4 * p.n_v, __builtin_huge_valf());
         stsf(p.roff + 4 * p.n_r, 0.0f);
         ctl[0] = 0; ctl[1] = 0;
         ctl[3] = 0;
+        nxt = atomicAdd(p.queue, 1);
         pop();
     }
     __syncthreads();
     int b = __builtin_amdgcn_readfirstlane(ctl[2]);
     while (b >= 0) {
         double *__restrict__ in = p.llr + (int64_t)b * p.n_v;
-        for (int v = tid; v < p.n_v; v += nt) {
-            const double raw = in[v];
-            const double x = clip_nan(raw, -500.0, 500.0);
-            if (x != raw) {                                      // in-place clip (:186), as in the parity kernel
-                if (x == x) {
-                    in[v] = x;
-                    if (p.clipped) *p.clipped = 1;
-                } else {
-                    ctl[3] = 1;
+        for (int v0 = tid; v0 < p.n_v; v0 += 4 * nt) {           // four requests in flight per thread (see ldpc_resident_kernel)
+            double rawv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) rawv[u] = in[v0 + u * nt < p.n_v ? v0 + u * nt : v0];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int v = v0 + u * nt;
+                if (v >= p.n_v) break;
+                const double raw = rawv[u];
+                const double x = clip_nan(raw, -500.0, 500.0);
+                if (x != raw) {                                  // in-place clip (:186), as in the parity kernel
+                    if (x == x) {
+                        in[v] = x;
+                        if (p.clipped) *p.clipped = 1;
+                    } else {
+                        ctl[3] = 1;
+                    }
                 }
+                stsf(4 * v, (float)x);
             }
-            stsf(4 * v, (float)x);
         }
         for (int e = tid; e < p.n_r; e += nt) stsf(p.roff + 4 * e, 0.0f);
         __syncthreads();
