@@ -217,13 +217,12 @@ __global__ __launch_bounds__(1024, 6) void ldpc_resident_kernel(ResParams p) {
     // queue -- sits in ONE if-block in the middle of the loop body, followed by a barrier.  With a thread-0 block at the end of
     // the body and another at its start the structuriser turned the loop inside out (lanes 1..63 of wave 0 went round to the
     // next s_barrier while lane 0 was still retiring): wave 0 met the barrier twice per block and the kernel hung.
-    // The queue is popped ONE BLOCK AHEAD (round 5): thread 0 publishes the number it fetched while the previous block was being
-    // decoded and requests the next one -- the atomic's round trip (~1.5 us, once per block, with every wave of the workgroup behind a
-    // barrier) is over long before its result is looked at.  A workgroup draws one number more than it decodes; past B they mean "stop".
-    int nxt = 0;
+    // (Round 5 measured popping the queue one block AHEAD -- the atomic's round trip off the critical path -- and lost: the extra live
+    // register spills in the sum-product kernels (+5 %), min-sum +1 %; the second workgroup on the compute unit already hides the
+    // round trip.  profiles/r05_ldpc_pop_hoist_ab.txt)
     auto pop = [&]() {                                           // thread 0 only
-        ctl[2] = nxt < p.B ? nxt : -1;
-        nxt = atomicAdd(p.queue, 1);
+        const int t = atomicAdd(p.queue, 1);
+        ctl[2] = t < p.B ? t : -1;
     };
     if (tid == 0) {
         stsd(8 * p.n_v, __builtin_huge_val());                   // dummy Q (row padding)
@@ -234,7 +233,6 @@ __global__ __launch_bounds__(1024, 6) void ldpc_resident_kernel(ResParams p) {
         for (int i = 0; i < 5; i++) stsd(p.roff + 8 * (p.n_r + i), 0.0);
         ctl[0] = 0; ctl[1] = 0;                                  // "unsatisfied" flags of the first block
         ctl[3] = 0;                                              // "a NaN among the LLRs of the current block"
-        nxt = atomicAdd(p.queue, 1);
         pop();
     }
     __syncthreads();
@@ -485,16 +483,14 @@ __global__ __launch_bounds__(1024, 6) void ldpc_resident_ratio_kernel(ResParams 
     int *ctl = reinterpret_cast<int *>(lds + p.ctl_off);
     const int tid = threadIdx.x, nt = blockDim.x;
     double *__restrict__ e0row = p.e0 + (int64_t)blockIdx.x * p.n_v;
-    int nxt = 0;                                                 // popped one block ahead (see ldpc_resident_kernel)
     auto pop = [&]() {                                           // thread 0 only
-        ctl[2] = nxt < p.B ? nxt : -1;
-        nxt = atomicAdd(p.queue, 1);
+        const int t = atomicAdd(p.queue, 1);
+        ctl[2] = t < p.B ? t : -1;
     };
     if (tid == 0) {
         stsd(8 * p.n_v, 1.0);                                    // dummy X (row padding; never read: the rows loop to their degree)
         for (int i = 0; i < 5; i++) stsd(p.roff + 8 * (p.n_r + i), 1.0);   // dummy rho (column padding): neutral in a product, log = 0
         for (int i = 0; i < 7; i++) if (i != 2) ctl[i] = 0;
-        nxt = atomicAdd(p.queue, 1);
         pop();
     }
     __syncthreads();
@@ -658,17 +654,15 @@ __global__ __launch_bounds__(1024, 8) void ldpc_resident_f32_kernel(ResParams p)
     if ((unsigned)(uintptr_t)lds != 0u) __builtin_trap();
     int *ctl = reinterpret_cast<int *>(lds + p.ctl_off);
     const int tid = threadIdx.x, nt = blockDim.x;
-    int nxt = 0;                                                 // popped one block ahead (see ldpc_resident_kernel)
     auto pop = [&]() {                                           // thread 0 only (control flow: see ldpc_resident_kernel)
-        ctl[2] = nxt < p.B ? nxt : -1;
-        nxt = atomicAdd(p.queue, 1);
+        const int t = atomicAdd(p.queue, 1);
+        ctl[2] = t < p.B ? t : -1;
     };
     if (tid == 0) {
         stsf(4 * p.n_v, __builtin_huge_valf());
         stsf(p.roff + 4 * p.n_r, 0.0f);
         ctl[0] = 0; ctl[1] = 0;
         ctl[3] = 0;
-        nxt = atomicAdd(p.queue, 1);
         pop();
     }
     __syncthreads();
