@@ -125,69 +125,93 @@ __global__ __launch_bounds__(LB) void ldpc_init_kernel(double *__restrict__ llr,
 template <int DEG>
 __device__ __forceinline__ void cn_spa_row(double *__restrict__ Rrow, const double *__restrict__ Qt,
                                            const int32_t *__restrict__ ev, int deg, int k, int32_t *st, int spa_exact) {
-    // DEG > 0: exact degree, fully unrolled, row in registers;  DEG == 0: any degree, the row's e values parked in R
-    // Exact degree: every operand of the row is requested before the first one is used (round 5: written edge by edge the compiler
-    // waited for each load in turn -- 22 memory latencies per row, 13 us per row and wavefront, the pass at 1.7 TB/s).
-    double v[DEG > 0 ? DEG : 1], qv[DEG > 0 ? DEG : 1], rv[DEG > 0 ? DEG : 1];
+    // DEG > 0: exact degree, fully unrolled, row in registers;  DEG == 0: any degree (13 .. 32 edges), the row's e values parked in R.
+    // Either way every operand of the row -- of a chunk of eight edges in the rolled form -- is requested before the first one is
+    // used (round 5: written edge by edge the compiler waited for each load in turn -- 22 memory latencies per 11-edge row, 13 us per
+    // row and wavefront, the pass at 1.7 TB/s instead of 4.3).
+    constexpr int CH = 8;
+    int sx = 0;
+    double U = 1.0, W = 1.0, emax = 0.0;
+    auto edge_in = [&](double q, double r) -> double {           // r: the edge's R of the previous iteration (not looked at when k == 0)
+        sx ^= __double2hiint(q);                                 // dec_word = out_llrs < 0 (:193, :248)
+        double m = 1.0 * q;                                      // message_matrix = H.multiply(llr) (:199)
+        if (k > 0) {
+            m = r * -1.0;                                        // data *= -1 (:244)
+            m += 1.0 * q;                                        // data += H.multiply(msg_sum + llr).data (:245)
+        }
+        double se, u, w;
+        spa_in(m, se, u, w);                                     // e = exp(-|m|): tanh(m / 2) = u / w (:210-211)
+        U *= u; W *= w;                                          // row product (reference: exp2(sum(log2)) :217-219)
+        emax = fmax(emax, fabs(se));
+        return se;
+    };
     if constexpr (DEG > 0) {
+        double v[DEG], qv[DEG], rv[DEG];
 #pragma unroll
         for (int j = 0; j < DEG; j++) qv[j] = Qt[(int64_t)ev[j] * 64];
+#pragma unroll
+        for (int j = 0; j < DEG; j++) rv[j] = 0.0;
         if (k > 0) {
 #pragma unroll
             for (int j = 0; j < DEG; j++) rv[j] = ntload(&Rrow[(int64_t)j * 64]);
-        } else {
-#pragma unroll
-            for (int j = 0; j < DEG; j++) rv[j] = 0.0;
         }
-    }
-    int sx = 0;
-    double U = 1.0, W = 1.0, emax = 0.0;
-#define CPX_SPA_IN(j)                                                                                 \
-    {                                                                                                 \
-        const double q = DEG > 0 ? qv[DEG > 0 ? (j) : 0] : Qt[(int64_t)ev[j] * 64];                   \
-        sx ^= __double2hiint(q);                             /* dec_word = out_llrs < 0 (:193, :248) */ \
-        double m = 1.0 * q;                                  /* message_matrix = H.multiply(llr) (:199) */ \
-        if (k > 0) {                                                                                  \
-            m = (DEG > 0 ? rv[DEG > 0 ? (j) : 0] : ntload(&Rrow[(int64_t)(j) * 64])) * -1.0;   /* data *= -1 (:244) */ \
-            m += 1.0 * q;                                    /* data += H.multiply(msg_sum + llr).data (:245) */ \
-        }                                                                                             \
-        double se, u, w;                                                                              \
-        spa_in(m, se, u, w);                                 /* e = exp(-|m|): tanh(m / 2) = u / w (:210-211) */ \
-        U *= u; W *= w;                                      /* row product (reference: exp2(sum(log2)) :217-219) */ \
-        emax = fmax(emax, fabs(se));                                                                  \
-        if (DEG > 0) v[DEG > 0 ? (j) : 0] = se; else Rrow[(int64_t)(j) * 64] = se;                     \
-    }
-#define CPX_SPA_SE(j) (DEG > 0 ? v[DEG > 0 ? (j) : 0] : Rrow[(int64_t)(j) * 64])
-    if (DEG > 0) {
 #pragma unroll
-        for (int j = 0; j < DEG; j++) CPX_SPA_IN(j)
-    } else {
-        for (int j = 0; j < deg; j++) CPX_SPA_IN(j)
-    }
-    if (sx < 0) *st = k + 1;                                     // odd row: iteration k is executed (:205)
-    const bool near = spa_exact || spa_row_near(U, W, emax);
-    if constexpr (DEG > 0) {
-        if (!near) {
+        for (int j = 0; j < DEG; j++) v[j] = edge_in(qv[j], rv[j]);
+        if (sx < 0) *st = k + 1;                                 // odd row: iteration k is executed (:205)
+        if (!(spa_exact || spa_row_near(U, W, emax))) {
 #pragma unroll
-            for (int j = 0; j < DEG; j++) ntstore(spa_out_fast(U, W, CPX_SPA_SE(j)), &Rrow[(int64_t)j * 64]);
+            for (int j = 0; j < DEG; j++) ntstore(spa_out_fast(U, W, v[j]), &Rrow[(int64_t)j * 64]);
         } else {                                                 // near saturation: the exact-order sequence (ldpc_dev.h)
             double prod = 1.0;
 #pragma unroll
-            for (int j = 0; j < DEG; j++) prod *= spa_exact_t(CPX_SPA_SE(j));
+            for (int j = 0; j < DEG; j++) prod *= spa_exact_t(v[j]);
 #pragma unroll
-            for (int j = 0; j < DEG; j++) ntstore(spa_out_exact(spa_exact_t(CPX_SPA_SE(j)), prod), &Rrow[(int64_t)j * 64]);
+            for (int j = 0; j < DEG; j++) ntstore(spa_out_exact(spa_exact_t(v[j]), prod), &Rrow[(int64_t)j * 64]);
         }
     } else {
-        if (!near) {
-            for (int j = 0; j < deg; j++) ntstore(spa_out_fast(U, W, CPX_SPA_SE(j)), &Rrow[(int64_t)j * 64]);
-        } else {
-            double prod = 1.0;
-            for (int j = 0; j < deg; j++) prod *= spa_exact_t(CPX_SPA_SE(j));
-            for (int j = 0; j < deg; j++) ntstore(spa_out_exact(spa_exact_t(CPX_SPA_SE(j)), prod), &Rrow[(int64_t)j * 64]);
+        // (an index past the row's end is clamped to its last edge: a valid address, loaded again and not used)
+        for (int j0 = 0; j0 < deg; j0 += CH) {
+            double qq[CH], rr[CH];
+#pragma unroll
+            for (int u = 0; u < CH; u++) qq[u] = Qt[(int64_t)ev[j0 + u < deg ? j0 + u : deg - 1] * 64];
+#pragma unroll
+            for (int u = 0; u < CH; u++) rr[u] = 0.0;
+            if (k > 0) {
+#pragma unroll
+                for (int u = 0; u < CH; u++) rr[u] = ntload(&Rrow[(int64_t)(j0 + u < deg ? j0 + u : deg - 1) * 64]);
+            }
+#pragma unroll
+            for (int u = 0; u < CH; u++)
+                if (j0 + u < deg) Rrow[(int64_t)(j0 + u) * 64] = edge_in(qq[u], rr[u]);
+        }
+        if (sx < 0) *st = k + 1;                                 // odd row: iteration k is executed (:205)
+        const bool near = spa_exact || spa_row_near(U, W, emax);
+        double prod = 1.0;
+        if (near) {
+            for (int j0 = 0; j0 < deg; j0 += CH) {
+                double se[CH];
+#pragma unroll
+                for (int u = 0; u < CH; u++) se[u] = Rrow[(int64_t)(j0 + u < deg ? j0 + u : deg - 1) * 64];
+#pragma unroll
+                for (int u = 0; u < CH; u++)
+                    if (j0 + u < deg) prod *= spa_exact_t(se[u]);
+            }
+        }
+        for (int j0 = 0; j0 < deg; j0 += CH) {
+            double se[CH];
+#pragma unroll
+            for (int u = 0; u < CH; u++) se[u] = Rrow[(int64_t)(j0 + u < deg ? j0 + u : deg - 1) * 64];
+            if (!near) {
+#pragma unroll
+                for (int u = 0; u < CH; u++)
+                    if (j0 + u < deg) ntstore(spa_out_fast(U, W, se[u]), &Rrow[(int64_t)(j0 + u) * 64]);
+            } else {                                             // near saturation: the exact-order sequence (ldpc_dev.h)
+#pragma unroll
+                for (int u = 0; u < CH; u++)
+                    if (j0 + u < deg) ntstore(spa_out_exact(spa_exact_t(se[u]), prod), &Rrow[(int64_t)(j0 + u) * 64]);
+            }
         }
     }
-#undef CPX_SPA_IN
-#undef CPX_SPA_SE
 }
 
 // ---- min-sum (:229-238): a row is kept as a record (MsaRec, ldpc_dev.h) -------------------------------------
@@ -197,9 +221,9 @@ __device__ __forceinline__ void cn_msa_row(const MsaRec &o, double *__restrict__
     int sx = 0, imin = 0;
     unsigned neg = 0;
     double m1 = __builtin_huge_val(), m2 = __builtin_huge_val();
-#define CPX_MSA_EDGE(j)                                                                               \
+#define CPX_MSA_EDGE(j, QV)                                                                           \
     {                                                                                                 \
-        const double q = Qt[(int64_t)ev[j] * 64];                                                     \
+        const double q = (QV);                                                                        \
         sx ^= __double2hiint(q);                             /* dec_word = out_llrs < 0 (:193, :248) */ \
         double m = q;                                        /* 1.0 * llr (:199) */                    \
         if (k > 0) m = msa_edge(o, (j), 1) + q;              /* data * -1 + 1.0 * (msg_sum + llr) (:244-245) */ \
@@ -212,9 +236,17 @@ __device__ __forceinline__ void cn_msa_row(const MsaRec &o, double *__restrict__
     }
     if (DEG > 0) {
 #pragma unroll
-        for (int j = 0; j < DEG; j++) CPX_MSA_EDGE(j)
+        for (int j = 0; j < DEG; j++) CPX_MSA_EDGE(j, Qt[(int64_t)ev[j] * 64])
     } else {
-        for (int j = 0; j < deg; j++) CPX_MSA_EDGE(j)
+        // rolled rows (13 .. 32 edges): eight Q rows requested at a time (an index past the end is clamped to the last edge)
+        for (int j0 = 0; j0 < deg; j0 += 8) {
+            double qq[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) qq[u] = Qt[(int64_t)ev[j0 + u < deg ? j0 + u : deg - 1] * 64];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (j0 + u < deg) CPX_MSA_EDGE(j0 + u, qq[u])
+        }
     }
 #undef CPX_MSA_EDGE
     if (sx < 0) *st = k + 1;                                     // odd row: iteration k is executed (:205)

@@ -159,6 +159,41 @@ def test_ldpc_random_structures(gpu, seed, n_v, n_c, lo, hi):
             assert np.mean(close) > 0.999, np.max(np.abs(out[fin] - oo[fin]))
 
 
+@pytest.mark.parametrize("seed,n_v,n_c,lo,hi", [(3, 96, 64, 13, 31), (4, 200, 24, 24, 28), (6, 150, 60, 2, 32)])
+def test_ldpc_rolled_rows_on_the_tiled_path(gpu, seed, n_v, n_c, lo, hi):
+    """Forced onto the tiled (beyond-LDS) kernels, rows of 13 .. 32 edges take the rolled form of both check passes -- eight edges'
+    operands requested at a time since round 5, the last chunk ragged.  Same operations in the same order as the LDS-resident
+    log-domain row: identical iteration counts, dec_word and out_llrs; and against the oracle."""
+    from commpy_amd import _lib
+    from commpy_amd.channelcoding import ldpc_bp_decode
+    from oracle import ldpc_bp_decode as ref_decode
+    rs = np.random.RandomState(500 + seed)
+    p = _random_ldpc(rs, n_v, n_c, rs.randint(lo, hi + 1, size=n_c))
+    B = 131
+    llr = (rs.randn(B * n_v) * 3.0 + 1.5)
+    llr[rs.randint(0, llr.size, 40)] = 0.0
+    for alg, iters in (("MSA", 7), ("SPA", 4)):
+        got = {}
+        for path in ("tiled", "resident-log"):
+            _lib.ldpc_set_path(path)
+            try:
+                got[path] = ldpc_bp_decode(llr.copy(), dict(p), alg, iters, return_iterations=True)
+                assert ("tiled" in _lib.last_kernel()) == (path == "tiled"), _lib.last_kernel()
+            finally:
+                _lib.ldpc_set_path(None)
+        for a, b in zip(got["tiled"], got["resident-log"]):
+            assert np.array_equal(a, b, equal_nan=True), alg
+        dec, out, its = got["tiled"]
+        do, oo, io = ref_decode(llr.copy(), dict(p), alg, iters, True)
+        assert np.array_equal(its, io), alg
+        if alg == "MSA":
+            assert np.array_equal(out, oo) and np.array_equal(dec, do)
+        else:
+            fin = np.isfinite(oo)
+            assert np.array_equal(np.isfinite(out), fin)
+            assert np.mean(np.abs(out[fin] - oo[fin]) <= 1e-5 + 1e-6 * np.abs(oo[fin])) > 0.999
+
+
 def test_ldpc_check_degree_above_32_takes_the_general_kernel(gpu):
     """Round 4: a check of more than 32 edges (rows are kept in registers / a 32-bit sign mask by the fast kernels) no longer
     raises: the literal kernel decodes the whole code, min-sum bit-identical to the oracle, sum-product within 1e-5."""
