@@ -241,7 +241,8 @@ def viterbi_set_path(mode):
 
 
 def demod_set_path(mode):
-    """Soft-demodulator form: None/'auto' (four exponentials per axis for square QAM of 64 points and more) or 'plain'."""
+    """Soft-demodulator form: None/'auto' (two exponentials per axis for square QAM of 64 points and more, table-driven exp / log),
+    'libm' (the same with the library's exp / log) or 'plain' (one exponential per level)."""
     check(load().cpx_demod_set_path(None if mode is None else mode.encode()))
 
 

@@ -79,9 +79,80 @@ __global__ __launch_bounds__(DEMOD_BLOCK) void demod_soft_kernel(const double2 *
 // LLR).  Where they could not -- a middle-level exponential below 1e-290, an axis whose sum is below 1e-30, or anything non-finite --
 // the symbol joins the point-by-point redo below (which the +-600 rule already sends the deep-underflow cases to); with both
 // guards passed and every |LLR| < 600, every term that contributes to a sum at the 1e-7 level is above 1e-300.
-template <int NH, bool RCP>
+// ---- table-driven exp / log for the separable kernel (round 5) -----------------------------------------------------------------------
+// The geometric-progression kernel is VALU bound on four `exp` (37 instructions each) and six `log` (36 each, of a quotient that
+// took nine more) per 64-QAM symbol.  With 32-entry tables in LDS -- 2^(j/32); 1/c_i and -log(1/c_i) for the 32 intervals of a
+// mantissa in [0.5, 1) -- an exponential is 16 instructions (x = (32 k' + j) ln2/32 + r, |r| <= ln2/64: 2^k' T[j] (1 + r + .. + r^6/720))
+// and a logarithm 17 (m invc[i] - 1 = r, |r| <= 1/64: k ln2 + logc[i] + r - r^2/2 + .. - r^8/8), both to an ulp or two of the result
+// (the bar on an LLR is 1e-5; measured against the oracle: tests/test_bcjr_ldpc_demod_gpu.py, bench.py other_configs).  A 32-entry
+// table of doubles covers the 64 LDS banks exactly once: lanes with equal indices are a broadcast, others never collide.  Special
+// values: a NaN comes out as a NaN, an argument past the range as 0 / inf / a denormal through ldexp -- every such symbol fails the
+// kernel's own guards and is decided point by point with the library functions, as before.
+__device__ const double DEMOD_TAB[96] = {
+    // 2^(j/32)
+    0x1.0000000000000p+0, 0x1.059b0d3158574p+0, 0x1.0b5586cf9890fp+0, 0x1.11301d0125b51p+0,
+    0x1.172b83c7d517bp+0, 0x1.1d4873168b9aap+0, 0x1.2387a6e756238p+0, 0x1.29e9df51fdee1p+0,
+    0x1.306fe0a31b715p+0, 0x1.371a7373aa9cbp+0, 0x1.3dea64c123422p+0, 0x1.44e086061892dp+0,
+    0x1.4bfdad5362a27p+0, 0x1.5342b569d4f82p+0, 0x1.5ab07dd485429p+0, 0x1.6247eb03a5585p+0,
+    0x1.6a09e667f3bcdp+0, 0x1.71f75e8ec5f74p+0, 0x1.7a11473eb0187p+0, 0x1.82589994cce13p+0,
+    0x1.8ace5422aa0dbp+0, 0x1.93737b0cdc5e5p+0, 0x1.9c49182a3f090p+0, 0x1.a5503b23e255dp+0,
+    0x1.ae89f995ad3adp+0, 0x1.b7f76f2fb5e47p+0, 0x1.c199bdd85529cp+0, 0x1.cb720dcef9069p+0,
+    0x1.d5818dcfba487p+0, 0x1.dfc97337b9b5fp+0, 0x1.ea4afa2a490dap+0, 0x1.f50765b6e4540p+0,
+    // invc[i] = double(1 / (0.5 + (i + 0.5) / 64))
+    0x1.f81f81f81f820p+0, 0x1.e9131abf0b767p+0, 0x1.dae6076b981dbp+0, 0x1.cd85689039b0bp+0,
+    0x1.c0e070381c0e0p+0, 0x1.b4e81b4e81b4fp+0, 0x1.a98ef606a63bep+0, 0x1.9ec8e951033d9p+0,
+    0x1.948b0fcd6e9e0p+0, 0x1.8acb90f6bf3aap+0, 0x1.8181818181818p+0, 0x1.78a4c8178a4c8p+0,
+    0x1.702e05c0b8170p+0, 0x1.6816816816817p+0, 0x1.6058160581606p+0, 0x1.58ed2308158edp+0,
+    0x1.51d07eae2f815p+0, 0x1.4afd6a052bf5bp+0, 0x1.446f86562d9fbp+0, 0x1.3e22cbce4a902p+0,
+    0x1.3813813813814p+0, 0x1.323e34a2b10bfp+0, 0x1.2c9fb4d812ca0p+0, 0x1.27350b8812735p+0,
+    0x1.21fb78121fb78p+0, 0x1.1cf06ada2811dp+0, 0x1.1811811811812p+0, 0x1.135c81135c811p+0,
+    0x1.0ecf56be69c90p+0, 0x1.0a6810a6810a7p+0, 0x1.0624dd2f1a9fcp+0, 0x1.0204081020408p+0,
+    // logc[i] = -log(invc[i])
+    -0x1.5af405c3649e0p-1, -0x1.4b6fd6f970c1fp-1, -0x1.3c6080c36bfb5p-1, -0x1.2dbf557b0df43p-1,
+    -0x1.1f8635fc61658p-1, -0x1.11af823c75aa8p-1, -0x1.04360be7603aep-1, -0x1.ee2a156b413e5p-2,
+    -0x1.d490246defa6ap-2, -0x1.bb9611b80e2fcp-2, -0x1.a33440224fa79p-2, -0x1.8b639a88b2df4p-2,
+    -0x1.741d876c67bb1p-2, -0x1.5d5bddf595f31p-2, -0x1.4718dc271c41cp-2, -0x1.314f1e1d35ce3p-2,
+    -0x1.1bf99635a6b95p-2, -0x1.07138604d5864p-2, -0x1.e530effe71013p-3, -0x1.bd087383bd8aap-3,
+    -0x1.95a5adcf70182p-3, -0x1.6f0128b756ab9p-3, -0x1.4913d8333b563p-3, -0x1.23d712a49c201p-3,
+    -0x1.fe89139dbd565p-4, -0x1.b6ac88dad5b1dp-4, -0x1.700d30aeac0e8p-4, -0x1.2aa04a44717a1p-4,
+    -0x1.ccb73cdddb2d0p-5, -0x1.466aed42de3f9p-5, -0x1.8492528c8cac5p-6, -0x1.010157588de69p-7
+};
+
+__device__ __forceinline__ double tab_exp(double x, const double *__restrict__ tab) {
+    constexpr double INV_L32 = 0x1.71547652b82fep+5, L32_HI = 0x1.62e42fefa39efp-6, L32_LO = 0x1.ac00000000000p-61;
+    const double k = __builtin_rint(x * INV_L32);
+    double r = __builtin_fma(-k, L32_HI, x);
+    r = __builtin_fma(-k, L32_LO, r);
+    const int ki = (int)k;                                        // v_cvt_i32_f64 saturates; a NaN gives 0 (r stays NaN)
+    const double T = tab[ki & 31];
+    double p = __builtin_fma(r, 1.0 / 720.0, 1.0 / 120.0);
+    p = __builtin_fma(r, p, 1.0 / 24.0);
+    p = __builtin_fma(r, p, 1.0 / 6.0);
+    p = __builtin_fma(r, p, 0.5);
+    p = __builtin_fma(r, p, 1.0);
+    p = r * p;
+    return __builtin_amdgcn_ldexp(__builtin_fma(T, p, T), ki >> 5);
+}
+
+__device__ __forceinline__ double tab_log(double x, const double *__restrict__ tab) {   // x: a positive normal number
+    constexpr double LN2 = 0x1.62e42fefa39efp-1;
+    const double m = __builtin_amdgcn_frexp_mant(x);              // [0.5, 1)
+    const int e = __builtin_amdgcn_frexp_exp(x);
+    const int i = (__double2hiint(m) >> 15) & 31;                 // the five leading fraction bits
+    const double r = __builtin_fma(m, tab[32 + i], -1.0);
+    double p = __builtin_fma(r, -1.0 / 8.0, 1.0 / 7.0);
+    p = __builtin_fma(r, p, -1.0 / 6.0);
+    p = __builtin_fma(r, p, 1.0 / 5.0);
+    p = __builtin_fma(r, p, -1.0 / 4.0);
+    p = __builtin_fma(r, p, 1.0 / 3.0);
+    p = __builtin_fma(r, p, -0.5);
+    p = __builtin_fma(r, p, 1.0);
+    return __builtin_fma((double)e, LN2, __builtin_fma(r, p, tab[64 + i]));
+}
+
+template <int NH, bool RCP, bool TAB>
 __device__ __forceinline__ bool axis_gp(double v, const double *ax, double d, double noise_var, double ninv, double c1, double c2,
-                                        double Q, double (&e)[1 << NH], double &sum) {
+                                        double Q, const double *__restrict__ tab, double (&e)[1 << NH], double &sum) {
     constexpr int R = 1 << NH, JL = R / 2 - 1, JH = R / 2;
     constexpr int GL = JL ^ (JL >> 1), GH = JH ^ (JH >> 1);       // labels of the two middle levels
     // Round 5: TWO exp per axis.  With rho = e[JH] / e[JL] = exp((2 d (x - p[JL]) - d^2) / N0), the ratio between the two middle levels,
@@ -90,8 +161,9 @@ __device__ __forceinline__ bool axis_gp(double v, const double *ax, double d, do
     // instructions -> 12 + 4).  rho itself must be a well-scaled normal number (it overflows only beyond Es/N0 ~ 33 dB, where the
     // middle exponential has long failed its own test); it joins the guard.
     const double dl = v - ax[GL];
-    const double el = exp(RCP ? (dl * dl) * ninv : (-(dl * dl)) / noise_var);
-    const double rho = exp(c1 * dl - c2);
+    const double xl = RCP ? (dl * dl) * ninv : (-(dl * dl)) / noise_var;
+    const double el = TAB ? tab_exp(xl, tab) : exp(xl);
+    const double rho = TAB ? tab_exp(c1 * dl - c2, tab) : exp(c1 * dl - c2);
     const double eh = el * rho;
     e[GL] = el;
     e[GH] = eh;
@@ -108,7 +180,7 @@ __device__ __forceinline__ bool axis_gp(double v, const double *ax, double d, do
     return !(fmin(el, eh) >= 1e-290) || !(rho > 1e-290 && rho < 1e290) || !(sum >= 1e-30);
 }
 
-template <int NH, bool RCP, bool GP>
+template <int NH, bool RCP, bool GP, bool TAB = false>
 __global__ __launch_bounds__(DEMOD_BLOCK) void demod_soft_sep_kernel(const double2 *__restrict__ y, int64_t Ns,
                                                                      const double *__restrict__ axes, double noise_var,
                                                                      double scale, double step_x, double step_y,
@@ -116,13 +188,18 @@ __global__ __launch_bounds__(DEMOD_BLOCK) void demod_soft_sep_kernel(const doubl
     const double ninv = -1.0 / noise_var;
     constexpr int R = 1 << NH, NB = 2 * NH;
     __shared__ double ax_s[2 * R];
+    __shared__ double tab_s[TAB ? 96 : 1];
     for (int m = threadIdx.x; m < 2 * R; m += DEMOD_BLOCK) ax_s[m] = axes[m];
+    if (TAB)
+        for (int m = threadIdx.x; m < 96; m += DEMOD_BLOCK) tab_s[m] = DEMOD_TAB[m];
     __syncthreads();
     // GP: per-call constants of the two axes (2 d / N0, d^2 / N0, Q)
     const double c1x = GP ? 2.0 * step_x / noise_var : 0.0, c2x = GP ? step_x * step_x / noise_var : 0.0, Qx = GP ? exp(-2.0 * c2x) : 0.0;
     const double c1y = GP ? 2.0 * step_y / noise_var : 0.0, c2y = GP ? step_y * step_y / noise_var : 0.0, Qy = GP ? exp(-2.0 * c2y) : 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * DEMOD_BLOCK + threadIdx.x; i < Ns; i += (int64_t)gridDim.x * DEMOD_BLOCK) {
-        const double2 cur = y[i];
+    // One symbol: cur -> NB LLRs in `pend` (two levels per axis: stored at once).
+    constexpr bool DEFER = !(GP && NH == 1);
+    double pend[DEFER ? NB : 1];
+    auto symbol = [&](const double2 cur, const int64_t i) __attribute__((always_inline)) {
         double ex[R], ey[R], sx = 0.0, sy = 0.0;
         bool redo = false;
         if constexpr (GP && NH == 1) {
@@ -152,11 +229,11 @@ __global__ __launch_bounds__(DEMOD_BLOCK) void demod_soft_sep_kernel(const doubl
             }
 #pragma unroll
             for (int b = 0; b < NB; b++) llr[i * NB + NB - 1 - b] = out[b] * scale;   // (:137)
-            continue;
+            return;
         }
         if (GP) {
-            redo |= axis_gp<NH, RCP>(cur.x, ax_s, step_x, noise_var, ninv, c1x, c2x, Qx, ex, sx);
-            redo |= axis_gp<NH, RCP>(cur.y, ax_s + R, step_y, noise_var, ninv, c1y, c2y, Qy, ey, sy);
+            redo |= axis_gp<NH, RCP, TAB>(cur.x, ax_s, step_x, noise_var, ninv, c1x, c2x, Qx, tab_s, ex, sx);
+            redo |= axis_gp<NH, RCP, TAB>(cur.y, ax_s + R, step_y, noise_var, ninv, c1y, c2y, Qy, tab_s, ey, sy);
         } else {
 #pragma unroll
             for (int a = 0; a < R; a++) {
@@ -181,8 +258,8 @@ __global__ __launch_bounds__(DEMOD_BLOCK) void demod_soft_sep_kernel(const doubl
             // non-finite rule below, tested on the quotient) are decided point by point anyway
             const double qa = div_nr(nx * sy, qx * sy), qb = div_nr(ny * sx, qy * sx);
             redo |= !(qa > 2.7e-261 && qa < 3.7e260) || !(qb > 2.7e-261 && qb < 3.7e260);
-            out[NH + b] = fast_log<false, true>(qa);
-            out[b] = fast_log<false, true>(qb);
+            out[NH + b] = TAB ? tab_log(qa, tab_s) : fast_log<false, true>(qa);
+            out[b] = TAB ? tab_log(qb, tab_s) : fast_log<false, true>(qb);
         }
         // The factorised sums are only as good as the reference's point-by-point ones while nothing is near the underflow
         // threshold: an LLR beyond +-600 (or non-finite) means some sum of e^{-d^2/N0} terms is down among the denormals, where
@@ -207,8 +284,34 @@ __global__ __launch_bounds__(DEMOD_BLOCK) void demod_soft_sep_kernel(const doubl
             for (int b = 0; b < NB; b++) out[b] = fast_log(num[b] / den[b]);
         }
 #pragma unroll
-        for (int b = 0; b < NB; b++) llr[i * NB + NB - 1 - b] = out[b] * scale;   // (:137)
+        for (int b = 0; b < NB; b++) pend[DEFER ? b : 0] = out[b] * scale;        // (:137)
+    };
+    auto flush = [&](const int64_t i) __attribute__((always_inline)) {
+        if (DEFER) {
+#pragma unroll
+            for (int b = 0; b < NB; b++) llr[i * NB + NB - 1 - b] = pend[DEFER ? b : 0];
+        }
+    };
+    // Software pipeline over a thread's symbols (round 5).  The load sat at the top of the loop body with its wait right behind it and
+    // the stores at the bottom, in front of the loop header's vmcnt(0): one load and one store round trip exposed per symbol, on four
+    // waves per SIMD.  Now the next symbol is requested and the previous symbol's LLRs are stored at the TOP of a trip -- both complete
+    // while the current symbol is computed, and the header's wait finds nothing outstanding.  The first trip is peeled off: a store
+    // that is there on one path into the header and not on the other makes the compiler wait for the worst case on both.
+    const int64_t stride = (int64_t)gridDim.x * DEMOD_BLOCK;
+    int64_t i = (int64_t)blockIdx.x * DEMOD_BLOCK + threadIdx.x;
+    if (i >= Ns) return;
+    double2 cur = y[i];
+    double2 nxt = y[i + stride < Ns ? i + stride : i];
+    symbol(cur, i);
+    int64_t prev = i;
+    for (i += stride; i < Ns; i += stride) {
+        cur = nxt;
+        flush(prev);
+        nxt = y[i + stride < Ns ? i + stride : i];
+        symbol(cur, i);
+        prev = i;
     }
+    flush(prev);
 }
 
 // ---- "fp32-fast" soft decisions (cpx_set_precision) ---------------------------------------------------------------------
@@ -449,16 +552,19 @@ __global__ __launch_bounds__(DEMOD_BLOCK) void demod_hard_any_kernel(const doubl
 
 // "plain": the R-exponentials-per-axis form of the separable kernel also where the progression applies (A/B runs, tests);
 // initial value from the environment variable CPX_DEMOD, changed through cpx_demod_set_path()
+// 0 auto; 1 "plain": R exponentials per axis, no progression; 2 "libm": the progression with the library's exp / log instead of the
+// table-driven ones (the round-4 / early round-5 kernel: kept as the row the table-driven kernel is tested against)
 std::atomic<int> g_demod_plain{-1};
-bool demod_plain() {
+int parse_demod_mode(const char *e) { return (e && strcmp(e, "plain") == 0) ? 1 : (e && strcmp(e, "libm") == 0) ? 2 : 0; }
+int demod_mode() {
     int v = g_demod_plain.load(std::memory_order_relaxed);
     if (v < 0) {
-        const char *e = getenv("CPX_DEMOD");
-        v = (e && strcmp(e, "plain") == 0) ? 1 : 0;
+        v = parse_demod_mode(getenv("CPX_DEMOD"));
         g_demod_plain.store(v, std::memory_order_relaxed);
     }
-    return v != 0;
+    return v;
 }
+bool demod_plain() { return demod_mode() == 1; }
 
 unsigned grid_for(int64_t Ns) {
     int64_t blocks = (Ns + DEMOD_BLOCK - 1) / DEMOD_BLOCK;
@@ -524,11 +630,11 @@ int cpx_modem_create(const double *constellation_re_im, int M, cpx_modem **out) 
 }
 
 int cpx_demod_set_path(const char *mode) {
-    if (mode && mode[0] && strcmp(mode, "auto") != 0 && strcmp(mode, "plain") != 0) {
-        set_error("cpx_demod_set_path: unknown mode '%s' (auto | plain)", mode);
+    if (mode && mode[0] && strcmp(mode, "auto") != 0 && strcmp(mode, "plain") != 0 && strcmp(mode, "libm") != 0) {
+        set_error("cpx_demod_set_path: unknown mode '%s' (auto | plain | libm)", mode);
         return CPX_EINVAL;
     }
-    g_demod_plain.store((mode && strcmp(mode, "plain") == 0) ? 1 : 0, std::memory_order_relaxed);
+    g_demod_plain.store(parse_demod_mode(mode), std::memory_order_relaxed);
     return CPX_OK;
 }
 
@@ -592,6 +698,7 @@ int cpx_demod_soft_scaled_dev(const cpx_modem *m, const double *d_y, int64_t Ns,
         return CPX_OK;
     }
     const bool gp = m->gp && (m->nbits >= 6 || m->nbits == 2) && !demod_plain();
+    const bool tab = gp && m->nbits >= 6 && demod_mode() != 2;       // table-driven exp / log (round 5); "libm" keeps the library's
     if (m->separable) {
         switch (m->nbits / 2) {
 #define LAUNCH(NH, RC, GPV) hipLaunchKernelGGL((demod_soft_sep_kernel<NH, RC, GPV>), grid, block, 0, st, y, Ns, m->d_axes, noise_var, \
@@ -603,9 +710,18 @@ int cpx_demod_soft_scaled_dev(const cpx_modem *m, const double *d_y, int64_t Ns,
         if (gp) { if (rcp) LAUNCH(NH, true, true); else LAUNCH(NH, false, true); }       \
         else { if (rcp) LAUNCH(NH, true, false); else LAUNCH(NH, false, false); }        \
         break;
-            CASE_GP(1) CASE(2) CASE_GP(3) CASE_GP(4)              // two levels: closed form; 8 and 16 levels: progression (4 exp instead of R)
+#define LAUNCH_T(NH, RC) hipLaunchKernelGGL((demod_soft_sep_kernel<NH, RC, true, true>), grid, block, 0, st, y, Ns, m->d_axes, noise_var, \
+                                            scale, m->gp_step[0], m->gp_step[1], d_llr)
+#define CASE_GT(NH) case NH:                                      \
+        if (tab) { if (rcp) LAUNCH_T(NH, true); else LAUNCH_T(NH, false); }              \
+        else if (gp) { if (rcp) LAUNCH(NH, true, true); else LAUNCH(NH, false, true); }  \
+        else { if (rcp) LAUNCH(NH, true, false); else LAUNCH(NH, false, false); }        \
+        break;
+            CASE_GP(1) CASE(2) CASE_GT(3) CASE_GT(4)              // two levels: closed form; 8 and 16 levels: progression (4 exp instead of R)
 #undef CASE
 #undef CASE_GP
+#undef CASE_GT
+#undef LAUNCH_T
 #undef LAUNCH
             default: set_error("demod: unsupported bits per symbol %d", m->nbits); return CPX_ELIMIT;
         }
@@ -621,7 +737,7 @@ int cpx_demod_soft_scaled_dev(const cpx_modem *m, const double *d_y, int64_t Ns,
         }
     }
     CPX_HIP(hipGetLastError());
-    if (m->separable) note_kernel("demod_soft_sep_kernel<%d,%s%s>", m->nbits / 2, rcp ? "rcp" : "div", gp ? ",gp" : "");
+    if (m->separable) note_kernel("demod_soft_sep_kernel<%d,%s%s%s>", m->nbits / 2, rcp ? "rcp" : "div", gp ? ",gp" : "", tab ? ",tab" : "");
     else note_kernel("demod_soft_kernel<%d,%s>", m->nbits, rcp ? "rcp" : "div");
     return CPX_OK;
 }

@@ -263,8 +263,9 @@ int cpx_modem_create(const double *constellation_re_im, int M, cpx_modem **out);
 int cpx_modem_destroy(cpx_modem *m);
 /* Implementation choice of the soft demodulator for tests and A/B runs (initial value: environment variable CPX_DEMOD):
  * NULL / "auto": square QAM of 64 points and more takes the four-exponentials-per-axis form (equally spaced Gray-labelled
- * levels: the exponentials of an axis are a geometric progression); "plain": one exponential per level everywhere.
- * Both are within 1e-5 of modulation.py:125-137 (measured: 1e-13); symbols near the underflow range are decided point by
+ * levels: the exponentials of an axis are a geometric progression) with table-driven exp / log (32-entry tables in LDS);
+ * "libm": the same form with the library's exp / log; "plain": one exponential per level everywhere.
+ * All are within 1e-5 of modulation.py:125-137 (measured: 1e-13); symbols near the underflow range are decided point by
  * point in the reference's order either way. */
 int cpx_demod_set_path(const char *mode);
 int cpx_demod_soft(const cpx_modem *m, const double *y_re_im, int64_t Ns, double noise_var, double *llr);
