@@ -381,3 +381,43 @@ def test_turbo_decode_extreme_regimes_follow_the_reference(gpu):
                 assert np.array_equal(dec[b], want), (amp, nv, lsc, iters, b)
                 n += 1
     assert n >= 60
+
+
+@pytest.mark.parametrize("m,snr_db", [(16, 10.0), (64, 8.0), (64, 24.0), (256, 14.0)])
+def test_soft_demod_ragged_sizes_path_modes_and_bounds(gpu, m, snr_db):
+    """The separable kernel stores a wave's 64 consecutive symbols as one contiguous run through an LDS transpose, works on a thread's
+    symbols as a software pipeline and evaluates exp / log from tables (round 5): every size around the wave and block boundaries, in
+    all three path modes, against the oracle on every symbol -- and nothing may be written behind the Ns * nb values of the result."""
+    from commpy_amd import _lib
+    from commpy_amd.devicelink import DeviceBuf
+    from commpy_amd.modulation import QAMModem
+    lib = _lib.load()
+    md = QAMModem(m)
+    nb = md.num_bits_symbol
+    rs = np.random.RandomState(m)
+    N0 = md.Es / 10 ** (snr_db / 10.0)
+    h = md._device_handle()
+    guard = 700
+    for ns in (1, 2, 63, 64, 65, 127, 255, 256, 257, 1000, 4099, 70001):
+        y = md.constellation[rs.randint(0, m, ns)] + np.sqrt(N0 / 2) * (rs.randn(ns) + 1j * rs.randn(ns))
+        want = oracle.demodulate(md.constellation, y, "soft", N0)
+        fin = np.isfinite(want)
+        d_y = DeviceBuf.from_array(y)
+        for mode in (None, "libm", "plain"):
+            d_l = DeviceBuf.from_array(np.full(ns * nb + guard, -777.25))
+            _lib.demod_set_path(mode)
+            try:
+                _lib.check(lib.cpx_demod_soft_dev(h, d_y.ptr, ns, float(N0), d_l.ptr, None))
+                _lib.check(lib.cpx_stream_sync(None))
+                kern = _lib.last_kernel()
+            finally:
+                _lib.demod_set_path(None)
+            got = d_l.to_array((ns * nb + guard,), np.float64)
+            d_l.free()
+            assert np.all(got[ns * nb:] == -777.25), (ns, mode, kern)
+            got = got[:ns * nb]
+            assert np.array_equal(np.isfinite(got), fin), (ns, mode, kern)
+            assert np.max(np.abs(got[fin] - want[fin]), initial=0.0) < 1e-9, (ns, mode, kern)
+            if m >= 64:
+                assert (",tab" in kern) == (mode is None) and (",gp" in kern) == (mode != "plain"), kern
+        d_y.free()
