@@ -230,3 +230,29 @@ def test_trellis_from_tables():
     import pytest
     with pytest.raises(ValueError):
         Trellis.from_tables(2, 2, 2, t.next_state_table, t.output_table)      # 2 ** k columns expected
+
+
+def test_demod_tables_in_the_kernel_source_are_what_their_comments_say():
+    """csrc/demod.hip carries three 32-entry tables as hex literals (2^(j/32); 1/c_i for the centres of 32 mantissa intervals; -log of the
+    ROUNDED 1/c_i): recomputed here in extended precision -- a pasted constant that is off by one digit would still pass the GPU parity
+    tests at 1e-5 and sit in the kernel unnoticed."""
+    import os
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "commpy_amd", "csrc", "demod.hip")).read()
+    body = src[src.index("__device__ const double DEMOD_TAB[96] = {"):]
+    body = body[:body.index("};")]
+    vals = [float.fromhex(v) for v in re.findall(r"-?0x1\.[0-9a-f]+p[+-]\d+", body)]
+    assert len(vals) == 96
+    ld = np.longdouble
+    for j in range(32):
+        assert vals[j] == float(ld(2) ** (ld(j) / ld(32))), j
+        c = ld(0.5) + (ld(j) + ld(0.5)) / ld(64)
+        assert vals[32 + j] == float(ld(1) / c), j
+        want = float(-np.log(ld(vals[32 + j])))
+        assert abs(vals[64 + j] - want) <= abs(want) * 2.3e-16, j
+    consts = dict(re.findall(r"(INV_L32|L32_HI|L32_LO|LN2) = (0x1\.[0-9a-f]+p[+-]\d+)", src))
+    l32 = np.log(ld(2)) / ld(32)
+    assert float.fromhex(consts["L32_HI"]) == float(l32)
+    assert abs(float.fromhex(consts["L32_LO"]) - float(l32 - ld(float(l32)))) < 1e-21
+    assert float.fromhex(consts["INV_L32"]) == float(ld(32) / np.log(ld(2)))
+    assert float.fromhex(consts["LN2"]) == float(np.log(ld(2)))
