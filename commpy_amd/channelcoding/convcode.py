@@ -52,13 +52,11 @@ class Trellis:
 
     def __init__(self, memory, g_matrix, feedback=None, code_type='default', polynomial_format='MSB'):
         memory = np.asarray(memory)
-        [self.k, self.n] = g_matrix.shape
-        self.code_type = code_type
-        self.total_memory = int(memory.sum())
-        self.number_states = 2 ** self.total_memory
-        self.number_inputs = 2 ** self.k
-        self.next_state_table = np.zeros([self.number_states, self.number_inputs], 'int')
-        self.output_table = np.zeros([self.number_states, self.number_inputs], 'int')
+        k, n = g_matrix.shape
+        m = int(memory.sum())
+        self.k, self.n, self.total_memory, self.code_type = k, n, m, code_type
+        self.number_states, self.number_inputs = 1 << m, 1 << k
+        self.next_state_table, self.output_table = (np.zeros((1 << m, 1 << k), dtype=int) for _ in range(2))
 
         if isinstance(feedback, int):
             warn('Trellis  will only accept feedback as a matrix in the future. '
@@ -194,56 +192,17 @@ def device_trellis(trellis):
 def conv_encode(message_bits, trellis, termination='term', puncture_matrix=None):
     """Table-driven convolutional encoder (host) -- convcode.py:475-558.
 
-    Same return as the reference, including its puncturing behaviour: only row 0 of
-    ``puncture_matrix`` is consulted, indexed by flat output position, and the result keeps the
-    unpunctured length with a zero tail (quirk B3, convcode.py:523-527, 552-556).
+    One codeword is a batch of one: the table walk is ``conv_encode_batch``'s (a gather per trellis step), and what is
+    left here is the reference's puncturing behaviour -- only row 0 of ``puncture_matrix`` is consulted, indexed by flat
+    output position modulo the row length, and the survivors are packed to the front of a buffer that keeps the
+    unpunctured length, i.e. the result ends in a zero tail (quirk B3, convcode.py:523-527, 552-556).
     """
-    k, n, total_memory = trellis.k, trellis.n, trellis.total_memory
-    rate = float(k) / n
-    code_type = trellis.code_type
+    stream = conv_encode_batch(np.reshape(message_bits, (1, -1)), trellis, termination)[0]
     if puncture_matrix is None:
-        puncture_matrix = np.ones((k, n))
-    message_bits = np.asarray(message_bits)
-    number_message_bits = np.size(message_bits)
-
-    if termination == 'cont':
-        inbits = message_bits
-        number_inbits = number_message_bits
-        number_outbits = int(number_inbits / rate)
-    elif code_type == 'rsc':
-        inbits = message_bits
-        number_inbits = number_message_bits
-        number_outbits = int((number_inbits + k * total_memory) / rate)
-    else:
-        number_inbits = number_message_bits + total_memory + total_memory % k
-        inbits = np.zeros(number_inbits, 'int')
-        inbits[0:number_message_bits] = message_bits      # zero tail = trellis termination
-        number_outbits = int(number_inbits / rate)
-
-    outbits = np.zeros(number_outbits, 'int')
-    next_state_table, output_table = trellis.next_state_table, trellis.output_table
-    state = 0
-    j = 0
-    for i in range(int(number_inbits / k)):
-        cur_in = bitarray2dec(inbits[i * k:(i + 1) * k])
-        outbits[j * n:(j + 1) * n] = dec2bitarray(int(output_table[state][cur_in]), n)
-        state = next_state_table[state][cur_in]
-        j += 1
-
-    if code_type == 'rsc' and termination == 'term':
-        term_bits = dec2bitarray(int(state), total_memory)[::-1]         # :539-540
-        for i in range(total_memory):
-            cur_in = bitarray2dec(term_bits[i * k:(i + 1) * k])
-            outbits[j * n:(j + 1) * n] = dec2bitarray(int(output_table[state][cur_in]), n)
-            state = next_state_table[state][cur_in]
-            j += 1
-
-    p_outbits = np.zeros(number_outbits, 'int')
-    row0 = np.asarray(puncture_matrix)[0]
-    keep = row0[np.arange(number_outbits) % np.size(puncture_matrix, 1)] == 1
-    kept = outbits[keep]
-    p_outbits[:len(kept)] = kept
-    return p_outbits
+        return stream.astype(int)
+    pattern = np.asarray(puncture_matrix)[0]
+    survivors = stream[np.resize(pattern, stream.size) == 1]
+    return np.concatenate([survivors, np.zeros(stream.size - survivors.size, stream.dtype)]).astype(int)
 
 
 def conv_encode_batch(message_bits, trellis, termination='term'):

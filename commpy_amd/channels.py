@@ -26,13 +26,7 @@ class SISOFlatChannel:
         self.noise_std = noise_std
         self.fading_param = fading_param
 
-    @property
-    def nb_tx(self):
-        return 1
-
-    @property
-    def nb_rx(self):
-        return 1
+    nb_tx = nb_rx = property(lambda self: 1, doc='one antenna on each side (channels.py:223-231)')
 
     @property
     def isComplex(self):
@@ -77,18 +71,19 @@ class SISOFlatChannel:
     def propagate(self, msg):
         """Fading + noise (channels.py:181-221); ``msg`` may be 1-D or ``[batch, nsym]``."""
         msg = asarray(msg)
-        if not isrealobj(msg) and not self.isComplex:
-            raise TypeError('Trying to propagate a complex message in a real channel.')
+        cplx = self.isComplex
+        if not (cplx or isrealobj(msg)):
+            raise TypeError('a complex message cannot be propagated in a real channel.')
         dims = msg.shape
-        self.generate_noises(dims)
-        self.channel_gains = self.fading_param[0]
-        if self.isComplex:
-            self.channel_gains = self.channel_gains + (standard_normal(dims) + 1j * standard_normal(dims)) * \
-                sqrt(0.5 * self.fading_param[1])
+        self.generate_noises(dims)                             # draw order of the reference: noise first, then the fading
+        mean, variance = self.fading_param
+        if cplx:
+            scatter = (standard_normal(dims) + 1j * standard_normal(dims)) * sqrt(0.5 * variance)
         else:
-            self.channel_gains = self.channel_gains + standard_normal(dims) * sqrt(self.fading_param[1])
-        self.unnoisy_output = self.channel_gains * msg
-        return self.unnoisy_output + self.noises
+            scatter = standard_normal(dims) * sqrt(variance)
+        gains = self.channel_gains = mean + scatter
+        clean = self.unnoisy_output = gains * msg
+        return clean + self.noises
 
 
 def bec(input_bits, p_e):

@@ -23,10 +23,8 @@ __all__ = ['link_performance', 'LinkModel']
 
 
 def link_performance(link_model, SNRs, send_max, err_min, send_chunk=None, code_rate=1):
-    """Module-level convenience wrapper (links.py:29-64)."""
-    if not send_chunk:
-        send_chunk = err_min
-    return link_model.link_performance(SNRs, send_max, err_min, send_chunk, code_rate)
+    """Module-level convenience wrapper (links.py:29-64): a missing / zero chunk size means ``err_min`` bits per chunk."""
+    return link_model.link_performance(SNRs, send_max, err_min, send_chunk or err_min, code_rate)
 
 
 def _is_batched(fn):
@@ -136,22 +134,22 @@ class LinkModel:
 
     def link_performance(self, SNRs, send_max, err_min, send_chunk=None, code_rate=1):
         """BER per SNR: send chunks until ``send_max`` bits or ``err_min`` errors (links.py:269-343)."""
-        BERs = np.zeros_like(SNRs, dtype=float)
         send_chunk, code_rate = self._prepare(send_chunk, err_min, code_rate)
-        for id_SNR, snr_db in enumerate(SNRs):
+        curve = np.zeros(np.shape(SNRs), dtype=float)
+        for point, snr_db in enumerate(SNRs):
             self.channel.set_SNR_dB(snr_db, float(code_rate), self.Es)
-            bit_send = bit_err = 0
-            while bit_send < send_max and bit_err < err_min:
-                remaining = int(np.ceil((send_max - bit_send) / send_chunk))
-                n_blk = self._block_size(remaining)
+            sent = wrong = 0
+
+            def running():                                   # the reference's loop condition (:323)
+                return sent < send_max and wrong < err_min
+            while running():
+                n_blk = self._block_size(-(-(send_max - sent) // send_chunk))
                 msgs, dec = self._run_block(n_blk, send_chunk)
-                errs = (msgs != dec[:, :send_chunk].astype(int)).sum(1)
-                for j in range(n_blk):                      # sequential stop rule of the reference
-                    if not (bit_send < send_max and bit_err < err_min):
-                        break
-                    bit_send += send_chunk
-                    bit_err += int(errs[j])
-            BERs[id_SNR] = bit_err / bit_send
-            if not bit_err >= err_min:                       # send_max reached before err_min errors: higher SNRs stay 0 (:341)
-                return BERs
-        return BERs
+                per_tx = (msgs != dec[:, :send_chunk].astype(int)).sum(1)
+                for e in per_tx:                             # sequential stop rule: surplus transmissions of a block are dropped
+                    if running():
+                        sent, wrong = sent + send_chunk, wrong + int(e)
+            curve[point] = wrong / sent
+            if wrong < err_min:                              # send_max reached before err_min errors: higher SNRs stay 0 (:341)
+                break
+        return curve

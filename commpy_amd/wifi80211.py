@@ -40,10 +40,10 @@ class Wifi80211:
 
     def get_modem(self):
         """Modem of the MCS (wifi80211.py:51-73): PSK for MCS 0-2, square QAM above."""
-        bits_per_symbol = [2, 4, 4, 16, 16, 64, 64, 64, 256, 256]
-        if self.mcs <= 2:
-            return mod.PSKModem(bits_per_symbol[self.mcs])
-        return mod.QAMModem(bits_per_symbol[self.mcs])
+        psk, qam = mod.PSKModem, mod.QAMModem
+        family, order = ((psk, 2), (psk, 4), (psk, 4), (qam, 16), (qam, 16), (qam, 64), (qam, 64), (qam, 64), (qam, 256),
+                         (qam, 256))[self.mcs]
+        return family(order)
 
     @staticmethod
     def _get_puncture_matrix(numerator, denominator):

@@ -1,6 +1,16 @@
-"""The Python mirror keeps the reference's NAMES and signatures, not its bodies: no run of four or more identical
-statements against the same-named reference file (round-3 review: turbo_encode / triang_ldpc_systematic_encode had been
-line-for-line).  Needs the reference checkout, so it runs in the build container and skips on the GPU box."""
+"""The Python mirror keeps the reference's NAMES and signatures, not its bodies.
+
+Two checks against the same-named reference file, both on the abstract syntax tree so that whitespace, comments, line
+breaks and docstrings cannot hide (or fake) a match (round-5 review: the raw-line version of this test let a transcribed
+``conv_encode`` through because ``int(a/b)`` and ``int(a / b)`` are different lines):
+
+* no run of more than three consecutive identical statements anywhere in a file (the one tolerated block is the legacy
+  ``feedback`` DeprecationWarning of ``Trellis.__init__`` whose text is API);
+* no same-named function of ten or more statements shares 30 % or more of its statements with the reference's.
+
+Needs the reference checkout, so it runs in the build container and skips on the GPU box."""
+import ast
+import collections
 import difflib
 import os
 
@@ -11,15 +21,52 @@ REF = "/root/reference/commpy"
 PAIRS = [("channelcoding/convcode.py",) * 2, ("channelcoding/turbo.py",) * 2, ("channelcoding/ldpc.py",) * 2,
          ("channelcoding/interleavers.py",) * 2, ("modulation.py",) * 2, ("utilities.py",) * 2, ("links.py",) * 2,
          ("channels.py",) * 2, ("wifi80211.py",) * 2]
+_BODIES = ("body", "orelse", "finalbody", "handlers")
+
+
+def _is_docstring(node):
+    return isinstance(node, ast.Expr) and isinstance(node.value, ast.Constant) and isinstance(node.value.value, str)
+
+
+def _flatten(stmts, out):
+    """Statements in source order, one normalised string each; a compound statement contributes its header only and is
+    then descended into."""
+    for node in stmts:
+        if _is_docstring(node):
+            continue
+        compound = any(getattr(node, f, None) for f in _BODIES if isinstance(getattr(node, f, None), list))
+        if compound:
+            out.append(ast.unparse(node).split("\n")[0])
+            for f in _BODIES:
+                sub = getattr(node, f, None)
+                if isinstance(sub, list):
+                    for h in sub:
+                        if isinstance(h, ast.ExceptHandler):
+                            out.append("except %s:" % (ast.unparse(h.type) if h.type else ""))
+                            _flatten(h.body, out)
+                    _flatten([s for s in sub if isinstance(s, ast.stmt)], out)
+        else:
+            out.append(ast.unparse(node))
+    return out
 
 
 def _statements(path):
-    out = []
-    for line in open(path).read().split("\n"):
-        t = line.strip()
-        if t and not t.startswith("#"):
-            out.append(t)
-    return out
+    return _flatten(ast.parse(open(path).read()).body, [])
+
+
+def _functions(path):
+    """{qualified name: [normalised statements of the body]} for every def, methods as Class.name."""
+    found = {}
+
+    def visit(body, prefix):
+        for node in body:
+            if isinstance(node, (ast.FunctionDef, ast.AsyncFunctionDef)):
+                found[prefix + node.name] = _flatten(node.body, [])
+                visit(node.body, prefix + node.name + ".")
+            elif isinstance(node, ast.ClassDef):
+                visit(node.body, prefix + node.name + ".")
+    visit(ast.parse(open(path).read()).body, "")
+    return found
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")
@@ -28,6 +75,37 @@ def test_no_run_of_identical_statements(ours, theirs):
     a = _statements(os.path.join(ROOT, "commpy_amd", ours))
     b = _statements(os.path.join(REF, theirs))
     m = difflib.SequenceMatcher(None, a, b, autojunk=False).find_longest_match(0, len(a), 0, len(b))
-    # the one tolerated block is the 4-line DeprecationWarning of the legacy-feedback Trellis path (its text is API)
-    limit = 4 if ours.endswith("convcode.py") else 3
-    assert m.size <= limit, a[m.a:m.a + m.size]
+    run = a[m.a:m.a + m.size]
+    if any("DeprecationWarning" in s for s in run):         # the warning text of the legacy-feedback Trellis path is API
+        run = [s for s in run if "warn" not in s and "DeprecationWarning" not in s]
+    assert len(run) <= 3, run
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")
+@pytest.mark.parametrize("ours,theirs", PAIRS)
+def test_same_named_functions_share_under_30_percent(ours, theirs):
+    mine = _functions(os.path.join(ROOT, "commpy_amd", ours))
+    ref = _functions(os.path.join(REF, theirs))
+    report = []
+    for name, stmts in mine.items():
+        if name not in ref or len(stmts) < 10:
+            continue
+        pool = collections.Counter(ref[name])
+        shared = 0
+        for s in stmts:
+            if pool[s] > 0:
+                pool[s] -= 1
+                shared += 1
+        if shared / len(stmts) >= 0.30:
+            report.append((name, shared, len(stmts)))
+    assert not report, report
+
+
+def test_the_normaliser_sees_through_spacing_and_comments(tmp_path):
+    """The property the raw-line version lacked."""
+    a = tmp_path / "a.py"
+    b = tmp_path / "b.py"
+    a.write_text("def f(x, y):\n    '''doc'''\n    n = int(x/y)   # comment\n    if n:\n        return (n +\n                1)\n    return 0\n")
+    b.write_text("def f(x, y):\n    n = int(x / y)\n    if n:\n        return n + 1\n    return 0\n")
+    assert _statements(str(a)) == _statements(str(b))
+    assert _functions(str(a))["f"] == ["n = int(x / y)", "if n:", "return n + 1", "return 0"]
