@@ -196,7 +196,7 @@ def bench_turbo(lib, scale, which, states=4):
         ms, _ = timeit(lib, lambda: _lib.check(lib.cpx_turbo_decode_batch_dev(h, d_s, d_p1, d_p2, None, d_perm, B, N, nv, 6,
                                                                              d_bits, None)), steps=3)
         bits = dev.get(d_bits, (B, N), np.uint8)
-        emit("turbo_decode (turbo_pass_kernel x 12 + turbo_stage_kernel)", "rate-1/3 %d-state RSC, N=1024, 6 iterations, Eb/N0=1.5 dB, B=%d" % (states, B), B * N,
+        emit("turbo_decode (turbo_pass_kernel x 12 + init + final)", "rate-1/3 %d-state RSC, N=1024, 6 iterations, Eb/N0=1.5 dB, B=%d" % (states, B), B * N,
              "info-bits", ms, B * 25600, "latency/valu", {"ber": float(np.mean(bits != msgs))})
     if "map" in which:
         ms, _ = timeit(lib, lambda: _lib.check(lib.cpx_map_decode_batch_dev(h, d_s, d_p1, d_zero, B, N, nv, 1, d_L, d_bits,

@@ -35,8 +35,8 @@
 // differ from the reference's only by rounding (measured <= 1e-13; tolerance 1e-5).
 // Waves of a workgroup only meet at the phase boundary and between the stages of turbo_decode (__syncthreads +
 // workgroup-scope fences: the partner's checkpoints are read through the CU's L1 / L2).  turbo_decode is a SEQUENCE of launches
-// (since round 3): one turbo_pass_kernel per MAP pass and one turbo_stage_kernel between passes -- slab initialisation,
-// interleaver / deinterleaver through LDS, final decisions -- see turbo_pass_kernel below.
+// (since round 3): turbo_init_kernel (slab), one turbo_pass_kernel per MAP pass -- since round 6 the slab is time-major and the
+// interleaver / deinterleaver are the ROW INDEX a pass reads its prior through -- and turbo_final_kernel (decisions); see TurboParams.
 #include "cpx_internal.h"
 #include "cpx_math.h"
 
@@ -67,6 +67,7 @@ constexpr int KNORM = CPX_KNORM;   // renormalise alpha / beta every KNORM steps
 // of equal parity (item_of).  Model: 0 conflict cycles on all 94 LDS instructions of a phase-2 chunk (round 3: 224).
 constexpr int XS_ROW = 2 * 64 + 2;   // doubles per step row of the parked branch products: [input 0 | input 1][64 lanes] + 2 pad
 constexpr int NPAIR = 4;       // (forward, reverse) wave pairs per full-size workgroup: 8 waves = 2 per SIMD of a CU
+constexpr unsigned TM_RW = 16; // codeword slots per row of turbo_decode's time-major slab (TurboParams): one 128-byte line of float64
 
 // ---- outside the reference's representable range: detect and redo --------------------------------------------------------
 // The recursions below are SCALE-FREE in the branch probabilities (a factor common to a trellis step is dropped) and
@@ -169,6 +170,23 @@ __device__ __forceinline__ void item_of(int lane, int q, int &gg, int &tl) {
     gg = (((bk & 3) << 1) | (bk >> 2)) + 8 * q;
     tl = (lane & 7) ^ ((((bk + 1) >> 1) & 1) << 2);
 }
+// TM (turbo_decode, round 6): the slab between the passes is TIME-MAJOR -- per array N rows of 16 codeword slots (TurboParams) -- so
+// eight consecutive lanes hold eight consecutive slots of ONE step (a 64-byte half row), a lane's two items are slots g and g + 8 of
+// that step and a chunk of an array is eight whole rows: the rows of a step can then sit ANYWHERE in the array, which is what lets
+// the interleaver disappear into the row index a pass reads through (turbo_pass_kernel).  One item per lane for GW <= 8, like
+// item_of.  (Adjacent slots 2 g, 2 g + 1 per lane and 16-byte accesses were built first: same time for 4 states -- 3.27 against
+// 3.28 ms per config-3 decode --, half the lanes idle in the stage / epilogue for 8 states: 7.39 against 6.90 ms; and the compiler
+// scheduled the VALU that overwrites its data straight behind `buffer_store_dwordx4 ..., s47 offen`, a hazard it only guards for a
+// constant scalar offset: lanes 4-7 of every eight stored the wrong first slot.  experiments/README.md.)
+template <bool TM>
+__device__ __forceinline__ void item_map(int lane, int q, int &gg, int &tl) {
+    if (TM) {
+        gg = (lane & 7) + 8 * q;
+        tl = lane >> 3;
+    } else {
+        item_of(lane, q, gg, tl);
+    }
+}
 
 template <int LGS>
 __device__ __forceinline__ void init_ctx(Ctx<LGS> &c, const MapTables &tb, unsigned char *smem, int GW) {
@@ -205,14 +223,19 @@ __device__ __forceinline__ void init_ctx(Ctx<LGS> &c, const MapTables &tb, unsig
 
 // flags raised during the pass -> flag bytes of the codewords they belong to (both waves of a pair may store the same 1): lane cw
 // looks up the lanes of its own codeword slot in the three masks
-template <int LGS>
+template <int LGS, bool TM = false>
 __device__ __forceinline__ void publish_flags(const Ctx<LGS> &c, uint8_t *flags, int ncw) {
     constexpr int S = Ctx<LGS>::S;
     if (flags && (c.bad_s | c.bad_i0 | c.bad_i1) != 0 && c.lane < ncw) {
         const int cw = c.lane;
         const unsigned long long st = (c.bad_s >> (cw * S)) & ((S == 64) ? ~0ull : ((1ull << S) - 1ull));
-        const int gg = cw & 7, bk = ((gg & 1) << 2) | (gg >> 1);      // item_of: block bk of eight lanes serves codeword slot gg (+ 8 q)
-        const unsigned long long it = (((cw >> 3) ? c.bad_i1 : c.bad_i0) >> (8 * bk)) & 0xffull;
+        unsigned long long it;
+        if (TM) {                                                     // item_map<true>: lanes 8 tl + (cw & 7), q = cw >> 3
+            it = (((cw >> 3) ? c.bad_i1 : c.bad_i0) >> (cw & 7)) & 0x0101010101010101ull;
+        } else {
+            const int gg = cw & 7, bk = ((gg & 1) << 2) | (gg >> 1);  // item_of: block bk of eight lanes serves codeword slot gg (+ 8 q)
+            it = (((cw >> 3) ? c.bad_i1 : c.bad_i0) >> (8 * bk)) & 0xffull;
+        }
         if ((st | it) != 0) flags[cw] = 1;
     }
     c.bad_s = 0; c.bad_i0 = 0; c.bad_i1 = 0;
@@ -257,6 +280,8 @@ __device__ __forceinline__ void exchange_pred(const Ctx<LGS> &c, double v, doubl
 // lanes hold the eight steps of one codeword: 64-byte segments of the pass's arrays.
 struct RawChunk {
     double r0[2], r1[2], li[2];
+    unsigned ridx;                // TM: the row (of the prior's array, and of the systematic array if it is gathered) of this lane's
+                                  // step in the chunk that will be loaded into this set NEXT (requested two chunks ahead of its use)
 };
 
 // The arrays of a pass, seen from the pair of wavefronts that runs it: every pointer is wave-uniform and already points at
@@ -281,6 +306,15 @@ struct PassIO {
     int lstride, ncw, N;          // ncw: codewords of the batch this pair really has (<= GW, may be <= 0)
     double nv2;
     double *ckpt;                 // this pair's checkpoint rows [nchunks + 1][64]
+    // TM (turbo_pass_kernel): rows of TM_RW slots, ALL arrays through rsys (one descriptor: a second and a third one pushed the kernel
+    // over its scalar registers -- 36 spilled, 72 v_readlane / v_writelane in the loops, the 8-state pass 476 -> 567 us); idx = the row
+    // index table of this pass (interleaver, its inverse or the identity: the prior's row of step t is idx[t], N entries), sysg = all
+    // ones when the systematic factors are gathered through it too (MAP 2) else 0; llr_in: the prior array holds LLRs, not P(bit = 0)
+    unsigned sysg;
+    unsigned odec;                // scalar byte offset of this pair's decision bytes
+    unsigned st_out, st_dec;      // all ones / 0: this pass stores its output array / its decisions (the last MAP 2 stores only those)
+    const int32_t *idx;
+    bool llr_in;
     uint8_t *flags;               // "detect and redo": one byte per codeword of the pair, set to 1 (never cleared here); may be null
     bool abort_ok;                // map_decode (round 5): its redo launch decodes a WHOLE pair again as soon as one codeword of it is flagged,
                                   // so a wave that has raised a flag may stop working (its pair's outputs are garbage until then)
@@ -339,8 +373,27 @@ __device__ __forceinline__ void st_off(double *base, unsigned elem, double v) {
     *reinterpret_cast<double *>(reinterpret_cast<char *>(base) + (elem * 8u)) = v;
 }
 
-template <int LGS, bool S32 = false>
-__device__ __forceinline__ void load_raw(const Ctx<LGS> &c, const PassIO &io, RawChunk &rc, int t0, int len) {
+// TM: requests the chunk [t0, t0 + len) into `rc` using the row index rc.ridx holds for it, then requests the row index of the chunk
+// [tn, ...) this set will be loaded with next time -- two loads ahead, so neither wait is ever on the critical path
+template <int LGS, bool S32 = false, bool TM = false>
+__device__ __forceinline__ void load_raw(const Ctx<LGS> &c, const PassIO &io, RawChunk &rc, int t0, int len, int tn = 0) {
+    if (TM) {
+        const int tl = c.lane >> 3, g0 = c.lane & 7;
+        const unsigned t = (unsigned)(t0 + tl);
+        const unsigned row = rc.ridx;
+        const unsigned srow = (row & io.sysg) | (t & ~io.sysg);
+#pragma unroll
+        for (int q = 0; q < 2; q++) {                                 // slots g0 and g0 + 8: the two 64-byte halves of the rows
+            const int gg = g0 + 8 * q;
+            const unsigned m = item_mask(gg, c.GW, tl, len);
+            rc.r0[q] = slab_ld<S32>(io.rsys, m, srow * TM_RW + gg, io.osys);
+            rc.r1[q] = slab_ld<S32>(io.rpar, m, t * TM_RW + gg, io.opar);
+            rc.li[q] = slab_ld<S32>(io.rlin, m, row * TM_RW + gg, io.olin);
+        }
+        const int tq = tn + tl;
+        rc.ridx = (unsigned)io.idx[tq < io.N ? tq : io.N - 1];        // (past the end of a partial last chunk: any valid row)
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < 2; q++) {
         int gg, tl;
@@ -373,15 +426,15 @@ __device__ __forceinline__ double signed_q(double r, double k4) { return __built
 // P(bit = 0) from the a-priori LLR, as the reference writes it (turbo.py:239)
 __device__ __forceinline__ double prior0(double L) { return 1.0 / (1.0 + exp(L)); }
 
-template <int LGS, bool PRE, bool LIT = false, bool S32 = false>
-__device__ __forceinline__ void stage_chunk(const Ctx<LGS> &c, const RawChunk &rc, double nv2, int ncw) {
+template <int LGS, bool PRE, bool LIT = false, bool S32 = false, bool TM = false>
+__device__ __forceinline__ void stage_chunk(const Ctx<LGS> &c, const RawChunk &rc, double nv2, int ncw, bool llr_in = false) {
     const int GW = c.GW;
     const double k4 = -4.0 / nv2;
     const double lim = T_A * nv2;
 #pragma unroll
     for (int q = 0; q < 2; q++) {
         int gg, tl;
-        item_of(c.lane, q, gg, tl);
+        item_map<TM>(c.lane, q, gg, tl);
         if (gg < GW) {
             const double r0 = rc.r0[q], r1 = rc.r1[q], li = rc.li[q];
             if (LIT) {
@@ -413,6 +466,10 @@ __device__ __forceinline__ void stage_chunk(const Ctx<LGS> &c, const RawChunk &r
             // of the batch reads zeros: it gets the prior of L_int = 0.)
             double p0 = PRE ? (gg < ncw ? li : 0.5) : prior0(li), p1 = 1.0 - p0;
             if (PRE && S32) dec_prior(gg < ncw ? li : 0.5, p0, p1);   // float32 slab: the smaller of (p0, p1), signed
+            if (TM && llr_in) {                                       // wave-uniform: the last MAP 2 of a decode reads L_int_2 itself (it
+                p0 = gg < ncw ? prior0(li) : 0.5;                     // needs it for the decision): the prior as the reference forms it
+                p1 = 1.0 - p0;
+            }
             // sign of the received value; the sign BIT, so that an underflowed factor stored as -0.0 keeps its sign
             const bool n0 = PRE ? __double2hiint(r0) < 0 : r0 < 0.0, n1 = PRE ? __double2hiint(r1) < 0 : r1 < 0.0;
             const double a0 = n0 ? 1.0 : qa, a1 = n0 ? qa : 1.0;  // systematic bit 0 (c0 = -1) / 1 (c0 = +1)
@@ -594,14 +651,14 @@ __device__ __forceinline__ void alpha_chunk(const Ctx<LGS> &c, double &a, int le
 }
 
 // time-parallel epilogue of a phase-2 chunk: app sums in state order, L = L_int + log(app1/app0) (:145)
-template <int LGS, bool BITS, bool LIT = false, bool S32 = false>
+template <int LGS, bool BITS, bool LIT = false, bool S32 = false, bool TM = false>
 __device__ __forceinline__ void epilogue(const Ctx<LGS> &c, const PassIO &io, const double (&li)[2], int t_lo, int len) {
     constexpr int S = Ctx<LGS>::S;
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int q = 0; q < 2; q++) {
         int gg, tl;
-        item_of(c.lane, q, gg, tl);
+        item_map<TM>(c.lane, q, gg, tl);
         const unsigned m = item_mask(gg, io.ncw, tl, len);        // no such item: computes on whatever LDS holds, stores nowhere
         const bool ok = m != 0;
         // the S products of input 0 and of input 1 of this item: the lanes of codeword slot gg are gg * S .. gg * S + S - 1
@@ -638,6 +695,16 @@ __device__ __forceinline__ void epilogue(const Ctx<LGS> &c, const PassIO &io, co
             L = io.ext ? lr : li[q] + lr;
         }
         const unsigned t = (unsigned)(t_lo + tl);
+        if (TM) {
+            // row t of the pass's output array: eight lanes write one 64-byte half of a 128-byte row, a chunk eight consecutive rows.
+            // The last MAP 2 stores its decision L_2 = L_int_2 + E_2 > 0 (:148-152, :326) INSTEAD -- one byte per slot, rows of TM_RW
+            // bytes at the start of the same array (nobody reads its E_2) -- for turbo_final_kernel to de-interleave (:331).
+            const unsigned ms = item_mask(gg, c.GW, tl, len);         // (slots past the end of the batch are the pair's own: written too)
+            const unsigned e = t * TM_RW + (unsigned)gg;
+            slab_st<S32>(io.rsys, ms & io.st_out, e, io.oout, L);
+            __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(li[q] + L > 0 ? 1 : 0), io.rsys, item_off(ms & io.st_dec, e), io.odec, 0);
+            continue;
+        }
         slab_st<S32>(io.rout, m, (unsigned)(gg * io.lstride) + t, io.oout, L);
         if (BITS) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)((io.want_bits && L > 0) ? 1 : 0), io.rbits,
                                              item_off(m, (unsigned)(gg * io.N) + t), 0, 0);               // (:148-152)
@@ -656,7 +723,7 @@ __device__ __forceinline__ void pair_sync() {
 }
 
 // One MAP pass over the GW codewords of this pair of wavefronts.  Collective over the workgroup (one pair_sync).
-template <int LGS, bool SR, bool PRE, bool LIT = false, bool S32 = false>
+template <int LGS, bool SR, bool PRE, bool LIT = false, bool S32 = false, bool TM = false>
 __device__ void map_pass(const Ctx<LGS> &c, const PassIO &io) {
     const int N = io.N;
     const int K = (N + CH - 1) / CH, K1 = K / 2;                  // F: chunks [0,K1) then [K1,K); R: [K1,K) then [0,K1)
@@ -675,8 +742,16 @@ __device__ void map_pass(const Ctx<LGS> &c, const PassIO &io) {
     // issuing VALU 53 % of the time, 22 % of the wave cycles in s_waitcnt and 29 % ready-but-not-issued.
     auto seq = [&](int i) { return c.fwd ? i : K - 1 - i; };
     // (past the end of the walk the last chunk is requested again: an `if` around the loads would bring the uncounted wait back)
-    auto fetch = [&](RawChunk &S, int i) { const int k = seq(i < K ? i : K - 1); load_raw<LGS, S32>(c, io, S, k * CH, clen(k)); };
+    auto fetch = [&](RawChunk &S, int i) {
+        const int k = seq(i < K ? i : K - 1), kn = seq(i + 2 < K ? i + 2 : K - 1);     // kn: what this set is loaded with next (TM)
+        load_raw<LGS, S32, TM>(c, io, S, k * CH, clen(k), kn * CH);
+    };
     RawChunk X, Y;
+    if (TM) {                                                     // row indices of the first two chunks of the walk
+        const int ta = seq(0) * CH + (c.lane >> 3), tb = seq(K > 1 ? 1 : 0) * CH + (c.lane >> 3);
+        X.ridx = (unsigned)io.idx[ta < N ? ta : N - 1];
+        Y.ridx = (unsigned)io.idx[tb < N ? tb : N - 1];
+    }
     fetch(X, 0);
     fetch(Y, 1);
     // runs step(i, set) for i = i0 .. i1-1, alternating X, Y; an odd count ends with the sets swapped by value (once per phase)
@@ -712,7 +787,7 @@ __device__ void map_pass(const Ctx<LGS> &c, const PassIO &io) {
         double a = (c.s == 0) ? 1.0 : 0.0;                        // f_state_metrics[0][0] = 1 (:221)
         run(0, K1, [&](int i, RawChunk &S) {
             ck_st(i, a);                                          // alpha at time i*CH (read by R in phase 2)
-            stage_chunk<LGS, PRE, LIT, S32>(c, S, io.nv2, io.ncw);
+            stage_chunk<LGS, PRE, LIT, S32, TM>(c, S, io.nv2, io.ncw, io.llr_in);
             fetch(S, i + 2);
             alpha_chunk<LGS, SR, false, LIT>(c, a, CH, arow);          // chunks below K1 are full
         });
@@ -721,22 +796,22 @@ __device__ void map_pass(const Ctx<LGS> &c, const PassIO &io) {
         if (!dead() && !run(K1, K, [&](int k, RawChunk &S) {
             const int len = clen(k);
             double b = ck_ld(k + 1);                              // beta at the upper boundary of chunk k
-            epilogue<LGS, !PRE, LIT, S32>(c, io, li_prev, t_prev, len_prev);
-            stage_chunk<LGS, PRE, LIT, S32>(c, S, io.nv2, io.ncw);
+            epilogue<LGS, !PRE, LIT, S32, TM>(c, io, li_prev, t_prev, len_prev);
+            stage_chunk<LGS, PRE, LIT, S32, TM>(c, S, io.nv2, io.ncw, io.llr_in);
             li_prev[0] = S.li[0]; li_prev[1] = S.li[1];
             fetch(S, k + 2);
             alpha_chunk<LGS, SR, true, LIT>(c, a, len, arow);
             beta_chunk<LGS, SR, true, LIT>(c, b, len, arow);
             t_prev = k * CH; len_prev = len;
         }))
-            epilogue<LGS, !PRE, LIT, S32>(c, io, li_prev, t_prev, len_prev);
+            epilogue<LGS, !PRE, LIT, S32, TM>(c, io, li_prev, t_prev, len_prev);
     } else {
         // ---------------- phase 1: beta over chunks K-1 .. K1, checkpoint before every chunk ----------------
         double b = 1.0;                                           // b_state_metrics[:, N] = 1 (:225)
         run(0, K - K1, [&](int i, RawChunk &S) {
             const int k = K - 1 - i;
             ck_st(k + 1, b);                                      // beta at the upper boundary of chunk k (read by F)
-            stage_chunk<LGS, PRE, LIT, S32>(c, S, io.nv2, io.ncw);
+            stage_chunk<LGS, PRE, LIT, S32, TM>(c, S, io.nv2, io.ncw, io.llr_in);
             fetch(S, i + 2);
             beta_chunk<LGS, SR, false, LIT>(c, b, clen(k), arow);
         });
@@ -745,17 +820,17 @@ __device__ void map_pass(const Ctx<LGS> &c, const PassIO &io) {
         if (!dead() && !run(K - K1, K, [&](int i, RawChunk &S) {
             const int k = K - 1 - i;
             double a = ck_ld(k);                                  // alpha at the lower boundary of chunk k
-            epilogue<LGS, !PRE, LIT, S32>(c, io, li_prev, t_prev, len_prev);      // of the previous chunk (see the forward wave)
-            stage_chunk<LGS, PRE, LIT, S32>(c, S, io.nv2, io.ncw);
+            epilogue<LGS, !PRE, LIT, S32, TM>(c, io, li_prev, t_prev, len_prev);      // of the previous chunk (see the forward wave)
+            stage_chunk<LGS, PRE, LIT, S32, TM>(c, S, io.nv2, io.ncw, io.llr_in);
             li_prev[0] = S.li[0]; li_prev[1] = S.li[1];
             fetch(S, i + 2);
             alpha_chunk<LGS, SR, true, LIT>(c, a, CH, arow);           // arow[tl] = alpha at time k*CH + tl
             beta_chunk<LGS, SR, true, LIT>(c, b, CH, arow);
             t_prev = k * CH; len_prev = CH;
         }))
-            epilogue<LGS, !PRE, LIT, S32>(c, io, li_prev, t_prev, len_prev);
+            epilogue<LGS, !PRE, LIT, S32, TM>(c, io, li_prev, t_prev, len_prev);
     }
-    if (!LIT) publish_flags<LGS>(c, io.flags, io.ncw);
+    if (!LIT) publish_flags<LGS, TM>(c, io.flags, io.ncw);
 }
 
 struct MapParams {
@@ -782,7 +857,7 @@ __global__ __launch_bounds__(128 * NPAIR) void map_decode_kernel(MapParams p) {
     const int64_t cw0 = pair * p.GW, o0 = cw0 * p.N;
     const int64_t left = p.B - cw0;
     PassIO io;
-    io.N = (int)p.N; io.sstride = io.pstride = io.lstride = io.N; io.ext = false; io.pout = false;
+    io.N = (int)p.N; io.sstride = io.pstride = io.lstride = io.N; io.ext = false; io.pout = false; io.llr_in = false; io.sysg = 0u;
     io.ncw = (int)(left < p.GW ? left : p.GW); io.nv2 = p.nv2;
     const unsigned span = io.ncw > 0 ? OOB : 0u;                  // a pair past the end of the batch: everything out of range
     io.rsys = pass_buffer(p.sys + o0, span); io.rpar = pass_buffer(p.par + o0, span);
@@ -829,7 +904,7 @@ __global__ __launch_bounds__(128 * NPAIR) void map_literal_kernel(MapParams p, R
     init_ctx<LGS>(c, p.tb, smem, p.GW);
     const int64_t K = (p.N + CH - 1) / CH, o0 = cw0 * p.N;
     PassIO io;
-    io.N = (int)p.N; io.sstride = io.pstride = io.lstride = io.N; io.ext = false; io.pout = false;
+    io.N = (int)p.N; io.sstride = io.pstride = io.lstride = io.N; io.ext = false; io.pout = false; io.llr_in = false; io.sysg = 0u;
     io.ncw = ncw; io.nv2 = p.nv2;
     io.rsys = pass_buffer(p.sys + o0, OOB); io.rpar = pass_buffer(p.par + o0, OOB);
     io.rlin = pass_buffer(p.Lin + o0, OOB); io.rout = pass_buffer(p.Lout + o0, OOB);
@@ -846,35 +921,46 @@ struct TurboParams {
     MapTables tb;
     const double *sys, *p1, *p2, *Lint;   // [B][N], Lint may be null
     const int32_t *perm;                  // [N]
+    const int32_t *iperm, *ident;         // [N] each: the inverse permutation and the identity (turbo_tables_kernel)
     uint8_t *bits;                        // [B][N]
     double *ckpt;                         // per pair: checkpoint rows [nchunks + 1][64]
-    // The slab: per codeword seven arrays [N] -- A (prior0 of L_int_1; from the last interleave on: L_int_2 itself, for the final
-    // decision), B (a pass's output), C (prior0 of L_int_2: a pass reads the PRIOR, see stage_chunk) and the signed channel factors
-    // (signed_q) of sys, interlv(sys) (:310), non_sys_1, non_sys_2 -- rows [B][7][N].  (A CHUNKED slab, [pair][array][chunk][GW][8]:
-    // the GW x 8 values a pass reads per array and chunk as ONE contiguous 1 KB line, was built and measured in round 3: the
-    // pass kernel did not move (337 us either way -- it is not the number of 64-byte segments that costs) and the stage
-    // kernels, whose per-codeword accesses become strided, lost 11 us each: 4.87 instead of 4.82 ms.  experiments/README.md.)
+    // The slab (round 6: TIME-MAJOR).  Per ROW GROUP five arrays of N rows; a row = RW = 16 codeword slots at one time step = one
+    // 128-byte line.  A pair of wavefronts decodes GW codewords, so a row group is 16 / GW consecutive pairs (one pair for the
+    // 16 codewords of a 4-state trellis, two for 8 states, ...) -- a gathered row is a whole line whatever the trellis.  Arrays:
+    //   0  what MAP 1 writes and MAP 2 reads as its prior     1  what MAP 2 writes and MAP 1 reads (initially prior0(L_int_1))
+    //   2, 3, 4  the signed channel factors (signed_q) of sys_symbols, non_sys_symbols_1, non_sys_symbols_2
+    // all in the NATURAL order of the pass that wrote them.  The interleaver is the same for every codeword
+    // (interleavers.py:13-47), so interlv / deinterlv (:310, :319, :329) move whole ROWS: a pass reads the row perm[t] (MAP 2; its
+    // systematic factors too) or inverse_perm[t] (MAP 1) of the other pass's output where it used to read row t of a permuted copy --
+    // eight 128-byte lines per load instruction either way -- and the thirteen permutation launches of rounds 3-5 (4.4 of a decode's
+    // 17.9 GB, 0.9 of its 3.9 ms) are gone.  (History: rows [B][7][N] until round 5 -- folding the permutation into THAT layout made
+    // every permuted 8-byte access its own memory request: 5.15 / 6.65 ms against 3.9; a chunked slab [pair][array][chunk][GW][8] was
+    // tried in round 3 and is codeword-major inside a chunk, so it could not fold either.  experiments/README.md.)
     double *larr;
+    // (the decisions of the last MAP 2 -- [N][RW] bytes, in ITS order -- take the place of its output at the start of array 1)
     uint8_t *flags;                       // [B] "detect and redo" (zeroed before the launch), may be null
     int64_t B, N;
     double nv2;
-    int n_iter, GW;
+    int n_iter, GW, RW;
+    int lgG;                              // pairs per row group = 16 / GW = 1 << lgG: codeword slot g of group r is codeword 16 r + g
+    // Every pair of wavefronts of the chip walks its arrays at the same pace: array and group strides are kept away from multiples
+    // of a large power of two -- an array has NR = N | 1 rows, an odd number of 128-byte lines, so row t of group r sits r * odd lines
+    // away from group 0's: all residues of any channel interleave.
+    int64_t NR;
 };
-// element t of array `a` (0 .. 6) of codeword cw
-__device__ __forceinline__ int64_t slab_off(const TurboParams &p, int a, int64_t cw, int64_t t) {
-    return (cw * 7 + a) * p.N + t;
-}
 
 // ---- turbo_decode as a SEQUENCE of launches (round 3) ------------------------------------------------------------------------
-// One launch per MAP pass (the pass of map_decode_kernel, reading the chunked slab) and one small launch per stage between
-// passes.  Round 2 ran everything in ONE persistent launch; inlined into that kernel's iteration loop the pass needed more
-// than 256 VGPRs -- 18 to 23 of them spilled, and a scratch reload retires through the same in-order counter as the prefetches,
+// One launch per MAP pass (the pass of map_decode_kernel, reading the time-major slab) between turbo_init_kernel and
+// turbo_final_kernel.  Round 2 ran everything in ONE persistent launch; inlined into that kernel's iteration loop the pass needed
+// more than 256 VGPRs -- 18 to 23 of them spilled, and a scratch reload retires through the same in-order counter as the prefetches,
 // i.e. it waits for the HBM round trip issued just before it (rocprofv3, round 2: 61 % of the wave cycles parked in s_waitcnt
-// where the stand-alone pass has 33 %).  As its own kernel the pass keeps the register allocation of map_decode_kernel (224
-// VGPRs, no scratch); a kernel boundary costs ~2 us, 25 of them per decode.  Measured, same box: 5.24 ms (persistent) -> 4.82 ms
-// (launch per pass, row slab) -> chunked slab: see DESIGN.md 4.2.
+// where the stand-alone pass has 33 %).  As its own kernel the pass keeps the register allocation of map_decode_kernel (no
+// scratch); a kernel boundary costs ~2 us.
+//   `second`: MAP 2 of an iteration (:326) else MAP 1 (:315);  `idx`: the row index table of the pass's prior (see TurboParams);
+//   `pout`: write prior0(E) instead of E (epilogue);  `llr_in`: the prior array holds LLRs (the pass before wrote E itself);
+//   `last`: the final MAP 2 -- it stores decisions and nothing else.
 template <int LGS, bool SR, bool S32 = false>
-__global__ __launch_bounds__(128 * NPAIR) void turbo_pass_kernel(TurboParams p, int second, int pout) {
+__global__ __launch_bounds__(128 * NPAIR) void turbo_pass_kernel(TurboParams p, const int32_t *idx, int second, int pout, int llr_in, int last) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Ctx<LGS> c;
     init_ctx<LGS>(c, p.tb, smem, p.GW);
@@ -882,112 +968,105 @@ __global__ __launch_bounds__(128 * NPAIR) void turbo_pass_kernel(TurboParams p, 
     const int64_t N = p.N, K = (N + CH - 1) / CH, cw0 = pair * p.GW;
     const int64_t left = p.B - cw0;
     PassIO io;
-    const int64_t ls = 7 * N;
-    io.lstride = io.sstride = io.pstride = (int)ls;
-    io.N = (int)N; io.nv2 = p.nv2; io.want_bits = 0;
+    io.lstride = io.sstride = io.pstride = 0;                     // (codeword-major strides: unused)
+    io.N = (int)N; io.nv2 = p.nv2; io.want_bits = last;
     io.ncw = (int)(left < p.GW ? left : p.GW);
     io.ckpt = p.ckpt + pair * (K + 1) * 64;
     io.flags = p.flags ? p.flags + cw0 : nullptr;
     io.abort_ok = false;                                          // turbo's redo is per codeword: the other codewords of a pair must be finished
     io.ext = true;                                                // the pass writes E = L - L_int (:318, :328) ...
     io.pout = pout != 0;                                          // ... or prior0(E) directly (epilogue)
+    io.llr_in = llr_in != 0;
+    io.sysg = second ? ~0u : 0u;                                  // MAP 2 decodes interlv(sys_symbols) (:310): same rows as its prior
     constexpr unsigned ES = S32 ? 4u : 8u;                         // bytes per slab element ("fp32-fast": float32 slab)
-    const char *base = reinterpret_cast<const char *>(p.larr) + cw0 * ls * ES;   // the pair's first codeword
+    const unsigned nb = (unsigned)p.NR * (unsigned)p.RW * ES;      // bytes of one array of a row group
+    const int64_t group = pair >> p.lgG;
+    const unsigned so = (unsigned)(pair & ((1 << p.lgG) - 1)) * (unsigned)p.GW;       // first slot of this pair in its group's rows
+    const char *base = reinterpret_cast<const char *>(p.larr) + group * 5 * (int64_t)nb;
+    const bool live = io.ncw > 0;                                  // a pair past the end of the batch: everything out of range
+    io.rsys = io.rpar = io.rlin = io.rout = io.rbits = pass_buffer(base, live ? OOB : 0u);
+    io.st_out = last ? 0u : ~0u;
+    io.st_dec = last ? ~0u : 0u;
+    io.idx = idx;
     //   first  half-iteration: [L_ext_1, _] = map_decode(sys,   non_sys_1, trellis, nv, L_int_1, 'compute')   (:315)
     //   second half-iteration: [L_2, bits]  = map_decode(sys_i, non_sys_2, trellis, nv, L_int_2, mode)        (:326)
-    io.rsys = io.rpar = io.rlin = io.rout = pass_buffer(base, io.ncw > 0 ? OOB : 0u);
-    io.rbits = pass_buffer(nullptr, 0u);
-    const unsigned nb = (unsigned)N * ES;
-    io.osys = __builtin_amdgcn_readfirstlane((second ? 4u : 3u) * nb);
-    io.opar = __builtin_amdgcn_readfirstlane((second ? 6u : 5u) * nb);
-    io.olin = __builtin_amdgcn_readfirstlane((second ? 2u : 0u) * nb);
-    io.oout = nb;
-    map_pass<LGS, SR, true, false, S32>(c, io);
+    io.osys = __builtin_amdgcn_readfirstlane(2u * nb + so * ES);
+    io.opar = __builtin_amdgcn_readfirstlane((second ? 4u : 3u) * nb + so * ES);
+    io.olin = __builtin_amdgcn_readfirstlane((second ? 0u : nb) + so * ES);
+    io.oout = __builtin_amdgcn_readfirstlane((second ? nb : 0u) + so * ES);
+    io.odec = __builtin_amdgcn_readfirstlane(nb + so);             // decisions: bytes, at the start of array 1
+    map_pass<LGS, SR, true, false, S32, true>(c, io);
 }
 
-// mode 0: slab initialisation (:305-310) + flag (A);  1: L_int_2 = interlv(E_1) (:318-319);  2: L_int_1 = deinterlv(E_2)
-// (:328-329) -- each stored as prior0(L_int), the only thing a pass uses it for --;  3: decoded_bits = deinterlv(L_2 > 0)
-// (:148-152, :331).  One wavefront per codeword, four per workgroup; `lds_n`
-// doubles of LDS per wavefront when a codeword's array fits -- the permutations then go THROUGH LDS: coalesced read, LDS
-// scatter / gather, coalesced write (round 1 gathered from HBM: a 64-byte line per 8-byte element) -- else 0.
-template <bool S32>
-__global__ __launch_bounds__(256) void turbo_stage_kernel(TurboParams p, int mode, int lds_n, int keep_l, int pin) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t cwg = (int64_t)blockIdx.x * 4 + wv;
-    if (cwg >= p.B) return;
-    const int64_t N = p.N;
-    double *buf = reinterpret_cast<double *>(smem) + (size_t)wv * lds_n;
-    const bool in_lds = lds_n >= N;
-    // the slab is float64, or float32 in the "fp32-fast" mode (see slab_ld): element access through ld / st
-    using T = typename std::conditional<S32, float, double>::type;
-    T *slab = reinterpret_cast<T *>(p.larr);
-    auto ld = [&](int a, int64_t t) -> double { return (double)slab[slab_off(p, a, cwg, t)]; };
-    auto st = [&](int a, int64_t t, double v) { slab[slab_off(p, a, cwg, t)] = (T)v; };
-    // what a pass reads as its prior: P(bit = 0) (float64 slab), or the smaller of (p0, p1), signed (float32 slab)
-    auto prior_of = [&](double L) -> double { return S32 ? enc_prior_odds(exp(L)) : prior0(L); };
-    if (mode == 0) {
-        const double k4 = -4.0 / p.nv2;
-        // (A) of "detect and redo" for every received value on its own: |r| > sqrt(T_A nv2 / 2) - 1 bounds
-        // (|r0| + 1)^2 + (|r1| + 1)^2 for any pairing
-        const double rmax = sqrt(0.5 * T_A * p.nv2) - 1.0;
-        const double *sy = p.sys + cwg * N, *y1 = p.p1 + cwg * N, *y2 = p.p2 + cwg * N;
-        bool far = false;
-#pragma unroll 2
-        for (int64_t t = lane; t < N; t += 64) {
-            st(0, t, prior_of(p.Lint ? p.Lint[cwg * N + t] : 0.0)); // prior of L_int_1 (:305-308, :239)
-            const double r1 = y1[t], r2 = y2[t], rs = sy[t];
-            far = far || !(fabs(r1) <= rmax) || !(fabs(r2) <= rmax) || !(fabs(rs) <= rmax);
-            st(5, t, signed_q(r1, k4));
-            st(6, t, signed_q(r2, k4));
-            const double v = signed_q(rs, k4);
-            st(3, t, v);
-            if (in_lds) buf[t] = v;
-        }
-        if (p.flags && __ballot(far) != 0 && lane == 0) p.flags[cwg] = 1;
-        asm volatile("" ::: "memory");                             // LDS operations of one wave execute in order
-        if (in_lds) {
-#pragma unroll 4
-            for (int64_t t = lane; t < N; t += 64) st(4, t, buf[p.perm[t]]);                // interlv(sys) (:310)
-        } else {
-#pragma unroll 2
-            for (int64_t t = lane; t < N; t += 64) st(4, t, signed_q(sy[p.perm[t]], k4));
-        }
-    } else if (mode == 1) {
-        if (in_lds) {
-#pragma unroll 4
-            for (int64_t t = lane; t < N; t += 64) buf[t] = ld(1, t);
-            asm volatile("" ::: "memory");
-#pragma unroll 4
-            for (int64_t t = lane; t < N; t += 64) {
-                const double L = buf[p.perm[t]];
-                st(2, t, pin ? L : prior_of(L));                    // pin: the pass already wrote the prior (turbo_pass_kernel, pout)
-                if (keep_l) st(0, t, L);                            // the last L_int_2 itself, for the final decision (mode 3)
-            }
-        } else {
-#pragma unroll 4
-            for (int64_t t = lane; t < N; t += 64) {
-                const double L = ld(1, p.perm[t]);
-                st(2, t, pin ? L : prior_of(L));
-                if (keep_l) st(0, t, L);
-            }
-        }
-    } else if (mode == 2) {
-        if (in_lds) {
-#pragma unroll 4
-            for (int64_t t = lane; t < N; t += 64) buf[p.perm[t]] = ld(1, t);
-            asm volatile("" ::: "memory");
-#pragma unroll 4
-            for (int64_t t = lane; t < N; t += 64) st(0, t, pin ? buf[t] : prior_of(buf[t]));
-        } else {
-#pragma unroll 4
-            for (int64_t t = lane; t < N; t += 64) st(0, p.perm[t], pin ? ld(1, t) : prior_of(ld(1, t)));
-        }
-    } else {
-#pragma unroll 4
-        for (int64_t t = lane; t < N; t += 64)
-            p.bits[cwg * N + p.perm[t]] = (uint8_t)((p.n_iter > 0 && ld(0, t) + ld(1, t) > 0) ? 1 : 0);   // L_2 = L_int_2 + E_2 (array 0: see mode 1)
+// inverse permutation and identity, once per decode (the row index tables of the passes)
+__global__ void turbo_tables_kernel(const int32_t *perm, int32_t *iperm, int32_t *ident, int64_t N) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) {
+        iperm[perm[i]] = (int32_t)i;
+        ident[i] = (int32_t)i;
     }
+}
+
+// Slab initialisation (:305-310): the caller's arrays [B][N] -> the time-major arrays 1 (prior0 of L_int_1, :239), 2, 3, 4 (channel
+// factors, evaluated ONCE per decode) of every pair, transposed through LDS -- a wavefront reads 64 steps of one codeword (512
+// contiguous bytes) and the workgroup writes 64 whole rows (8 KB contiguous per array) -- plus flag (A) of "detect and redo".
+// Slots past the end of the batch get zeros.  One workgroup per (row group, 64-step tile).
+constexpr int IT = 64;                    // steps per tile
+constexpr int IT_ROW = IT + 2;            // doubles per codeword row of the LDS tile (2 GW + t: conflict-free b64 column reads)
+template <bool S32>
+__global__ __launch_bounds__(256) void turbo_init_kernel(TurboParams p, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *tile = reinterpret_cast<double *>(smem);              // [4 arrays][RW][IT_ROW]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t group = blockIdx.x / ntiles, N = p.N;
+    const int64_t t0 = (int64_t)(blockIdx.x % ntiles) * IT, t = t0 + lane;
+    const int RW = p.RW;
+
+    const double k4 = -4.0 / p.nv2;
+    // (A) of "detect and redo" for every received value on its own: |r| > sqrt(T_A nv2 / 2) - 1 bounds
+    // (|r0| + 1)^2 + (|r1| + 1)^2 for any pairing
+    const double rmax = sqrt(0.5 * T_A * p.nv2) - 1.0;
+    for (int g = wv; g < RW; g += 4) {
+        const int64_t cw = group * RW + g;                        // slot g of row group r: codeword 16 r + g
+        const bool have = cw < p.B && t < N;
+        double v[4] = {0.0, 0.0, 0.0, 0.0};
+        bool far = false;
+        if (have) {
+            const double rs = p.sys[cw * N + t], r1 = p.p1[cw * N + t], r2 = p.p2[cw * N + t];
+            far = !(fabs(r1) <= rmax) || !(fabs(r2) <= rmax) || !(fabs(rs) <= rmax);
+            const double L = p.Lint ? p.Lint[cw * N + t] : 0.0;
+            v[0] = S32 ? enc_prior_odds(exp(L)) : prior0(L);      // what a pass reads as its prior (stage_chunk)
+            v[1] = signed_q(rs, k4);
+            v[2] = signed_q(r1, k4);
+            v[3] = signed_q(r2, k4);
+        }
+        if (p.flags && __ballot(far) != 0 && lane == 0) p.flags[cw] = 1;
+#pragma unroll
+        for (int a = 0; a < 4; a++) tile[(a * RW + g) * IT_ROW + lane] = v[a];
+    }
+    __syncthreads();
+    using T = typename std::conditional<S32, float, double>::type;
+    const int64_t arr = p.NR * RW;                                // elements of one array of a pair
+    T *dst = reinterpret_cast<T *>(p.larr) + group * 5 * arr;
+    const int rows = (int)(N - t0 < IT ? N - t0 : IT);
+    for (int e = threadIdx.x; e < rows * RW; e += 256) {
+        const int r = e / RW, g = e - r * RW;
+#pragma unroll
+        for (int a = 0; a < 4; a++) dst[(a + 1) * arr + (t0 + r) * RW + g] = (T)tile[(a * RW + g) * IT_ROW + r];
+    }
+}
+
+// decoded_bits = deinterlv(L_2 > 0) (:148-152, :331): the last MAP 2 left its decisions as rows of RW bytes in its own (interleaved)
+// order; output position d of every codeword of the row group is row inverse_perm[d].  One workgroup per (row group, 256 positions).
+constexpr int FT = 256;
+template <bool S32>
+__global__ __launch_bounds__(FT) void turbo_final_kernel(TurboParams p, int ntiles) {
+    const int64_t group = blockIdx.x / ntiles, N = p.N;
+    const int64_t d = (int64_t)(blockIdx.x % ntiles) * FT + threadIdx.x;
+    if (d >= N) return;
+    constexpr int64_t ES = S32 ? 4 : 8;
+    const uint8_t *row = reinterpret_cast<const uint8_t *>(p.larr) + (group * 5 + 1) * p.NR * p.RW * ES + (int64_t)p.iperm[d] * p.RW;
+    for (int g = 0; g < p.RW && group * p.RW + g < p.B; g++) p.bits[(group * p.RW + g) * N + d] = row[g];   // consecutive lanes, consecutive bytes
 }
 
 // ---- turbo_decode, the LITERAL redo (round 5): flagged pairs decode their codewords again, all iterations, in ONE launch -----------
@@ -997,15 +1076,16 @@ __global__ __launch_bounds__(256) void turbo_stage_kernel(TurboParams p, int mod
 // between them, elementwise in the pair's own rows of the slab (the fast sequence is done with them), what the reference writes:
 //   L_ext_1 = L_ext_1 - L_int_1 (:318), L_int_2 = interlv(L_ext_1) (:319), L_int_1 = deinterlv(L_2 - L_int_2) (:328-329),
 //   decoded_bits = deinterlv(L_2 > 0) of the last iteration (:148-152, :331).
-// Slab arrays reused: 0 L_int_1, 1 a pass's output (L_int + log(app1 / app0), i.e. L_ext_1 before the subtraction / L_2), 2 L_int_2,
-// 4 interlv(sys_symbols) as RAW symbols.  ONE pair per workgroup (a pair that is not flagged leaves at once; the barriers below only
+// The pair's share of its row group's slab (5 NR GW doubles; the fast sequence is done with it) is reused CODEWORD-major, four arrays [N] per
+// codeword: 0 L_int_1, 1 a pass's output (L_int + log(app1 / app0), i.e. L_ext_1 before the subtraction / L_2), 2 L_int_2,
+// 3 interlv(sys_symbols) as RAW symbols.  ONE pair per workgroup (a pair that is not flagged leaves at once; the barriers below only
 // ever meet the two waves of a pair), a rare path: speed is what the wave-parallel pass gives (~0.5 ms per MAP pass of a full
 // config-3 batch against 7 ms per flagged codeword before), not a goal of its own.
 template <int LGS, bool SR>
 __global__ __launch_bounds__(128) void turbo_literal_kernel(TurboParams p, RedoCounter redo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int64_t pair = blockIdx.x;
-    const int64_t N = p.N, K = (N + CH - 1) / CH, cw0 = pair * p.GW, left = p.B - cw0, ls = 7 * N;
+    const int64_t N = p.N, K = (N + CH - 1) / CH, cw0 = pair * p.GW, left = p.B - cw0, ls = 4 * N;
     const int ncw = (int)(left < p.GW ? left : p.GW);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long hit = __ballot(lane < ncw && p.flags[cw0 + (lane < ncw ? lane : 0)] != 0);
@@ -1015,19 +1095,19 @@ __global__ __launch_bounds__(128) void turbo_literal_kernel(TurboParams p, RedoC
     }
     Ctx<LGS> c;
     init_ctx<LGS>(c, p.tb, smem, p.GW);
-    double *slab = p.larr + cw0 * ls;
-    auto at = [&](int a, int g, int64_t t) -> double & { return slab[((int64_t)g * 7 + a) * N + t]; };
+    double *slab = p.larr + pair * 5 * p.NR * p.GW;        // this pair's share of its row group's region (always float64 here)
+    auto at = [&](int a, int g, int64_t t) -> double & { return slab[((int64_t)g * 4 + a) * N + t]; };
     // elementwise work: the pair's codewords alternate between its two waves
     for (int g = wave; g < ncw; g += 2)
         for (int64_t t = lane; t < N; t += 64) {
             at(0, g, t) = p.Lint ? p.Lint[(cw0 + g) * N + t] : 0.0;                   // L_int_1 (:305-308)
-            at(4, g, t) = p.sys[(cw0 + g) * N + p.perm[t]];                           // interlv(sys_symbols) (:310)
+            at(3, g, t) = p.sys[(cw0 + g) * N + p.perm[t]];                           // interlv(sys_symbols) (:310)
         }
     pair_sync();
     PassIO io;
     io.N = (int)N; io.nv2 = p.nv2; io.want_bits = 0; io.ncw = ncw;
     io.ckpt = p.ckpt + pair * (K + 1) * 64;
-    io.flags = nullptr; io.abort_ok = false; io.ext = false; io.pout = false;
+    io.flags = nullptr; io.abort_ok = false; io.ext = false; io.pout = false; io.llr_in = false; io.sysg = 0u;
     io.rbits = pass_buffer(nullptr, 0u);
     io.rlin = io.rout = pass_buffer(slab, OOB);
     io.lstride = (int)ls;
@@ -1047,7 +1127,7 @@ __global__ __launch_bounds__(128) void turbo_literal_kernel(TurboParams p, RedoC
             }
         pair_sync();
         // MAP 2 (:326): interleaved systematic symbols (array 4), non_sys_2, L_int_2 (array 2)
-        io.rsys = pass_buffer(slab, OOB); io.osys = 4u * nb; io.sstride = (int)ls;
+        io.rsys = pass_buffer(slab, OOB); io.osys = 3u * nb; io.sstride = (int)ls;
         io.rpar = pass_buffer(p.p2 + cw0 * N, OOB); io.opar = 0u; io.pstride = (int)N;
         io.olin = 2u * nb;
         map_pass<LGS, SR, false, true>(c, io);
@@ -1195,27 +1275,47 @@ int cpx_turbo_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const 
     p.B = B; p.N = N; p.nv2 = 2 * noise_variance; p.n_iter = n_iter;
     CPX_REQUIRE(nblocks < (1ll << 31), CPX_ELIMIT, "turbo_decode: batch too large");
     if ((rc = workspace(st, 0, sizeof(double) * (size_t)(nblocks * np * (K + 1) * 64), (void **)&p.ckpt))) return rc;
-    if ((rc = workspace(st, 1, sizeof(double) * (size_t)(B * 7 * N), (void **)&p.larr))) return rc;
+    // the time-major slab (TurboParams): five arrays of N rows of 16 slots per row group; sized in float64 whatever the precision
+    // mode (the literal redo kernel reuses a pair's share as float64 scratch)
+    const int RW = (int)TM_RW;
+    p.RW = RW;
+    p.lgG = 0;
+    while ((GW << p.lgG) < RW) p.lgG++;
+    const int64_t ngroups = (npairs + (1 << p.lgG) - 1) >> p.lgG;
+    p.NR = N | 1;
+    CPX_REQUIRE(5 * p.NR * RW * 8 < (1ll << 31), CPX_ELIMIT, "turbo_decode: block too long for 31-bit lane offsets into a row group's slab");
+    if ((rc = workspace(st, 1, sizeof(double) * (size_t)(ngroups * 5 * p.NR * RW), (void **)&p.larr))) return rc;
     // "detect and redo", as in cpx_map_decode_batch_dev (round 5: redone by turbo_literal_kernel, no block-length limit)
     if ((rc = workspace(st, 3, (size_t)B, (void **)&p.flags))) return rc;
     CPX_HIP(hipMemsetAsync(p.flags, 0, (size_t)B, st));
     CPX_REQUIRE(npairs < (1ll << 31), CPX_ELIMIT, "turbo_decode: batch too large");
+    // the two row index tables the library derives from the interleaver
+    {
+        int32_t *tabs = nullptr;
+        if ((rc = workspace(st, 11, 2 * sizeof(int32_t) * (size_t)N, (void **)&tabs))) return rc;
+        p.iperm = tabs; p.ident = tabs + N;
+        hipLaunchKernelGGL(turbo_tables_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, d_perm, tabs, tabs + N, N);
+    }
+    if (n_iter == 0) {                                            // the reference's loop never runs: no decision is ever taken
+        CPX_HIP(hipMemsetAsync(d_bits, 0, (size_t)(B * N), st));
+        note_kernel("turbo_decode: 0 iterations");
+        return CPX_OK;
+    }
     dim3 grid((unsigned)nblocks), block(128 * np);
-    // one launch per MAP pass, one small launch per stage (see turbo_pass_kernel)
-    const int lds_n = (N * 8 * 4 <= 64 * 1024) ? (int)N : 0;
-    CPX_REQUIRE((B + 3) / 4 < (1ll << 31), CPX_ELIMIT, "turbo_decode: batch too large");
-    const dim3 sgrid((unsigned)((B + 3) / 4)), sblock(256);
-    const size_t slds = (size_t)lds_n * 8 * 4;
     // "fp32-fast" (cpx_set_precision; not the parity mode): the slab between the passes in float32 (slab_ld), arithmetic unchanged
     const bool s32 = precision_fast();
-    auto stage = [&](int mode, int keep_l = 0, int pin = 0) {
-        if (s32) hipLaunchKernelGGL(turbo_stage_kernel<true>, sgrid, sblock, slds, st, p, mode, lds_n, keep_l, pin);
-        else hipLaunchKernelGGL(turbo_stage_kernel<false>, sgrid, sblock, slds, st, p, mode, lds_n, keep_l, pin);
-    };
-    auto pass = [&](int second, int pout) -> int {
+    const int itiles = (int)((N + IT - 1) / IT), ftiles = (int)((N + FT - 1) / FT);
+    CPX_REQUIRE(ngroups * itiles < (1ll << 31) && ngroups * ftiles < (1ll << 31), CPX_ELIMIT, "turbo_decode: batch too large");
+    {
+        const dim3 igrid((unsigned)(ngroups * itiles));
+        const size_t ilds = sizeof(double) * 4 * (size_t)RW * IT_ROW;
+        if (s32) hipLaunchKernelGGL(turbo_init_kernel<true>, igrid, dim3(256), ilds, st, p, itiles);
+        else hipLaunchKernelGGL(turbo_init_kernel<false>, igrid, dim3(256), ilds, st, p, itiles);
+    }
+    auto pass = [&](const int32_t *idx, int second, int pout, int llr_in, int last) -> int {
         switch (p.tb.lgS) {
-#define LAUNCH(LG, SRV) do { if (s32) hipLaunchKernelGGL((turbo_pass_kernel<LG, SRV, true>), grid, block, sizeof(double) * 2 * np * wave_lds_doubles<LG>(GW), st, p, second, pout); \
-                             else hipLaunchKernelGGL((turbo_pass_kernel<LG, SRV, false>), grid, block, sizeof(double) * 2 * np * wave_lds_doubles<LG>(GW), st, p, second, pout); } while (0)
+#define LAUNCH(LG, SRV) do { if (s32) hipLaunchKernelGGL((turbo_pass_kernel<LG, SRV, true>), grid, block, sizeof(double) * 2 * np * wave_lds_doubles<LG>(GW), st, p, idx, second, pout, llr_in, last); \
+                             else hipLaunchKernelGGL((turbo_pass_kernel<LG, SRV, false>), grid, block, sizeof(double) * 2 * np * wave_lds_doubles<LG>(GW), st, p, idx, second, pout, llr_in, last); } while (0)
 #define CASE(LG) case LG: LAUNCH(LG, false); break;
             case 2:
                 if (p.tb.sr4) LAUNCH(2, true);
@@ -1228,18 +1328,23 @@ int cpx_turbo_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const 
         }
         return CPX_OK;
     };
-    stage(0);
     static const bool no_pout = [] { const char *e = getenv("CPX_TURBO_POUT"); return e && e[0] == '0'; }();   // A/B runs
+    int prev_pout = 1;                                            // (turbo_init_kernel wrote a prior)
     for (int h = 0; h < 2 * n_iter; h++) {
         // every pass but the last two hands prior0(E) to the next one directly (epilogue): the last MAP 2 needs L_int_2 and E_2 as
-        // LLRs for the decision L_2 = L_int_2 + E_2 > 0 (:148-152, :326-331)
+        // LLRs for the decision L_2 = L_int_2 + E_2 > 0 (:148-152, :326-331), so the last MAP 1 writes E_1 itself
         const int pout = (h <= 2 * n_iter - 3 && !no_pout) ? 1 : 0;
-        if ((rc = pass(h & 1, pout))) return rc;
-        if (h < 2 * n_iter - 1) stage(1 + (h & 1), h == 2 * n_iter - 2, pout);   // the last interleave also keeps L_int_2 itself
+        const int last = h == 2 * n_iter - 1;
+        // the prior of MAP 2 is interlv(E_1) (:319): row perm[t]; of MAP 1 deinterlv(E_2) (:329): row inverse_perm[t]; of the very
+        // first pass L_int_1 as turbo_init_kernel laid it out: row t
+        const int32_t *idx = (h & 1) ? d_perm : (h == 0 ? p.ident : p.iperm);
+        if ((rc = pass(idx, h & 1, pout, (h > 0 && !prev_pout) ? 1 : 0, last))) return rc;
+        prev_pout = pout;
     }
-    stage(3);
+    if (s32) hipLaunchKernelGGL(turbo_final_kernel<true>, dim3((unsigned)(ngroups * ftiles)), dim3(FT), 0, st, p, ftiles);
+    else hipLaunchKernelGGL(turbo_final_kernel<false>, dim3((unsigned)(ngroups * ftiles)), dim3(FT), 0, st, p, ftiles);
     CPX_HIP(hipGetLastError());
-    note_kernel("turbo_pass_kernel<%d,%s%s> x %d + turbo_stage_kernel (%d wave pairs per workgroup, %d codewords per pair)", p.tb.lgS,
+    note_kernel("turbo_pass_kernel<%d,%s%s> x %d (time-major slab, interleaver folded into the row index) + turbo_init_kernel + turbo_final_kernel (%d wave pairs per workgroup, %d codewords per pair)", p.tb.lgS,
                 (p.tb.lgS == 2 && p.tb.sr4) ? "true" : "false", s32 ? ",f32 slab" : "", 2 * n_iter, np, GW);
     // redo: one launch; a pair with a flagged codeword decodes its codewords again, literally, all iterations (turbo_literal_kernel)
     const RedoCounter redo = redo_counter();

@@ -30,6 +30,10 @@ def _batched(fn):
 class Wifi80211:
     memory = np.array(6, ndmin=1)
     generator_matrix = np.array((133, 171), ndmin=2)     # decimal, exactly as wifi80211.py:49 (quirk B1)
+    # transmissions generated / demodulated / decoded per GPU batch (None: LinkModel's default).  1 reproduces the reference's
+    # sequence draw for draw -- one message, one noise vector at a time from NumPy's global stream -- and with it the reference's
+    # per-transmission error counts under the same seed (tests/test_wifi_gpu.py pins that against tests/golden/wifi.npz)
+    tx_batch = None
 
     def __init__(self, mcs, generator_matrix=None):
         self.mcs = mcs
@@ -107,6 +111,8 @@ class Wifi80211:
 
         self.model = lk.LinkModel(modulate, channel, receiver, modem.num_bits_symbol, modem.constellation, modem.Es,
                                   decoder_soft, coding[0] / coding[1])
+        if self.tx_batch is not None:
+            self.model.tx_batch = int(self.tx_batch)
         return self.model.link_performance_full_metrics(SNRs, tx_max, err_min=err_min, send_chunk=send_chunk,
                                                         code_rate=coding[0] / coding[1],
                                                         number_chunks_per_send=frame_aggregation,

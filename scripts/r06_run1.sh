@@ -1,0 +1,4 @@
+export TMPDIR=/tmp
+mkdir -p gpurun_out/r06a
+timeout 900 python -m pytest tests/test_bcjr_ldpc_demod_gpu.py tests/test_abnormal_golden_gpu.py tests/test_config_sizes_gpu.py tests/test_fp32_fast_gpu.py tests/test_general_gpu.py tests/test_large_sizes_gpu.py tests/test_encoders_gpu.py -m gpu -q -x --timeout 300 -k "turbo or map" 2>&1 | tail -30 | tee gpurun_out/r06a/pytest_turbo.txt
+bash scripts/ab_kernels.sh r06a turbo 3 ab/libcommpy_r05.so default 2>&1 | tail -20

@@ -451,54 +451,84 @@ GENS = {
 
 
 
+WIFI_RUNS = ((1, [3.0, 5.0, 7.0], 64), (5, [15.0, 18.0, 21.0], 64), (3, [9.0, 12.0], 64))
+
+
+def _wifi_one(args):
+    """One seeded sweep of the live reference's Wifi80211.link_performance; also records what the reference's receive
+    chain saw (the channel output y of every transmission, in order) so that a test can replay the receiver alone."""
+    os.environ["OMP_NUM_THREADS"] = "1"
+    gname, gm, mcs, snrs, tx = args
+    from commpy.wifi80211 import Wifi80211
+    from commpy.channels import SISOFlatChannel
+    Wifi80211.generator_matrix = gm
+    np.random.seed(2024 + mcs)
+    w = Wifi80211(mcs)
+    ch = SISOFlatChannel(fading_param=(1 + 0j, 0j))
+    t0 = time.time()
+    bers, bes, ces, ncs = w.link_performance(ch, np.array(snrs), tx, 1, 600, stop_on_surpass_error=False)
+    print("wifi %s mcs=%d snrs=%s -> BER %s (%.0fs)" % (gname, mcs, snrs, bers, time.time() - t0), flush=True)
+    return gname, mcs, snrs, tx, np.asarray(bers), np.asarray(bes), np.asarray(ces), np.asarray(ncs)
+
+
 def gen_wifi():
     """Wifi80211 link BER points (config 5 semantics, wifi80211.py:132-216 + links.py:155-267) from the live
     reference: decimal generators as shipped (quirk B1, catastrophic code) and the intended octal ones
-    (class attribute overridden).  Statistical fixtures: the GPU path uses another RNG stream."""
-    from commpy.wifi80211 import Wifi80211
-    from commpy.channels import SISOFlatChannel
+    (class attribute overridden).  Every sweep runs under ``np.random.seed(2024 + mcs)`` with the argument list
+    ``(channel, snrs, tx, 1, 600, stop_on_surpass_error=False)``, so the per-transmission error counts ``bes`` are a
+    DETERMINISTIC fixture for any implementation that consumes NumPy's global stream in the reference's order
+    (tests/test_wifi_gpu.py::test_wifi80211_error_counts_equal_the_reference) and a statistical one for the batched
+    GPU path.  Round 6: 64 transmissions per point (was 12-30); the six sweeps run in parallel processes, each seeded
+    on its own, so the result equals the sequential run's."""
+    import multiprocessing as mp
+    jobs = [(gname, gm, mcs, snrs, tx)
+            for gname, gm in (("decimal", np.array((133, 171), ndmin=2)), ("octal", np.array((0o133, 0o171), ndmin=2)))
+            for mcs, snrs, tx in WIFI_RUNS]
     out = {}
     names = []
-    for gname, gm in (("decimal", np.array((133, 171), ndmin=2)), ("octal", np.array((0o133, 0o171), ndmin=2))):
-        Wifi80211.generator_matrix = gm
-        for mcs, snrs, tx in ((1, [3.0, 5.0, 7.0], 30), (5, [15.0, 18.0, 21.0], 12), (3, [9.0, 12.0], 16)):
-            np.random.seed(2024 + mcs)
-            w = Wifi80211(mcs)
-            ch = SISOFlatChannel(fading_param=(1 + 0j, 0j))
-            t0 = time.time()
-            bers, bes, ces, ncs = w.link_performance(ch, np.array(snrs), tx, 1, 600, stop_on_surpass_error=False)
+    with mp.Pool(min(6, os.cpu_count())) as pool:
+        for gname, mcs, snrs, tx, bers, bes, ces, ncs in pool.map(_wifi_one, jobs, chunksize=1):
             key = "w_%s_mcs%d" % (gname, mcs)
             names.append(key)
             out[key + "__snrs"] = np.array(snrs)
-            out[key + "__ber"] = np.asarray(bers)
-            out[key + "__bes"] = np.asarray(bes)
+            out[key + "__ber"] = bers
+            out[key + "__bes"] = bes
+            out[key + "__ces"] = ces
+            out[key + "__ncs"] = ncs
             out[key + "__tx"] = np.array(tx)
-            print("wifi %s mcs=%d snrs=%s -> BER %s (%.0fs)" % (gname, mcs, snrs, bers, time.time() - t0))
-    Wifi80211.generator_matrix = np.array((133, 171), ndmin=2)
     out["names"] = np.array(names)
     save("wifi", **out)
 
 
 GENS["wifi"] = gen_wifi
 
+def _ber_one(args):
+    os.environ["OMP_NUM_THREADS"] = "1"
+    llr, msg = args
+    tr = Trellis(np.array([6]), np.array([[0o133, 0o171]]))
+    dec = viterbi_decode(llr.copy(), tr, None, "soft")
+    return int(np.sum(dec[:1024] != msg))
+
+
 def gen_viterbi_ber():
     """BER-vs-Eb/N0 reference points for BASELINE config 2 (K=7 soft Viterbi, 1024-bit blocks, QPSK + AWGN):
-    error counts of the live reference per Eb/N0, for the statistical overlay of the GPU curve."""
-    out = {}
+    error counts of the live reference per Eb/N0 AND per codeword (``cw_errors``: the burstiness of Viterbi error
+    events is then measured instead of assumed), for the statistical overlay of the GPU curve.  Round 6: 224 codewords
+    (229 376 bits) per point, was 20-28."""
+    import multiprocessing as mp
     ebn0s = [0.0, 1.0, 2.0, 3.0, 4.0]
-    errs, nbits = [], []
-    for i, e in enumerate(ebn0s):
-        B = 20 if e < 3 else 28
-        tr, msg, llr, N0 = c2_inputs(B, e, seed_msg=300 + i, seed_noise=400 + i)
-        t0 = time.time()
-        ne = 0
-        for b in range(B):
-            dec = viterbi_decode(llr[b].copy(), tr, None, "soft")
-            ne += int(np.sum(dec[:1024] != msg[b]))
-        errs.append(ne)
-        nbits.append(B * 1024)
-        print("viterbi_ber Eb/N0=%.1f: %d errors in %d bits (%.0fs)" % (e, ne, B * 1024, time.time() - t0))
-    save("viterbi_ber", ebn0=np.array(ebn0s), errors=np.array(errs), bits=np.array(nbits))
+    B = 224
+    errs, nbits, per_cw = [], [], []
+    with mp.Pool(min(6, os.cpu_count())) as pool:
+        for i, e in enumerate(ebn0s):
+            tr, msg, llr, N0 = c2_inputs(B, e, seed_msg=300 + i, seed_noise=400 + i)
+            t0 = time.time()
+            cw = np.array(pool.map(_ber_one, [(llr[b], msg[b]) for b in range(B)], chunksize=4))
+            per_cw.append(cw)
+            errs.append(int(cw.sum()))
+            nbits.append(B * 1024)
+            print("viterbi_ber Eb/N0=%.1f: %d errors in %d bits (%.0fs)" % (e, errs[-1], B * 1024, time.time() - t0), flush=True)
+    save("viterbi_ber", ebn0=np.array(ebn0s), errors=np.array(errs), bits=np.array(nbits), cw_errors=np.stack(per_cw))
 
 
 GENS["viterbi_ber"] = gen_viterbi_ber

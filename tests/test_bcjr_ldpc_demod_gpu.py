@@ -421,3 +421,31 @@ def test_soft_demod_ragged_sizes_path_modes_and_bounds(gpu, m, snr_db):
             if m >= 64:
                 assert (",tab" in kern) == (mode is None) and (",gp" in kern) == (mode != "plain"), kern
         d_y.free()
+
+
+# ------------------------------------------------------------------ turbo: the time-major slab at every geometry (round 6)
+@pytest.mark.parametrize("tname", ["rsc_legacy_4", "rsc_legacy_8", "k5_23_35"])
+def test_turbo_ragged_shapes_vs_oracle(gpu, tname):
+    """Since round 6 the slab between the MAP passes is time-major per pair of wavefronts and the interleaver is the row index of
+    a pass's loads (csrc/bcjr.hip TurboParams).  Everything that depends on the geometry -- block lengths that are not multiples of
+    the 8-step chunk, of the 64-step init tile or of the 256-position final tile; batches that give 1, 2, 4, 8 or 16 codewords per
+    pair, with and without a partial last pair; a caller's L_int; 1 to 3 iterations -- against the CPU oracle, every codeword."""
+    from commpy_amd import _lib
+    from commpy_amd.channelcoding import turbo_decode
+    tr = make_trellis(tname)
+    rs = np.random.RandomState(sum(map(ord, tname)))
+    seen = set()
+    for N, B, iters, with_lint in ((1, 3, 1, False), (7, 1, 2, False), (8, 2, 1, True), (9, 5, 2, False), (63, 17, 1, False),
+                                   (64, 33, 2, True), (65, 4, 3, False), (100, 40, 2, False), (257, 19, 2, True),
+                                   (300, 1100, 1, False), (40, 2500, 2, False), (72, 5000, 1, True), (24, 17000, 1, False)):
+        perm = rs.permutation(N)
+        s, p1, p2 = (np.sign(rs.randn(B, N)) + 0.9 * rs.randn(B, N) for _ in range(3))
+        lint = rs.randn(B, N) if with_lint else None
+        dec = turbo_decode(s, p1, p2, tr, 0.81, iters, Perm(perm), lint)
+        seen.add(_lib.last_kernel().split("wave pairs per workgroup, ")[1].split(" codewords")[0])
+        assert dec.shape == (B, N)
+        check = range(B) if B <= 64 else sorted(set(rs.randint(0, B, 24)) | {0, B - 1, B - 2})
+        for b in check:
+            want = oracle.turbo_decode(s[b], p1[b], p2[b], tr, 0.81, iters, Perm(perm), None if lint is None else lint[b])
+            assert np.array_equal(dec[b], want), (tname, N, B, iters, b)
+    assert len(seen) >= 3, seen                     # several codewords-per-pair geometries were really exercised

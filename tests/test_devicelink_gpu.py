@@ -64,22 +64,22 @@ def test_philox_bits_and_awgn_statistics(gpu):
 
 @pytest.mark.parametrize("gname,mcs", [("octal", 1), ("octal", 5), ("octal", 3), ("decimal", 1)])
 def test_device_wifi_link_overlays_reference(gpu, gname, mcs):
+    """Device-resident link (Philox streams) against the reference's points: the mean errors per 600-bit transmission have to agree
+    within 4.5 standard errors of the REFERENCE's 64-transmission sample (its spread is in tests/golden/wifi.npz; the device sample
+    is 32 - 128 times larger) -- round 5 asserted factor-2 ... 8 bands.  tests/test_wifi_gpu.py holds the deterministic comparison."""
     from commpy_amd.devicelink import DeviceWifiLink
     g = golden("wifi")
     key = "w_%s_mcs%d" % (gname, mcs)
-    snrs, ref = g[key + "__snrs"], g[key + "__ber"]
+    snrs, ref_ber, ref_bes = g[key + "__snrs"], g[key + "__ber"], g[key + "__bes"].astype(float)
     link = DeviceWifiLink(mcs, 600, generator_matrix=[[0o133, 0o171]] if gname == "octal" else None, seed=11 + mcs)
-    ref_bits = int(g[key + "__tx"]) * 600
     # per-point calls, and the whole sweep through one Viterbi call (the large-batch kernel from 29 492 frames)
-    for bers in (link.ber_sweep(snrs, 600 * 2048), link.ber_sweep_batched(snrs, 600 * 8192)):
-        for s, b, r in zip(snrs, bers, ref):
-            ref_errors = r * ref_bits
-            if ref_errors >= 100:
-                assert r / 2 <= b <= 2 * r, (key, s, b, r)
-            elif ref_errors >= 10:
-                assert r / 4 <= b <= 4 * r, (key, s, b, r)
-            else:
-                assert b <= max(8 * r, 100.0 / ref_bits), (key, s, b, r)
+    for frames, bers in ((2048, link.ber_sweep(snrs, 600 * 2048)), (8192, link.ber_sweep_batched(snrs, 600 * 8192))):
+        for i, (s, b) in enumerate(zip(snrs, bers)):
+            if i > 0 and ref_ber[i - 1] == 0:                 # the reference's sweep had stopped (links.py:262)
+                break
+            r = ref_bes[i]
+            se = r.std(ddof=1) / np.sqrt(r.size) * np.sqrt(1.0 + r.size / frames)
+            assert abs(b * 600 - r.mean()) <= 4.5 * se + 0.5, (key, float(s), b * 600, r.mean(), se)
 
 
 def test_device_wifi_link_matches_host_pipeline(gpu):
