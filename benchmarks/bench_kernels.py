@@ -78,6 +78,33 @@ def bench_demod(lib, scale):
         emit(_lib.last_kernel(), "%d-QAM hard decision, %d symbols" % (m, ns), ns, "symbols", ms,
              ns * (16 + md.num_bits_symbol), "hbm")
         dev.free()
+    # generic constellations (round 6: demod_soft_gen_kernel): two inputs used in turn so that every byte comes from HBM (2 x 170 MB
+    # of symbols > the 256 MiB Infinity Cache), and the literal kernel ("libm") beside it
+    from commpy_amd.modulation import PSKModem
+    for m, snr_db in ((8, 10.0), (16, 16.0)):
+        md = PSKModem(m)
+        nb = md.num_bits_symbol
+        ns = int(10616832 * scale)
+        rs = np.random.RandomState(32)
+        N0 = md.Es / 10 ** (snr_db / 10.0)
+        dev = Dev(lib)
+        d_ys = [dev.put(md.constellation[rs.randint(0, m, ns)] + np.sqrt(N0 / 2) * (rs.randn(ns) + 1j * rs.randn(ns))) for _ in range(2)]
+        d_ls = [dev.empty(ns * nb * 8) for _ in range(2)]
+        h = md._device_handle()
+        for mode in (None, "libm"):
+            _lib.demod_set_path(mode)
+            try:
+                cnt = [0]
+
+                def step():
+                    cnt[0] += 1
+                    _lib.check(lib.cpx_demod_soft_dev(h, d_ys[cnt[0] % 2], ns, float(N0), d_ls[cnt[0] % 2], None))
+                ms, _ = timeit(lib, step, steps=6, warmup=2)
+                emit(_lib.last_kernel(), "%d-PSK soft LLR, %d symbols, HBM-resident (2 inputs in turn)" % (m, ns), ns, "symbols", ms,
+                     ns * (16 + 8 * nb), "hbm + valu")
+            finally:
+                _lib.demod_set_path(None)
+        dev.free()
 
 
 def bench_ldpc(lib, scale):

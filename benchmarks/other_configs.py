@@ -16,6 +16,11 @@ checker here, never the thing measured): decoded bits exact, min-sum LLRs <= 1e-
   configs[3]  one GPU's share (B = 32 768 blocks) of the 802.11n (1944,1296) chain: 64-QAM symbols + AWGN at Eb/N0 = 8 dB ->
               soft demodulator (modulation.py:100-141) with the sign flip -> ldpc_bp_decode <= 50 iterations, min-sum and
               sum-product (ldpc.py:144-254)                               17 n B per block (decoder state resident)
+  configs[4]  Wifi80211 MCS 5 (64-QAM, K = 7 r = 1/2 punctured to 2/3) end-to-end BER sweep Eb/N0 = 0 .. 10 dB, 1e8 information bits,
+              everything device-resident (commpy_amd.devicelink.DeviceWifiLink; wifi80211.py:132-216, links.py:155-267); a step =
+              the whole sweep; stage breakdown from HIP events between the stages (round 6)
+  configs[0]  K = 3 (5,7) r = 1/2, 64-bit blocks, hard-decision Viterbi over a BSC(0.05) -- the reference's CPU plumbing case, here
+              device-generated at B = 2^20 blocks (DeviceBscLink; test_convcode.py:133-178, channels.py:652-673) (round 6)
   demod       the 64-QAM soft demodulator of that chain alone, (a) on the chain's 170 MB input, which FITS the 256 MiB
               Infinity Cache and is re-read every repetition, and (b) on rotating inputs of > 256 MiB in total, so that
               every byte comes from HBM                                   64 B per symbol
@@ -333,12 +338,126 @@ def run_config4(lib, steps, warmup, B=32768, ebn0=8.0, n_check=24, big_rotation_
     return out
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+def run_config5(lib, steps, warmup, total_bits=1e8, n_check=48):
+    """configs[4]: one step = the whole 11-point sweep.  Parity of what was timed: the decoder's bits for sampled frames of the LAST
+    timed sweep against the oracle on the very LLRs the device chain produced, and those LLRs (last SNR point: its symbols are still
+    in HBM) against the oracle's demodulator + depuncturing."""
+    import math
+    import oracle
+    from commpy_amd.devicelink import DeviceWifiLink
+    link = DeviceWifiLink(5, 1200, generator_matrix=[[0o133, 0o171]], seed=2026)
+    ebn0 = np.arange(0.0, 10.5, 1.0)
+    snrs = ebn0 + 10 * math.log10(link.rate * link.modem.num_bits_symbol)
+    per_point = int(total_bits / len(snrs))
+    marks = ("front end (bits, conv_encode, puncture, 64-QAM, AWGN, soft demod, depuncture) x 11 points", "viterbi_decode, all frames",
+             "error count")
+    state = {"bers": None, "tm": None, "i": 0}
+
+    def sweep():
+        state["bers"] = link.ber_sweep_batched(snrs, per_point, mark=state["mark"])
+
+    state["mark"] = None
+    warm(lib, sweep, warmup, min_busy_s=0.05)
+    tm_all = Timers(lib, steps)
+    tm_stage = Timers(lib, 3 * steps)
+
+    def mark_fn(k, start):                                          # k-th stage of step state["i"]
+        j = 3 * state["i"] + k
+        (tm_stage.start if start else tm_stage.stop)(j)
+    state["mark"] = mark_fn
+    for i in range(steps):
+        state["i"] = i
+        tm_all.start(i)
+        sweep()
+        tm_all.stop(i)
+    _lib.check(lib.cpx_stream_sync(None))
+    ms = tm_all.read()
+    st = tm_stage.read().reshape(steps, 3)
+    kname = _lib.last_kernel()
+    bers = state["bers"]
+    # ---- parity of the last timed sweep ----
+    bufs = link._bufs
+    T = int(math.ceil(per_point / link.nbits))
+    R = len(snrs) * T
+    rs = np.random.RandomState(3)
+    rows = sorted(set(rs.randint(0, R, n_check).tolist()) | {0, R - 1, 65535, min(65536, R - 1)})
+    t0 = time.perf_counter()
+    mism = 0
+    for r in rows:
+        llr = np.empty(link.nde)
+        _lib.check(lib.cpx_memcpy_d2h(_lib.ptr(llr), ctypes.c_void_p(bufs['llr_all'].ptr.value + r * link.nde * 8), llr.nbytes))
+        dec = np.empty(link.nbits, np.uint8)
+        _lib.check(lib.cpx_memcpy_d2h(_lib.ptr(dec), ctypes.c_void_p(bufs['dec'].ptr.value + r * link.nbits), dec.nbytes))
+        mism += int(np.sum(oracle.viterbi_decode(llr, link.trellis, None, "soft")[:link.nbits] != dec))
+    # demodulator + depuncturing of the last point, first frames
+    nf = 4
+    y = np.empty(nf * link.nsym, np.complex128)
+    _lib.check(lib.cpx_memcpy_d2h(_lib.ptr(y), bufs['sym'].ptr, y.nbytes))
+    noise_std = math.sqrt(2.0 * link.modem.Es / (link.rate * 10 ** (float(snrs[-1]) / 10.0)))
+    want = oracle.demodulate(link.modem.constellation, y, "soft", noise_std ** 2).reshape(nf, -1)
+    got = np.empty((nf, link.nde))
+    _lib.check(lib.cpx_memcpy_d2h(_lib.ptr(got), ctypes.c_void_p(bufs['llr_all'].ptr.value + (len(snrs) - 1) * T * link.nde * 8), got.nbytes))
+    full = np.zeros((nf, link.nde))
+    if link.de_idx is not None:
+        keep = link.de_idx >= 0
+        full[:, keep] = want[:, link.de_idx[keep]]
+    else:
+        full = want
+    llr_err = float(np.max(np.abs(full - got)))
+    total = R * link.nbits
+    front_bytes = R * (link.nbits + link.ncoded + link.ntx + link.nsym * 16 * 3 + link.nsym * 6 * 8 * 2 + link.nde * 8)
+    alg = R * (link.nde * 8 + link.nbits)                            # decoder model, SURVEY 8d: LLRs in, bits out
+    return entry("configs[4] (one GPU)", "Wifi80211 MCS 5 (64-QAM, K=7 (133,171) r=1/2 punctured to 2/3), frames of %d info bits, "
+                 "Eb/N0 = 0..10 dB in 11 points, %d frames = %.3g info bits per sweep; a step = the whole device-resident sweep"
+                 % (link.nbits, R, total), kname, ms, total, "simulated info-bits", alg, "valu (Viterbi) + hbm (front end)",
+                 {"vs": "oracle viterbi_decode (convcode.py:661-749) on the LLRs of the last timed sweep; oracle demodulate "
+                        "(modulation.py:100-141) + depuncturing (convcode.py:777-804) on the symbols of its last point",
+                  "frames": len(rows), "mismatched_bits": mism, "demod_depuncture_max_abs_err": llr_err, "tolerance": 1e-5,
+                  "ok": mism == 0 and llr_err < 1e-5, "oracle_s": round(time.perf_counter() - t0, 2)},
+                 {"stage_ms": {m: float(np.mean(st[:, k])) for k, m in enumerate(marks)},
+                  "ebn0_db": ebn0.tolist(), "ber": [float(b) for b in bers],
+                  "bytes_model": "decoder only (SURVEY 8d): %d x 8 B of LLRs in + %d B of bits out per frame; the front end moves ~%d MB "
+                                 "more per sweep (messages, coded bits, symbols written / read / noised, LLRs written, gathered)"
+                                 % (link.nde, link.nbits, front_bytes >> 20),
+                  "reference_cpu": "Wifi80211(5).link_performance: ~1e3 info-bits/s on one core (BASELINE.md)"})
+
+
+def run_config1(lib, steps, warmup, B=1 << 20, n_check=3000):
+    """configs[0] on the device: the timed step is the hard-decision decode of B blocks; messages, encoder and BSC are generated once."""
+    import warnings
+    import oracle
+    from commpy_amd.channelcoding import Trellis
+    from commpy_amd.devicelink import DeviceBscLink
+    tr = Trellis(np.array([2]), np.array([[5, 7]]))
+    link = DeviceBscLink(tr, 64, seed=2)
+    bufs = link.generate(0.05, B)
+    ms = time_steps(lib, lambda: link.decode(B), steps, warmup)
+    kname = _lib.last_kernel()
+    _lib.check(lib.cpx_stream_sync(None))
+    idx = np.r_[0:n_check // 2, B - n_check // 2:B]
+    rx = np.concatenate([bufs['rx'].to_array((B, link.ncoded), np.float64)[idx]])
+    dec = bufs['dec'].to_array((B, link.L), np.uint8)
+    msg = bufs['msg'].to_array((B, 64), np.uint8)
+    t0 = time.perf_counter()
+    mism = int(np.sum(oracle.viterbi_decode(rx, tr, None, "hard") != dec[idx]))
+    return entry("configs[0], device-generated", "K=3 (5,7) r=1/2, 64-bit blocks ('term': 132 coded bits), hard-decision Viterbi over "
+                 "BSC(0.05), tb_depth=10, B=%d blocks generated on the device" % B, kname, ms, B * 64, "info-bits",
+                 B * (link.ncoded * 8 + link.L), "hbm + valu",
+                 {"vs": "oracle viterbi_decode 'hard' (convcode.py:661-749) on the device-generated channel output", "codewords": len(idx),
+                  "mismatched_bits": mism, "ok": mism == 0, "oracle_s": round(time.perf_counter() - t0, 2)},
+                 {"ber": float(np.mean(dec[:, :64] != msg)),
+                  "bytes_model": "SURVEY 8d form: %d float64 received values in + %d decoded bytes out per block" % (link.ncoded, link.L)})
+
+
 def run(lib, steps=20, warmup=3, scale=1.0, log=None):
     """All entries; never raises for a failing workload (the headline line must not be lost): a failure becomes an entry with
     `error`."""
     out = []
     for name, fn in (("turbo", lambda: [run_turbo(lib, steps, warmup, B=int(16384 * scale))]),
-                     ("config4", lambda: run_config4(lib, steps, warmup, B=int(32768 * scale)))):
+                     ("config4", lambda: run_config4(lib, steps, warmup, B=int(32768 * scale))),
+                     ("config5", lambda: [run_config5(lib, steps, warmup, total_bits=1e8 * scale)]),
+                     ("config1", lambda: [run_config1(lib, steps, warmup, B=int((1 << 20) * scale))])):
         t0 = time.perf_counter()
         try:
             got = fn()

@@ -197,8 +197,8 @@ def current_device():
 
 def last_kernel():
     """Name of the kernel the last decoder call of this thread launched (cpx_last_kernel)."""
-    buf = ctypes.create_string_buffer(200)
-    check(load().cpx_last_kernel(buf, 200))
+    buf = ctypes.create_string_buffer(400)
+    check(load().cpx_last_kernel(buf, 400))
     return buf.value.decode()
 
 

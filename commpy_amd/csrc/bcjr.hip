@@ -1344,7 +1344,7 @@ int cpx_turbo_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const 
     if (s32) hipLaunchKernelGGL(turbo_final_kernel<true>, dim3((unsigned)(ngroups * ftiles)), dim3(FT), 0, st, p, ftiles);
     else hipLaunchKernelGGL(turbo_final_kernel<false>, dim3((unsigned)(ngroups * ftiles)), dim3(FT), 0, st, p, ftiles);
     CPX_HIP(hipGetLastError());
-    note_kernel("turbo_pass_kernel<%d,%s%s> x %d (time-major slab, interleaver folded into the row index) + turbo_init_kernel + turbo_final_kernel (%d wave pairs per workgroup, %d codewords per pair)", p.tb.lgS,
+    note_kernel("turbo_pass_kernel<%d,%s%s> x %d (time-major slab, interleaver = row index) + turbo_init_kernel + turbo_final_kernel (%d wave pairs per workgroup, %d codewords per pair)", p.tb.lgS,
                 (p.tb.lgS == 2 && p.tb.sr4) ? "true" : "false", s32 ? ",f32 slab" : "", 2 * n_iter, np, GW);
     // redo: one launch; a pair with a flagged codeword decodes its codewords again, literally, all iterations (turbo_literal_kernel)
     const RedoCounter redo = redo_counter();

@@ -94,6 +94,7 @@ int load_rccl() {
 }  // namespace
 
 struct cpx_comm {
+    __attribute__((visibility("hidden"))) ~cpx_comm() = default;   // (see cpx_trellis, cpx_internal.h)
     int nranks = 0;                     // ranks of the whole communicator
     int nlocal = 0;                     // ranks driven by this process (1 for init_rank)
     int rank0 = 0;                      // rank of local device 0 (init_all: 0)

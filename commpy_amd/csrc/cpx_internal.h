@@ -162,6 +162,8 @@ struct ArenaBuf {
 #define CPX_MAX_N 6
 
 struct cpx_trellis {
+    __attribute__((visibility("hidden"))) ~cpx_trellis() = default;   // (the handle types are declared in the public header, i.e. with
+                                                                      //  default visibility: keep their implicit members out of the ABI)
     int k, n, S, I;
     int device;
     // host copies

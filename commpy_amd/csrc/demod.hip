@@ -180,11 +180,128 @@ __device__ __forceinline__ bool axis_gp(double v, const double *ax, double d, do
     return !(fmin(el, eh) >= 1e-290) || !(rho > 1e-290 && rho < 1e290) || !(sum >= 1e-30);
 }
 
+// ---- generic constellations (PSK, custom tables), M <= MAX_M: the fast form (round 6) ------------------------------------------------
+// demod_soft_kernel above is the reference's formula instruction for instruction -- hypot, exp, a division per exponent, per LLR a
+// division and a logarithm, and NB doubles per lane stored at an 8 NB-byte stride: ~870 vector instructions per 8-PSK symbol, a
+// quarter of the HBM rate by arithmetic alone, and the store pattern that held the 64-QAM kernel at 36 % until round 5.  Here:
+//   * |y - c|^2 = dx^2 + dy^2 (no hypot), the exponent by the reciprocal (RCP), exp / log from the 32-entry tables of the separable
+//     kernel, the quotient by div_nr -- ~270 instructions per 8-PSK symbol; sums still in increasing constellation index (:128-136);
+//   * the NB LLRs of a wave's 64 symbols leave as ONE contiguous run through a wave-private LDS tile (16 bytes per lane, consecutive
+//     lanes consecutive addresses), any NB, with an 8-byte form for a caller's odd output pointer (round-5 advisor finding);
+//   * the same guard as the separable kernel: a symbol whose total is below 1e-290, or any of whose quotients leaves (e^-600, e^600)
+//     or is not finite, is decided again by the literal formula, so the reference's -inf / NaN pattern and rounding near the
+//     underflow range are kept (modulation.py:134-137).
+// cpx_demod_set_path("libm") keeps the literal kernel for every symbol (the row this one is tested against).
+template <int NB, bool RCP>
+__global__ __launch_bounds__(DEMOD_BLOCK) void demod_soft_gen_kernel(const double2 *__restrict__ y, int64_t Ns,
+                                                                     const double2 *__restrict__ cst, double noise_var, double scale,
+                                                                     double *__restrict__ llr, int al16) {
+    constexpr int M = 1 << NB;
+    __shared__ double2 c_s[M];
+    __shared__ double tab_s[96];
+    for (int m = threadIdx.x; m < M; m += DEMOD_BLOCK) c_s[m] = cst[m];
+    for (int m = threadIdx.x; m < 96; m += DEMOD_BLOCK) tab_s[m] = DEMOD_TAB[m];
+    __syncthreads();
+    const double ninv = -1.0 / noise_var;
+    double pend[NB];
+    auto symbol = [&](const double2 cur) __attribute__((always_inline)) {
+        double num[NB], den[NB];
+#pragma unroll
+        for (int b = 0; b < NB; b++) { num[b] = 0.0; den[b] = 0.0; }
+        auto point = [&](const int m) __attribute__((always_inline)) {
+            const double2 c = c_s[m];
+            const double dx = cur.x - c.x, dy = cur.y - c.y;
+            const double q = dx * dx + dy * dy;
+            const double e = tab_exp(RCP ? q * ninv : (-q) / noise_var, tab_s);
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+                if ((m >> b) & 1) num[b] += e; else den[b] += e;
+            }
+        };
+        if constexpr (M <= 16) {                                      // unrolled: the bit tests are compile-time, a sum is one addition
+#pragma unroll
+            for (int m = 0; m < M; m++) point(m);
+        } else {
+#pragma unroll 8
+            for (int m = 0; m < M; m++) point(m);
+        }
+        bool redo = !(num[0] + den[0] >= 1e-290);                     // every point's probability down among the denormals
+        double out[NB];
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const double qa = div_nr(num[b], den[b]);
+            redo |= !(qa > 2.7e-261 && qa < 3.7e260);
+            out[b] = tab_log(qa, tab_s);
+        }
+        if (redo) {                                                   // the reference's way, as demod_soft_kernel
+#pragma unroll
+            for (int b = 0; b < NB; b++) { num[b] = 0.0; den[b] = 0.0; }
+            for (int m = 0; m < M; m++) {
+                const double2 c = c_s[m];
+                const double a = hypot(cur.x - c.x, cur.y - c.y);
+                const double e = exp((-(a * a)) / noise_var);
+#pragma unroll
+                for (int b = 0; b < NB; b++) {
+                    if ((m >> b) & 1) num[b] += e; else den[b] += e;
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < NB; b++) out[b] = fast_log(num[b] / den[b]);
+        }
+#pragma unroll
+        for (int b = 0; b < NB; b++) pend[b] = out[b] * scale;        // (:137)
+    };
+    constexpr int WAVES = DEMOD_BLOCK / 64;
+    __shared__ double xpose[WAVES * 64 * NB];
+    const int lane = threadIdx.x & 63;
+    double *tile = xpose + (threadIdx.x >> 6) * 64 * NB;
+    auto flush = [&](const int64_t base, const bool full) __attribute__((always_inline)) {   // base: the wave's first symbol of that trip
+#pragma unroll
+        for (int b = 0; b < NB; b++) tile[lane * NB + NB - 1 - b] = pend[b];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int64_t total = Ns * NB, g0 = base * NB;
+#pragma unroll
+        for (int k = 0; k < (NB + 1) / 2; k++) {
+            const int e = k * 128 + lane * 2;
+            if (e < 64 * NB) {                                        // (odd NB: the last store instruction is half a wave)
+                const double2 v = *reinterpret_cast<const double2 *>(tile + e);
+                if (al16 && (full || g0 + e + 1 < total)) *reinterpret_cast<double2 *>(llr + g0 + e) = v;
+                else {
+                    if (full || g0 + e < total) llr[g0 + e] = v.x;
+                    if (full || g0 + e + 1 < total) llr[g0 + e + 1] = v.y;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    // the software pipeline of demod_soft_sep_kernel: next symbol requested and previous LLRs stored at the top of a trip
+    const int64_t stride = (int64_t)gridDim.x * DEMOD_BLOCK;
+    int64_t base = (int64_t)blockIdx.x * DEMOD_BLOCK + (threadIdx.x & ~63);     // wave-uniform
+    if (base >= Ns) return;
+    auto at = [&](int64_t wb) { return y[wb + lane < Ns ? wb + lane : Ns - 1]; };
+    double2 cur = at(base);
+    double2 nxt = at(base + stride < Ns ? base + stride : base);
+    symbol(cur);
+    int64_t prev = base;
+    for (base += stride; base < Ns; base += stride) {
+        cur = nxt;
+        flush(prev, true);
+        nxt = at(base + stride < Ns ? base + stride : base);
+        symbol(cur);
+        prev = base;
+    }
+    flush(prev, prev + 64 <= Ns);
+}
+
 template <int NH, bool RCP, bool GP, bool TAB = false>
 __global__ __launch_bounds__(DEMOD_BLOCK) void demod_soft_sep_kernel(const double2 *__restrict__ y, int64_t Ns,
                                                                      const double *__restrict__ axes, double noise_var,
                                                                      double scale, double step_x, double step_y,
-                                                                     double *__restrict__ llr) {
+                                                                     double *__restrict__ llr, int al16) {
     const double ninv = -1.0 / noise_var;
     constexpr int R = 1 << NH, NB = 2 * NH;
     __shared__ double ax_s[2 * R];
@@ -307,8 +424,11 @@ __global__ __launch_bounds__(DEMOD_BLOCK) void demod_soft_sep_kernel(const doubl
             for (int k = 0; k < NB / 2; k++) {
                 const int e = k * 128 + lane * 2;
                 const double2 v = *reinterpret_cast<const double2 *>(tile + e);
-                if (full || g0 + e + 1 < total) *reinterpret_cast<double2 *>(llr + g0 + e) = v;
-                else if (g0 + e < total) llr[g0 + e] = v.x;
+                if (al16 && (full || g0 + e + 1 < total)) *reinterpret_cast<double2 *>(llr + g0 + e) = v;   // (al16: the caller's array is
+                else {                                                                                      //  16-byte aligned; else 8-byte stores)
+                    if (full || g0 + e < total) llr[g0 + e] = v.x;
+                    if (full || g0 + e + 1 < total) llr[g0 + e + 1] = v.y;
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -721,12 +841,14 @@ int cpx_demod_soft_scaled_dev(const cpx_modem *m, const double *d_y, int64_t Ns,
         }
         return CPX_OK;
     }
+    const bool gen = demod_mode() != 2;                            // generic constellations: the table-driven kernel unless "libm"
+    const int al16 = ((uintptr_t)d_llr & 15) == 0;
     const bool gp = m->gp && (m->nbits >= 6 || m->nbits == 2) && !demod_plain();
     const bool tab = gp && m->nbits >= 6 && demod_mode() != 2;       // table-driven exp / log (round 5); "libm" keeps the library's
     if (m->separable) {
         switch (m->nbits / 2) {
 #define LAUNCH(NH, RC, GPV) hipLaunchKernelGGL((demod_soft_sep_kernel<NH, RC, GPV>), grid, block, 0, st, y, Ns, m->d_axes, noise_var, \
-                                               scale, m->gp_step[0], m->gp_step[1], d_llr)
+                                               scale, m->gp_step[0], m->gp_step[1], d_llr, al16)
 #define CASE(NH) case NH:                                         \
         if (rcp) LAUNCH(NH, true, false); else LAUNCH(NH, false, false);  \
         break;
@@ -735,7 +857,7 @@ int cpx_demod_soft_scaled_dev(const cpx_modem *m, const double *d_y, int64_t Ns,
         else { if (rcp) LAUNCH(NH, true, false); else LAUNCH(NH, false, false); }        \
         break;
 #define LAUNCH_T(NH, RC) hipLaunchKernelGGL((demod_soft_sep_kernel<NH, RC, true, true>), grid, block, 0, st, y, Ns, m->d_axes, noise_var, \
-                                            scale, m->gp_step[0], m->gp_step[1], d_llr)
+                                            scale, m->gp_step[0], m->gp_step[1], d_llr, al16)
 #define CASE_GT(NH) case NH:                                      \
         if (tab) { if (rcp) LAUNCH_T(NH, true); else LAUNCH_T(NH, false); }              \
         else if (gp) { if (rcp) LAUNCH(NH, true, true); else LAUNCH(NH, false, true); }  \
@@ -752,7 +874,9 @@ int cpx_demod_soft_scaled_dev(const cpx_modem *m, const double *d_y, int64_t Ns,
     } else {
         switch (m->nbits) {
 #define CASE(NB) case NB:                                                                                                \
-        if (rcp) hipLaunchKernelGGL((demod_soft_kernel<NB, true>), grid, block, 0, st, y, Ns, c, m->M, noise_var, scale, d_llr);   \
+        if (gen && rcp) hipLaunchKernelGGL((demod_soft_gen_kernel<NB, true>), grid, block, 0, st, y, Ns, c, noise_var, scale, d_llr, al16);   \
+        else if (gen) hipLaunchKernelGGL((demod_soft_gen_kernel<NB, false>), grid, block, 0, st, y, Ns, c, noise_var, scale, d_llr, al16);   \
+        else if (rcp) hipLaunchKernelGGL((demod_soft_kernel<NB, true>), grid, block, 0, st, y, Ns, c, m->M, noise_var, scale, d_llr);   \
         else hipLaunchKernelGGL((demod_soft_kernel<NB, false>), grid, block, 0, st, y, Ns, c, m->M, noise_var, scale, d_llr);   \
         break;
             CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
@@ -762,7 +886,7 @@ int cpx_demod_soft_scaled_dev(const cpx_modem *m, const double *d_y, int64_t Ns,
     }
     CPX_HIP(hipGetLastError());
     if (m->separable) note_kernel("demod_soft_sep_kernel<%d,%s%s%s>", m->nbits / 2, rcp ? "rcp" : "div", gp ? ",gp" : "", tab ? ",tab" : "");
-    else note_kernel("demod_soft_kernel<%d,%s>", m->nbits, rcp ? "rcp" : "div");
+    else note_kernel("%s<%d,%s>", gen ? "demod_soft_gen_kernel" : "demod_soft_kernel", m->nbits, rcp ? "rcp" : "div");
     return CPX_OK;
 }
 

@@ -35,7 +35,7 @@ hipStream_t lib_stream() {
     return g_streams[dev];
 }
 
-static thread_local char g_kernel[160] = "";
+static thread_local char g_kernel[256] = "";
 
 // "detect and redo" made visible (round 5): a decoder whose redo launch counts the items it decoded again gets a device word here,
 // the count is copied to a pinned host word behind the launch (same stream), and cpx_last_kernel appends "redo: n of N" READING THAT

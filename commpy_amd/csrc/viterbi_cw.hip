@@ -206,7 +206,9 @@ __device__ __forceinline__ void cw_step(double (&pm)[1 << LGS], double r0, doubl
         // table took 1.94.  Now the mode is switched on once per step with index 0 -- harmless for every other vector instruction --
         // and a butterfly costs two scalar instructions: its index in, index 0 back.
         const cpx_d4 tab = {bmv[0], bmv[1], bmv[2], bmv[3]}, rtab = {bmv[3], bmv[2], bmv[1], bmv[0]};
-        asm volatile("s_set_gpr_idx_on 0, 1" ::: "memory");
+        // (every statement that sets the index names m0 as clobbered -- s_set_gpr_idx_on / _idx write M0[7:0] -- and
+        //  tests/test_isa_guards.py scans the built code object: between `on` and `off` nothing else may write or consume M0.)
+        asm volatile("s_set_gpr_idx_on 0, 1" ::: "memory", "m0");
         auto acs_pair = [&](int j, double a0, double a1, double b0, double b1) {
             const int x = rotl<LGS>(2 * j, R), y = rotl<LGS>(2 * j + 1, R);
             if (TYPE == CPX_VIT_UNQUANTIZED) {
@@ -246,7 +248,7 @@ __device__ __forceinline__ void cw_step(double (&pm)[1 << LGS], double r0, doubl
                                [d0] "=&v"(d0), [d1] "=&v"(d1), [da] "+v"(da), [db] "+v"(db)
                              : [i0] "s"(gidx[j]), [i1] "s"(gidx[j + 1]), [a] "v"(a), [b] "v"(b), [c] "v"(c), [d] "v"(d),
                                "{v[248:255]}"(tab), "{v[240:247]}"(rtab)
-                             : "vcc");
+                             : "vcc", "m0");
                 pm[x0] = a0; pm[y0] = b0;                          // state j now lives in register rotl(j, R+1) = x0, state j+S/2 in y0
                 pm[x1] = c0; pm[y1] = d0;
             }
@@ -263,11 +265,12 @@ __device__ __forceinline__ void cw_step(double (&pm)[1 << LGS], double r0, doubl
                              "v_add_f64 %[b0], v[240:241], %[a]\n\t"
                              "s_set_gpr_idx_idx 0"
                              : [a0] "=&v"(a0), [a1] "=&v"(a1), [b0] "=&v"(b0), [b1] "=&v"(b1)
-                             : [ic] "s"(gidx[j]), [a] "v"(a), [b] "v"(b), "{v[248:255]}"(tab), "{v[240:247]}"(rtab));
+                             : [ic] "s"(gidx[j]), [a] "v"(a), [b] "v"(b), "{v[248:255]}"(tab), "{v[240:247]}"(rtab)
+                             : "m0");
                 acs_pair(j, a0, a1, b0, b1);
             }
         }
-        asm volatile("s_set_gpr_idx_off" ::: "memory");
+        asm volatile("s_set_gpr_idx_off" ::: "memory", "m0");
     } else {
 #pragma unroll
         for (int j = 0; j < H; j++) {

@@ -460,8 +460,9 @@ class DeviceWifiLink:
             out.append(errs / done)
         return np.array(out)
 
-    def ber_sweep_batched(self, snrs_db, n_bits):
+    def ber_sweep_batched(self, snrs_db, n_bits, mark=None):
         """Same result statistics as :meth:`ber_sweep`, with ONE Viterbi call for the whole sweep.
+        ``mark(k, start)`` (benchmarks): called around stage k = 0 front end, 1 decoder, 2 error count -- e.g. to record HIP events.
 
         The element-wise stages (bits, encode, puncture, modulate, AWGN, demod, depuncture) run per SNR point on their
         slice of sweep-sized buffers; the decoder and the error counter then see all ``len(snrs) * T`` frames at once,
@@ -493,6 +494,8 @@ class DeviceWifiLink:
         def at(buf, nbytes):
             return ctypes.c_void_p(buf.ptr.value + nbytes)
 
+        mark = mark or (lambda k, start: None)
+        mark(0, True)
         for i, snr_db in enumerate(snrs_db):
             noise_std = math.sqrt(2.0 * self.modem.Es / (self.rate * 10 ** (float(snr_db) / 10.0)))   # channels.py:74
             self._calls += 1
@@ -512,14 +515,19 @@ class DeviceWifiLink:
                 ck(lib.cpx_gather_f64_dev(bufs['llr'].ptr, T, self.ntx, bufs['de_idx'].ptr, self.nde, llr_out, None))
             else:
                 ck(lib.cpx_demod_soft_dev(h_md, bufs['sym'].ptr, T * self.nsym, noise_std ** 2, llr_out, None))
+        mark(0, False)
         m = self.trellis.total_memory
         length = self.nde
         L = int(length * 0.5)
         n_steps = int((L + m) / 1) - 1
+        mark(1, True)
         ck(lib.cpx_viterbi_decode_batch_dev(h_tr, bufs['llr_all'].ptr, R, length, L, n_steps, min(5 * m, L), 1,
                                             bufs['dec'].ptr, None))
+        mark(1, False)
+        mark(2, True)
         ck(lib.cpx_count_errors_dev(bufs['msg'].ptr, self.nbits, bufs['dec'].ptr, L, R, self.agg, self.send_chunk,
                                     bufs['errs'].ptr, None))
+        mark(2, False)
         ck(lib.cpx_stream_sync(None))
         errs = bufs['errs'].to_array((P, T * self.agg), np.int32)
         return errs.sum(axis=1) / float(T * self.nbits)

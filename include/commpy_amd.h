@@ -29,6 +29,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: what this header declares is ALL it exports */
+#pragma GCC visibility push(default)
 
 #define CPX_OK 0
 #define CPX_EINVAL (-1)   /* bad argument (Python: ValueError) */
@@ -52,7 +54,9 @@ int cpx_device_count(int *n);
 int cpx_set_device(int device);
 int cpx_get_device(int *device);
 /* Name of the (dominant) kernel the last decoder call of the calling thread launched, e.g.
- * "viterbi_cw_fused_kernel<6,0155,0117,soft,28>": benchmarks and tests report what really ran. */
+ * "viterbi_cw_fused_kernel<6,0155,0117,soft,28>": benchmarks and tests report what really ran.  Decoders with a "detect and redo"
+ * path append "; redo: n of N ..." -- n is written by the redo kernel itself, so that suffix is only valid once the issuing stream
+ * has been synchronised (the host-buffer entry points return synchronised; after a *_dev call, cpx_stream_sync first). */
 int cpx_last_kernel(char *name, int cap);
 /* Precision mode of the process ("fp64-parity default vs fp32-fast"), initial value from the environment variable
  * CPX_PRECISION.  "fp64-parity" (default): every kernel computes in float64 in the reference's operation order -- the mode all
@@ -372,6 +376,7 @@ int cpx_comm_allreduce_i64(cpx_comm *c, const void *const *d_send, void *const *
 int cpx_comm_allreduce_f64(cpx_comm *c, const void *const *d_send, void *const *d_recv, size_t count, int op,
                            void *const *streams);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -3,6 +3,8 @@ golden vectors from the live reference and the CPU oracle.
 
 Tolerances (BASELINE.json north_star): decoded bits / dec_word / hard decisions bit-exact;
 float LLR outputs within 1e-5 absolute."""
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -420,6 +422,51 @@ def test_soft_demod_ragged_sizes_path_modes_and_bounds(gpu, m, snr_db):
             assert np.max(np.abs(got[fin] - want[fin]), initial=0.0) < 1e-9, (ns, mode, kern)
             if m >= 64:
                 assert (",tab" in kern) == (mode is None) and (",gp" in kern) == (mode != "plain"), kern
+        d_y.free()
+
+
+@pytest.mark.parametrize("kind,m,snr_db", [("psk", 2, 4.0), ("psk", 4, 6.0), ("psk", 8, 9.0), ("psk", 16, 14.0), ("psk", 32, 18.0),
+                                           ("custom", 8, 7.0), ("psk", 8, 45.0)])
+def test_generic_soft_demod_fast_kernel(gpu, kind, m, snr_db):
+    """Round 6: PSK / arbitrary tables run demod_soft_gen_kernel -- table-driven exp / log, no hypot, the LLRs of a wave stored as one
+    contiguous run (any bits per symbol, odd ones too), an 8-byte store form for a caller's odd output pointer, point-by-point redo of
+    the symbols near the reference's underflow range.  Against the oracle on every symbol (1e-9; where the oracle is not finite the
+    same non-finite value), for every size around the wave / block boundaries, the literal kernel ('libm') beside it, nothing written
+    behind the result, and the same values through a misaligned output pointer.  45 dB: most symbols take the redo path."""
+    from commpy_amd import _lib
+    from commpy_amd.devicelink import DeviceBuf
+    from commpy_amd.modulation import Modem, PSKModem
+    lib = _lib.load()
+    rs = np.random.RandomState(m + int(snr_db))
+    md = PSKModem(m) if kind == "psk" else Modem(rs.randn(m) + 1j * rs.randn(m))
+    nb = md.num_bits_symbol
+    N0 = md.Es / 10 ** (snr_db / 10.0)
+    h = md._device_handle()
+    guard = 300
+    for ns in (1, 2, 63, 64, 65, 127, 129, 255, 256, 257, 1000, 4099, 70001):
+        y = md.constellation[rs.randint(0, m, ns)] + np.sqrt(N0 / 2) * (rs.randn(ns) + 1j * rs.randn(ns))
+        if ns >= 1000:
+            y[5] = 40.0 - 3j                                   # a far outlier: every point probability underflows
+        want = oracle.demodulate(md.constellation, y, "soft", N0)
+        fin = np.isfinite(want)
+        d_y = DeviceBuf.from_array(y)
+        for mode, off in ((None, 0), ("libm", 0), (None, 8)):  # off = 8: an output pointer that is only 8-byte aligned
+            d_l = DeviceBuf.from_array(np.full(ns * nb + guard + 1, -777.25))
+            _lib.demod_set_path(mode)
+            try:
+                _lib.check(lib.cpx_demod_soft_dev(h, d_y.ptr, ns, float(N0), ctypes.c_void_p(d_l.ptr.value + off), None))
+                _lib.check(lib.cpx_stream_sync(None))
+                kern = _lib.last_kernel()
+            finally:
+                _lib.demod_set_path(None)
+            got = d_l.to_array((ns * nb + guard + 1,), np.float64)[off // 8:]
+            d_l.free()
+            assert ("demod_soft_gen_kernel" in kern) == (mode is None), kern
+            assert np.all(got[ns * nb:] == -777.25), (ns, mode, off, kern)
+            got = got[:ns * nb]
+            assert np.array_equal(np.isfinite(got), fin), (ns, mode, off)
+            assert np.array_equal(got[~fin], want[~fin], equal_nan=True), (ns, mode, off)
+            assert np.max(np.abs(got[fin] - want[fin]), initial=0.0) < 1e-9, (ns, mode, off, np.max(np.abs(got[fin] - want[fin])))
         d_y.free()
 
 
