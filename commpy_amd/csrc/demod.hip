@@ -187,7 +187,9 @@ __device__ __forceinline__ bool axis_gp(double v, const double *ax, double d, do
 //   * |y - c|^2 = dx^2 + dy^2 (no hypot), the exponent by the reciprocal (RCP), exp / log from the 32-entry tables of the separable
 //     kernel, the quotient by div_nr -- ~270 instructions per 8-PSK symbol; sums still in increasing constellation index (:128-136);
 //   * the NB LLRs of a wave's 64 symbols leave as ONE contiguous run through a wave-private LDS tile (16 bytes per lane, consecutive
-//     lanes consecutive addresses), any NB, with an 8-byte form for a caller's odd output pointer (round-5 advisor finding);
+//     lanes consecutive addresses), any NB.  The 16-byte stores need a 16-byte aligned output array: a caller's odd pointer (a
+//     sub-buffer at an odd element offset; round-5 advisor finding) is served by the literal kernel, whose stores are per element --
+//     a run-time choice INSIDE the fast kernels cost the 64-QAM one 5 % (a store that exists on one path only is waited for on both);
 //   * the same guard as the separable kernel: a symbol whose total is below 1e-290, or any of whose quotients leaves (e^-600, e^600)
 //     or is not finite, is decided again by the literal formula, so the reference's -inf / NaN pattern and rounding near the
 //     underflow range are kept (modulation.py:134-137).
@@ -195,24 +197,40 @@ __device__ __forceinline__ bool axis_gp(double v, const double *ax, double d, do
 template <int NB, bool RCP>
 __global__ __launch_bounds__(DEMOD_BLOCK) void demod_soft_gen_kernel(const double2 *__restrict__ y, int64_t Ns,
                                                                      const double2 *__restrict__ cst, double noise_var, double scale,
-                                                                     double *__restrict__ llr, int al16) {
+                                                                     double *__restrict__ llr) {
     constexpr int M = 1 << NB;
     __shared__ double2 c_s[M];
+    __shared__ double2 cn_s[RCP ? M : 1];                             // RCP: the points in units of sqrt(noise_var)
     __shared__ double tab_s[96];
-    for (int m = threadIdx.x; m < M; m += DEMOD_BLOCK) c_s[m] = cst[m];
+    // RCP: symbol and points are scaled by 1 / sqrt(noise_var) once, so that the exponent -(dx^2 + dy^2) / noise_var is a
+    // multiplication and a fused multiply-add per point instead of two multiplications, an addition and the scaling (the literal
+    // redo below works on the unscaled values)
+    const double rs = RCP ? sqrt(1.0 / noise_var) : 1.0;
+    for (int m = threadIdx.x; m < M; m += DEMOD_BLOCK) {
+        const double2 c = cst[m];
+        c_s[m] = c;
+        if (RCP) cn_s[m] = make_double2(c.x * rs, c.y * rs);
+    }
     for (int m = threadIdx.x; m < 96; m += DEMOD_BLOCK) tab_s[m] = DEMOD_TAB[m];
     __syncthreads();
-    const double ninv = -1.0 / noise_var;
     double pend[NB];
     auto symbol = [&](const double2 cur) __attribute__((always_inline)) {
         double num[NB], den[NB];
 #pragma unroll
         for (int b = 0; b < NB; b++) { num[b] = 0.0; den[b] = 0.0; }
+        const double ux = cur.x * rs, uy = cur.y * rs;
         auto point = [&](const int m) __attribute__((always_inline)) {
-            const double2 c = c_s[m];
-            const double dx = cur.x - c.x, dy = cur.y - c.y;
-            const double q = dx * dx + dy * dy;
-            const double e = tab_exp(RCP ? q * ninv : (-q) / noise_var, tab_s);
+            double x;
+            if (RCP) {
+                const double2 c = cn_s[m];
+                const double dx = ux - c.x, dy = uy - c.y;
+                x = __builtin_fma(-dx, dx, -(dy * dy));
+            } else {
+                const double2 c = c_s[m];
+                const double dx = cur.x - c.x, dy = cur.y - c.y;
+                x = (-(dx * dx + dy * dy)) / noise_var;
+            }
+            const double e = tab_exp(x, tab_s);
 #pragma unroll
             for (int b = 0; b < NB; b++) {
                 if ((m >> b) & 1) num[b] += e; else den[b] += e;
@@ -267,11 +285,8 @@ __global__ __launch_bounds__(DEMOD_BLOCK) void demod_soft_gen_kernel(const doubl
             const int e = k * 128 + lane * 2;
             if (e < 64 * NB) {                                        // (odd NB: the last store instruction is half a wave)
                 const double2 v = *reinterpret_cast<const double2 *>(tile + e);
-                if (al16 && (full || g0 + e + 1 < total)) *reinterpret_cast<double2 *>(llr + g0 + e) = v;
-                else {
-                    if (full || g0 + e < total) llr[g0 + e] = v.x;
-                    if (full || g0 + e + 1 < total) llr[g0 + e + 1] = v.y;
-                }
+                if (full || g0 + e + 1 < total) *reinterpret_cast<double2 *>(llr + g0 + e) = v;
+                else if (g0 + e < total) llr[g0 + e] = v.x;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -301,7 +316,7 @@ template <int NH, bool RCP, bool GP, bool TAB = false>
 __global__ __launch_bounds__(DEMOD_BLOCK) void demod_soft_sep_kernel(const double2 *__restrict__ y, int64_t Ns,
                                                                      const double *__restrict__ axes, double noise_var,
                                                                      double scale, double step_x, double step_y,
-                                                                     double *__restrict__ llr, int al16) {
+                                                                     double *__restrict__ llr) {
     const double ninv = -1.0 / noise_var;
     constexpr int R = 1 << NH, NB = 2 * NH;
     __shared__ double ax_s[2 * R];
@@ -424,11 +439,8 @@ __global__ __launch_bounds__(DEMOD_BLOCK) void demod_soft_sep_kernel(const doubl
             for (int k = 0; k < NB / 2; k++) {
                 const int e = k * 128 + lane * 2;
                 const double2 v = *reinterpret_cast<const double2 *>(tile + e);
-                if (al16 && (full || g0 + e + 1 < total)) *reinterpret_cast<double2 *>(llr + g0 + e) = v;   // (al16: the caller's array is
-                else {                                                                                      //  16-byte aligned; else 8-byte stores)
-                    if (full || g0 + e < total) llr[g0 + e] = v.x;
-                    if (full || g0 + e + 1 < total) llr[g0 + e + 1] = v.y;
-                }
+                if (full || g0 + e + 1 < total) *reinterpret_cast<double2 *>(llr + g0 + e) = v;   // (16-byte aligned: the host sends a
+                else if (g0 + e < total) llr[g0 + e] = v.x;                                         //  caller's odd pointer to demod_soft_kernel)
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -841,14 +853,14 @@ int cpx_demod_soft_scaled_dev(const cpx_modem *m, const double *d_y, int64_t Ns,
         }
         return CPX_OK;
     }
-    const bool gen = demod_mode() != 2;                            // generic constellations: the table-driven kernel unless "libm"
-    const int al16 = ((uintptr_t)d_llr & 15) == 0;
+    const bool al16 = ((uintptr_t)d_llr & 15) == 0;                // the fast kernels store 16 bytes per lane
+    const bool gen = demod_mode() != 2 && al16;                   // generic constellations: the table-driven kernel unless "libm"
     const bool gp = m->gp && (m->nbits >= 6 || m->nbits == 2) && !demod_plain();
     const bool tab = gp && m->nbits >= 6 && demod_mode() != 2;       // table-driven exp / log (round 5); "libm" keeps the library's
-    if (m->separable) {
+    if (m->separable && al16) {
         switch (m->nbits / 2) {
 #define LAUNCH(NH, RC, GPV) hipLaunchKernelGGL((demod_soft_sep_kernel<NH, RC, GPV>), grid, block, 0, st, y, Ns, m->d_axes, noise_var, \
-                                               scale, m->gp_step[0], m->gp_step[1], d_llr, al16)
+                                               scale, m->gp_step[0], m->gp_step[1], d_llr)
 #define CASE(NH) case NH:                                         \
         if (rcp) LAUNCH(NH, true, false); else LAUNCH(NH, false, false);  \
         break;
@@ -857,7 +869,7 @@ int cpx_demod_soft_scaled_dev(const cpx_modem *m, const double *d_y, int64_t Ns,
         else { if (rcp) LAUNCH(NH, true, false); else LAUNCH(NH, false, false); }        \
         break;
 #define LAUNCH_T(NH, RC) hipLaunchKernelGGL((demod_soft_sep_kernel<NH, RC, true, true>), grid, block, 0, st, y, Ns, m->d_axes, noise_var, \
-                                            scale, m->gp_step[0], m->gp_step[1], d_llr, al16)
+                                            scale, m->gp_step[0], m->gp_step[1], d_llr)
 #define CASE_GT(NH) case NH:                                      \
         if (tab) { if (rcp) LAUNCH_T(NH, true); else LAUNCH_T(NH, false); }              \
         else if (gp) { if (rcp) LAUNCH(NH, true, true); else LAUNCH(NH, false, true); }  \
@@ -874,8 +886,8 @@ int cpx_demod_soft_scaled_dev(const cpx_modem *m, const double *d_y, int64_t Ns,
     } else {
         switch (m->nbits) {
 #define CASE(NB) case NB:                                                                                                \
-        if (gen && rcp) hipLaunchKernelGGL((demod_soft_gen_kernel<NB, true>), grid, block, 0, st, y, Ns, c, noise_var, scale, d_llr, al16);   \
-        else if (gen) hipLaunchKernelGGL((demod_soft_gen_kernel<NB, false>), grid, block, 0, st, y, Ns, c, noise_var, scale, d_llr, al16);   \
+        if (gen && rcp) hipLaunchKernelGGL((demod_soft_gen_kernel<NB, true>), grid, block, 0, st, y, Ns, c, noise_var, scale, d_llr);   \
+        else if (gen) hipLaunchKernelGGL((demod_soft_gen_kernel<NB, false>), grid, block, 0, st, y, Ns, c, noise_var, scale, d_llr);   \
         else if (rcp) hipLaunchKernelGGL((demod_soft_kernel<NB, true>), grid, block, 0, st, y, Ns, c, m->M, noise_var, scale, d_llr);   \
         else hipLaunchKernelGGL((demod_soft_kernel<NB, false>), grid, block, 0, st, y, Ns, c, m->M, noise_var, scale, d_llr);   \
         break;
@@ -885,7 +897,7 @@ int cpx_demod_soft_scaled_dev(const cpx_modem *m, const double *d_y, int64_t Ns,
         }
     }
     CPX_HIP(hipGetLastError());
-    if (m->separable) note_kernel("demod_soft_sep_kernel<%d,%s%s%s>", m->nbits / 2, rcp ? "rcp" : "div", gp ? ",gp" : "", tab ? ",tab" : "");
+    if (m->separable && al16) note_kernel("demod_soft_sep_kernel<%d,%s%s%s>", m->nbits / 2, rcp ? "rcp" : "div", gp ? ",gp" : "", tab ? ",tab" : "");
     else note_kernel("%s<%d,%s>", gen ? "demod_soft_gen_kernel" : "demod_soft_kernel", m->nbits, rcp ? "rcp" : "div");
     return CPX_OK;
 }

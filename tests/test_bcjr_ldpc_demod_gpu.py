@@ -426,19 +426,19 @@ def test_soft_demod_ragged_sizes_path_modes_and_bounds(gpu, m, snr_db):
 
 
 @pytest.mark.parametrize("kind,m,snr_db", [("psk", 2, 4.0), ("psk", 4, 6.0), ("psk", 8, 9.0), ("psk", 16, 14.0), ("psk", 32, 18.0),
-                                           ("custom", 8, 7.0), ("psk", 8, 45.0)])
+                                           ("custom", 8, 7.0), ("psk", 8, 45.0), ("qam", 64, 12.0)])
 def test_generic_soft_demod_fast_kernel(gpu, kind, m, snr_db):
     """Round 6: PSK / arbitrary tables run demod_soft_gen_kernel -- table-driven exp / log, no hypot, the LLRs of a wave stored as one
-    contiguous run (any bits per symbol, odd ones too), an 8-byte store form for a caller's odd output pointer, point-by-point redo of
-    the symbols near the reference's underflow range.  Against the oracle on every symbol (1e-9; where the oracle is not finite the
+    contiguous run (any bits per symbol, odd ones too), point-by-point redo of the symbols near the reference's underflow range; a
+    caller's output pointer that is only 8-byte aligned is served by the literal kernel (separable constellations too: 64-QAM row).  Against the oracle on every symbol (1e-9; where the oracle is not finite the
     same non-finite value), for every size around the wave / block boundaries, the literal kernel ('libm') beside it, nothing written
     behind the result, and the same values through a misaligned output pointer.  45 dB: most symbols take the redo path."""
     from commpy_amd import _lib
     from commpy_amd.devicelink import DeviceBuf
-    from commpy_amd.modulation import Modem, PSKModem
+    from commpy_amd.modulation import Modem, PSKModem, QAMModem
     lib = _lib.load()
     rs = np.random.RandomState(m + int(snr_db))
-    md = PSKModem(m) if kind == "psk" else Modem(rs.randn(m) + 1j * rs.randn(m))
+    md = PSKModem(m) if kind == "psk" else QAMModem(m) if kind == "qam" else Modem(rs.randn(m) + 1j * rs.randn(m))
     nb = md.num_bits_symbol
     N0 = md.Es / 10 ** (snr_db / 10.0)
     h = md._device_handle()
@@ -461,7 +461,10 @@ def test_generic_soft_demod_fast_kernel(gpu, kind, m, snr_db):
                 _lib.demod_set_path(None)
             got = d_l.to_array((ns * nb + guard + 1,), np.float64)[off // 8:]
             d_l.free()
-            assert ("demod_soft_gen_kernel" in kern) == (mode is None), kern
+            fast = "demod_soft_sep_kernel" if kind == "qam" else "demod_soft_gen_kernel"
+            assert (fast in kern) == (off == 0 and (mode is None or kind == "qam")), kern
+            if off:
+                assert kern.startswith("demod_soft_kernel<"), kern
             assert np.all(got[ns * nb:] == -777.25), (ns, mode, off, kern)
             got = got[:ns * nb]
             assert np.array_equal(np.isfinite(got), fin), (ns, mode, off)
