@@ -126,7 +126,51 @@ def time_steps(lib, fn, steps, warmup):
     return tm.read()
 
 
-def entry(config, workload, kernel, ms, units, unit_name, alg_bytes, bound, parity, extra=None, dtype="f64"):
+PMC_DIR = os.path.join(ROOT, "profiles")
+PMC_ROUNDS = ("r06",)                                               # newest first; files <round>_oc_<name>_pmc.json
+
+
+def pmc_fields(name, mix):
+    """Counter figures for one entry from the committed rocprofv3 passes over THIS script (scripts/collect_pmc.py -- --which <name>;
+    round-5 verdict item 4): `traffic` = HBM bytes of one step = sum over the step's kernels of launches x (FETCH_SIZE x gfx950
+    correction + WRITE_SIZE) per launch, `valu.busy_frac` of the kernel a step spends most of its time in.  `mix` = {kernel-name
+    prefix: launches per step}.  Counters cannot be read inside an unprofiled run, so they are quoted only when the file was recorded
+    by a library built from exactly the sources of the one loaded now (cpx_build_id 'full' digest); otherwise the fields are null."""
+    import json
+    none = {"traffic": None, "traffic_source": None, "valu": None}
+    build = _lib.build_id()
+    for rnd in PMC_ROUNDS:
+        path = os.path.join(PMC_DIR, "%s_oc_%s_pmc.json" % (rnd, name))
+        try:
+            with open(path) as f:
+                tj = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if not build.get("full") or (tj.get("build_id") or {}).get("full") != build.get("full"):
+            continue
+        traffic, per_kernel, dom, dom_ns = 0.0, {}, None, -1.0
+        for prefix, launches in mix.items():
+            hit = [(k, v) for k, v in tj.get("kernels", {}).items() if k.startswith(prefix) and "traffic_bytes_per_launch" in v]
+            if not hit:
+                return none
+            k, v = max(hit, key=lambda kv: kv[1].get("duration_ns_avg", 0) * kv[1].get("calls", 1))
+            traffic += launches * v["traffic_bytes_per_launch"]
+            per_kernel[k] = {"launches_per_step": launches, "traffic_bytes_per_launch": v["traffic_bytes_per_launch"],
+                             "duration_us_under_profiler": v.get("duration_ns_avg", 0) / 1e3,
+                             "valu_busy_frac": (v.get("valu") or {}).get("busy_frac"),
+                             "lds_bank_conflict_frac_of_lds_active": (v["SQ_LDS_BANK_CONFLICT"] / v["SQ_ACTIVE_INST_LDS"]
+                                                                      if v.get("SQ_ACTIVE_INST_LDS") else None)}
+            if launches * v.get("duration_ns_avg", 0) > dom_ns:
+                dom, dom_ns = v, launches * v.get("duration_ns_avg", 0)
+        return {"traffic": traffic, "valu": dom.get("valu"), "per_kernel": per_kernel,
+                "traffic_source": "profiles/%s (rocprofv3 FETCH_SIZE x %.1f + WRITE_SIZE passes over benchmarks/other_configs.py "
+                                  "--which %s; git %s, build id %s = the loaded library's)"
+                                  % (os.path.basename(path), tj.get("fetch_scale", 2.0), name, str(tj.get("git_head"))[:12],
+                                     build.get("full"))}
+    return none
+
+
+def entry(config, workload, kernel, ms, units, unit_name, alg_bytes, bound, parity, extra=None, dtype="f64", pmc=None):
     avg = float(np.mean(ms))
     ach = alg_bytes / (avg * 1e-3) / 1e9
     d = {"config": config, "workload": workload, "kernel": kernel, "ms": avg, "ms_min": float(np.min(ms)),
@@ -135,6 +179,13 @@ def entry(config, workload, kernel, ms, units, unit_name, alg_bytes, bound, pari
          "roofline": {"bound": bound, "achieved": ach, "peak": HBM_PEAK, "unit": "GB/s", "frac": ach / HBM_PEAK,
                       "algorithmic_bytes_per_launch": int(alg_bytes)},
          "parity": parity}
+    if pmc is not None:
+        got = pmc_fields(*pmc)
+        d["roofline"]["traffic"] = got["traffic"]
+        d["roofline"]["traffic_source"] = got["traffic_source"]
+        d["roofline"]["valu"] = got["valu"]
+        if got.get("per_kernel"):
+            d["roofline"]["per_kernel"] = got["per_kernel"]
     if extra:
         d.update(extra)
     return d
@@ -187,8 +238,9 @@ def run_turbo(lib, steps, warmup, B=16384, n_check=64):
                   "ok": mism == 0, "oracle_s": round(time.perf_counter() - t0, 2)},
                  {"ber": float(np.mean(bits != msgs)),
                   "bytes_model": "SURVEY 8d: 3 x 8 N in + N out = 25 600 B per codeword; the decoder really moves ~40 x that "
-                                 "between its passes (profiles/*_turbo_c3_pmc.json), so this kernel is far from the HBM roofline "
-                                 "by construction"})
+                                 "between its passes (roofline.traffic), so this kernel is far from the HBM roofline "
+                                 "by construction"},
+                 pmc=("turbo", {"turbo_pass_kernel": 2 * n_iter, "turbo_init_kernel": 1, "turbo_final_kernel": 1}))
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
@@ -299,7 +351,8 @@ def run_config4(lib, steps, warmup, B=32768, ebn0=8.0, n_check=24, big_rotation_
                               "chain_info_bits_per_s": B * k / (float(np.mean(ms_demod + ms_dec)) * 1e-3),
                               "bytes_model": "SURVEY 8d resident model: 17 n B per block (llr in, out_llrs + dec_word out), whatever the "
                                              "iteration count; the decoder state lives in LDS",
-                              "survey_8d_streaming_formulation_bytes_per_launch": int(its.sum()) * (4 * E + 2 * n) * 8 + B * n * 17}))
+                              "survey_8d_streaming_formulation_bytes_per_launch": int(its.sum()) * (4 * E + 2 * n) * 8 + B * n * 17},
+                             pmc=("config4", {"ldpc_resident_kernel<": 1} if name == "MSA" else {"ldpc_resident_ratio_kernel": 1})))
             if name == "MSA":
                 ms_demod_chain = ms_demod
 
@@ -332,7 +385,8 @@ def run_config4(lib, steps, warmup, B=32768, ebn0=8.0, n_check=24, big_rotation_
                              "comes from HBM -- THIS is the HBM fraction" % (nrot, in_bytes >> 20, (nrot * in_bytes) >> 20))):
             out.append(entry("64-QAM soft demodulator, " + tag, "QAMModem(64).demodulate(y, 'soft', N0), %d symbols, Es/N0 of the "
                              "config-3 chain; %s" % (ns, wl), kname, ms, ns, "symbols", ns * 64, "valu (exp/log) + hbm", par,
-                             {"bytes_model": "SURVEY 8d: 16 + 8 x 6 = 64 B per symbol", "chain_demod_ms": float(np.mean(ms_demod_chain))}))
+                             {"bytes_model": "SURVEY 8d: 16 + 8 x 6 = 64 B per symbol", "chain_demod_ms": float(np.mean(ms_demod_chain))},
+                             pmc=("config4", {"demod_soft_sep_kernel<3": 1})))
     finally:
         dev.free()
     return out
@@ -350,7 +404,8 @@ def run_config5(lib, steps, warmup, total_bits=1e8, n_check=48):
     ebn0 = np.arange(0.0, 10.5, 1.0)
     snrs = ebn0 + 10 * math.log10(link.rate * link.modem.num_bits_symbol)
     per_point = int(total_bits / len(snrs))
-    marks = ("front end (bits, conv_encode, puncture, 64-QAM, AWGN, soft demod, depuncture) x 11 points", "viterbi_decode, all frames",
+    marks = ("front end (bits, conv_encode, puncture, 64-QAM, AWGN, soft demod, depuncture: %s) x 11 points"
+             % ("one fused launch per point" if link._front is not None else "seven kernels per point"), "viterbi_decode, all frames",
              "error count")
     state = {"bers": None, "tm": None, "i": 0}
 
@@ -392,9 +447,16 @@ def run_config5(lib, steps, warmup, total_bits=1e8, n_check=48):
         mism += int(np.sum(oracle.viterbi_decode(llr, link.trellis, None, "soft")[:link.nbits] != dec))
     # demodulator + depuncturing of the last point, first frames
     nf = 4
-    y = np.empty(nf * link.nsym, np.complex128)
-    _lib.check(lib.cpx_memcpy_d2h(_lib.ptr(y), bufs['sym'].ptr, y.nbytes))
     noise_std = math.sqrt(2.0 * link.modem.Es / (link.rate * 10 ** (float(snrs[-1]) / 10.0)))
+    fused = link._front is not None and "link_front" in link.front_last_kernel
+    if fused:
+        # the fused launch never stores the symbols: the first frames of the last point once more from the same counter-based streams,
+        # this time with them (front_sample) -- and the LLRs of that launch must be the sweep's own, bit for bit
+        _, y2, llr2 = link.front_sample(nf, float(snrs[-1]), link._calls)
+        y = y2.reshape(-1)
+    else:
+        y = np.empty(nf * link.nsym, np.complex128)
+        _lib.check(lib.cpx_memcpy_d2h(_lib.ptr(y), bufs['sym'].ptr, y.nbytes))
     want = oracle.demodulate(link.modem.constellation, y, "soft", noise_std ** 2).reshape(nf, -1)
     got = np.empty((nf, link.nde))
     _lib.check(lib.cpx_memcpy_d2h(_lib.ptr(got), ctypes.c_void_p(bufs['llr_all'].ptr.value + (len(snrs) - 1) * T * link.nde * 8), got.nbytes))
@@ -405,12 +467,16 @@ def run_config5(lib, steps, warmup, total_bits=1e8, n_check=48):
     else:
         full = want
     llr_err = float(np.max(np.abs(full - got)))
+    if fused and not np.array_equal(llr2.view(np.uint64), got.view(np.uint64)):
+        llr_err = float("inf")                                      # the regenerated launch is not the sweep's
     total = R * link.nbits
-    front_bytes = R * (link.nbits + link.ncoded + link.ntx + link.nsym * 16 * 3 + link.nsym * 6 * 8 * 2 + link.nde * 8)
+    front_bytes = (R * (link.nbits + link.nde * 8) if fused else
+                   R * (link.nbits + link.ncoded + link.ntx + link.nsym * 16 * 3 + link.nsym * 6 * 8 * 2 + link.nde * 8))
     alg = R * (link.nde * 8 + link.nbits)                            # decoder model, SURVEY 8d: LLRs in, bits out
     return entry("configs[4] (one GPU)", "Wifi80211 MCS 5 (64-QAM, K=7 (133,171) r=1/2 punctured to 2/3), frames of %d info bits, "
                  "Eb/N0 = 0..10 dB in 11 points, %d frames = %.3g info bits per sweep; a step = the whole device-resident sweep"
-                 % (link.nbits, R, total), kname, ms, total, "simulated info-bits", alg, "valu (Viterbi) + hbm (front end)",
+                 % (link.nbits, R, total), kname + (" <- " + link.front_last_kernel.split(" (")[0] if fused else ""), ms, total,
+                 "simulated info-bits", alg, "valu (Viterbi) + " + ("valu (front end)" if fused else "hbm (front end)"),
                  {"vs": "oracle viterbi_decode (convcode.py:661-749) on the LLRs of the last timed sweep; oracle demodulate "
                         "(modulation.py:100-141) + depuncturing (convcode.py:777-804) on the symbols of its last point",
                   "frames": len(rows), "mismatched_bits": mism, "demod_depuncture_max_abs_err": llr_err, "tolerance": 1e-5,
@@ -418,9 +484,13 @@ def run_config5(lib, steps, warmup, total_bits=1e8, n_check=48):
                  {"stage_ms": {m: float(np.mean(st[:, k])) for k, m in enumerate(marks)},
                   "ebn0_db": ebn0.tolist(), "ber": [float(b) for b in bers],
                   "bytes_model": "decoder only (SURVEY 8d): %d x 8 B of LLRs in + %d B of bits out per frame; the front end moves ~%d MB "
-                                 "more per sweep (messages, coded bits, symbols written / read / noised, LLRs written, gathered)"
-                                 % (link.nde, link.nbits, front_bytes >> 20),
-                  "reference_cpu": "Wifi80211(5).link_performance: ~1e3 info-bits/s on one core (BASELINE.md)"})
+                                 "per sweep (%s)"
+                                 % (link.nde, link.nbits, front_bytes >> 20, "fused launch: only the message bits and the decoder's "
+                                    "LLRs are written" if fused else "messages, coded bits, symbols written / read / noised, LLRs "
+                                    "written, gathered"),
+                  "reference_cpu": "Wifi80211(5).link_performance: ~1e3 info-bits/s on one core (BASELINE.md)"},
+                 pmc=("config5", {"viterbi_cw_fused_kernel": 1, "viterbi_wave_kernel": 1, "link_front_kernel": len(snrs),
+                                  "count_errors_kernel": 1}))
 
 
 def run_config1(lib, steps, warmup, B=1 << 20, n_check=3000):
@@ -446,18 +516,21 @@ def run_config1(lib, steps, warmup, B=1 << 20, n_check=3000):
                  B * (link.ncoded * 8 + link.L), "hbm + valu",
                  {"vs": "oracle viterbi_decode 'hard' (convcode.py:661-749) on the device-generated channel output", "codewords": len(idx),
                   "mismatched_bits": mism, "ok": mism == 0, "oracle_s": round(time.perf_counter() - t0, 2)},
+                 pmc=("config1", {"viterbi_cw_fused_kernel": 1}), extra=
                  {"ber": float(np.mean(dec[:, :64] != msg)),
                   "bytes_model": "SURVEY 8d form: %d float64 received values in + %d decoded bytes out per block" % (link.ncoded, link.L)})
 
 
-def run(lib, steps=20, warmup=3, scale=1.0, log=None):
-    """All entries; never raises for a failing workload (the headline line must not be lost): a failure becomes an entry with
-    `error`."""
+def run(lib, steps=20, warmup=3, scale=1.0, log=None, which=None):
+    """All entries (or the ones named in `which`); never raises for a failing workload (the headline line must not be lost): a
+    failure becomes an entry with `error`."""
     out = []
     for name, fn in (("turbo", lambda: [run_turbo(lib, steps, warmup, B=int(16384 * scale))]),
                      ("config4", lambda: run_config4(lib, steps, warmup, B=int(32768 * scale))),
                      ("config5", lambda: [run_config5(lib, steps, warmup, total_bits=1e8 * scale)]),
                      ("config1", lambda: [run_config1(lib, steps, warmup, B=int((1 << 20) * scale))])):
+        if which and name not in which:
+            continue
         t0 = time.perf_counter()
         try:
             got = fn()
@@ -478,8 +551,9 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--which", default="", help="comma list of turbo,config4,config5,config1 (default: all)")
     a = ap.parse_args()
     lib = _lib.load()
     _lib.require_device()
-    for e in run(lib, a.steps, a.warmup, a.scale):
+    for e in run(lib, a.steps, a.warmup, a.scale, which=set(a.which.split(",")) if a.which else None):
         print(json.dumps(e), flush=True)

@@ -104,6 +104,10 @@ SYMBOLS = {
     "cpx_bsc_dev": (c_int, [c_void_p, c_int64, c_double, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p]),
     "cpx_bec_dev": (c_int, [c_void_p, c_int64, c_double, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p]),
     "cpx_count_errors_dev": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
+    "cpx_link_front_create": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, POINTER(c_void_p)]),
+    "cpx_link_front_destroy": (c_int, [c_void_p]),
+    "cpx_link_front_run_dev": (c_int, [c_void_p, c_int64, c_double, c_double, c_double, c_double, c_uint64, c_uint64, c_uint64,
+                                       c_void_p, c_void_p, c_void_p, c_void_p]),
     "cpx_turbo_encode_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_int64, c_int, c_void_p]),
     "cpx_ldpc_encoder_create": (c_int, [c_void_p, c_int64, c_int64, POINTER(c_void_p)]),

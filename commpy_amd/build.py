@@ -26,7 +26,7 @@ def _hipcc():
     return "hipcc"
 
 
-HEADERS = [os.path.join(CSRC, h) for h in ("cpx_internal.h", "cpx_math.h", "demod_dev.h", "ldpc_dev.h", "viterbi_cw_asm.h")] + [os.path.join(INCLUDE, "commpy_amd.h")]
+HEADERS = [os.path.join(CSRC, h) for h in ("cpx_internal.h", "cpx_math.h", "demod_dev.h", "cpx_rng.h", "ldpc_dev.h", "viterbi_cw_asm.h")] + [os.path.join(INCLUDE, "commpy_amd.h")]
 OBJDIR = os.path.join(CSRC, "build")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden", "-Wall", "-Wno-unused-result",
          "-I", INCLUDE, "-I", CSRC]

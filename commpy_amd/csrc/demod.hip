@@ -22,6 +22,7 @@
 #include "cpx_internal.h"
 #include "cpx_math.h"
 #include "demod_dev.h"
+#include "cpx_rng.h"
 
 #include <algorithm>
 #include <atomic>
@@ -312,102 +313,44 @@ __global__ __launch_bounds__(DEMOD_BLOCK) void demod_soft_gen_kernel(const doubl
     flush(prev, prev + 64 <= Ns);
 }
 
-template <int NH, bool RCP, bool GP, bool TAB = false>
-__global__ __launch_bounds__(DEMOD_BLOCK) void demod_soft_sep_kernel(const double2 *__restrict__ y, int64_t Ns,
-                                                                     const double *__restrict__ axes, double noise_var,
-                                                                     double scale, double step_x, double step_y,
-                                                                     double *__restrict__ llr) {
-    const double ninv = -1.0 / noise_var;
-    constexpr int R = 1 << NH, NB = 2 * NH;
-    __shared__ double ax_s[2 * R];
-    __shared__ double tab_s[TAB ? 96 : 1];
-    for (int m = threadIdx.x; m < 2 * R; m += DEMOD_BLOCK) ax_s[m] = axes[m];
-    if (TAB)
-        for (int m = threadIdx.x; m < 96; m += DEMOD_BLOCK) tab_s[m] = DEMOD_TAB[m];
-    __syncthreads();
+// One symbol of an axis-separable constellation -> its NB = 2 NH LLRs (label bit b in out[b], unscaled): the arithmetic of
+// demod_soft_sep_kernel, shared with link_front_kernel (the transmit chain + channel fused in front of it, round 6).
+struct SepCtx {
+    const double *ax, *tab;                                        // LDS: [xs | ys] levels; exp / log tables (TAB)
+    double noise_var, ninv, step_x, step_y, c1x, c2x, Qx, c1y, c2y, Qy;
+};
+
+template <bool GP>
+__device__ __forceinline__ SepCtx sep_ctx(const double *ax, const double *tab, double noise_var, double step_x, double step_y) {
+    SepCtx c;
+    c.ax = ax; c.tab = tab; c.noise_var = noise_var; c.ninv = -1.0 / noise_var; c.step_x = step_x; c.step_y = step_y;
     // GP: per-call constants of the two axes (2 d / N0, d^2 / N0, Q)
-    const double c1x = GP ? 2.0 * step_x / noise_var : 0.0, c2x = GP ? step_x * step_x / noise_var : 0.0, Qx = GP ? exp(-2.0 * c2x) : 0.0;
-    const double c1y = GP ? 2.0 * step_y / noise_var : 0.0, c2y = GP ? step_y * step_y / noise_var : 0.0, Qy = GP ? exp(-2.0 * c2y) : 0.0;
-    // One symbol: cur -> NB LLRs in `pend` (two levels per axis: stored at once).
-    constexpr bool DEFER = !(GP && NH == 1);
-    double pend[DEFER ? NB : 1];
-    auto symbol = [&](const double2 cur, const int64_t i) __attribute__((always_inline)) {
-        double ex[R], ey[R], sx = 0.0, sy = 0.0;
-        bool redo = false;
-        if constexpr (GP && NH == 1) {
-            // Two levels per axis (QPSK / 4-QAM): LLR(bit of the real axis) = log(e[1] sy / (e[0] sy)) = (dx0^2 - dx1^2) / N0 -- no
-            // exp, no log, no division; the kernel is then bound by its 32 bytes per symbol.  Valid while every one of the four
-            // point probabilities exp(-(dx^2 + dy^2) / N0) the reference adds up is a normal number with room to spare: all four
-            // exponents below 650 (e^-650 = 1e-282).  Beyond that -- far outliers, Es/N0 above ~22 dB -- the reference's sums
-            // underflow in its own pattern (-inf, NaN) and the symbol is decided point by point below, as before.
-            const double dx0 = cur.x - ax_s[0], dx1 = cur.x - ax_s[1], dy0 = cur.y - ax_s[R], dy1 = cur.y - ax_s[R + 1];
-            const double qx0 = dx0 * dx0, qx1 = dx1 * dx1, qy0 = dy0 * dy0, qy1 = dy1 * dy1;
-            const double worst = RCP ? (fmax(qx0, qx1) + fmax(qy0, qy1)) * -ninv : (fmax(qx0, qx1) + fmax(qy0, qy1)) / noise_var;
-            double out[NB];
-            out[1] = RCP ? (qx1 - qx0) * ninv : (qx0 - qx1) / noise_var;           // label bit 1 = real-axis index
-            out[0] = RCP ? (qy1 - qy0) * ninv : (qy0 - qy1) / noise_var;           // label bit 0 = imag-axis index
-            if (!(worst < 650.0)) {
-                double num[NB] = {0.0, 0.0}, den[NB] = {0.0, 0.0};
-                for (int m = 0; m < R * R; m++) {
-                    const double h = hypot(cur.x - ax_s[m >> NH], cur.y - ax_s[R + (m & (R - 1))]);
-                    const double e = exp((-(h * h)) / noise_var);
-#pragma unroll
-                    for (int b = 0; b < NB; b++) {
-                        if ((m >> b) & 1) num[b] += e; else den[b] += e;
-                    }
-                }
-#pragma unroll
-                for (int b = 0; b < NB; b++) out[b] = fast_log(num[b] / den[b]);
-            }
-#pragma unroll
-            for (int b = 0; b < NB; b++)
-                if (i < Ns) llr[i * NB + NB - 1 - b] = out[b] * scale;                // (:137)
-            return;
-        }
-        if (GP) {
-            redo |= axis_gp<NH, RCP, TAB>(cur.x, ax_s, step_x, noise_var, ninv, c1x, c2x, Qx, tab_s, ex, sx);
-            redo |= axis_gp<NH, RCP, TAB>(cur.y, ax_s + R, step_y, noise_var, ninv, c1y, c2y, Qy, tab_s, ey, sy);
-        } else {
-#pragma unroll
-            for (int a = 0; a < R; a++) {
-                const double dx = cur.x - ax_s[a], dy = cur.y - ax_s[R + a];
-                ex[a] = exp(RCP ? (dx * dx) * ninv : (-(dx * dx)) / noise_var);
-                ey[a] = exp(RCP ? (dy * dy) * ninv : (-(dy * dy)) / noise_var);
-                sx += ex[a];
-                sy += ey[a];
-            }
-        }
-        double out[NB];
-#pragma unroll
-        for (int b = 0; b < NH; b++) {
-            double nx = 0.0, qx = 0.0, ny = 0.0, qy = 0.0;
-#pragma unroll
-            for (int a = 0; a < R; a++) {
-                if ((a >> b) & 1) { nx += ex[a]; ny += ey[a]; } else { qx += ex[a]; qy += ey[a]; }
-            }
-            // label bit NH+b = bit b of the real-axis index a, label bit b = bit b of the imag-axis index.  Round 4: the quotient by
-            // reciprocal + Newton and the logarithm without its special-value selects (cpx_math.h: -20 instructions per LLR) -- the
-            // symbols those would be needed for (a quotient outside (e^-600, e^600), zero, inf or NaN: exactly the |LLR| >= 600 /
-            // non-finite rule below, tested on the quotient) are decided point by point anyway
-            const double qa = div_nr(nx * sy, qx * sy), qb = div_nr(ny * sx, qy * sx);
-            redo |= !(qa > 2.7e-261 && qa < 3.7e260) || !(qb > 2.7e-261 && qb < 3.7e260);
-            out[NH + b] = TAB ? tab_log(qa, tab_s) : fast_log<false, true>(qa);
-            out[b] = TAB ? tab_log(qb, tab_s) : fast_log<false, true>(qb);
-        }
-        // The factorised sums are only as good as the reference's point-by-point ones while nothing is near the underflow
-        // threshold: an LLR beyond +-600 (or non-finite) means some sum of e^{-d^2/N0} terms is down among the denormals, where
-        // sum-of-products and product-of-sums round differently (measured at 29 dB: 0.9 apart at |LLR| = 740, a handful of
-        // inf / finite flips).  Such a symbol is redone the reference's way -- every point, hypot, division, increasing label --
-        // so that its rounding and its +-inf / NaN pattern are the reference's (modulation.py:125-137).
-#pragma unroll
-        for (int b = 0; b < NB; b++) redo |= !(fabs(out[b]) < 600.0);
-        if (redo) {
-            double num[NB], den[NB];
-#pragma unroll
-            for (int b = 0; b < NB; b++) { num[b] = 0.0; den[b] = 0.0; }
+    c.c1x = GP ? 2.0 * step_x / noise_var : 0.0; c.c2x = GP ? step_x * step_x / noise_var : 0.0; c.Qx = GP ? exp(-2.0 * c.c2x) : 0.0;
+    c.c1y = GP ? 2.0 * step_y / noise_var : 0.0; c.c2y = GP ? step_y * step_y / noise_var : 0.0; c.Qy = GP ? exp(-2.0 * c.c2y) : 0.0;
+    return c;
+}
+
+template <int NH, bool RCP, bool GP, bool TAB>
+__device__ __forceinline__ void sep_symbol(const SepCtx &c, const double2 cur, double (&out)[2 * NH]) {
+    constexpr int R = 1 << NH, NB = 2 * NH;
+    double ex[R], ey[R], sx = 0.0, sy = 0.0;
+    bool redo = false;
+    if constexpr (GP && NH == 1) {
+        // Two levels per axis (QPSK / 4-QAM): LLR(bit of the real axis) = log(e[1] sy / (e[0] sy)) = (dx0^2 - dx1^2) / N0 -- no
+        // exp, no log, no division; the kernel is then bound by its 32 bytes per symbol.  Valid while every one of the four
+        // point probabilities exp(-(dx^2 + dy^2) / N0) the reference adds up is a normal number with room to spare: all four
+        // exponents below 650 (e^-650 = 1e-282).  Beyond that -- far outliers, Es/N0 above ~22 dB -- the reference's sums
+        // underflow in its own pattern (-inf, NaN) and the symbol is decided point by point below, as before.
+        const double dx0 = cur.x - c.ax[0], dx1 = cur.x - c.ax[1], dy0 = cur.y - c.ax[R], dy1 = cur.y - c.ax[R + 1];
+        const double qx0 = dx0 * dx0, qx1 = dx1 * dx1, qy0 = dy0 * dy0, qy1 = dy1 * dy1;
+        const double worst = RCP ? (fmax(qx0, qx1) + fmax(qy0, qy1)) * -c.ninv : (fmax(qx0, qx1) + fmax(qy0, qy1)) / c.noise_var;
+        out[1] = RCP ? (qx1 - qx0) * c.ninv : (qx0 - qx1) / c.noise_var;           // label bit 1 = real-axis index
+        out[0] = RCP ? (qy1 - qy0) * c.ninv : (qy0 - qy1) / c.noise_var;           // label bit 0 = imag-axis index
+        if (!(worst < 650.0)) {
+            double num[NB] = {0.0, 0.0}, den[NB] = {0.0, 0.0};
             for (int m = 0; m < R * R; m++) {
-                const double h = hypot(cur.x - ax_s[m >> NH], cur.y - ax_s[R + (m & (R - 1))]);
-                const double e = exp((-(h * h)) / noise_var);
+                const double h = hypot(cur.x - c.ax[m >> NH], cur.y - c.ax[R + (m & (R - 1))]);
+                const double e = exp((-(h * h)) / c.noise_var);
 #pragma unroll
                 for (int b = 0; b < NB; b++) {
                     if ((m >> b) & 1) num[b] += e; else den[b] += e;
@@ -416,8 +359,88 @@ __global__ __launch_bounds__(DEMOD_BLOCK) void demod_soft_sep_kernel(const doubl
 #pragma unroll
             for (int b = 0; b < NB; b++) out[b] = fast_log(num[b] / den[b]);
         }
+        return;
+    }
+    if (GP) {
+        redo |= axis_gp<NH, RCP, TAB>(cur.x, c.ax, c.step_x, c.noise_var, c.ninv, c.c1x, c.c2x, c.Qx, c.tab, ex, sx);
+        redo |= axis_gp<NH, RCP, TAB>(cur.y, c.ax + R, c.step_y, c.noise_var, c.ninv, c.c1y, c.c2y, c.Qy, c.tab, ey, sy);
+    } else {
 #pragma unroll
-        for (int b = 0; b < NB; b++) pend[DEFER ? b : 0] = out[b] * scale;        // (:137)
+        for (int a = 0; a < R; a++) {
+            const double dx = cur.x - c.ax[a], dy = cur.y - c.ax[R + a];
+            ex[a] = exp(RCP ? (dx * dx) * c.ninv : (-(dx * dx)) / c.noise_var);
+            ey[a] = exp(RCP ? (dy * dy) * c.ninv : (-(dy * dy)) / c.noise_var);
+            sx += ex[a];
+            sy += ey[a];
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < NH; b++) {
+        double nx = 0.0, qx = 0.0, ny = 0.0, qy = 0.0;
+#pragma unroll
+        for (int a = 0; a < R; a++) {
+            if ((a >> b) & 1) { nx += ex[a]; ny += ey[a]; } else { qx += ex[a]; qy += ey[a]; }
+        }
+        // label bit NH+b = bit b of the real-axis index a, label bit b = bit b of the imag-axis index.  Round 4: the quotient by
+        // reciprocal + Newton and the logarithm without its special-value selects (cpx_math.h: -20 instructions per LLR) -- the
+        // symbols those would be needed for (a quotient outside (e^-600, e^600), zero, inf or NaN: exactly the |LLR| >= 600 /
+        // non-finite rule below, tested on the quotient) are decided point by point anyway
+        const double qa = div_nr(nx * sy, qx * sy), qb = div_nr(ny * sx, qy * sx);
+        redo |= !(qa > 2.7e-261 && qa < 3.7e260) || !(qb > 2.7e-261 && qb < 3.7e260);
+        out[NH + b] = TAB ? tab_log(qa, c.tab) : fast_log<false, true>(qa);
+        out[b] = TAB ? tab_log(qb, c.tab) : fast_log<false, true>(qb);
+    }
+    // The factorised sums are only as good as the reference's point-by-point ones while nothing is near the underflow
+    // threshold: an LLR beyond +-600 (or non-finite) means some sum of e^{-d^2/N0} terms is down among the denormals, where
+    // sum-of-products and product-of-sums round differently (measured at 29 dB: 0.9 apart at |LLR| = 740, a handful of
+    // inf / finite flips).  Such a symbol is redone the reference's way -- every point, hypot, division, increasing label --
+    // so that its rounding and its +-inf / NaN pattern are the reference's (modulation.py:125-137).
+#pragma unroll
+    for (int b = 0; b < NB; b++) redo |= !(fabs(out[b]) < 600.0);
+    if (redo) {
+        double num[NB], den[NB];
+#pragma unroll
+        for (int b = 0; b < NB; b++) { num[b] = 0.0; den[b] = 0.0; }
+        for (int m = 0; m < R * R; m++) {
+            const double h = hypot(cur.x - c.ax[m >> NH], cur.y - c.ax[R + (m & (R - 1))]);
+            const double e = exp((-(h * h)) / c.noise_var);
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+                if ((m >> b) & 1) num[b] += e; else den[b] += e;
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < NB; b++) out[b] = fast_log(num[b] / den[b]);
+    }
+}
+
+template <int NH, bool RCP, bool GP, bool TAB = false>
+__global__ __launch_bounds__(DEMOD_BLOCK) void demod_soft_sep_kernel(const double2 *__restrict__ y, int64_t Ns,
+                                                                     const double *__restrict__ axes, double noise_var,
+                                                                     double scale, double step_x, double step_y,
+                                                                     double *__restrict__ llr) {
+    constexpr int R = 1 << NH, NB = 2 * NH;
+    __shared__ double ax_s[2 * R];
+    __shared__ double tab_s[TAB ? 96 : 1];
+    for (int m = threadIdx.x; m < 2 * R; m += DEMOD_BLOCK) ax_s[m] = axes[m];
+    if (TAB)
+        for (int m = threadIdx.x; m < 96; m += DEMOD_BLOCK) tab_s[m] = DEMOD_TAB[m];
+    __syncthreads();
+    const SepCtx ctx = sep_ctx<GP>(ax_s, tab_s, noise_var, step_x, step_y);
+    // One symbol: cur -> NB LLRs in `pend` (two levels per axis: stored at once).
+    constexpr bool DEFER = !(GP && NH == 1);
+    double pend[DEFER ? NB : 1];
+    auto symbol = [&](const double2 cur, const int64_t i) __attribute__((always_inline)) {
+        double out[NB];
+        sep_symbol<NH, RCP, GP, TAB>(ctx, cur, out);
+        if constexpr (!DEFER) {
+#pragma unroll
+            for (int b = 0; b < NB; b++)
+                if (i < Ns) llr[i * NB + NB - 1 - b] = out[b] * scale;                // (:137)
+        } else {
+#pragma unroll
+            for (int b = 0; b < NB; b++) pend[b] = out[b] * scale;                    // (:137)
+        }
     };
     // The NB LLRs of a wave's 64 consecutive symbols are one contiguous run of 64 NB doubles.  Stored lane by lane (16 bytes per lane at
     // a 48-byte stride for 64-QAM) each store instruction touched 48 cache lines, and the kernel ran at the speed of that pattern alone:
@@ -468,6 +491,129 @@ __global__ __launch_bounds__(DEMOD_BLOCK) void demod_soft_sep_kernel(const doubl
         prev = base;
     }
     flush(prev, prev + 64 <= Ns);
+}
+
+// ---- the transmit chain and the channel fused in front of the separable soft demodulator (round 6) ------------------------
+// A Monte-Carlo link point used to be seven element-wise kernels -- random message bits, conv_encode, puncturing gather, modulate,
+// AWGN, soft demodulation, depuncturing gather (linksim.hip, devicelink.py) -- each writing an array the next one read back:
+// ~65 KB of HBM traffic per 1200-bit MCS-5 frame for 20.4 KB of results, 2.2 of the 5.2 ms of a BASELINE config-5 sweep.  Every stage
+// is a pure function of (frame, position) and of counter-based random numbers (cpx_rng.h), so ONE kernel can produce a symbol's LLRs
+// from nothing but its index: the lane of symbol (f, s)
+//   * regenerates the message bits its coded bits depend on (16 bits per Philox counter value: at most four values cover the window
+//     of a symbol -- checked when the plan is made) and stores the message bits it owns, [s nbits / nsym, (s + 1) nbits / nsym);
+//   * walks the feed-forward encoder table for the NB coded positions the puncturing keeps for it (convcode.py:531-550, :752-774),
+//     MSB-first label -> the constellation point (modulation.py:93-96), adds the noise of element f nsym + s (channels.py:37-55);
+//   * runs sep_symbol -- the arithmetic of demod_soft_sep_kernel, same template arguments the staged path would use (modulation.py:
+//     125-137);
+//   * the wave's 64 NB LLRs go through the LDS tile and leave in transmitted-bit order, each to its decoder-input position with
+//     the punctured positions behind it set to 0.0 (convcode.py:777-804): consecutive lanes, near-consecutive addresses.
+// The values are those of the staged kernels bit for bit (same generators, same streams, same arithmetic;
+// tests/test_devicelink_gpu.py::test_fused_front_end_equals_staged_chain); the only HBM traffic left is the results.
+struct LinkFrontParams {
+    int32_t T;                                                     // transmissions (T nsym < 2^31)
+    int nbits, mem;                                                // message bits per transmission; encoder memory
+    int ntx, nsym, nde;                                            // transmitted bits, symbols, decoder inputs per transmission
+    const int32_t *jo, *pg;                                        // [ntx], per transmitted bit t: (trellis step << 4) | output bit counted from the
+                                                                   // MSB of the code word;  decoder-input position | (punctured positions behind it << 26)
+    int lead;                                                      // punctured decoder-input positions in front of transmitted bit 0
+    const int32_t *out_tab;                                        // [2^mem][2] encoder outputs
+    const double *axes;
+    double step_x, step_y, noise_var, scale_re, scale_im, llr_scale;
+    uint64_t seed, stream_bits, stream_noise;
+    uint8_t *msg;
+    double *llr;
+    double2 *rx;                                                   // optional: the noisy symbols (tests)
+};
+
+template <int NH, bool RCP, bool GP, bool TAB>
+__global__ __launch_bounds__(DEMOD_BLOCK) void link_front_kernel(const LinkFrontParams p) {
+    constexpr int R = 1 << NH, NB = 2 * NH, WAVES = DEMOD_BLOCK / 64;
+    __shared__ double ax_s[2 * R];
+    __shared__ double tab_s[TAB ? 96 : 1];
+    __shared__ int32_t out_s[128];
+    __shared__ double xpose[WAVES * 64 * NB];
+    for (int m = threadIdx.x; m < 2 * R; m += DEMOD_BLOCK) ax_s[m] = p.axes[m];
+    if (TAB)
+        for (int m = threadIdx.x; m < 96; m += DEMOD_BLOCK) tab_s[m] = DEMOD_TAB[m];
+    for (int m = threadIdx.x; m < (2 << p.mem); m += DEMOD_BLOCK) out_s[m] = p.out_tab[m];
+    __syncthreads();
+    const SepCtx ctx = sep_ctx<GP>(ax_s, tab_s, p.noise_var, p.step_x, p.step_y);
+    const int lane = threadIdx.x & 63;
+    double *tile = xpose + (threadIdx.x >> 6) * 64 * NB;
+    const uint32_t Ns = (uint32_t)p.T * (uint32_t)p.nsym, stride = gridDim.x * DEMOD_BLOCK;
+    const int nbits = p.nbits, mem = p.mem, nsym = p.nsym;
+    const uint32_t fmask = (2u << mem) - 1u, smask = (1u << mem) - 1u;
+    for (uint32_t base = blockIdx.x * DEMOD_BLOCK + (threadIdx.x & ~63u); base < Ns; base += stride) {
+        // the wave's first symbol: transmission and position by one scalar division, the lanes count on from there
+        const uint32_t wbase = __builtin_amdgcn_readfirstlane(base);
+        const uint32_t f0 = wbase / (uint32_t)nsym;
+        const int s0 = (int)(wbase - f0 * (uint32_t)nsym);
+        const bool live = wbase + lane < Ns;
+        uint32_t f = f0;
+        int s = s0 + (live ? lane : 0);
+        while (s >= nsym) { s -= nsym; f++; }
+        // ---- message window: bit (j - lo) of `win` = message bit j of this transmission, 0 outside [0, nbits) ----
+        int jo[NB];
+#pragma unroll
+        for (int q = 0; q < NB; q++) jo[q] = p.jo[s * NB + q];
+        const int o0 = (int)((uint32_t)s * (uint32_t)nbits / (uint32_t)nsym), o1 = (int)(((uint32_t)s + 1u) * (uint32_t)nbits / (uint32_t)nsym);
+        int lo = (jo[0] >> 4) - mem, hi = jo[NB - 1] >> 4;
+        lo = lo < o0 ? lo : o0;
+        hi = hi > o1 - 1 ? hi : o1 - 1;
+        hi = hi > nbits - 1 ? nbits - 1 : hi;
+        const int lo0 = lo < 0 ? 0 : lo;                           // first real message bit of the window
+        const int64_t fbit = (int64_t)f * nbits;                   // index of the transmission's first message bit in the point's stream
+        const int64_t w0 = (fbit + lo0) >> 4, w1 = (fbit + hi) >> 4;
+        uint64_t win = 0;
+        for (int64_t w = w0; w <= w1; w++) win |= (uint64_t)message_bits16((uint64_t)w, p.stream_bits, p.seed) << (16 * (int)(w - w0));
+        win >>= (int)(fbit + lo0 - (w0 << 4));                      // bit 0 = message bit lo0
+        const int valid = hi - lo0 + 1;                            // (1 .. 49: checked when the plan was made)
+        win &= (~0ull) >> (64 - valid);
+        win <<= lo0 - lo;                                          // zeros for the positions in front of the transmission
+        if (live)
+            for (int j = o0; j < o1; j++) p.msg[fbit + j] = (uint8_t)((win >> (j - lo)) & 1u);
+        // ---- encoder at the kept positions (state = the previous mem bits, most recent = MSB), label, constellation point, noise ----
+        int label = 0;
+#pragma unroll
+        for (int q = 0; q < NB; q++) {
+            const int j = jo[q] >> 4;
+            const uint32_t fld = (uint32_t)(win >> (j - mem - lo)) & fmask;       // bits j - mem .. j
+            const int code = out_s[(fld & smask) * 2 + (fld >> mem)];
+            label = (label << 1) | ((code >> (jo[q] & 15)) & 1);                   // dec2bitarray(o, n), MSB first (:535)
+        }
+        const double2 x = make_double2(ax_s[label >> NH], ax_s[R + (label & (R - 1))]);
+        const double2 y = awgn_add(x, (uint64_t)f * (uint64_t)nsym + (uint64_t)s, p.scale_re, p.scale_im, p.seed, p.stream_noise);
+        if (p.rx && live) p.rx[wbase + lane] = y;
+        // ---- LLRs ----
+        double out[NB];
+        sep_symbol<NH, RCP, GP, TAB>(ctx, y, out);
+#pragma unroll
+        for (int b = 0; b < NB; b++) tile[lane * NB + NB - 1 - b] = out[b] * p.llr_scale;   // (:137)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- transmitted-bit order -> decoder-input positions, zeros behind (and, for bit 0, in front of) the kept ones ----
+        const uint32_t left = (Ns - wbase) * NB;                    // transmitted bits from the wave's first one to the end (>= 1)
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            const uint32_t e = k * 64 + lane;
+            if (e < left) {
+                uint32_t ff = f0;
+                int t = s0 * NB + (int)e;
+                while (t >= p.ntx) { t -= p.ntx; ff++; }
+                const int pg = p.pg[t];
+                const int P = pg & 0x3FFFFFF, gap = (int)((uint32_t)pg >> 26);
+                double *o = p.llr + (int64_t)ff * p.nde + P;
+                o[0] = tile[e];
+                for (int z = 1; z <= gap; z++) o[z] = 0.0;
+                if (t == 0)
+                    for (int z = 1; z <= p.lead; z++) o[-z] = 0.0;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
 }
 
 // ---- "fp32-fast" soft decisions (cpx_set_precision) ---------------------------------------------------------------------
@@ -967,6 +1113,115 @@ int cpx_demod_hard(const cpx_modem *m, const double *y_re_im, int64_t Ns, int8_t
     if ((rc = cpx_demod_hard_dev(m, din.as<double>(), Ns, dout.as<int8_t>(), st))) return rc;
     CPX_HIP(hipMemcpyAsync(bits, dout.p, out_bytes, hipMemcpyDeviceToHost, st));
     CPX_HIP(hipStreamSynchronize(st));
+    return CPX_OK;
+}
+
+// ---- fused link front end (link_front_kernel) ----------------------------------------------------------------------------------
+struct cpx_link_front {
+    __attribute__((visibility("hidden"))) ~cpx_link_front() = default;
+    const cpx_trellis *t;
+    const cpx_modem *m;
+    int device;
+    int nbits, mem, ntx, nsym, nde, lead;
+    int32_t *d_jo = nullptr, *d_pg = nullptr;
+};
+
+int cpx_link_front_create(const cpx_trellis *t, const cpx_modem *m, int64_t nbits, const int32_t *keep_idx, int64_t ntx,
+                          const int32_t *pos_idx, int64_t nde, cpx_link_front **out) {
+    CPX_TRACE("cpx_link_front_create");
+    CPX_REQUIRE(t && m && out, CPX_EINVAL, "link_front: null pointer");
+    if (int rcd = check_handle_device(t->device, "link_front")) return rcd;
+    if (int rcd = check_handle_device(m->device, "link_front")) return rcd;
+    CPX_REQUIRE(nbits > 0 && ntx > 0 && nde >= ntx, CPX_EINVAL, "link_front: sizes");
+    // what the kernel is built for -- anything else stays on the staged kernels (CPX_ELIMIT tells the caller so)
+    int mem = 0;
+    while ((1 << mem) < t->S) mem++;
+    bool ff = t->k == 1 && t->I == 2 && mem >= 1 && mem <= 6 && (1 << mem) == t->S && t->n >= 1 && t->n <= 8;
+    for (int s2 = 0; s2 < t->S && ff; s2++)
+        for (int b2 = 0; b2 < 2; b2++)
+            if (t->next_state[s2 * 2 + b2] != ((b2 << (mem - 1)) | (s2 >> 1))) ff = false;
+    if (!ff) { set_error("link_front: not a feed-forward k = 1 shift-register trellis of <= 64 states"); return CPX_ELIMIT; }
+    const int nb = m->nbits;
+    if (!m->separable || (nb != 2 && nb != 4 && nb != 6 && nb != 8)) { set_error("link_front: modem is not a square QAM of 4..256 points"); return CPX_ELIMIT; }
+    if ((nb >= 6 || nb == 2) && !m->gp) { set_error("link_front: axis levels are not equally spaced Gray levels"); return CPX_ELIMIT; }
+    if (ntx % nb) { set_error("link_front: %lld transmitted bits are not a whole number of symbols", (long long)ntx); return CPX_ELIMIT; }
+    const int64_t nsym = ntx / nb, ncoded = nbits * t->n;
+    if (nbits >= (1 << 24) || nde >= (1 << 26) || nbits * nsym >= (1ll << 31)) { set_error("link_front: frame too long"); return CPX_ELIMIT; }
+    // transmitted bit q comes from coded position keep[q] (increasing) and goes to decoder input pos[q] (increasing); the kernel's tables:
+    // jo[q] = (trellis step << 4) | shift of that output bit in the code word, pg[q] = pos | (punctured positions behind it << 26)
+    std::vector<int32_t> jo((size_t)ntx), pg((size_t)ntx);
+    int64_t last_c = -1, last_p = -1;
+    for (int64_t q = 0; q < ntx; q++) {
+        const int64_t c = keep_idx ? keep_idx[q] : q, pp = pos_idx ? pos_idx[q] : q;
+        CPX_REQUIRE(c > last_c && c < ncoded && pp > last_p && pp < nde, CPX_EINVAL, "link_front: index tables must increase and stay in range");
+        last_c = c; last_p = pp;
+        const int64_t next = q + 1 < ntx ? (pos_idx ? pos_idx[q + 1] : q + 1) : nde;
+        if (next - pp - 1 > 63) { set_error("link_front: more than 63 punctured positions in a row"); return CPX_ELIMIT; }
+        jo[(size_t)q] = (int32_t)(((c / t->n) << 4) | (t->n - 1 - c % t->n));
+        pg[(size_t)q] = (int32_t)((uint32_t)pp | ((uint32_t)(next > pp ? next - pp - 1 : 0) << 26));
+    }
+    const int64_t lead = pos_idx ? pos_idx[0] : 0;
+    // every symbol's message window must fit the kernel's 64-bit register (four Philox values of 16 bits)
+    for (int64_t sy = 0; sy < nsym; sy++) {
+        const int64_t c0 = keep_idx ? keep_idx[sy * nb] : sy * nb, c1 = keep_idx ? keep_idx[sy * nb + nb - 1] : sy * nb + nb - 1;
+        const int64_t lo = std::min<int64_t>(c0 / t->n - mem, sy * nbits / nsym), hi = std::min<int64_t>(std::max<int64_t>(c1 / t->n, (sy + 1) * nbits / nsym - 1), nbits - 1);
+        if (hi - lo + 1 > 49) { set_error("link_front: a symbol depends on %lld message bits (limit 49)", (long long)(hi - lo + 1)); return CPX_ELIMIT; }
+    }
+    cpx_link_front *lf = new (std::nothrow) cpx_link_front();
+    CPX_REQUIRE(lf, CPX_ENOMEM, "link_front: out of memory");
+    lf->t = t; lf->m = m; lf->device = t->device; lf->nbits = (int)nbits; lf->mem = mem; lf->ntx = (int)ntx; lf->nsym = (int)nsym; lf->nde = (int)nde;
+    lf->lead = (int)lead;
+    auto up = [&](const std::vector<int32_t> &h, int32_t **d) -> int {
+        if (hipMalloc((void **)d, sizeof(int32_t) * h.size()) != hipSuccess) return CPX_ENOMEM;
+        return hipMemcpy(*d, h.data(), sizeof(int32_t) * h.size(), hipMemcpyHostToDevice) == hipSuccess ? CPX_OK : CPX_EHIP;
+    };
+    int rc = up(jo, &lf->d_jo);
+    if (!rc) rc = up(pg, &lf->d_pg);
+    if (rc) { cpx_link_front_destroy(lf); set_error("link_front: table upload failed"); return rc; }
+    *out = lf;
+    return CPX_OK;
+}
+
+int cpx_link_front_destroy(cpx_link_front *lf) {
+    if (!lf) return CPX_OK;
+    if (lf->d_jo) (void)hipFree(lf->d_jo);
+    if (lf->d_pg) (void)hipFree(lf->d_pg);
+    delete lf;
+    return CPX_OK;
+}
+
+int cpx_link_front_run_dev(const cpx_link_front *lf, int64_t T, double noise_var, double scale_re, double scale_im, double llr_scale,
+                           uint64_t seed, uint64_t stream_bits, uint64_t stream_noise, uint8_t *d_msg, double *d_llr, double *d_rx_re_im,
+                           void *stream) {
+    CPX_TRACE("cpx_link_front_run_dev");
+    CPX_REQUIRE(lf && (T == 0 || (d_msg && d_llr)), CPX_EINVAL, "link_front: null pointer");
+    if (int rcd = check_handle_device(lf->device, "link_front")) return rcd;
+    CPX_REQUIRE(T >= 0, CPX_EINVAL, "link_front: negative size");
+    if (T == 0) return CPX_OK;
+    if (T * (int64_t)lf->nsym >= (1ll << 31) / 8) { set_error("link_front: %lld transmissions in one call (limit: 2^28 symbols)", (long long)T); return CPX_ELIMIT; }
+    const cpx_modem *m = lf->m;
+    // the demodulator variant the staged path would run for this modem and mode (cpx_demod_soft_scaled_dev); other modes: staged
+    const bool rcp = noise_var > 1e-290 && noise_var < 1e290;
+    if (!rcp || precision_fast() || demod_mode() != 0) {
+        set_error("link_front: only the default float64 demodulator path is fused (noise_var %g, mode %d)", noise_var, demod_mode());
+        return CPX_ELIMIT;
+    }
+    LinkFrontParams p;
+    p.T = (int32_t)T; p.nbits = lf->nbits; p.mem = lf->mem; p.ntx = lf->ntx; p.nsym = lf->nsym; p.nde = lf->nde;
+    p.jo = lf->d_jo; p.pg = lf->d_pg; p.lead = lf->lead; p.out_tab = lf->t->d_out; p.axes = m->d_axes;
+    p.step_x = m->gp_step[0]; p.step_y = m->gp_step[1]; p.noise_var = noise_var; p.scale_re = scale_re; p.scale_im = scale_im;
+    p.llr_scale = llr_scale; p.seed = seed; p.stream_bits = stream_bits; p.stream_noise = stream_noise;
+    p.msg = d_msg; p.llr = d_llr; p.rx = reinterpret_cast<double2 *>(d_rx_re_im);
+    dim3 grid(grid_for(T * (int64_t)lf->nsym)), block(DEMOD_BLOCK);
+    hipStream_t st = pick_stream(stream);
+    switch (m->nbits / 2) {                                       // <NH, RCP, GP, TAB> as in cpx_demod_soft_scaled_dev's default mode
+        case 1: hipLaunchKernelGGL((link_front_kernel<1, true, true, false>), grid, block, 0, st, p); break;
+        case 2: hipLaunchKernelGGL((link_front_kernel<2, true, false, false>), grid, block, 0, st, p); break;
+        case 3: hipLaunchKernelGGL((link_front_kernel<3, true, true, true>), grid, block, 0, st, p); break;
+        default: hipLaunchKernelGGL((link_front_kernel<4, true, true, true>), grid, block, 0, st, p); break;
+    }
+    CPX_HIP(hipGetLastError());
+    note_kernel("link_front_kernel<%d> (bits, conv_encode, puncture, modulate, AWGN, soft demod, depuncture fused)", m->nbits / 2);
     return CPX_OK;
 }
 

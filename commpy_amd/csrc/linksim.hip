@@ -11,6 +11,7 @@
 // the reference goldens; the random stages are statistical (different generator than the reference).
 // All kernels are byte/element-wise streams: HBM bound, one codeword row or one element per lane.
 #include "cpx_internal.h"
+#include "cpx_rng.h"
 
 using namespace cpx;
 
@@ -23,31 +24,6 @@ unsigned ls_grid(int64_t n) {
     if (blocks > 256 * 32) blocks = 256 * 32;
     if (blocks < 1) blocks = 1;
     return (unsigned)blocks;
-}
-
-// ---- Philox4x32-10 counter-based generator (Salmon et al., SC'11) -------------------------------------------
-struct Philox {
-    uint32_t c[4];
-};
-
-__device__ __forceinline__ Philox philox4x32_10(uint64_t ctr_lo, uint64_t ctr_hi, uint64_t key) {
-    uint32_t c0 = (uint32_t)ctr_lo, c1 = (uint32_t)(ctr_lo >> 32), c2 = (uint32_t)ctr_hi, c3 = (uint32_t)(ctr_hi >> 32);
-    uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; r++) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    return Philox{{c0, c1, c2, c3}};
-}
-
-// uniform in (0, 1] with 53 bits
-__device__ __forceinline__ double u01(uint32_t hi, uint32_t lo) {
-    const uint64_t m = ((uint64_t)(hi >> 5) << 26) | (uint64_t)(lo >> 6);
-    return ((double)m + 1.0) * (1.0 / 9007199254740992.0);
 }
 
 // ---- random message bits ------------------------------------------------------------------------------------
@@ -188,14 +164,7 @@ __global__ __launch_bounds__(LS_BLOCK) void awgn_kernel(const double2 *__restric
                                                         double scale_im, uint64_t seed, uint64_t stream,
                                                         double2 *__restrict__ y) {
     for (int64_t i = (int64_t)blockIdx.x * LS_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * LS_BLOCK) {
-        const Philox r = philox4x32_10((uint64_t)i, stream, seed);
-        const double u1 = u01(r.c[0], r.c[1]), u2 = u01(r.c[2], r.c[3]);
-        const double rad = sqrt(-2.0 * log(u1));
-        double sn, cs;
-        sincos(6.283185307179586476925286766559 * u2, &sn, &cs);
-        double2 v = x[i];
-        v.x += scale_re * rad * cs;
-        v.y += scale_im * rad * sn;
+        const double2 v = awgn_add(x[i], (uint64_t)i, scale_re, scale_im, seed, stream);
         y[i] = v;
     }
 }

@@ -359,7 +359,10 @@ class DeviceWifiLink:
     like links.py:212-214), ``frame_aggregation`` the number of frames per transmission.
     """
 
-    def __init__(self, mcs, send_chunk=600, frame_aggregation=1, generator_matrix=None, seed=1):
+    def __init__(self, mcs, send_chunk=600, frame_aggregation=1, generator_matrix=None, seed=1, fused=None):
+        """``fused``: None = use the fused front-end kernel (``cpx_link_front_*``: bits ... depuncturing in one launch per point)
+        where the library supports the combination, the staged kernels otherwise; False = staged kernels only; True = fused or
+        ``ValueError``.  Both produce the same bits and LLRs (same counter-based streams, same arithmetic)."""
         self.lib = _lib.load()
         _lib.require_device()
         self.wifi = Wifi80211(mcs, generator_matrix=generator_matrix)
@@ -392,6 +395,73 @@ class DeviceWifiLink:
             raise ValueError('send_chunk does not give an integer number of symbols')
         self.nsym = self.ntx // nb
         self._bufs = {}
+        self._front = None
+        self.keep_rx = False                                          # tests: the fused launch also stores the noisy symbols (bufs['rx'])
+        self.front_reason = 'fused=False'
+        if fused is None or fused:
+            self._make_front(bool(fused))
+
+    def _make_front(self, required):
+        """The plan of the fused front end, or the reason why the staged kernels stay (``front_reason``)."""
+        pos = None
+        if self.de_idx is not None:
+            mapped = np.flatnonzero(self.de_idx >= 0).astype(np.int32)      # decoder-input position of transmitted bit t
+            if len(mapped) != self.ntx:
+                self.front_reason = 'depuncturing leaves %d of %d transmitted bits unused' % (self.ntx - len(mapped), self.ntx)
+                if required:
+                    raise ValueError(self.front_reason)
+                return
+            pos = np.ascontiguousarray(mapped)
+        keep = None if self.keep_idx is None else np.ascontiguousarray(self.keep_idx, dtype=np.int32)
+        h = ctypes.c_void_p()
+        rc = self.lib.cpx_link_front_create(self.trellis._device_handle(), self.modem._device_handle(), self.nbits,
+                                            None if keep is None else _lib.ptr(keep), self.ntx,
+                                            None if pos is None else _lib.ptr(pos), self.nde, ctypes.byref(h))
+        if rc == _lib.CPX_ELIMIT and not required:
+            self.front_reason = _lib.last_error()
+            return
+        _lib.check(rc)
+        self._front = h
+        self.front_reason = None
+
+    def _front_end(self, T, noise_std, calls, d_msg, d_llr, d_rx=None):
+        """One launch for the stages in front of the decoder; False when this call has to take the staged kernels (a
+        non-default demodulator mode or precision)."""
+        self.front_last_kernel = 'staged'
+        if self._front is None:
+            return False
+        rc = self.lib.cpx_link_front_run_dev(self._front, T, noise_std ** 2, noise_std * 0.5, noise_std * 0.5, 1.0, self.seed,
+                                             2 * calls, 2 * calls + 1, d_msg, d_llr, d_rx, None)
+        if rc == _lib.CPX_ELIMIT:
+            return False
+        _lib.check(rc)
+        self.front_last_kernel = _lib.last_kernel()
+        return True
+
+    def front_sample(self, nf, snr_db, calls):
+        """Tests / benchmarks: the first ``nf`` transmissions of the point that was generated with call number ``calls`` at ``snr_db``,
+        once more, this time with the noisy symbols stored -- (msg [nf, nbits] uint8, rx [nf, nsym] complex, llr [nf, nde] float64).
+        The streams are counter based, so these are the values the sweep's own launch produced for those transmissions."""
+        if self._front is None:
+            raise ValueError('no fused front end: ' + str(self.front_reason))
+        noise_std = math.sqrt(2.0 * self.modem.Es / (self.rate * 10 ** (float(snr_db) / 10.0)))
+        d_msg, d_llr, d_rx = DeviceBuf(nf * self.nbits), DeviceBuf(nf * self.nde * 8), DeviceBuf(nf * self.nsym * 16)
+        try:
+            if not self._front_end(nf, noise_std, calls, d_msg.ptr, d_llr.ptr, d_rx.ptr):
+                raise ValueError('the fused front end refused this call: ' + _lib.last_error())
+            _lib.check(self.lib.cpx_stream_sync(None))
+            return (d_msg.to_array((nf, self.nbits), np.uint8), d_rx.to_array((nf, self.nsym), np.complex128),
+                    d_llr.to_array((nf, self.nde), np.float64))
+        finally:
+            d_msg.free(); d_llr.free(); d_rx.free()
+
+    def __del__(self):
+        try:
+            if self._front is not None:
+                self.lib.cpx_link_front_destroy(self._front)
+                self._front = None
+        except Exception:
+            pass
 
     # -- buffers --------------------------------------------------------------------------------------------
     def _alloc(self, T):
@@ -414,6 +484,26 @@ class DeviceWifiLink:
         self._bufs = bufs
         return bufs
 
+    def _staged_front(self, T, noise_std, calls, bufs):
+        """The stages in front of the decoder as one kernel each (what the fused kernel replaces)."""
+        lib, ck = self.lib, _lib.check
+        h_tr, h_md = self.trellis._device_handle(), self.modem._device_handle()
+        ck(lib.cpx_random_bits_dev(bufs['msg'].ptr, T * self.nbits, self.seed, 2 * calls, None))
+        ck(lib.cpx_conv_encode_batch_dev(h_tr, bufs['msg'].ptr, T, self.nbits, 0, 0, bufs['coded'].ptr, self.ncoded, None))
+        tx = bufs['coded']
+        if self.keep_idx is not None:
+            ck(lib.cpx_gather_u8_dev(bufs['coded'].ptr, T, self.ncoded, bufs['keep_idx'].ptr, self.ntx, bufs['tx'].ptr, None))
+            tx = bufs['tx']
+        ck(lib.cpx_modulate_dev(h_md, tx.ptr, T * self.nsym, bufs['sym'].ptr, None))
+        ck(lib.cpx_awgn_dev(bufs['sym'].ptr, T * self.nsym, noise_std * 0.5, noise_std * 0.5, self.seed, 2 * calls + 1,
+                            bufs['rx'].ptr, None))
+        ck(lib.cpx_demod_soft_dev(h_md, bufs['rx'].ptr, T * self.nsym, noise_std ** 2, bufs['llr'].ptr, None))
+        llr, length = bufs['llr'], self.ntx
+        if self.keep_idx is not None:
+            ck(lib.cpx_gather_f64_dev(bufs['llr'].ptr, T, self.ntx, bufs['de_idx'].ptr, self.nde, bufs['llr_de'].ptr, None))
+            llr, length = bufs['llr_de'], self.nde
+        return llr, length
+
     # -- one batch of T transmissions at one SNR ----------------------------------------------------------------
     def run_batch(self, snr_db, T):
         """Simulate ``T`` transmissions; returns int32 ``[T, frame_aggregation]`` bit errors per frame."""
@@ -424,20 +514,11 @@ class DeviceWifiLink:
         noise_std = math.sqrt(2.0 * self.modem.Es / (self.rate * 10 ** (snr_db / 10.0)))
         self._calls += 1
         ck = _lib.check
-        ck(lib.cpx_random_bits_dev(bufs['msg'].ptr, T * self.nbits, self.seed, 2 * self._calls, None))
-        ck(lib.cpx_conv_encode_batch_dev(h_tr, bufs['msg'].ptr, T, self.nbits, 0, 0, bufs['coded'].ptr, self.ncoded, None))
-        tx = bufs['coded']
-        if self.keep_idx is not None:
-            ck(lib.cpx_gather_u8_dev(bufs['coded'].ptr, T, self.ncoded, bufs['keep_idx'].ptr, self.ntx, bufs['tx'].ptr, None))
-            tx = bufs['tx']
-        ck(lib.cpx_modulate_dev(h_md, tx.ptr, T * self.nsym, bufs['sym'].ptr, None))
-        ck(lib.cpx_awgn_dev(bufs['sym'].ptr, T * self.nsym, noise_std * 0.5, noise_std * 0.5, self.seed, 2 * self._calls + 1,
-                            bufs['rx'].ptr, None))
-        ck(lib.cpx_demod_soft_dev(h_md, bufs['rx'].ptr, T * self.nsym, noise_std ** 2, bufs['llr'].ptr, None))
-        llr, length = bufs['llr'], self.ntx
-        if self.keep_idx is not None:
-            ck(lib.cpx_gather_f64_dev(bufs['llr'].ptr, T, self.ntx, bufs['de_idx'].ptr, self.nde, bufs['llr_de'].ptr, None))
-            llr, length = bufs['llr_de'], self.nde
+        if self._front_end(T, noise_std, self._calls, bufs['msg'].ptr, (bufs['llr_de'] if self.keep_idx is not None else bufs['llr']).ptr,
+                           bufs['rx'].ptr if self.keep_rx else None):
+            llr, length = (bufs['llr_de'], self.nde) if self.keep_idx is not None else (bufs['llr'], self.ntx)
+        else:
+            llr, length = self._staged_front(T, noise_std, self._calls, bufs)
         m = self.trellis.total_memory
         L = int(length * 0.5)
         n_steps = int((L + m) / 1) - 1
@@ -501,6 +582,8 @@ class DeviceWifiLink:
             self._calls += 1
             msg = at(bufs['msg'], i * T * self.nbits)
             llr_out = at(bufs['llr_all'], i * T * self.nde * 8)
+            if self._front_end(T, noise_std, self._calls, msg, llr_out):
+                continue
             ck(lib.cpx_random_bits_dev(msg, T * self.nbits, self.seed, 2 * self._calls, None))
             ck(lib.cpx_conv_encode_batch_dev(h_tr, msg, T, self.nbits, 0, 0, bufs['coded'].ptr, self.ncoded, None))
             tx = bufs['coded']

@@ -324,6 +324,29 @@ int cpx_bec_dev(const uint8_t *d_bits, int64_t n, double p_e, uint64_t seed, uin
 int cpx_count_errors_dev(const uint8_t *d_msg, int64_t msg_stride, const uint8_t *d_dec, int64_t dec_stride,
                          int64_t B, int64_t nchunks, int64_t chunk, int32_t *d_errs, void *stream);
 
+/* ---- the stages of one Monte-Carlo point in front of the decoder as ONE kernel (round 6; same SURVEY 8f rows) ----------------------
+ * random bits -> conv_encode ('cont') -> puncturing -> Modem.modulate -> AWGN -> Modem.demodulate('soft') -> depuncturing
+ * (links.py:229-250, wifi80211.py:178-206, convcode.py:475-558, :752-804, modulation.py:79-141, channels.py:37-55) for T
+ * transmissions of `nbits` message bits, without the five intermediate arrays: every lane produces one symbol's LLRs from its index
+ * and the counter-based streams (seed, stream_bits) / (seed, stream_noise).  The results equal those of the staged calls
+ * cpx_random_bits_dev(d_msg, T*nbits, seed, stream_bits) ... cpx_gather_f64_dev bit for bit.
+ *   cpx_link_front_create   HOST tables: keep_idx[ntx] = coded position of transmitted bit t (NULL: no puncturing), pos_idx[ntx] =
+ *                           decoder-input position of transmitted bit t among nde (NULL: t; the others are set to 0.0), both
+ *                           increasing.  CPX_ELIMIT when the combination is not what the kernel is built for (feed-forward k = 1
+ *                           trellis of <= 64 states, square QAM of 4..256 points with equally spaced Gray levels, a symbol depending on
+ *                           <= 49 message bits): the caller keeps the staged calls.  The handle refers to `t` and `m`: destroy it first.
+ *   cpx_link_front_run_dev  d_msg [T][nbits] uint8, d_llr [T][nde] float64 (LLR * llr_scale), d_rx_re_im optional [T][ntx/nb][2]
+ *                           noisy symbols (NULL: not stored).  scale_re / scale_im as cpx_awgn_dev.  CPX_ELIMIT in the non-default
+ *                           demodulator modes (cpx_demod_set_path, fp32-fast) and when 1 / noise_var is not a normal number.
+ */
+typedef struct cpx_link_front cpx_link_front;
+int cpx_link_front_create(const cpx_trellis *t, const cpx_modem *m, int64_t nbits, const int32_t *keep_idx, int64_t ntx,
+                          const int32_t *pos_idx, int64_t nde, cpx_link_front **out);
+int cpx_link_front_destroy(cpx_link_front *lf);
+int cpx_link_front_run_dev(const cpx_link_front *lf, int64_t T, double noise_var, double scale_re, double scale_im,
+                           double llr_scale, uint64_t seed, uint64_t stream_bits, uint64_t stream_noise, uint8_t *d_msg,
+                           double *d_llr, double *d_rx_re_im, void *stream);
+
 /* ---- channel encoders on the device ("next" rows) --------------------------------
  * Device pointers, asynchronous on `stream`; bit-exact integer work.
  *   cpx_turbo_encode_batch_dev  turbo_encode(msg, trellis1, trellis2, interleaver) commpy/channelcoding/turbo.py:14-59

@@ -7,7 +7,7 @@
 #             c(alibration of FETCH_SIZE / WRITE_SIZE on known byte counts, scripts/micro/fetch_calib.py)
 #             f(uzz: scripts/fuzz_gpu.py for 90 s) L(ong run: bench.py --steps 500) T(olerance table of the sum-product decoder)
 #             o(ther_configs on their own) h(igh-SNR map_decode probe + PMC of the literal kernel) R(ow-vs-row sum-product table)
-#             P(robe check: does the shader-clock probe disturb what it measures)
+#             P(robe check: does the shader-clock probe disturb what it measures) O(ther_configs PMC passes, one workload at a time)
 TAG=${1:-r05}
 SEC=${2:-tsbdklvu}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -63,6 +63,13 @@ if [[ $SEC == *T* ]]; then
 fi
 if [[ $SEC == *o* ]]; then
   timeout 600 python benchmarks/other_configs.py --steps 20 --warmup 5 2>&1 | grep "^{" | tee $OUT/bench_other_configs.jsonl | cut -c1-260
+fi
+if [[ $SEC == *O* ]]; then
+  # counters for what the driver times (round-5 verdict item 4): PMC passes over benchmarks/other_configs.py itself, one workload at a time
+  for w in turbo config4 config5 config1; do
+    timeout 1500 python scripts/collect_pmc.py --out $OUT --name oc_$w --match _kernel --fetch-scale 2 -- \
+        python $R/benchmarks/other_configs.py --which $w --steps 10 --warmup 3 2>&1 | tail -3 | cut -c1-300
+  done
 fi
 if [[ $SEC == *h* ]]; then
   timeout 300 python scripts/micro/map_highsnr_probe.py 2>&1 | tee $OUT/map_highsnr_probe.txt

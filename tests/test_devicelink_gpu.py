@@ -115,6 +115,89 @@ def test_device_wifi_link_batched_sweep_noiseless_and_equal_paths(gpu):
     assert np.array_equal(res["wave"], res["auto"]) and res["auto"][0] > 0
 
 
+@pytest.mark.parametrize("mcs,gens,T,snr", [(3, None, 37, 9.0), (4, [[0o133, 0o171]], 5, 12.0), (5, None, 129, 14.0),
+                                            (5, [[0o133, 0o171]], 64, 3.0), (7, [[0o133, 0o171]], 21, 17.0),
+                                            (8, [[0o133, 0o171]], 11, 22.0), (9, None, 3, 60.0)])
+def test_fused_front_end_equals_staged_chain(gpu, mcs, gens, T, snr):
+    """Round 6: link_front_kernel (random bits, conv_encode, puncturing, modulate, AWGN, soft demodulation, depuncturing in one
+    launch) against the seven staged kernels on the same counter-based streams: message bits, noisy symbols and decoder-input LLRs
+    (punctured positions = 0.0 included) bit for bit, hence the same decoded bits and error counts; the LLRs also against the oracle's
+    demodulator + depuncturing on those symbols (modulation.py:100-141, convcode.py:777-804), and the transmitted symbols against the
+    host encoder / puncturing / modulator on those message bits (convcode.py:475-558, :752-774, modulation.py:79-98)."""
+    import oracle
+    from commpy_amd import _lib
+    from commpy_amd.channelcoding import conv_encode_batch
+    from commpy_amd.channelcoding.convcode import puncture_keep_mask
+    from commpy_amd.devicelink import DeviceWifiLink
+    got = {}
+    for fused in (True, False):
+        link = DeviceWifiLink(mcs, 1200, frame_aggregation=1, generator_matrix=gens, seed=17, fused=fused)
+        link.keep_rx = True
+        assert (link._front is not None) == fused, link.front_reason
+        errs = link.run_batch(snr, T)
+        assert ("link_front_kernel" in link.front_last_kernel) == fused, link.front_last_kernel
+        b = link._bufs
+        nb = link.modem.num_bits_symbol
+        llr = (b['llr_de'] if link.keep_idx is not None else b['llr']).to_array((T, link.nde), np.float64)
+        got[fused] = (errs, b['msg'].to_array((T, link.nbits), np.uint8), b['rx'].to_array((T, link.nsym), np.complex128), llr,
+                      b['dec'].to_array((T, link.nbits), np.uint8))
+    f, s = got[True], got[False]
+    assert np.array_equal(f[1], s[1])                                                  # message bits
+    assert np.array_equal(f[2].view(np.uint64), s[2].view(np.uint64))                  # noisy symbols, bit patterns
+    assert np.array_equal(f[3].view(np.uint64), s[3].view(np.uint64))                  # LLRs and zeros, bit patterns
+    assert np.array_equal(f[4], s[4]) and np.array_equal(f[0], s[0])
+    # the chain itself: oracle demodulator + depuncturing on the fused launch's symbols
+    noise_var = 2.0 * link.modem.Es / (link.rate * 10 ** (snr / 10.0))
+    want = oracle.demodulate(link.modem.constellation, f[2].reshape(-1), "soft", noise_var).reshape(T, -1)
+    full = np.zeros((T, link.nde))
+    if link.de_idx is not None:
+        keep = link.de_idx >= 0
+        full[:, keep] = want[:, link.de_idx[keep]]
+    else:
+        full = want
+    fin = np.isfinite(full)
+    assert np.array_equal(fin, np.isfinite(f[3])) and np.max(np.abs(full[fin] - f[3][fin])) < 1e-5
+    # noise-free part: symbols at 300 dB are the modulated, punctured code bits of the stored messages
+    clean = DeviceWifiLink(mcs, 1200, generator_matrix=gens, seed=17, fused=True)
+    clean.keep_rx = True
+    clean.run_batch(300.0, T)
+    cb = clean._bufs
+    msg = cb['msg'].to_array((T, clean.nbits), np.uint8)
+    coded = conv_encode_batch(msg, clean.trellis, 'cont')
+    pvec = clean.wifi._get_puncture_matrix(*clean.coding)
+    if pvec is not None:
+        coded = coded[:, puncture_keep_mask(coded.shape[1], pvec)]
+    sym = clean.modem.modulate(coded.reshape(-1)).reshape(T, -1)
+    assert np.max(np.abs(cb['rx'].to_array((T, clean.nsym), np.complex128) - sym)) < 1e-12
+
+
+def test_fused_front_end_sweep_and_fallbacks(gpu):
+    """The batched sweep gives the same BER per point through the fused launch and the staged kernels; PSK modems (MCS 0-2), recursive
+    or non-shift-register trellises are refused by cpx_link_front_create with CPX_ELIMIT and the link keeps the staged kernels; a
+    non-default demodulator mode makes a fused link take the staged kernels for that call."""
+    from commpy_amd import _lib
+    from commpy_amd.devicelink import DeviceWifiLink
+    snrs = np.array([13.0, 15.0, 17.0])
+    a = DeviceWifiLink(5, 1200, generator_matrix=[[0o133, 0o171]], seed=9, fused=True).ber_sweep_batched(snrs, 1200 * 3000)
+    b = DeviceWifiLink(5, 1200, generator_matrix=[[0o133, 0o171]], seed=9, fused=False).ber_sweep_batched(snrs, 1200 * 3000)
+    assert np.array_equal(a, b) and a[0] > 0
+    psk = DeviceWifiLink(1, 600, generator_matrix=[[0o133, 0o171]], seed=3)
+    assert psk._front is None and "QAM" in psk.front_reason
+    with pytest.raises(ValueError):
+        DeviceWifiLink(1, 600, generator_matrix=[[0o133, 0o171]], seed=3, fused=True)
+    link = DeviceWifiLink(5, 1200, generator_matrix=[[0o133, 0o171]], seed=9, fused=True)
+    _lib.demod_set_path("libm")
+    try:
+        e_libm = link.run_batch(15.0, 40)
+        assert "link_front" not in link.front_last_kernel
+    finally:
+        _lib.demod_set_path(None)
+    link2 = DeviceWifiLink(5, 1200, generator_matrix=[[0o133, 0o171]], seed=9, fused=True)
+    e_def = link2.run_batch(15.0, 40)
+    assert "link_front" in link2.front_last_kernel
+    assert abs(int(e_libm.sum()) - int(e_def.sum())) <= max(4, 0.02 * e_def.sum())    # same streams, libm vs table exp / log: ~same decisions
+
+
 def test_device_wifi_link_noiseless(gpu):
     from commpy_amd.devicelink import DeviceWifiLink
     for mcs in (0, 2, 4, 5, 7, 9):
