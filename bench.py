@@ -518,10 +518,12 @@ def main():
     # time = cycles per launch, which is what rocprofv3's GRBM_GUI_ACTIVE / 8 reports for the same kernel at the lower clock it runs
     # at under the profiler (profiles/README.md) -- recorded instead of argued.
     clock = None
+    probe = ctypes.c_void_p()
     try:
         probe = ctypes.c_void_p()                                   # a throw-away probe first: its one-time costs (stream, buffer, code
         _lib.check(lib.cpx_sclk_probe_start(ctypes.byref(probe), 0.2))   # object) must not leave the GPU idle in front of the real interval
         _lib.check(lib.cpx_sclk_probe_read(probe, None, None))
+        probe = ctypes.c_void_p()
         for _ in range(max(args.warmup, 8)):                       # the host read the timers meanwhile: no idle clock in the interval
             step(None, False)
         sync()
@@ -535,7 +537,8 @@ def main():
         for tmr in tm2:
             lib.cpx_timer_destroy(tmr)
         mhz, ival = ctypes.c_double(), ctypes.c_double()
-        _lib.check(lib.cpx_sclk_probe_read(probe, ctypes.byref(mhz), ctypes.byref(ival)))
+        started, probe = probe, ctypes.c_void_p()                   # (read frees the probe whatever it returns)
+        _lib.check(lib.cpx_sclk_probe_read(started, ctypes.byref(mhz), ctypes.byref(ival)))
         clock = {"sclk_mhz": mhz.value, "probe_interval_ms": ival.value, "kernel_ms_avg_during_probe": float(np.mean(ms2)),
                  "kernel_ms_median_during_probe": float(np.median(ms2)),
                  "shader_cycles_per_launch": mhz.value * 1e3 * float(np.median(ms2)),
@@ -543,6 +546,8 @@ def main():
                         "wavefront on its own stream while the same K steps ran again, outside the timed region"}
     except Exception as exc:                                       # evidence, never a reason to lose the line
         clock = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
+        if probe:                                                  # a probe that was started and never read goes back to the library
+            lib.cpx_sclk_probe_destroy(probe)
     comm_world = None
     if comm is not None:
         nr, nl, fr = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()

@@ -52,6 +52,7 @@ SYMBOLS = {
     "cpx_timer_destroy": (c_int, [c_void_p]),
     "cpx_sclk_probe_start": (c_int, [POINTER(c_void_p), c_double]),
     "cpx_sclk_probe_read": (c_int, [c_void_p, POINTER(c_double), POINTER(c_double)]),
+    "cpx_sclk_probe_destroy": (c_int, [c_void_p]),
     "cpx_trellis_create": (c_int, [c_int, c_int, c_int, c_int, _i32p, _i32p, POINTER(c_void_p)]),
     "cpx_trellis_destroy": (c_int, [c_void_p]),
     "cpx_viterbi_decode_batch": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int,

@@ -1232,7 +1232,7 @@ int cpx_map_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const do
     }
     CPX_HIP(hipGetLastError());
     // redo: pairs with a flagged codeword, literally (map_literal_kernel), same launch geometry
-    const RedoCounter redo = redo_counter();
+    const RedoCounter redo = redo_counter(st);
     switch (p.tb.lgS) {
 #define CASE(LG) case LG: hipLaunchKernelGGL((map_literal_kernel<LG, false>), grid, block, sizeof(double) * 2 * np * wave_lds_doubles<LG>(GW), st, p, redo); break;
         case 2:
@@ -1347,7 +1347,7 @@ int cpx_turbo_decode_batch_dev(const cpx_trellis *t, const double *d_sys, const 
     note_kernel("turbo_pass_kernel<%d,%s%s> x %d (time-major slab, interleaver = row index) + turbo_init_kernel + turbo_final_kernel (%d wave pairs per workgroup, %d codewords per pair)", p.tb.lgS,
                 (p.tb.lgS == 2 && p.tb.sr4) ? "true" : "false", s32 ? ",f32 slab" : "", 2 * n_iter, np, GW);
     // redo: one launch; a pair with a flagged codeword decodes its codewords again, literally, all iterations (turbo_literal_kernel)
-    const RedoCounter redo = redo_counter();
+    const RedoCounter redo = redo_counter(st);
     {
         const dim3 lgrid((unsigned)npairs), lblock(128);
         switch (p.tb.lgS) {

@@ -23,7 +23,7 @@ const char *last_kernel_name();
 // count to *host and zeroes the device words.  note_redo() AFTER the final note_kernel() makes cpx_last_kernel append
 // "redo: <host word> of <total> <what>" (pointers null: no counter available)
 struct RedoCounter { unsigned *dev, *host; };
-RedoCounter redo_counter();
+RedoCounter redo_counter(hipStream_t st);
 #ifdef __HIPCC__
 // collective over the workgroup (one __syncthreads); `mine` = this workgroup's contribution, added by thread 0
 __device__ __forceinline__ void redo_finish(RedoCounter rc, unsigned mine) {
@@ -53,7 +53,7 @@ int resident_blocks(const void *fn, int threads);
 // released by cpx_release_workspace().  Kernels of one stream serialise, so one arena per stream is safe.
 // (Stream-ordered hipMallocAsync/hipFreeAsync was measured to hand out memory that is still in use on this
 //  stack -- 45/120 corrupted LDPC decodes -- so the engine never uses it.)
-int workspace(hipStream_t stream, int slot, size_t bytes, void **out);
+int workspace(hipStream_t stream, int slot, size_t bytes, void **out, bool *fresh = nullptr);   // fresh: the block was (re)allocated by this call
 
 #define CPX_HIP(call)                                                                          \
     do {                                                                                       \

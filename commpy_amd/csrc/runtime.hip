@@ -52,29 +52,26 @@ void note_kernel(const char *fmt, ...) {
     g_redo_total = -1;
 }
 
-static thread_local unsigned *g_redo_dev = nullptr;
-static thread_local int g_redo_dev_device = -1;
-
 // {device words [count, workgroups done] -- zero between launches: the kernel's last workgroup resets them --, pinned host word}.
-// No memset and no copy on the stream: the redo kernel's LAST workgroup stores the count to the host word itself (round 5b; a
-// memset + a 4-byte D2H copy per decode cost ~8 us of a 0.33 ms map_decode).
-RedoCounter redo_counter() {
+// No memset and no copy on the stream per decode: the redo kernel's LAST workgroup stores the count to the host word itself (round 5b;
+// a memset + a 4-byte D2H copy per decode cost ~8 us of a 0.33 ms map_decode).  Round 6 (advisor): the device words belong to the
+// (device, STREAM) the decode is issued on -- scratch slot 12 of that stream, zeroed once when the block is created, released with the
+// stream's other scratch blocks (cpx_stream_destroy / cpx_release_workspace) -- so two redo launches in flight on two streams never
+// share a counter, and launches on one stream are ordered.  The pinned host word stays per calling thread: it is what
+// cpx_last_kernel(), a per-thread string, reads.
+RedoCounter redo_counter(hipStream_t st) {
     RedoCounter rc{nullptr, nullptr};
-    int dev = -1;
-    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return rc; }
     if (!g_redo_word) {
         void *p = nullptr;
         if (hipHostMalloc(&p, 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return rc; }
         g_redo_word = static_cast<unsigned *>(p);
         *g_redo_word = 0;
     }
-    if (!g_redo_dev || g_redo_dev_device != dev) {               // (a thread that moved to another device: the old words are left to the driver)
-        void *p = nullptr;
-        if (hipMalloc(&p, 64) != hipSuccess || hipMemset(p, 0, 64) != hipSuccess) { (void)hipGetLastError(); return rc; }
-        g_redo_dev = static_cast<unsigned *>(p);
-        g_redo_dev_device = dev;
-    }
-    rc.dev = g_redo_dev;
+    void *w = nullptr;
+    bool fresh = false;
+    if (workspace(st, 12, 64, &w, &fresh) != CPX_OK) return rc;
+    if (fresh && hipMemsetAsync(w, 0, 64, st) != hipSuccess) { (void)hipGetLastError(); return rc; }
+    rc.dev = static_cast<unsigned *>(w);
     rc.host = g_redo_word;
     return rc;
 }
@@ -99,7 +96,8 @@ struct WsEntry { int dev; hipStream_t st; int slot; void *p; size_t cap; };
 static std::vector<WsEntry> g_ws;
 static std::mutex g_ws_mu;
 
-int workspace(hipStream_t stream, int slot, size_t bytes, void **out) {
+int workspace(hipStream_t stream, int slot, size_t bytes, void **out, bool *fresh) {
+    if (fresh) *fresh = false;
     int dev = 0;
     CPX_HIP(hipGetDevice(&dev));
     if (bytes == 0) bytes = 8;
@@ -113,6 +111,7 @@ int workspace(hipStream_t stream, int slot, size_t bytes, void **out) {
                 hipError_t er = hipMalloc(&e.p, bytes);
                 if (er != hipSuccess) { set_error("workspace hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(er)); return CPX_ENOMEM; }
                 e.cap = bytes;
+                if (fresh) *fresh = true;
             }
             *out = e.p;
             return CPX_OK;
@@ -123,6 +122,7 @@ int workspace(hipStream_t stream, int slot, size_t bytes, void **out) {
     e.cap = bytes;
     g_ws.push_back(e);
     *out = e.p;
+    if (fresh) *fresh = true;
     return CPX_OK;
 }
 
@@ -406,12 +406,11 @@ int cpx_stream_create(void **stream) {
 int cpx_stream_destroy(void *stream) {
     if (!stream) return CPX_OK;
     hipStream_t st = (hipStream_t)stream;
+    (void)hipStreamSynchronize(st);                               // outside the lock: other threads' workspace() calls do not wait for this stream
     {
         std::lock_guard<std::mutex> lk(g_ws_mu);
-        bool synced = false;
         for (size_t i = 0; i < g_ws.size();) {
             if (g_ws[i].st != st) { i++; continue; }
-            if (!synced) { (void)hipStreamSynchronize(st); synced = true; }
             (void)hipFree(g_ws[i].p);
             g_ws.erase(g_ws.begin() + i);
         }
@@ -493,6 +492,7 @@ struct cpx_sclk_probe_t {
     hipStream_t st;
     uint64_t *d;          // device: r0, c0, r1, c1
     int ref_khz;
+    int dev, slot;        // the result slot this probe owns (cpx_sclk_probe_start)
 };
 
 __global__ void sclk_probe_kernel(uint64_t *out, uint64_t ref_ticks) {
@@ -511,9 +511,14 @@ __global__ void sclk_probe_kernel(uint64_t *out, uint64_t ref_ticks) {
 //  time that took -- plus the probe kernel's first-launch cost -- left the GPU idle long enough to drop its clock right before the
 //  interval it was meant to measure: 2246 MHz / 1.60 ms in the first repetition of scripts/micro/sclk_probe_check.py, 2380 MHz / 1.54 ms
 //  in every later one)
-static thread_local hipStream_t g_probe_stream = nullptr;
-static thread_local uint64_t *g_probe_buf = nullptr;
-static thread_local int g_probe_dev = -1;
+// Round 6 (advisor): one probe stream and one block of 16 result slots PER DEVICE (not per thread): every outstanding probe owns a
+// slot of its own, a seventeenth is refused, a thread that changes devices leaks nothing, and a probe that is never read is given back
+// with cpx_sclk_probe_destroy.
+constexpr int PROBE_SLOTS = 16;
+static std::mutex g_probe_mu;
+static hipStream_t g_probe_stream[64] = {};
+static uint64_t *g_probe_buf[64] = {};
+static unsigned g_probe_busy[64] = {};                            // bit i: slot i belongs to an outstanding probe
 
 int cpx_sclk_probe_start(void **probe, double spin_ms) {
     CPX_REQUIRE(probe && spin_ms > 0.0 && spin_ms <= 10000.0, CPX_EINVAL, "cpx_sclk_probe_start: bad argument");
@@ -521,20 +526,46 @@ int cpx_sclk_probe_start(void **probe, double spin_ms) {
     if (rc) return rc;
     int dev = 0, khz = 0;
     CPX_HIP(hipGetDevice(&dev));
+    CPX_REQUIRE(dev >= 0 && dev < 64, CPX_ELIMIT, "cpx_sclk_probe_start: device index %d", dev);
     CPX_HIP(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev));
     CPX_REQUIRE(khz > 0, CPX_EHIP, "cpx_sclk_probe_start: the device reports no wall-clock rate");
-    if (!g_probe_stream || g_probe_dev != dev) {
-        CPX_HIP(hipStreamCreateWithFlags(&g_probe_stream, hipStreamNonBlocking));
-        CPX_HIP(hipMalloc((void **)&g_probe_buf, 4 * sizeof(uint64_t)));
-        g_probe_dev = dev;
+    int slot = -1;
+    {
+        std::lock_guard<std::mutex> lk(g_probe_mu);
+        if (!g_probe_stream[dev]) {
+            CPX_HIP(hipStreamCreateWithFlags(&g_probe_stream[dev], hipStreamNonBlocking));
+            CPX_HIP(hipMalloc((void **)&g_probe_buf[dev], PROBE_SLOTS * 4 * sizeof(uint64_t)));
+        }
+        for (int i = 0; i < PROBE_SLOTS && slot < 0; i++)
+            if (!(g_probe_busy[dev] & (1u << i))) slot = i;
+        CPX_REQUIRE(slot >= 0, CPX_ELIMIT, "cpx_sclk_probe_start: %d probes are outstanding on device %d (read or destroy them)", PROBE_SLOTS, dev);
+        g_probe_busy[dev] |= 1u << slot;
     }
     cpx_sclk_probe_t *q = new cpx_sclk_probe_t;
     q->ref_khz = khz;
-    q->st = g_probe_stream;
-    q->d = g_probe_buf;
+    q->st = g_probe_stream[dev];
+    q->d = g_probe_buf[dev] + 4 * slot;
+    q->dev = dev;
+    q->slot = slot;
     hipLaunchKernelGGL(sclk_probe_kernel, dim3(1), dim3(64), 0, q->st, q->d, (uint64_t)(spin_ms * (double)khz));
-    CPX_HIP(hipGetLastError());
+    if (hipGetLastError() != hipSuccess) {
+        cpx_sclk_probe_destroy(q);
+        set_error("cpx_sclk_probe_start: launch failed");
+        return CPX_EHIP;
+    }
     *probe = q;
+    return CPX_OK;
+}
+
+int cpx_sclk_probe_destroy(void *probe) {
+    cpx_sclk_probe_t *q = (cpx_sclk_probe_t *)probe;
+    if (!q) return CPX_OK;
+    (void)hipStreamSynchronize(q->st);                            // the slot may be handed out again: its kernel must be done
+    {
+        std::lock_guard<std::mutex> lk(g_probe_mu);
+        g_probe_busy[q->dev] &= ~(1u << q->slot);
+    }
+    delete q;
     return CPX_OK;
 }
 
@@ -542,12 +573,14 @@ int cpx_sclk_probe_read(void *probe, double *sclk_mhz, double *interval_ms) {
     cpx_sclk_probe_t *q = (cpx_sclk_probe_t *)probe;
     CPX_REQUIRE(q, CPX_EINVAL, "cpx_sclk_probe_read: null probe");
     uint64_t h[4] = {0, 0, 0, 0};
-    CPX_HIP(hipStreamSynchronize(q->st));
-    CPX_HIP(hipMemcpy(h, q->d, sizeof(h), hipMemcpyDeviceToHost));
-    const double dt_ms = (double)(h[2] - h[0]) / (double)q->ref_khz;
+    hipError_t e = hipStreamSynchronize(q->st);
+    if (e == hipSuccess) e = hipMemcpy(h, q->d, sizeof(h), hipMemcpyDeviceToHost);
+    const int khz = q->ref_khz;
+    cpx_sclk_probe_destroy(q);                                    // (stream and slots stay with the device)
+    if (e != hipSuccess) { set_error("cpx_sclk_probe_read: %s", hipGetErrorString(e)); return CPX_EHIP; }
+    const double dt_ms = (double)(h[2] - h[0]) / (double)khz;
     if (interval_ms) *interval_ms = dt_ms;
     if (sclk_mhz) *sclk_mhz = dt_ms > 0.0 ? (double)(h[3] - h[1]) / dt_ms * 1e-3 : 0.0;
-    delete q;                                                     // (stream and buffer stay with the thread)
     return CPX_OK;
 }
 

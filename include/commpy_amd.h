@@ -93,9 +93,12 @@ int cpx_timer_destroy(void *timer);
 /* Shader-clock probe (round 5; measurement support, no reference counterpart): cpx_sclk_probe_start launches one mostly sleeping
  * wavefront on a stream of its own for `spin_ms` milliseconds of the constant-rate device clock; cpx_sclk_probe_read waits for it
  * and returns the average shader clock (MHz) over the interval it really covered (`interval_ms`) -- the clock the kernels on the
- * OTHER streams ran at meanwhile -- and frees the probe.  bench.py records it next to its per-launch times. */
+ * OTHER streams ran at meanwhile -- and frees the probe.  bench.py records it next to its per-launch times.  Every outstanding
+ * probe owns one of 16 result slots of its device (a 17th start: CPX_ELIMIT); cpx_sclk_probe_destroy gives back a probe that is never
+ * read (it waits for the probe's wavefront first). */
 int cpx_sclk_probe_start(void **probe, double spin_ms);
 int cpx_sclk_probe_read(void *probe, double *sclk_mhz, double *interval_ms);
+int cpx_sclk_probe_destroy(void *probe);
 
 /* ---- convolutional codes: Viterbi ---------------------------------------------------------------
  * cpx_trellis_create: device copy of the code description built by the host Trellis class.
@@ -266,9 +269,12 @@ int cpx_ldpc_set_path(const char *mode);
 int cpx_modem_create(const double *constellation_re_im, int M, cpx_modem **out);
 int cpx_modem_destroy(cpx_modem *m);
 /* Implementation choice of the soft demodulator for tests and A/B runs (initial value: environment variable CPX_DEMOD):
- * NULL / "auto": square QAM of 64 points and more takes the four-exponentials-per-axis form (equally spaced Gray-labelled
- * levels: the exponentials of an axis are a geometric progression) with table-driven exp / log (32-entry tables in LDS);
- * "libm": the same form with the library's exp / log; "plain": one exponential per level everywhere.
+ * NULL / "auto": square QAM of 64 points and more takes the geometric-progression form (equally spaced Gray-labelled levels:
+ * TWO exponentials and one division per axis, every other level by two multiplications) with table-driven exp / log (32-entry
+ * tables in LDS); PSK and arbitrary constellations take the table-driven point-by-point kernel (round 6).  Both store a wave's LLRs
+ * as one contiguous run of 16-byte stores: an output pointer that is only 8-byte aligned is served by the literal kernel instead.
+ * "libm": the same forms with the library's exp / log (generic constellations: the literal kernel); "plain": one exponential per
+ * level everywhere.
  * All are within 1e-5 of modulation.py:125-137 (measured: 1e-13); symbols near the underflow range are decided point by
  * point in the reference's order either way. */
 int cpx_demod_set_path(const char *mode);

@@ -137,6 +137,7 @@ class FakeLib:
     def cpx_timer_elapsed_ms(self, t, ms): a, b = self.timers[_addr(t)]; _out(ms, max((b - a) * 1e3, 1e-3)); return 0
     def cpx_timer_destroy(self, t): self.timers.pop(_addr(t), None); return 0
     def cpx_sclk_probe_start(self, ref, ms): _out(ref, 1); return 0
+    def cpx_sclk_probe_destroy(self, p): return 0
     def cpx_sclk_probe_read(self, p, mhz, iv):
         if mhz is not None: _out(mhz, 1.0)
         if iv is not None: _out(iv, 1.0)

@@ -332,3 +332,32 @@ def test_stream_destroy_retires_its_scratch_blocks(gpu):
             b.free()
     for o in outs[1:]:
         assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(o, outs[0]))
+
+
+def test_sclk_probes_own_their_result_slots(gpu):
+    """Round 6 (advisor): every outstanding shader-clock probe owns one of 16 result slots of its device -- two probes started before a
+    read no longer alias the same four words --, the 17th start is refused (CPX_ELIMIT -> ValueError), an unread probe goes back with
+    cpx_sclk_probe_destroy, and overlapping probes report plausible, separate intervals."""
+    from commpy_amd import _lib
+    lib = _lib.load()
+    probes = []
+    for i in range(16):
+        p = ctypes.c_void_p()
+        _lib.check(lib.cpx_sclk_probe_start(ctypes.byref(p), 0.5 + 0.25 * i))
+        probes.append(p)
+    extra = ctypes.c_void_p()
+    with pytest.raises(ValueError):
+        _lib.check(lib.cpx_sclk_probe_start(ctypes.byref(extra), 0.5))
+    got = []
+    for p in probes[:8]:
+        mhz, ival = ctypes.c_double(), ctypes.c_double()
+        _lib.check(lib.cpx_sclk_probe_read(p, ctypes.byref(mhz), ctypes.byref(ival)))
+        got.append((mhz.value, ival.value))
+    for p in probes[8:]:
+        _lib.check(lib.cpx_sclk_probe_destroy(p))
+    for i, (mhz, ival) in enumerate(got):                          # each probe measured ITS interval (they ran one after the other on the probe stream)
+        assert 100.0 < mhz < 4000.0, got
+        assert 0.5 + 0.25 * i <= ival < 0.5 + 0.25 * i + 0.2, got
+    p = ctypes.c_void_p()                                           # all slots free again
+    _lib.check(lib.cpx_sclk_probe_start(ctypes.byref(p), 0.2))
+    _lib.check(lib.cpx_sclk_probe_read(p, None, None))
