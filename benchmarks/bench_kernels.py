@@ -240,8 +240,14 @@ def bench_viterbi_variants(lib, scale):
     B = int(65536 * scale)
     rs = np.random.RandomState(4)
     for gm, tb, path, what in (([0o133, 0o171], 40, None, "tb_depth = 40"), ([0o135, 0o147], 30, None, "(135,147), no compiled-in instantiation"),
+                               ([0o135, 0o147], 30, "jit", "(135,147), its own code object (Trellis.specialize, commpy_amd/jit.py)"),
                                ([0o133, 0o171], 30, "wave", "state-per-lane kernels")):
         tr = Trellis(np.array([6]), np.array([gm]))
+        if path == "jit":
+            path = None
+            if not tr.specialize():
+                print("# (135,147): no code object (%s)" % __import__("commpy_amd.jit", fromlist=["x"]).viterbi_code_object.last_error, flush=True)
+                continue
         coded = conv_encode_batch(rs.randint(0, 2, (B, 1024)).astype(np.uint8), tr).astype(np.float64)
         llr = np.ascontiguousarray(4.0 * coded - 2 + rs.standard_normal(coded.shape).astype(np.float32) * 1.4, dtype=np.float64)
         dev = Dev(lib)

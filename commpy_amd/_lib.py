@@ -62,6 +62,10 @@ SYMBOLS = {
     "cpx_viterbi_decode_batch_i64": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int,
                                      c_void_p]),
     "cpx_viterbi_set_path": (c_int, [c_char_p]),
+    "cpx_trellis_viterbi_spec_query": (c_int, [c_void_p, POINTER(c_int), POINTER(ctypes.c_uint), POINTER(ctypes.c_uint)]),
+    "cpx_trellis_attach_viterbi_code": (c_int, [c_void_p, c_void_p, ctypes.c_size_t]),
+    "cpx_trellis_detach_viterbi_code": (c_int, [c_void_p]),
+    "cpx_trellis_has_viterbi_code": (c_int, [c_void_p]),
     "cpx_ldpc_set_path": (c_int, [c_char_p]),
     "cpx_demod_set_path": (c_int, [c_char_p]),
     "cpx_demod_hard_viterbi_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int,

@@ -15,6 +15,7 @@ The kernels are table-driven: they never re-derive tables from polynomials (the 
 matrix feedback constructions give different RSC output tables).
 """
 import ctypes
+import os
 import math
 from warnings import warn
 
@@ -166,9 +167,26 @@ class Trellis:
                                                           nxt.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
                                                           out.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
                                                           ctypes.byref(h)))
+                if self.__dict__.get('_cpx_specialize') or os.environ.get('CPX_VITERBI_JIT', '0') not in ('', '0'):
+                    from commpy_amd import jit
+                    jit.specialize_trellis(h)                     # (no compiler / nothing to gain: the handle stays as it is)
                 return h
             hs = self.__dict__['_cpx_handles'] = _lib.DeviceHandles(create, 'cpx_trellis_destroy')
         return hs.get()
+
+    def specialize(self):
+        """Compile (once, cached on disk) and attach the fused Viterbi kernels for THIS code's generators -- extension, no reference
+        counterpart (commpy_amd/jit.py).  Rate-1/2 codes of full constraint length that are not among the built-in pairs otherwise
+        run a table-driven kernel that is ~15 % slower on large batches; the decoded bits are identical.  Returns True when the
+        current device's handle carries a code object afterwards; handles created later (other devices) follow suit."""
+        from commpy_amd import jit
+        self.__dict__['_cpx_specialize'] = True
+        hs = self.__dict__.get('_cpx_handles')
+        fresh = hs is None
+        h = self._device_handle()                                  # (a handle created here has been specialised already)
+        if not fresh:
+            jit.specialize_trellis(h)
+        return bool(jit.has_code_object(h))
 
 
 def device_trellis(trellis):

@@ -172,6 +172,12 @@ struct cpx_trellis {
     // device tables (int32)
     int32_t *d_next = nullptr, *d_out = nullptr;             // [S][I]
     int32_t *d_pred_state = nullptr, *d_pred_input = nullptr, *d_pred_code = nullptr;  // [S][I]
+    // the fused codeword-per-lane Viterbi kernels compiled for THIS code's generators (cpx_trellis_attach_viterbi_code, round 6):
+    // [decoding type][run-time hop count]; null module: none attached (built-in pair or table-driven kernel)
+    hipModule_t spec_mod = nullptr;
+    hipFunction_t spec_fn[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+    int spec_lg = 0;
+    unsigned spec_g0 = 0, spec_g1 = 0;
 };
 
 struct cpx_ldpc {

@@ -690,6 +690,7 @@ int cpx_trellis_create(int k, int n, int n_states, int n_inputs, const int32_t *
 
 int cpx_trellis_destroy(cpx_trellis *t) {
     if (!t) return CPX_OK;
+    if (t->spec_mod) (void)hipModuleUnload(t->spec_mod);
     (void)hipFree(t->d_next); (void)hipFree(t->d_out);
     (void)hipFree(t->d_pred_state); (void)hipFree(t->d_pred_input); (void)hipFree(t->d_pred_code);
     delete t;

@@ -585,14 +585,20 @@ __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_fused_kernel(CwPara
     constexpr int S = 1 << LGS, FR_GROUPS = FR_CHUNK / LGS, CHUNK = FR_GROUPS * LGS;
     static_assert(HT >= 0 && HT + 1 <= RING && (RING & (RING - 1)) == 0 && CHUNK + 1 <= FR_OBPAD, "ring / tile too small");
     const int H = RT ? p.tb - 2 : HT;                                              // hops of a walk = tb_depth - 2
+    constexpr bool GEN = G0 == 0 && G1 == 0;                                        // table-driven code (cw_step)
+#ifdef CPX_VIT_SPEC_LG
+    // per-pair code object (see the end of the file): launched through hipModuleLaunchKernel, whose functions have no
+    // "dynamic LDS above 64 KiB" attribute to raise -- the ring and the tiles are a static array of the same size instead
+    __shared__ __attribute__((aligned(16))) unsigned char smem[ACS_WAVES * fused_wave_lds<RING, MIR, GEN>()];
+#else
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#endif
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t grp = (int64_t)blockIdx.x * ACS_WAVES + wv;
     const int64_t cw = grp * 64 + lane;
     if (grp * 64 >= p.B) return;                                                   // whole wave beyond the batch
     const bool valid = cw < p.B;
     const double *x = p.coded + (valid ? cw : 0) * p.len;
-    constexpr bool GEN = G0 == 0 && G1 == 0;                                        // table-driven code (cw_step)
     static_assert(!GEN || (!MIR && std::is_same<F, double>::value), "table-driven codes: unmirrored ring, float64");
     unsigned long long *ring = reinterpret_cast<unsigned long long *>(smem + (size_t)wv * fused_wave_lds<RING, MIR, GEN>());
     unsigned char *obuf = reinterpret_cast<unsigned char *>(ring + fused_slots<RING, MIR>() * 64);
@@ -956,6 +962,29 @@ int launch_fused(const CwParams &p, hipStream_t st) {
 
 }  // namespace
 
+#ifdef CPX_VIT_SPEC_LG
+// ---- a code object for ONE generator pair (round 6) ------------------------------------------------------------------------------
+// Any rate-1/2 code of full constraint length runs the table-driven flavour above (branch metric selected by VGPR index mode: 1.78 ms
+// on the config-2 geometry where a compiled-in pair takes 1.55).  Compiled with
+//     hipcc --offload-arch=gfx950 --cuda-device-only -DCPX_VIT_SPEC_LG=6 -DCPX_VIT_SPEC_G0=<g0> -DCPX_VIT_SPEC_G1=<g1> -c viterbi_cw.hip
+// this file yields a code object that holds nothing but the six fused kernels of THAT pair (three decoding types x {default depth,
+// run-time hop count}), generators as template arguments like the built-in pairs; commpy_amd/jit.py builds and caches it,
+// cpx_trellis_attach_viterbi_code loads it (hipModuleLoadData) and viterbi_codeword_path launches it in place of the table-driven
+// kernel.  Generators in the template's convention ("MSB taps the input", see CPX_TRY below).  64 states: the mirrored 32-slot ring of
+// launch_fused_typed; fewer: the small unmirrored ring of launch_fused_small_typed.
+namespace {
+constexpr int SPEC_LG = CPX_VIT_SPEC_LG;
+constexpr int SPEC_RING = SPEC_LG == 6 ? FR_RING : (5 * SPEC_LG - 1 <= 16 ? 16 : 32);
+constexpr bool SPEC_MIR = SPEC_LG == 6;
+#define CPX_SPEC(TYPE, RT)                                                                                                  \
+    template __global__ void viterbi_cw_fused_kernel<SPEC_LG, CPX_VIT_SPEC_G0, CPX_VIT_SPEC_G1, TYPE, 5 * SPEC_LG - 2, RT, double, \
+                                                     SPEC_RING, SPEC_MIR>(CwParams);
+CPX_SPEC(CPX_VIT_HARD, false) CPX_SPEC(CPX_VIT_HARD, true) CPX_SPEC(CPX_VIT_SOFT, false) CPX_SPEC(CPX_VIT_SOFT, true)
+CPX_SPEC(CPX_VIT_UNQUANTIZED, false) CPX_SPEC(CPX_VIT_UNQUANTIZED, true)
+#undef CPX_SPEC
+}  // namespace
+#else
+
 namespace cpx {
 
 // Kernel-path override (tests, benchmarks): bit 0 = "wave" (state-per-lane kernels only), bit 1 = forced codeword path,
@@ -1068,6 +1097,22 @@ bool viterbi_codeword_path(const cpx_trellis *t, const double *d_coded, int64_t 
     CPX_TRY_SMALL(2, 05u, 07u)
     CPX_TRY_SMALL(4, 031u, 027u)
 #undef CPX_TRY_SMALL
+    // a code object compiled for this code's generators (cpx_trellis_attach_viterbi_code): the built-in pairs' kernel, from a module
+    if (t->spec_mod && tb >= 2 && tb <= 5 * t->spec_lg && !two_kernels && !f32) {
+        const bool rt = tb != 5 * t->spec_lg;
+        hipFunction_t fn = t->spec_fn[type][rt ? 1 : 0];
+        const unsigned groups32 = (unsigned)groups, blocks = (groups32 + ACS_WAVES - 1) / ACS_WAVES;
+        void *args[] = {(void *)&p};
+        if (hipModuleLaunchKernel(fn, blocks, 1, 1, 64 * ACS_WAVES, 1, 1, 0, st, args, nullptr) != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("viterbi (per-pair code object): launch failed");
+            *rc = CPX_EHIP;
+            return true;
+        }
+        note_kernel("viterbi_cw_fused_kernel<%d,0%o,0%o,%s,%d%s> (code object of this pair)", t->spec_lg, t->spec_g0, t->spec_g1,
+                    type_name(type), 5 * t->spec_lg - 2, rt ? ",runtime hops" : "");
+        return true;
+    }
     // any other rate-1/2 shift-register code of full constraint length (4 .. 64 states), up to its default traceback depth: the
     // table-driven fused kernel (deeper windows, and the fp32-fast mode, go to the state-per-lane kernels)
 #define CPX_TRY_TABLE(LG)                                                                                               \
@@ -1092,3 +1137,103 @@ extern "C" int cpx_viterbi_set_path(const char *mode) {
     cpx::g_vit_path.store((mode && strcmp(mode, "auto") != 0) ? cpx::parse_path(mode) : 0, std::memory_order_relaxed);
     return CPX_OK;
 }
+
+// ---- per-pair code objects (round 6): query and attach -------------------------------------------------------------------------
+namespace {
+// generators of a rate-1/2, k = 1 shift-register trellis in the kernel template's convention (bit lg = the input tap), or false
+bool runtime_generators(const cpx_trellis *t, int &lg, unsigned &g0, unsigned &g1) {
+    lg = 0;
+    while ((1 << lg) < t->S) lg++;
+    if (t->I != 2 || t->k != 1 || t->n != 2 || (1 << lg) != t->S || lg < 2 || lg > 6) return false;
+    const int S = t->S;
+    auto code_of = [&](unsigned reg) -> int {                    // reg = [input bit | predecessor state]
+        const int pred = (int)(reg & (unsigned)(S - 1)), b = (int)(reg >> lg);
+        const int s = (pred >> 1) | (b << (lg - 1)), j = pred & 1;
+        return t->pred_code[s * 2 + j];
+    };
+    g0 = g1 = 0;
+    for (int i = 0; i <= lg; i++) {                               // a linear code: the output of a unit register is the generators' bit i
+        const int c = code_of(1u << i);
+        if (c < 0 || c > 3) return false;
+        g0 |= (unsigned)((c >> 1) & 1) << i;
+        g1 |= (unsigned)(c & 1) << i;
+    }
+    for (int s = 0; s < S; s++)
+        for (int j = 0; j < 2; j++) {
+            if (t->pred_state[s * 2 + j] != (((s << 1) & (S - 1)) | j) || t->pred_input[s * 2 + j] != (s >> (lg - 1))) return false;
+            const unsigned reg = ((unsigned)(s >> (lg - 1)) << lg) | (unsigned)(((s << 1) & (S - 1)) | j);
+            const int want = ((__builtin_popcount(reg & g0) & 1) << 1) | (__builtin_popcount(reg & g1) & 1);
+            if (t->pred_code[s * 2 + j] != want) return false;
+        }
+    return true;
+}
+bool builtin_pair(const cpx_trellis *t) {
+    return tables_match<6, 0155u, 0117u>(t) || tables_match<6, 0117u, 0155u>(t) || tables_match<6, 0133u, 0171u>(t) ||
+           tables_match<6, 0171u, 0133u>(t) || tables_match<6, 0120u, 0152u>(t) || tables_match<2, 05u, 07u>(t) ||
+           tables_match<4, 031u, 027u>(t);
+}
+}  // namespace
+
+extern "C" int cpx_trellis_viterbi_spec_query(const cpx_trellis *t, int *lg, unsigned *g0, unsigned *g1) {
+    CPX_REQUIRE(t && lg && g0 && g1, CPX_EINVAL, "cpx_trellis_viterbi_spec_query: null pointer");
+    *lg = 0; *g0 = 0; *g1 = 0;
+    int l = 0;
+    unsigned a = 0, b = 0;
+    unsigned goff[4];
+    // what the table-driven kernel serves today and a compiled pair would serve faster: full-constraint-length codes that are not built in
+    const bool table = (t->S == 64 && generic_match<6>(t, goff)) || (t->S == 32 && generic_match<5>(t, goff)) ||
+                       (t->S == 16 && generic_match<4>(t, goff)) || (t->S == 8 && generic_match<3>(t, goff)) ||
+                       (t->S == 4 && generic_match<2>(t, goff));
+    if (!table || builtin_pair(t) || t->spec_mod || !runtime_generators(t, l, a, b)) return CPX_OK;
+    *lg = l; *g0 = a; *g1 = b;
+    return CPX_OK;
+}
+
+extern "C" int cpx_trellis_attach_viterbi_code(cpx_trellis *t, const void *image, size_t bytes) {
+    CPX_REQUIRE(t && image && bytes >= 64, CPX_EINVAL, "cpx_trellis_attach_viterbi_code: null / empty image");
+    if (int rcd = cpx::check_handle_device(t->device, "attach_viterbi_code")) return rcd;
+    CPX_REQUIRE(!t->spec_mod, CPX_EINVAL, "cpx_trellis_attach_viterbi_code: the trellis already has a code object");
+    int lg = 0;
+    unsigned g0 = 0, g1 = 0;
+    CPX_REQUIRE(runtime_generators(t, lg, g0, g1), CPX_EINVAL,
+                "cpx_trellis_attach_viterbi_code: not a rate-1/2 shift-register code of 4 .. 64 states");
+    hipModule_t mod = nullptr;
+    if (hipModuleLoadData(&mod, image) != hipSuccess) {
+        (void)hipGetLastError();
+        cpx::set_error("cpx_trellis_attach_viterbi_code: hipModuleLoadData refused the image");
+        return CPX_EHIP;
+    }
+    // the kernels are looked up BY THE GENERATORS OF THIS TRELLIS: an image compiled for another pair has no such symbols and is refused
+    const int ring = lg == 6 ? FR_RING : (5 * lg - 1 <= 16 ? 16 : 32);
+    hipFunction_t fn[3][2];
+    for (int type = 0; type < 3; type++)
+        for (int rt = 0; rt < 2; rt++) {
+            char name[200];
+            snprintf(name, sizeof(name), "_ZN12_GLOBAL__N_123viterbi_cw_fused_kernelILi%dELj%uELj%uELi%dELi%dELb%dEdLi%dELb%dEEEvNS_8CwParamsE",
+                     lg, g0, g1, type, 5 * lg - 2, rt, ring, lg == 6 ? 1 : 0);
+            if (hipModuleGetFunction(&fn[type][rt], mod, name) != hipSuccess) {
+                (void)hipGetLastError();
+                (void)hipModuleUnload(mod);
+                cpx::set_error("cpx_trellis_attach_viterbi_code: the image has no kernel %s (compiled for other generators, or from other sources)", name);
+                return CPX_EINVAL;
+            }
+        }
+    t->spec_mod = mod;
+    memcpy(t->spec_fn, fn, sizeof(fn));
+    t->spec_lg = lg; t->spec_g0 = g0; t->spec_g1 = g1;
+    return CPX_OK;
+}
+
+extern "C" int cpx_trellis_has_viterbi_code(const cpx_trellis *t) { return (t && t->spec_mod) ? 1 : 0; }
+
+extern "C" int cpx_trellis_detach_viterbi_code(cpx_trellis *t) {
+    CPX_REQUIRE(t, CPX_EINVAL, "cpx_trellis_detach_viterbi_code: null trellis");
+    if (t->spec_mod) {
+        (void)hipDeviceSynchronize();                             // nothing may still run from the module
+        (void)hipModuleUnload(t->spec_mod);
+        t->spec_mod = nullptr;
+        t->spec_lg = 0;
+    }
+    return CPX_OK;
+}
+#endif  // CPX_VIT_SPEC_LG

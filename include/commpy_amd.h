@@ -149,6 +149,23 @@ int cpx_viterbi_decode_batch_dev(const cpx_trellis *t, const double *d_coded, in
 /* Kernel-path override for tests and benchmarks (initial value: environment variable CPX_VITERBI_PATH):
  * NULL / "" / "auto" = automatic, "wave", "cw", "cw!", "cw2", "cw2!" as described above, "general" = the general kernel. */
 int cpx_viterbi_set_path(const char *mode);
+/* Per-pair code objects for the codeword-per-lane kernels (round 6).  A rate-1/2 code of full constraint length that is not one of
+ * the built-in generator pairs runs the TABLE-DRIVEN fused kernel (branch metric selected by VGPR index mode: 1.78 ms on the config-2
+ * geometry where a built-in pair takes 1.55).  The same source file compiled with the pair as template arguments
+ *     hipcc --offload-arch=gfx950 --cuda-device-only --no-gpu-bundle-output -O3 -std=c++17 -ffp-contract=off \
+ *           -DCPX_VIT_SPEC_LG=<lg> -DCPX_VIT_SPEC_G0=<g0>u -DCPX_VIT_SPEC_G1=<g1>u -c commpy_amd/csrc/viterbi_cw.hip
+ * gives a code object with the six fused kernels of THAT pair; commpy_amd/jit.py builds and caches it by (generators, build id).
+ *   cpx_trellis_viterbi_spec_query   *lg = log2(states) and the generators in the kernel template's convention when the trellis would
+ *                                    gain from such an object (else *lg = 0: built-in pair, other structure, or already attached)
+ *   cpx_trellis_attach_viterbi_code  loads the image (hipModuleLoadData) and looks its kernels up BY THIS TRELLIS'S GENERATORS: an
+ *                                    image of another pair or of other sources is refused (CPX_EINVAL), the trellis stays as it was;
+ *                                    afterwards viterbi_decode batches that take the codeword-per-lane path launch the module's
+ *                                    kernels (cpx_last_kernel: "... (code object of this pair)"); results are bit-identical
+ *   cpx_trellis_detach_viterbi_code  back to the table-driven kernel (tests) */
+int cpx_trellis_viterbi_spec_query(const cpx_trellis *t, int *lg, unsigned *g0, unsigned *g1);
+int cpx_trellis_attach_viterbi_code(cpx_trellis *t, const void *image, size_t bytes);
+int cpx_trellis_detach_viterbi_code(cpx_trellis *t);
+int cpx_trellis_has_viterbi_code(const cpx_trellis *t);   /* 1: a code object is attached */
 /* Fused hard demodulation + hard-decision Viterbi: replaces the pair
  *   bits = modem.demodulate(y, 'hard')            commpy/modulation.py:121-123
  *   viterbi_decode(bits, trellis, tb_depth, 'hard')  commpy/channelcoding/convcode.py:578-580, 661-749
