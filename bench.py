@@ -40,7 +40,7 @@ MSG_BITS = 1024
 EBN0_DB = 3.0
 ALG_BYTES_PER_CW = 2060 * 8 + 1030 * 1      # float64 LLRs in + uint8 bits out
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: 8.0 TB/s spec
-PMC_FILES = ("r05_viterbi_c2_pmc.json", "r04_viterbi_c2_pmc.json")   # written by scripts/collect_pmc.py from rocprofv3 passes over this script; newest first
+PMC_FILES = ("r06_viterbi_c2_pmc.json", "r05_viterbi_c2_pmc.json", "r04_viterbi_c2_pmc.json")   # written by scripts/collect_pmc.py from rocprofv3 passes over this script; newest first
 
 
 def synth_inputs(B, seed_msg, seed_noise):

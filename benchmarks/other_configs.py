@@ -21,6 +21,8 @@ checker here, never the thing measured): decoded bits exact, min-sum LLRs <= 1e-
               the whole sweep; stage breakdown from HIP events between the stages (round 6)
   configs[0]  K = 3 (5,7) r = 1/2, 64-bit blocks, hard-decision Viterbi over a BSC(0.05) -- the reference's CPU plumbing case, here
               device-generated at B = 2^20 blocks (DeviceBscLink; test_convcode.py:133-178, channels.py:652-673) (round 6)
+  pair        a K = 7 generator pair without a built-in instantiation, (135,147), on the configs[1] geometry: table-driven kernel and the
+              pair's own code object (commpy_amd/jit.py, round 6)       17 510 B per codeword
   demod       the 64-QAM soft demodulator of that chain alone, (a) on the chain's 170 MB input, which FITS the 256 MiB
               Infinity Cache and is re-read every repetition, and (b) on rotating inputs of > 256 MiB in total, so that
               every byte comes from HBM                                   64 B per symbol
@@ -521,6 +523,48 @@ def run_config1(lib, steps, warmup, B=1 << 20, n_check=3000):
                   "bytes_model": "SURVEY 8d form: %d float64 received values in + %d decoded bytes out per block" % (link.ncoded, link.L)})
 
 
+def run_pair(lib, steps, warmup, B=65536, n_check=192):
+    """Round 6: a K = 7 pair that is NOT built in -- (135,147) -- on the headline geometry (1024-bit blocks, soft, tb_depth 30), through the
+    table-driven fused kernel and through the pair's own code object (Trellis.specialize, commpy_amd/jit.py: compiled by hipcc when the
+    on-disk cache does not have it).  Both against the oracle on sampled codewords, and against each other on the whole batch."""
+    import oracle
+    from commpy_amd import jit
+    from commpy_amd.channelcoding import Trellis, conv_encode_batch
+    tr = Trellis(np.array([6]), np.array([[0o135, 0o147]]))
+    rs = np.random.RandomState(4)
+    coded = conv_encode_batch(rs.randint(0, 2, (B, 1024)).astype(np.uint8), tr).astype(np.float64)
+    llr = np.ascontiguousarray(4.0 * coded - 2 + rs.standard_normal(coded.shape).astype(np.float32) * 1.4, dtype=np.float64)
+    del coded
+    dev = Dev(lib)
+    out = []
+    try:
+        d_in, d_out = dev.put(llr), dev.empty(B * 1030)
+        h = tr._device_handle()
+        idx = np.r_[0:n_check // 2, B - n_check // 2:B]
+        want = oracle.viterbi_decode_mt(llr[idx], tr, None, "soft")
+        bits = {}
+        for what in ("table-driven kernel", "its own code object"):
+            t0 = time.perf_counter()
+            if what == "its own code object" and not tr.specialize():
+                out.append({"config": "configs[1] geometry, pair (135,147), " + what, "skipped": "no code object: %s" % jit.viterbi_code_object.last_error})
+                continue
+            t_jit = time.perf_counter() - t0
+            ms = time_steps(lib, lambda: _lib.check(lib.cpx_viterbi_decode_batch_dev(h, d_in, B, 2060, 1030, 1030, 30, 1, d_out, None)), steps, warmup)
+            kname = _lib.last_kernel()
+            bits[what] = dev.get(d_out, (B, 1030), np.uint8)
+            mism = int(np.sum(bits[what][idx] != want))
+            par = {"vs": "oracle viterbi_decode 'soft' (convcode.py:661-749)", "codewords": len(idx), "mismatched_bits": mism, "ok": mism == 0}
+            if len(bits) == 2:
+                par["bits_differing_from_the_table_driven_kernel_whole_batch"] = int(np.sum(bits["table-driven kernel"] != bits[what]))
+                par["ok"] = par["ok"] and par["bits_differing_from_the_table_driven_kernel_whole_batch"] == 0
+            out.append(entry("configs[1] geometry, pair (135,147), " + what, "K=7 (135,147) r=1/2 -- no built-in instantiation --, 1024-bit blocks, soft "
+                             "Viterbi, tb_depth=30, B=%d" % B, kname, ms, B * 1024, "info-bits", B * 17510, "valu", par,
+                             {"specialize_s": round(t_jit, 2)} if what != "table-driven kernel" else None))
+    finally:
+        dev.free()
+    return out
+
+
 def run(lib, steps=20, warmup=3, scale=1.0, log=None, which=None):
     """All entries (or the ones named in `which`); never raises for a failing workload (the headline line must not be lost): a
     failure becomes an entry with `error`."""
@@ -528,7 +572,8 @@ def run(lib, steps=20, warmup=3, scale=1.0, log=None, which=None):
     for name, fn in (("turbo", lambda: [run_turbo(lib, steps, warmup, B=int(16384 * scale))]),
                      ("config4", lambda: run_config4(lib, steps, warmup, B=int(32768 * scale))),
                      ("config5", lambda: [run_config5(lib, steps, warmup, total_bits=1e8 * scale)]),
-                     ("config1", lambda: [run_config1(lib, steps, warmup, B=int((1 << 20) * scale))])):
+                     ("config1", lambda: [run_config1(lib, steps, warmup, B=int((1 << 20) * scale))]),
+                     ("pair", lambda: run_pair(lib, steps, warmup, B=int(65536 * scale)))):
         if which and name not in which:
             continue
         t0 = time.perf_counter()
@@ -551,7 +596,7 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scale", type=float, default=1.0)
-    ap.add_argument("--which", default="", help="comma list of turbo,config4,config5,config1 (default: all)")
+    ap.add_argument("--which", default="", help="comma list of turbo,config4,config5,config1,pair (default: all)")
     a = ap.parse_args()
     lib = _lib.load()
     _lib.require_device()
