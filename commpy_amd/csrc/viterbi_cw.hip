@@ -1218,10 +1218,10 @@ extern "C" int cpx_trellis_attach_viterbi_code(cpx_trellis *t, const void *image
                 return CPX_EINVAL;
             }
         }
-    t->spec_mod = mod;
     memcpy(t->spec_fn, fn, sizeof(fn));
     t->spec_lg = lg; t->spec_g0 = g0; t->spec_g1 = g1;
-    return CPX_OK;
+    t->spec_mod = mod;                                            // last: the dispatcher tests this field (attach while another thread
+    return CPX_OK;                                                //  decodes with the same handle is still the caller's to serialise)
 }
 
 extern "C" int cpx_trellis_has_viterbi_code(const cpx_trellis *t) { return (t && t->spec_mod) ? 1 : 0; }

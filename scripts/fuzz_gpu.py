@@ -6,7 +6,8 @@
 Draws cases until the time is up: Viterbi (hard / soft / unquantized, random batch, block length, traceback depth, kernel path,
 +-inf / 0 values), LDPC min-sum (random Tanner graphs, both decoder paths, special values; exact equality) and LDPC
 sum-product (dec_word / iterations equal, LLRs within the suite's criterion), MAP decoding (4- and 8-state RSC, <= 1e-5),
-turbo decoding (decoded bits equal except where the final LLR is ~0) and PSK / QAM demodulation (hard: equal; soft: <= 1e-5).
+turbo decoding (decoded bits equal except where the final LLR is ~0), PSK / QAM demodulation (hard: equal; soft: <= 1e-5) and -- round 6 --
+the fused link front end against the staged kernels (bit patterns equal) and the oracle's demodulator.
 Prints one line per failing case and a summary; exit status 1 if anything failed."""
 import argparse
 import os
@@ -39,11 +40,11 @@ def main(argv=None):
         rsc = [make_trellis("rsc_legacy_4"), make_trellis("rsc_legacy_8")]
     others = {}
     t_end = time.time() + a.seconds
-    n = {"viterbi": 0, "ldpc": 0, "map": 0, "turbo": 0, "demod": 0, "general": 0}
+    n = {"viterbi": 0, "ldpc": 0, "map": 0, "turbo": 0, "demod": 0, "general": 0, "link": 0}
     modems = [QAMModem(4), QAMModem(16), QAMModem(64), QAMModem(256), PSKModem(2), PSKModem(4), PSKModem(8), PSKModem(16)]
     bad = []
     while time.time() < t_end:
-        kind = rs.choice(["viterbi", "viterbi", "ldpc", "map", "turbo", "demod", "general"])
+        kind = rs.choice(["viterbi", "viterbi", "ldpc", "map", "turbo", "demod", "general", "link"])
         n[kind] += 1
         try:
             if kind == "viterbi" and rs.rand() < 0.35:
@@ -89,6 +90,44 @@ def main(argv=None):
                     _lib.viterbi_set_path(None)
                     if not np.array_equal(got, want):
                         bad.append(("viterbi-small-cw", name, dtype, B, steps, tb, _lib.last_kernel(), int(np.sum(got != want))))
+            elif kind == "link":
+                # round 6: the fused link front end (one launch: bits, conv_encode, puncturing, modulate, AWGN, soft demod, depuncturing)
+                # against the seven staged kernels on the same counter-based streams -- message bits, noisy symbols, LLRs (zeros at the
+                # punctured positions included) and error counts bit for bit; the LLRs against the oracle's demodulator on those symbols
+                from commpy_amd.devicelink import DeviceWifiLink
+                mcs = int(rs.choice([3, 4, 5, 6, 7, 8, 9]))
+                gens = None if rs.rand() < 0.3 else [[0o133, 0o171]]
+                chunk, agg = int(rs.choice([24, 120, 600, 1200, 2400])), int(rs.choice([1, 1, 2, 3]))
+                T, snr, seed = int(rs.choice([1, 2, 7, 33, 64, 65, 200])), float(rs.uniform(-2.0, 45.0)), int(rs.randint(1, 1 << 30))
+                got = {}
+                try:
+                    DeviceWifiLink(mcs, chunk, frame_aggregation=agg, generator_matrix=gens, seed=seed, fused=False)
+                except ValueError:                                  # this chunk is not a whole number of symbols for this MCS
+                    n[kind] -= 1
+                    continue
+                for fused in (True, False):
+                    link = DeviceWifiLink(mcs, chunk, frame_aggregation=agg, generator_matrix=gens, seed=seed, fused=fused)
+                    link.keep_rx = True
+                    link._calls = int(seed % 5)                    # different stream ids
+                    errs = link.run_batch(snr, T)
+                    b = link._bufs
+                    llr = (b['llr_de'] if link.keep_idx is not None else b['llr']).to_array((T, link.nde), np.float64)
+                    got[fused] = (errs, b['msg'].to_array((T, link.nbits), np.uint8), b['rx'].to_array((T, link.nsym), np.complex128), llr)
+                f_, s_ = got[True], got[False]
+                same = (np.array_equal(f_[0], s_[0]) and np.array_equal(f_[1], s_[1]) and np.array_equal(f_[2].view(np.uint64), s_[2].view(np.uint64))
+                        and np.array_equal(f_[3].view(np.uint64), s_[3].view(np.uint64)))
+                nv = 2.0 * link.modem.Es / (link.rate * 10 ** (snr / 10.0))
+                want = oracle.demodulate(link.modem.constellation, f_[2][:2].reshape(-1), "soft", nv).reshape(min(T, 2), -1)
+                full = np.zeros((want.shape[0], link.nde))
+                if link.de_idx is not None:
+                    keep = link.de_idx >= 0
+                    full[:, keep] = want[:, link.de_idx[keep]]
+                else:
+                    full = want
+                fin = np.isfinite(full)
+                ok = np.array_equal(fin, np.isfinite(f_[3][:2])) and (not fin.any() or np.max(np.abs(full[fin] - f_[3][:2][fin])) < 1e-5)
+                if not same or not ok:
+                    bad.append(("link", mcs, gens is None, chunk, agg, T, snr, seed, same, ok))
             elif kind == "viterbi" and rs.rand() < 0.25:
                 # round 3: a random 64-state pair with both end taps through the table-driven fused kernel (default depth) or, at other
                 # depths, whatever the forced-but-not-strict codeword path falls back to
