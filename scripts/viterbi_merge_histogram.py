@@ -117,6 +117,37 @@ def main():
     lines.append("mean depth: %.2f hops per codeword, **%.2f hops per wavefront** (a wave-uniform exit walks the largest depth of its "
                  "lanes); walks of <= 4 hops: %.1f %% of codeword steps, %.1f %% of wavefront steps."
                  % (mean_lane, mean_wave, 100.0 * lane_hist[:4].sum() / lt, 100.0 * wave_hist[:4].sum() / wt))
+    # ---- all 64 survivors: after how many hops have the paths of ALL states merged into one? (what a traceback from ANY state, i.e.
+    # without the first-argmin, would need) -- the survivor set as a 64-bit mask per codeword, one hop = (M & ~W, M & W) folded and
+    # interleaved, W = the step's decision word
+    Wd = np.zeros((n_steps + 1, B), np.uint64)
+    for s_ in range(S):
+        Wd |= (choice[:, :, s_].astype(np.uint64) << np.uint64(s_))
+
+    def spread(x):
+        x = x.astype(np.uint64)
+        for sh, mk in ((16, 0x0000FFFF0000FFFF), (8, 0x00FF00FF00FF00FF), (4, 0x0F0F0F0F0F0F0F0F), (2, 0x3333333333333333), (1, 0x5555555555555555)):
+            x = (x | (x << np.uint64(sh))) & np.uint64(mk)
+        return x
+    full = np.full((n_steps + 1, B), H + 1)
+    m32 = np.uint64(0xFFFFFFFF)
+    for t in range(H + 1, n_steps + 1):
+        M = np.full(B, np.uint64(0xFFFFFFFFFFFFFFFF))
+        for dd in range(1, H + 1):
+            w = Wd[t - dd + 1]
+            E, O = M & ~w, M & w
+            M = spread((E | (E >> np.uint64(32))) & m32) | (spread((O | (O >> np.uint64(32))) & m32) << np.uint64(1))
+            single = (M & (M - np.uint64(1))) == 0
+            full[t] = np.where(single & (full[t] == H + 1), dd, full[t])
+    fd = full[H + 1:]
+    fl = np.bincount(fd.reshape(-1), minlength=H + 2)
+    fw = np.bincount(fd.reshape(fd.shape[0], B // 64, 64).max(axis=2).reshape(-1), minlength=H + 2)
+    lines.append("")
+    lines.append("All 64 survivors (a walk that starts from ANY state instead of the first-argmin state is exact only where they have all merged "
+                 "inside the walk): merged within %d hops in %.1f %% of the codeword steps (mean depth %.1f hops), i.e. NOT merged in %.1f %% of "
+                 "them and in %.1f %% of the wavefront steps -- the first-argmin cannot be dropped behind a merge test either."
+                 % (H, 100.0 * (1 - fl[H + 1] / fl.sum()), (fl * np.arange(H + 2)).sum() / fl.sum(), 100.0 * fl[H + 1] / fl.sum(),
+                    100.0 * fw[H + 1] / fw.sum()))
     text = "\n".join(lines)
     print(text)
     if a.out:
