@@ -198,6 +198,47 @@ def test_fused_front_end_sweep_and_fallbacks(gpu):
     assert abs(int(e_libm.sum()) - int(e_def.sum())) <= max(4, 0.02 * e_def.sum())    # same streams, libm vs table exp / log: ~same decisions
 
 
+def test_link_front_plan_validation(gpu):
+    """cpx_link_front_create / _run_dev argument checks: index tables that do not increase or leave their range are CPX_EINVAL; a
+    recursive trellis, a PSK modem, a frame whose symbols would depend on more than 49 message bits and a call of 2^28 symbols or more
+    are CPX_ELIMIT (the caller keeps the staged kernels); T = 0 is a no-op; destroy(NULL) is fine."""
+    import warnings
+    from commpy_amd import _lib
+    from commpy_amd.channelcoding import Trellis
+    from commpy_amd.modulation import PSKModem, QAMModem
+    lib = _lib.load()
+    tr = Trellis(np.array([6]), np.array([[0o133, 0o171]]))
+    md = QAMModem(16)
+    h = ctypes.c_void_p()
+
+    def create(trellis, modem, nbits, keep, ntx, pos, nde):
+        k = None if keep is None else np.ascontiguousarray(keep, dtype=np.int32)
+        p = None if pos is None else np.ascontiguousarray(pos, dtype=np.int32)
+        return lib.cpx_link_front_create(trellis._device_handle(), modem._device_handle(), nbits, None if k is None else _lib.ptr(k), ntx,
+                                         None if p is None else _lib.ptr(p), nde, ctypes.byref(h))
+    assert create(tr, md, 64, None, 128, None, 128) == _lib.CPX_OK
+    assert lib.cpx_link_front_run_dev(h, 0, 1.0, 0.5, 0.5, 1.0, 1, 2, 3, None, None, None, None) == _lib.CPX_OK      # T = 0
+    assert lib.cpx_link_front_run_dev(h, (1 << 28) // 32, 1.0, 0.5, 0.5, 1.0, 1, 2, 3, ctypes.c_void_p(8), ctypes.c_void_p(8), None, None) == _lib.CPX_ELIMIT
+    assert lib.cpx_link_front_run_dev(h, 4, 0.0, 0.5, 0.5, 1.0, 1, 2, 3, ctypes.c_void_p(8), ctypes.c_void_p(8), None, None) == _lib.CPX_ELIMIT   # 1 / noise_var
+    assert lib.cpx_link_front_destroy(h) == _lib.CPX_OK and lib.cpx_link_front_destroy(None) == _lib.CPX_OK
+    keep = np.arange(128)
+    bad = keep.copy(); bad[5] = bad[4]
+    assert create(tr, md, 64, bad, 128, None, 128) == _lib.CPX_EINVAL                       # not increasing
+    bad = keep.copy(); bad[-1] = 128
+    assert create(tr, md, 64, bad, 128, None, 128) == _lib.CPX_EINVAL                       # coded position out of range
+    assert create(tr, md, 64, None, 128, np.arange(128) * 2, 200) == _lib.CPX_EINVAL        # decoder position out of range
+    assert create(tr, md, 64, None, 126, None, 126) == _lib.CPX_ELIMIT                      # not a whole number of 16-QAM symbols
+    assert create(tr, PSKModem(4), 64, None, 128, None, 128) == _lib.CPX_ELIMIT
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        rsc = Trellis(np.array([2]), np.array([[1, 7]]), 5, 'rsc')
+    assert create(rsc, md, 64, None, 128, None, 128) == _lib.CPX_ELIMIT
+    # a puncturing that keeps one coded bit in sixteen: a 256-QAM symbol then spans 64 trellis steps -> more than 49 message bits
+    sparse = np.arange(0, 4096, 16)
+    assert create(tr, QAMModem(256), 2048, sparse, len(sparse), None, len(sparse)) == _lib.CPX_ELIMIT
+    assert "message bits" in _lib.last_error()
+
+
 def test_device_wifi_link_noiseless(gpu):
     from commpy_amd.devicelink import DeviceWifiLink
     for mcs in (0, 2, 4, 5, 7, 9):
