@@ -127,6 +127,7 @@ bool trace_enabled();
 // precision mode (cpx_set_precision / CPX_PRECISION): false = fp64-parity (default), true = fp32-fast
 bool precision_fast();
 
+void viterbi_lean_ring(bool on);   // thread-local: the next 64-state rounds of this thread take the unmirrored ring where that flavour exists
 void viterbi_prefer_cw(bool on);   // thread-local: the next dispatches of this thread take the codeword path whatever the batch size
 int viterbi_path_flags();   // bit 0 wave only, bit 1 codeword path forced, bit 2 strict, bit 3 two-kernel form, bit 4 general kernel
 // the general Viterbi kernel (viterbi_generic.hip): any trellis cpx_trellis_create accepts, any traceback depth

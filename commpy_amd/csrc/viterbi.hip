@@ -766,6 +766,39 @@ struct DemodSrc {                  // fused hard demodulation: symbols instead o
     int64_t nsym;
 };
 
+// ---- side stream of the remainder (viterbi_dispatch, round 6) -------------------------------------------------------------------
+static bool overlap_enabled() {
+    static const bool on = [] { const char *e = getenv("CPX_VITERBI_OVERLAP"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+// One lowest-priority stream per device, shared by the host threads (its queue orders their remainders); the fork / join events are
+// per THREAD and device: a shared pair would let thread B's record slip between thread A's record and A's hipStreamWaitEvent, and A's
+// remainder would then wait for B's stream instead of its own inputs.  (An event may be re-recorded while an earlier wait on it is
+// pending: the wait took the record that was current when it was issued.  A thread's pair lives as long as the process.)
+static int side_stream(hipStream_t *st, hipEvent_t *fork, hipEvent_t *join) {
+    static std::mutex mu;
+    static hipStream_t s_side[64] = {};
+    static thread_local hipEvent_t tl_ev[64][2] = {};
+    int dev = 0;
+    CPX_HIP(hipGetDevice(&dev));
+    CPX_REQUIRE(dev >= 0 && dev < 64, CPX_ELIMIT, "viterbi: device index %d", dev);
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!s_side[dev]) {
+            int least = 0, greatest = 0;
+            CPX_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            CPX_HIP(hipStreamCreateWithPriority(&s_side[dev], hipStreamNonBlocking, least));
+        }
+    }
+    if (!tl_ev[dev][0]) {
+        CPX_HIP(hipEventCreateWithFlags(&tl_ev[dev][0], hipEventDisableTiming));
+        CPX_HIP(hipEventCreateWithFlags(&tl_ev[dev][1], hipEventDisableTiming));
+    }
+    *st = s_side[dev]; *fork = tl_ev[dev][0]; *join = tl_ev[dev][1];
+    return CPX_OK;
+}
+
 static int viterbi_dispatch(const cpx_trellis *t, const double *d_coded, const DemodSrc *dm, int64_t B, int64_t len, int64_t L,
                             int64_t n_steps, int tb_depth, int decoding_type, uint8_t *d_bits, void *stream) {
     CPX_REQUIRE(t, CPX_EINVAL, "viterbi: null trellis");
@@ -814,6 +847,17 @@ static int viterbi_dispatch(const cpx_trellis *t, const double *d_coded, const D
         while ((1 << lg) < t->S) lg++;
         p.lgS = lg;
     };
+    hipStream_t st_rem = st;                                     // the stream of the state-per-lane launches below
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool overlapped = false;
+    auto join = [&](int rc) {                                    // every exit below the fork: `st` continues behind the side stream
+        if (overlapped && (hipEventRecord(ev_join, st_rem) != hipSuccess || hipStreamWaitEvent(st, ev_join, 0) != hipSuccess)) {
+            (void)hipStreamSynchronize(st_rem);
+            set_error("viterbi: joining the side stream failed");
+            return rc ? rc : CPX_EHIP;
+        }
+        return rc;
+    };
     if (!dm) {   // large batches of the standard rate-1/2 codes: one codeword per lane (viterbi_cw.hip).  That path runs in rounds
         // of one wavefront of 64 codewords per SIMD, each as long as a full one; a last round that would fill less than 45 % of
         // the chip is cheaper on the wave kernels below, whose time is proportional to the batch (config 2: 54 us per 1000
@@ -822,8 +866,22 @@ static int viterbi_dispatch(const cpx_trellis *t, const double *d_coded, const D
         const int64_t round = (int64_t)device_cus() * 4 * 64;
         int64_t Bcw = B;
         if (!(viterbi_path_flags() & 2) && B > round && 20 * (B % round) < 9 * round) Bcw = B / round * round;
+        // Round 6: the remainder runs BESIDE the rounds.  The rounds take the 32-slot ring stored once (launch_fused_lean: 93 instead of
+        // 157 KB of LDS per workgroup, priority 3), which leaves the remainder's state-per-lane waves room on every CU; they are issued on a
+        // lowest-priority side stream, forked from `st` before the rounds are launched (same inputs) and joined behind them, so that the
+        // dispatcher places the round's 256 workgroups first -- one per CU -- and the remainder around them.  'soft', default depth, float64,
+        // built-in 64-state pairs only (where the lean flavour exists); CPX_VITERBI_OVERLAP=0 keeps one stream and the mirrored ring.
+        hipStream_t st_side = nullptr;
+        bool armed = false;
+        if (Bcw < B && overlap_enabled() && t->S == 64 && decoding_type == CPX_VIT_SOFT && tb_depth == 30 && !precision_fast()) {
+            armed = side_stream(&st_side, &ev_fork, &ev_join) == CPX_OK && hipEventRecord(ev_fork, st) == hipSuccess;
+            if (!armed) (void)hipGetLastError();
+        }
         int rc_cw = CPX_OK;
-        if (viterbi_codeword_path(t, d_coded, Bcw, len, L, n_steps, tb_depth, decoding_type, d_bits, nanflags, st, &rc_cw)) {
+        viterbi_lean_ring(armed);
+        const bool took_cw = viterbi_codeword_path(t, d_coded, Bcw, len, L, n_steps, tb_depth, decoding_type, d_bits, nanflags, st, &rc_cw);
+        viterbi_lean_ring(false);
+        if (took_cw) {
             if (rc_cw != CPX_OK) return rc_cw;
             if (nanflags) {
                 // codeword path: one flag per item of the redo kernel -- 64 / S consecutive codewords, the codewords of one
@@ -835,6 +893,10 @@ static int viterbi_dispatch(const cpx_trellis *t, const double *d_coded, const D
                 nanflags += items;
             }
             if (Bcw == B) return CPX_OK;
+            if (armed && strstr(last_kernel_name(), "ring stored once")) {   // (the rounds are in `st`'s queue already: dispatched first)
+                if (hipStreamWaitEvent(st_side, ev_fork, 0) == hipSuccess) { st_rem = st_side; overlapped = true; }
+                else (void)hipGetLastError();
+            }
             d_coded += Bcw * len;
             d_bits += Bcw * L;
             B -= Bcw;
@@ -852,28 +914,28 @@ static int viterbi_dispatch(const cpx_trellis *t, const double *d_coded, const D
     }
     const int lgS = p.lgS;
     size_t lds = 0;
-    if (int rcl = wave_lds(t, p, &lds)) return rcl;
+    if (int rcl = wave_lds(t, p, &lds)) return join(rcl);
     if (t->S > 64) {                                             // 128 states: two states per lane
-        CPX_REQUIRE(B < (1ll << 31), CPX_ELIMIT, "viterbi: batch too large");
-        if (t->S == 256) hipLaunchKernelGGL((viterbi_wide_kernel<4, 2>), dim3((unsigned)B), dim3(64), lds, st, p);
-        else if (t->I == 2) hipLaunchKernelGGL((viterbi_wide_kernel<2, 2>), dim3((unsigned)B), dim3(64), lds, st, p);
-        else hipLaunchKernelGGL((viterbi_wide_kernel<2, 4>), dim3((unsigned)B), dim3(64), lds, st, p);
+        if (B >= (1ll << 31)) { set_error("viterbi: batch too large"); return join(CPX_ELIMIT); }
+        if (t->S == 256) hipLaunchKernelGGL((viterbi_wide_kernel<4, 2>), dim3((unsigned)B), dim3(64), lds, st_rem, p);
+        else if (t->I == 2) hipLaunchKernelGGL((viterbi_wide_kernel<2, 2>), dim3((unsigned)B), dim3(64), lds, st_rem, p);
+        else hipLaunchKernelGGL((viterbi_wide_kernel<2, 4>), dim3((unsigned)B), dim3(64), lds, st_rem, p);
         CPX_HIP(hipGetLastError());
-        if (p.nanflags) if (int rcr = launch_redo(t, p, B, st)) return rcr;
+        if (p.nanflags) if (int rcr = launch_redo(t, p, B, st_rem)) return join(rcr);
         note_kernel("viterbi_wide_kernel<%d,%d>", t->S / 64, t->I);
-        return CPX_OK;
+        return join(CPX_OK);
     }
     const int S = t->S, G = 64 / S;
     const int64_t nblocks = (B + G - 1) / G;
-    CPX_REQUIRE(nblocks < (1ll << 31), CPX_ELIMIT, "viterbi: batch too large");
+    if (nblocks >= (1ll << 31)) { set_error("viterbi: batch too large"); return join(CPX_ELIMIT); }
     dim3 grid((unsigned)nblocks), block(64);
     const bool sr = shift_register(t);                       // => arithmetic traceback (no predecessor table lookups)
 #define VIT_LAUNCH(LG, IT, SRV)                                                                             \
     do {                                                                                                    \
-        if (dm) hipLaunchKernelGGL((viterbi_wave_kernel<LG, IT, SRV, 0, true>), grid, block, lds, st, p);    \
-        else if (t->n == 2) hipLaunchKernelGGL((viterbi_wave_kernel<LG, IT, SRV, 2>), grid, block, lds, st, p);    \
-        else if (t->n == 3) hipLaunchKernelGGL((viterbi_wave_kernel<LG, IT, SRV, 3>), grid, block, lds, st, p); \
-        else hipLaunchKernelGGL((viterbi_wave_kernel<LG, IT, SRV, 0>), grid, block, lds, st, p);             \
+        if (dm) hipLaunchKernelGGL((viterbi_wave_kernel<LG, IT, SRV, 0, true>), grid, block, lds, st_rem, p);    \
+        else if (t->n == 2) hipLaunchKernelGGL((viterbi_wave_kernel<LG, IT, SRV, 2>), grid, block, lds, st_rem, p);    \
+        else if (t->n == 3) hipLaunchKernelGGL((viterbi_wave_kernel<LG, IT, SRV, 3>), grid, block, lds, st_rem, p); \
+        else hipLaunchKernelGGL((viterbi_wave_kernel<LG, IT, SRV, 0>), grid, block, lds, st_rem, p);             \
     } while (0)
 #define VIT_CASE(LG)                                       \
     case LG:                                               \
@@ -883,19 +945,20 @@ static int viterbi_dispatch(const cpx_trellis *t, const double *d_coded, const D
         break;
     switch (lgS) {
         VIT_CASE(1) VIT_CASE(2) VIT_CASE(3) VIT_CASE(4) VIT_CASE(5) VIT_CASE(6)
-        default: set_error("viterbi: unsupported number of states %d", S); return CPX_ELIMIT;
+        default: set_error("viterbi: unsupported number of states %d", S); return join(CPX_ELIMIT);
     }
 #undef VIT_CASE
 #undef VIT_LAUNCH
     CPX_HIP(hipGetLastError());
-    if (p.nanflags) if (int rcr = launch_redo(t, p, nblocks, st)) return rcr;
+    if (p.nanflags) if (int rcr = launch_redo(t, p, nblocks, st_rem)) return join(rcr);
     {
         char first[160];                                         // a leading round on the codeword path, if any
         snprintf(first, sizeof(first), "%s", last_kernel_name());
-        note_kernel("%s%sviterbi_wave_kernel<%d,%d,%s,%d%s>", first, first[0] ? " + " : "", lgS, t->I,
-                    (t->I == 2 && sr) ? "true" : "false", (!dm && (t->n == 2 || t->n == 3)) ? t->n : 0, dm ? ",demod" : "");
+        note_kernel("%s%sviterbi_wave_kernel<%d,%d,%s,%d%s>%s", first, first[0] ? " + " : "", lgS, t->I,
+                    (t->I == 2 && sr) ? "true" : "false", (!dm && (t->n == 2 || t->n == 3)) ? t->n : 0, dm ? ",demod" : "",
+                    overlapped ? " (beside the round, side stream)" : "");
     }
-    return CPX_OK;
+    return join(CPX_OK);
 }
 
 int cpx_viterbi_decode_batch_dev(const cpx_trellis *t, const double *d_coded, int64_t B, int64_t len, int64_t L,

@@ -597,6 +597,7 @@ __global__ __launch_bounds__(64 * ACS_WAVES) void viterbi_cw_fused_kernel(CwPara
     const int64_t grp = (int64_t)blockIdx.x * ACS_WAVES + wv;
     const int64_t cw = grp * 64 + lane;
     if (grp * 64 >= p.B) return;                                                   // whole wave beyond the batch
+    if constexpr (LGS == 6 && !MIR && !GEN && RING == FR_RING) __builtin_amdgcn_s_setprio(3);   // launch_fused_lean: another kernel's waves share the SIMD
     const bool valid = cw < p.B;
     const double *x = p.coded + (valid ? cw : 0) * p.len;
     static_assert(!GEN || (!MIR && std::is_same<F, double>::value), "table-driven codes: unmirrored ring, float64");
@@ -911,6 +912,31 @@ int launch_fused_typed(const CwParams &p, hipStream_t st) {
     return 1;
 }
 
+// 64 states on the 32-slot ring stored ONCE ('soft', default depth, float64): 93 KB of LDS per workgroup instead of 157, one more
+// instruction per traceback hop.  Used for the round(s) of a batch that ALSO has a remainder on the state-per-lane kernels
+// (viterbi_dispatch, round 6): with the mirrored ring a round's workgroup holds the CU's whole LDS and the remainder's workgroups are
+// not placed until it retires (profiles/r06_viterbi_remainder_overlap_ab.txt); with this one they run beside it.
+template <int LGS, unsigned G0, unsigned G1>
+int launch_fused_lean(const CwParams &p, hipStream_t st) {
+    auto *fn = viterbi_cw_fused_kernel<LGS, G0, G1, CPX_VIT_SOFT, fused_tb<LGS>() - 2, false, double, FR_RING, false>;
+    const size_t lds = ACS_WAVES * fused_wave_lds<FR_RING, false>();
+    static bool raised[64] = {};
+    static std::mutex raised_mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    std::lock_guard<std::mutex> lk(raised_mu);
+    if (!raised[dev]) {
+        if (hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            (void)hipGetLastError();
+            return 0;
+        }
+        raised[dev] = true;
+    }
+    const unsigned groups = (unsigned)((p.B + 63) / 64), blocks = (groups + ACS_WAVES - 1) / ACS_WAVES;
+    hipLaunchKernelGGL(fn, dim3(blocks), dim3(64 * ACS_WAVES), lds, st, p);
+    return 1;
+}
+
 // Small trellises (4 and 16 states) at their default depth: the same fused kernel on a 16- or 32-slot unmirrored ring -- 14.6 /
 // 22.8 KB of LDS per wave instead of 39, so that two workgroups fit a CU (the one-wave-per-SIMD structure of the 64-state kernel
 // leaves a 4-state step, ~60 instructions, waiting for its own latencies: 0.77 ms on BASELINE config 1 where the state-per-lane
@@ -1016,6 +1042,10 @@ int viterbi_path_flags() {
 // kernel -- and with it the precision mode -- then serves the host API exactly as it serves the device API).
 static thread_local bool tl_prefer_cw = false;
 void viterbi_prefer_cw(bool on) { tl_prefer_cw = on; }
+// Set by viterbi_dispatch around the round(s) of a batch whose remainder it runs beside them: the 64-state built-in pairs then take
+// the unmirrored ring (launch_fused_lean) where that flavour exists ('soft', default depth, float64).
+static thread_local bool tl_lean_ring = false;
+void viterbi_lean_ring(bool on) { tl_lean_ring = on; }
 
 static const char *type_name(int type) { return type == CPX_VIT_HARD ? "hard" : type == CPX_VIT_SOFT ? "soft" : "unquantized"; }
 
@@ -1053,6 +1083,11 @@ bool viterbi_codeword_path(const cpx_trellis *t, const double *d_coded, int64_t 
     const bool f32 = precision_fast() && T < (1ll << 22);
 #define CPX_TRY(LG, GA, GB)                                                                                         \
     if (tables_match<LG, GA, GB>(t)) {                                                                              \
+        if (tl_lean_ring && type == CPX_VIT_SOFT && tb == fused_tb<LG>() && !two_kernels && !f32 && launch_fused_lean<LG, GA, GB>(p, st)) { \
+            if (hipGetLastError() != hipSuccess) { set_error("viterbi (fused codeword path): launch failed"); *rc = CPX_EHIP; } \
+            note_kernel("viterbi_cw_fused_kernel<%d,0%o,0%o,%s,%d,ring stored once>", LG, GA, GB, type_name(type), fused_tb<LG>() - 2); \
+            return true;                                                                                            \
+        }                                                                                                           \
         if (tb >= 2 && tb <= fused_tb_deep<LG>() && !two_kernels &&                                                 \
             (f32 ? launch_fused<LG, GA, GB, float>(p, st) : launch_fused<LG, GA, GB, double>(p, st))) {                 \
             const bool deep = tb > fused_tb<LG>();                                                                  \

@@ -305,3 +305,47 @@ def test_full_size_default_dispatch_equals_wave_kernels(gpu):
     sel = np.r_[0:48, 65536 - 24:65536 + 24, B - 48:B]
     assert np.array_equal(auto[sel], oracle.viterbi_decode(rx[sel], tr, None, "soft"))
     assert 0 < np.mean(auto[:, :1024] != msgs) < 0.05
+
+
+def test_remainder_runs_beside_the_round(gpu):
+    """Round 6: a 'soft' batch of one full round plus a remainder (65 536 + 3 000 codewords, K = 7, default depth) -- the round takes the
+    32-slot ring stored once and the state-per-lane remainder is issued on the library's side stream beside it (cpx_last_kernel says
+    so); the bits equal the state-per-lane kernels' on every codeword and the oracle's on the first / last ones, the noiseless batch
+    decodes to the messages, and two host threads doing this at the same time (thread-private fork / join events, one shared side
+    stream) get the same bits as one thread alone."""
+    import threading
+    from commpy_amd import _lib
+    from commpy_amd.channelcoding import conv_encode_batch, viterbi_decode
+    import os
+    if os.environ.get("CPX_VITERBI_OVERLAP", "1")[:1] == "0":
+        pytest.skip("overlap switched off in the environment")
+    tr = make_trellis("k7_133_171")
+    B, nbits = 65536 + 3000, 96
+    out = {}
+
+    def work(seed):
+        rs = np.random.RandomState(seed)
+        msgs = rs.randint(0, 2, (B, nbits))
+        coded = conv_encode_batch(msgs, tr).astype(np.float64)
+        rx = 4.0 * coded - 2 + rs.randn(*coded.shape) * 1.5
+        got = viterbi_decode(rx, tr, None, "soft")
+        out[seed] = (rx, got, _lib.last_kernel(), msgs)
+    work(1)
+    rx, got, note, msgs = out[1]
+    assert "ring stored once" in note and "beside the round" in note, note
+    assert np.array_equal(got, _decode(rx, tr, None, "soft", "wave"))
+    for lo in (0, 65536 - 200, B - 400):
+        assert np.array_equal(got[lo:lo + 400], oracle.viterbi_decode_mt(rx[lo:lo + 400], tr, None, "soft"))
+    clean = viterbi_decode(4.0 * conv_encode_batch(msgs, tr).astype(np.float64) - 2, tr, None, "soft")
+    assert np.array_equal(clean[:, :nbits], msgs)
+    single = {seed: None for seed in (2, 3)}
+    for seed in single:
+        work(seed)
+        single[seed] = out[seed][1].copy()
+    th = [threading.Thread(target=work, args=(seed,)) for seed in single]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    for seed in single:
+        assert np.array_equal(out[seed][1], single[seed]), seed
