@@ -779,7 +779,9 @@ static bool overlap_enabled() {
 static int side_stream(hipStream_t *st, hipEvent_t *fork, hipEvent_t *join) {
     static std::mutex mu;
     static hipStream_t s_side[64] = {};
-    static thread_local hipEvent_t tl_ev[64][2] = {};
+    constexpr int PAIRS = 4;                                      // consecutive calls of a thread take different pairs (belt and braces:
+    static thread_local hipEvent_t tl_ev[64][2 * PAIRS] = {};     //  a re-record never touches an event whose wait was issued one call ago)
+    static thread_local unsigned tl_next[64] = {};
     int dev = 0;
     CPX_HIP(hipGetDevice(&dev));
     CPX_REQUIRE(dev >= 0 && dev < 64, CPX_ELIMIT, "viterbi: device index %d", dev);
@@ -791,11 +793,12 @@ static int side_stream(hipStream_t *st, hipEvent_t *fork, hipEvent_t *join) {
             CPX_HIP(hipStreamCreateWithPriority(&s_side[dev], hipStreamNonBlocking, least));
         }
     }
-    if (!tl_ev[dev][0]) {
-        CPX_HIP(hipEventCreateWithFlags(&tl_ev[dev][0], hipEventDisableTiming));
-        CPX_HIP(hipEventCreateWithFlags(&tl_ev[dev][1], hipEventDisableTiming));
+    const unsigned k = 2 * (tl_next[dev]++ % PAIRS);
+    if (!tl_ev[dev][k]) {
+        CPX_HIP(hipEventCreateWithFlags(&tl_ev[dev][k], hipEventDisableTiming));
+        CPX_HIP(hipEventCreateWithFlags(&tl_ev[dev][k + 1], hipEventDisableTiming));
     }
-    *st = s_side[dev]; *fork = tl_ev[dev][0]; *join = tl_ev[dev][1];
+    *st = s_side[dev]; *fork = tl_ev[dev][k]; *join = tl_ev[dev][k + 1];
     return CPX_OK;
 }
 
