@@ -559,7 +559,9 @@ def run_pair(lib, steps, warmup, B=65536, n_check=192):
                 par["ok"] = par["ok"] and par["bits_differing_from_the_table_driven_kernel_whole_batch"] == 0
             out.append(entry("configs[1] geometry, pair (135,147), " + what, "K=7 (135,147) r=1/2 -- no built-in instantiation --, 1024-bit blocks, soft "
                              "Viterbi, tb_depth=30, B=%d" % B, kname, ms, B * 1024, "info-bits", B * 17510, "valu", par,
-                             {"specialize_s": round(t_jit, 2)} if what != "table-driven kernel" else None))
+                             {"specialize_s": round(t_jit, 2)} if what != "table-driven kernel" else None,
+                             pmc=("pair", {"viterbi_cw_fused_kernel<6, 0u, 0u": 1} if what == "table-driven kernel" else
+                                  {"viterbi_cw_fused_kernel<6, 93u, 115u": 1})))
     finally:
         dev.free()
     return out

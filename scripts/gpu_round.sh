@@ -66,7 +66,7 @@ if [[ $SEC == *o* ]]; then
 fi
 if [[ $SEC == *O* ]]; then
   # counters for what the driver times (round-5 verdict item 4): PMC passes over benchmarks/other_configs.py itself, one workload at a time
-  for w in turbo config4 config5 config1; do
+  for w in turbo config4 config5 config1 pair; do
     timeout 1500 python scripts/collect_pmc.py --out $OUT --name oc_$w --match _kernel --fetch-scale 2 -- \
         python $R/benchmarks/other_configs.py --which $w --steps 10 --warmup 3 2>&1 | tail -3 | cut -c1-300
   done
