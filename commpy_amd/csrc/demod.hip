@@ -525,8 +525,10 @@ struct LinkFrontParams {
     double2 *rx;                                                   // optional: the noisy symbols (tests)
 };
 
+// (four waves per SIMD for up to 64-QAM: 128 VGPRs and six spilled values instead of 147 -- front end of the config-5 sweep 0.985 -> 0.94 ms,
+//  same box, alternating; five / six waves spill 38 / 57 values and lose: 1.36 / 1.69 ms)
 template <int NH, bool RCP, bool GP, bool TAB>
-__global__ __launch_bounds__(DEMOD_BLOCK) void link_front_kernel(const LinkFrontParams p) {
+__global__ __launch_bounds__(DEMOD_BLOCK, (NH <= 3 ? 4 : 3)) void link_front_kernel(const LinkFrontParams p) {
     constexpr int R = 1 << NH, NB = 2 * NH, WAVES = DEMOD_BLOCK / 64;
     __shared__ double ax_s[2 * R];
     __shared__ double tab_s[TAB ? 96 : 1];
