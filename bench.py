@@ -320,6 +320,8 @@ def main():
                     help="accepted for older command lines; N > 1 always times both regions (decode alone -> value, decode + "
                          "RCCL all-gather of the decoded bits on the decode stream -> value_with_gather)")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the second (decode + all-gather) timed region")
+    ap.add_argument("--sustain-seconds", type=float, default=2.0,
+                    help="N = 1: after the timed region run the same step back to back for this long (GPU-busy evidence; 0 = skip)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="N = 1: skip the `other_configs` lines (turbo, LDPC chain, soft demodulator; ~15 s)")
     ap.add_argument("--synth", choices=("device", "host"), default="device",
@@ -548,6 +550,24 @@ def main():
         clock = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
         if probe:                                                  # a probe that was started and never read goes back to the library
             lib.cpx_sclk_probe_destroy(probe)
+    # Sustained phase (round 6), untimed for `value`: the K timed steps are ~30 ms of a run that lasts many seconds, so an outside sampler
+    # (rocm-smi style GPU-busy polling, the driver's own clock) cannot see them.  The same step then runs back to back for
+    # --sustain-seconds of wall time; its average per step is reported next to the timed one and has to agree with it.
+    sustained = None
+    if world == 1 and args.sustain_seconds > 0:
+        try:
+            t0s, n_s = time.perf_counter(), 0
+            while time.perf_counter() - t0s < args.sustain_seconds:
+                for _ in range(100):
+                    step(None, False)
+                sync()
+                n_s += 100
+            dts = time.perf_counter() - t0s
+            sustained = {"steps": n_s, "seconds": dts, "ms_per_step": dts / n_s * 1e3, "info_bits_per_s": B * MSG_BITS * n_s / dts,
+                         "note": "the headline step back to back (host clock around batches of 100 launches + a stream sync), after the timed "
+                                 "region; not part of `value`"}
+        except Exception as exc:                                   # evidence, never a reason to lose the line
+            sustained = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
     comm_world = None
     if comm is not None:
         nr, nl, fr = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
@@ -663,7 +683,7 @@ def main():
                          "steady_state": {"ms_per_launch_median": float(np.median(kernel_ms)),
                                           "info_bits_per_s_per_gpu": B * MSG_BITS / (float(np.median(kernel_ms)) * 1e-3)},
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_CW * B,
-                         "clock": clock,
+                         "clock": clock, "sustained": sustained,
                          "valu": valu,
                          "note": "serial float64 add-compare-select recursion: VALU-issue bound (valu.busy_frac), the HBM "
                                  "fraction is reported because the metric asks for it"},

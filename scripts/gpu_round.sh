@@ -42,7 +42,7 @@ if [[ $SEC == *l* ]]; then
 fi
 if [[ $SEC == *v* ]]; then
   timeout 1500 python scripts/collect_pmc.py --out $OUT --name viterbi_c2 --match viterbi --batch 65536 -- \
-      python $R/bench.py --steps 25 --warmup 5 --no-cpu-baseline --no-other-configs 2>&1 | tail -40
+      python $R/bench.py --steps 25 --warmup 5 --no-cpu-baseline --no-other-configs --sustain-seconds 0 2>&1 | tail -40
 fi
 if [[ $SEC == *u* ]]; then
   timeout 1500 python scripts/collect_pmc.py --out $OUT --name turbo_c3 --match _kernel --fetch-scale 2 -- \
@@ -89,7 +89,7 @@ if [[ $SEC == *f* ]]; then
   timeout 300 python scripts/fuzz_gpu.py --seconds 90 2>&1 | tail -4 | tee $OUT/fuzz.txt
 fi
 if [[ $SEC == *L* ]]; then
-  timeout 600 python bench.py --gpus 1 --steps 500 --warmup 5 --no-cpu-baseline 2>&1 | tail -1 | tee $OUT/bench_n1_steps500.json | cut -c1-300
+  timeout 600 python bench.py --gpus 1 --steps 500 --warmup 5 --no-cpu-baseline --sustain-seconds 0 2>&1 | tail -1 | tee $OUT/bench_n1_steps500.json | cut -c1-300
 fi
 if [[ $SEC == *r* ]]; then
   # roctx ranges of the entry points (CPX_TRACE=1) next to the kernels: rocprofv3 marker trace of the host-API benchmark
