@@ -256,3 +256,33 @@ def test_demod_tables_in_the_kernel_source_are_what_their_comments_say():
     assert abs(float.fromhex(consts["L32_LO"]) - float(l32 - ld(float(l32)))) < 1e-21
     assert float.fromhex(consts["INV_L32"]) == float(ld(32) / np.log(ld(2)))
     assert float.fromhex(consts["LN2"]) == float(np.log(ld(2)))
+
+
+def test_other_configs_quotes_counters_only_from_the_same_build(tmp_path, monkeypatch):
+    """benchmarks/other_configs.py::pmc_fields (round 6): `traffic` = sum over a step's kernels of launches x bytes per launch, `valu` of the
+    kernel a step spends most of its time in -- and nothing at all when the PMC file was recorded by another build, when a kernel of the
+    step is missing from it, or when there is no file."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from benchmarks import other_configs as oc
+    monkeypatch.setattr(oc, "PMC_DIR", str(tmp_path))
+    monkeypatch.setattr(oc._lib, "build_id", lambda: {"full": "abc", "viterbi": "v"})
+    none = {"traffic": None, "traffic_source": None, "valu": None}
+    assert oc.pmc_fields("turbo", {"k_pass": 12}) == none                                  # no file
+    doc = {"build_id": {"full": "abc"}, "git_head": "deadbeefcafe", "fetch_scale": 2.0,
+           "kernels": {"k_pass<2, true>": {"traffic_bytes_per_launch": 100.0, "duration_ns_avg": 10.0, "calls": 12,
+                                           "valu": {"busy_frac": 0.5}, "SQ_LDS_BANK_CONFLICT": 2.0, "SQ_ACTIVE_INST_LDS": 8.0},
+                       "k_init": {"traffic_bytes_per_launch": 1000.0, "duration_ns_avg": 50.0, "calls": 1, "valu": {"busy_frac": 0.9}}}}
+    path = tmp_path / "r06_oc_turbo_pmc.json"
+    path.write_text(json.dumps(doc))
+    got = oc.pmc_fields("turbo", {"k_pass": 12, "k_init": 1})
+    assert got["traffic"] == 12 * 100.0 + 1000.0
+    assert got["valu"] == {"busy_frac": 0.5}                                               # 12 x 10 ns > 1 x 50 ns: the pass dominates
+    assert got["per_kernel"]["k_pass<2, true>"]["lds_bank_conflict_frac_of_lds_active"] == 0.25
+    assert "r06_oc_turbo_pmc.json" in got["traffic_source"] and "abc" in got["traffic_source"]
+    assert oc.pmc_fields("turbo", {"k_pass": 12, "k_missing": 1}) == none                  # a kernel of the step is not in the file
+    doc["build_id"]["full"] = "other"
+    path.write_text(json.dumps(doc))
+    assert oc.pmc_fields("turbo", {"k_pass": 12, "k_init": 1}) == none                     # recorded by another build
